@@ -1,0 +1,353 @@
+"""pluto-gps-sim_amd — MI355X-native GPS L1 C/A baseband IQ synthesis (libgpsbb) for Python callers.
+
+This is only a ctypes veneer over the C ABI in include/gpsbb.h: the product is libgpsbb.so
+(hand-written HIP for gfx950 in csrc/).  There is no Python or CPU implementation of the fill here; every
+fill call goes through the shared library and raises when the library or a GPU is missing.
+
+The directory name contains '-' (it mirrors the reference's repo name), so import it by path:
+
+    import importlib.util, sys
+    spec = importlib.util.spec_from_file_location("pluto_gps_sim_amd", ".../pluto-gps-sim_amd/__init__.py")
+    mod = importlib.util.module_from_spec(spec); sys.modules[spec.name] = mod; spec.loader.exec_module(mod)
+
+(`__graft_entry__.load_package()` and tests/conftest.py do exactly that.)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgpsbb.so")
+
+MAX_CHAN = 16
+N_DWRD = 60
+
+CHAN_DTYPE = np.dtype([("prn", "<i4"), ("iword", "<i4"), ("ibit", "<i4"), ("icode", "<i4"),
+                       ("f_carr", "<f8"), ("f_code", "<f8"), ("carr_phase", "<f8"),
+                       ("code_phase", "<f8"), ("gain", "<f8"), ("dwrd", "<u4", (N_DWRD,))])
+STATE_DTYPE = np.dtype([("carr_phase", "<f8"), ("code_phase", "<f8"), ("iword", "<i4"),
+                        ("ibit", "<i4"), ("icode", "<i4"), ("dataBit", "<i4"), ("codeCA", "<i4"),
+                        ("_pad", "<i4")])
+ROW_DTYPE = np.dtype([("n0", "<i4"), ("nav", "<u4"), ("xb", "<u8"), ("inc", "<i8")])
+assert CHAN_DTYPE.itemsize == 296 and STATE_DTYPE.itemsize == 40 and ROW_DTYPE.itemsize == 24
+
+CHAIN_CARRIER = 1
+
+ERRORS = {0: "GPSBB_OK", -1: "GPSBB_E_BADARG", -2: "GPSBB_E_BADCHAN", -3: "GPSBB_E_HIP", -4: "GPSBB_E_NOMEM",
+          -5: "GPSBB_E_INTERNAL", -6: "GPSBB_E_NODEVICE", -7: "GPSBB_E_STATE"}
+
+# every symbol include/gpsbb.h declares
+API_SYMBOLS = [
+    "gpsbb_create", "gpsbb_destroy", "gpsbb_strerror", "gpsbb_last_hip_error", "gpsbb_version",
+    "gpsbb_fill_block", "gpsbb_fill_block_ref", "gpsbb_batch_create", "gpsbb_batch_destroy",
+    "gpsbb_batch_iq_bytes", "gpsbb_batch_run", "gpsbb_sync", "gpsbb_batch_read", "gpsbb_batch_device_iq",
+    "gpsbb_get_hazards", "gpsbb_batch_last_timing", "gpsbb_batch_timing_stats", "gpsbb_fill_ceiling", "gpsbb_stream_create",
+    "gpsbb_stream_destroy", "gpsbb_stream_push", "gpsbb_stream_pop", "gpsbb_stream_pending",
+    "gpsbb_codegen", "gpsbb_sincos_tables", "gpsbb_chain_carrier_host",
+]
+
+
+class GpsbbError(RuntimeError):
+    def __init__(self, rc, what=""):
+        self.rc = rc
+        super().__init__("%s failed: %s (%d)" % (what, ERRORS.get(rc, "?"), rc))
+
+
+def build(force=False):
+    """Compile csrc/ for gfx950 with hipcc into libgpsbb.so next to this file (in-tree, so it travels)."""
+    if force or not os.path.exists(LIB_PATH) or any(
+            os.path.getmtime(os.path.join(HERE, "csrc", f)) > os.path.getmtime(LIB_PATH)
+            for f in os.listdir(os.path.join(HERE, "csrc"))):
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "csrc")])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded libgpsbb.so (never a fallback: raises if it is not built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libgpsbb.so is not built (run __graft_entry__.build() or make -C %s/csrc)" % HERE)
+        L = C.CDLL(LIB_PATH)
+        vp, i, d, u = C.c_void_p, C.c_int, C.c_double, C.c_uint
+        L.gpsbb_create.argtypes = [C.POINTER(vp), i]
+        L.gpsbb_destroy.argtypes = [vp]
+        L.gpsbb_destroy.restype = None
+        L.gpsbb_strerror.argtypes = [i]
+        L.gpsbb_strerror.restype = C.c_char_p
+        L.gpsbb_last_hip_error.argtypes = [vp]
+        L.gpsbb_fill_block.argtypes = [vp, vp, i, d, i, vp, vp]
+        L.gpsbb_fill_block_ref.argtypes = [vp, vp, vp, i, vp, d, i, vp]
+        L.gpsbb_batch_create.argtypes = [vp, vp, i, i, d, i, u, C.POINTER(vp)]
+        L.gpsbb_batch_destroy.argtypes = [vp]
+        L.gpsbb_batch_destroy.restype = None
+        L.gpsbb_batch_iq_bytes.argtypes = [vp]
+        L.gpsbb_batch_iq_bytes.restype = C.c_size_t
+        L.gpsbb_batch_run.argtypes = [vp, vp]
+        L.gpsbb_sync.argtypes = [vp]
+        L.gpsbb_batch_read.argtypes = [vp, vp, vp]
+        L.gpsbb_batch_device_iq.argtypes = [vp]
+        L.gpsbb_batch_device_iq.restype = vp
+        L.gpsbb_get_hazards.argtypes = [vp, vp, i]
+        L.gpsbb_batch_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.gpsbb_batch_timing_stats.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                               C.POINTER(C.c_float), i]
+        L.gpsbb_fill_ceiling.argtypes = [vp, vp, C.c_size_t, i, C.POINTER(C.c_float)]
+        L.gpsbb_stream_create.argtypes = [vp, i, d, i, i, i, u, C.POINTER(vp)]
+        L.gpsbb_stream_destroy.argtypes = [vp]
+        L.gpsbb_stream_destroy.restype = None
+        L.gpsbb_stream_push.argtypes = [vp, vp]
+        L.gpsbb_stream_pop.argtypes = [vp, C.POINTER(vp), vp]
+        L.gpsbb_stream_pending.argtypes = [vp]
+        L.gpsbb_codegen.argtypes = [i, vp]
+        L.gpsbb_sincos_tables.argtypes = [vp, vp]
+        L.gpsbb_chain_carrier_host.argtypes = [vp, i, i, d, i, vp, i]
+        # test hooks (csrc/gpsbb_testhooks.h)
+        L.gpsbb_test_carr_jump.argtypes = [d, d, C.c_longlong]
+        L.gpsbb_test_carr_jump.restype = d
+        L.gpsbb_test_code_jump.argtypes = [d, d, C.c_longlong, C.POINTER(C.c_longlong)]
+        L.gpsbb_test_code_jump.restype = d
+        L.gpsbb_test_build_rows.argtypes = [i, d, d, u, i, vp, i, C.POINTER(d), C.POINTER(u)]
+        L.gpsbb_test_row_bound.argtypes = [i, d, i]
+        L.gpsbb_test_row_bound.restype = C.c_ulonglong
+        _lib = L
+    return _lib
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise GpsbbError(rc, what)
+
+
+def _as_chan(ch):
+    ch = np.ascontiguousarray(ch, dtype=CHAN_DTYPE)
+    if ch.ndim == 1:
+        ch = ch[None, :]
+    if ch.ndim != 2:
+        raise ValueError("descriptors must be [nblocks, nch]")
+    return ch
+
+
+# ---- host helpers ------------------------------------------------------------------------------------
+
+def codegen(prn):
+    ca = np.zeros(1023, np.uint8)
+    _chk(lib().gpsbb_codegen(prn, ca.ctypes.data), "gpsbb_codegen")
+    return ca
+
+
+def sincos_tables():
+    s = np.zeros(512, np.int32)
+    c = np.zeros(512, np.int32)
+    _chk(lib().gpsbb_sincos_tables(s.ctypes.data, c.ctypes.data), "gpsbb_sincos_tables")
+    return s, c
+
+
+def chain_carrier_host(ch, delt, nsamp, nthreads=0):
+    ch = _as_chan(ch)
+    nb, nch = ch.shape
+    seed = np.zeros((nb, nch), np.float64)
+    _chk(lib().gpsbb_chain_carrier_host(ch.ctypes.data, nb, nch, delt, nsamp, seed.ctypes.data, nthreads),
+         "gpsbb_chain_carrier_host")
+    return seed
+
+
+# ---- device objects ----------------------------------------------------------------------------------
+
+class Synth:
+    """One libgpsbb handle: one GPU, one producer thread (gpsbb_create / gpsbb_destroy)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _chk(lib().gpsbb_create(C.byref(self._h), device), "gpsbb_create")
+
+    def close(self):
+        if self._h:
+            lib().gpsbb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def fill_block(self, ch, delt, nsamp):
+        """gpsbb_fill_block: ch = CHAN_DTYPE[nch] -> (int16 [nsamp,2], STATE_DTYPE[nch])"""
+        ch = np.ascontiguousarray(ch, dtype=CHAN_DTYPE)
+        iq = np.empty((nsamp, 2), np.int16)
+        st = np.zeros(ch.shape[0], STATE_DTYPE)
+        _chk(lib().gpsbb_fill_block(self._h, ch.ctypes.data, ch.shape[0], delt, nsamp, iq.ctypes.data,
+                                    st.ctypes.data), "gpsbb_fill_block")
+        return iq, st
+
+    def batch(self, ch, delt, nsamp, flags=0):
+        return Batch(self, ch, delt, nsamp, flags)
+
+    def stream(self, nch, delt, nsamp, blocks_per_slot, depth=3, flags=0):
+        return Stream(self, nch, delt, nsamp, blocks_per_slot, depth, flags)
+
+    def sync(self):
+        _chk(lib().gpsbb_sync(self._h), "gpsbb_sync")
+
+    def hazards(self, reset=False):
+        v = np.zeros(2, np.uint64)
+        _chk(lib().gpsbb_get_hazards(self._h, v.ctypes.data, int(reset)), "gpsbb_get_hazards")
+        return {"itable_512": int(v[0]), "dwrd_oob": int(v[1])}
+
+    def fill_ceiling(self, d_ptr, nbytes, iters=10):
+        ms = C.c_float()
+        _chk(lib().gpsbb_fill_ceiling(self._h, d_ptr, nbytes, iters, C.byref(ms)), "gpsbb_fill_ceiling")
+        return ms.value
+
+
+class Batch:
+    """Block descriptors resident in HBM (gpsbb_batch_*)."""
+
+    def __init__(self, synth, ch, delt, nsamp, flags=0):
+        ch = _as_chan(ch)
+        self.synth = synth
+        self.nblocks, self.nch = ch.shape
+        self.nsamp = nsamp
+        self._b = C.c_void_p()
+        _chk(lib().gpsbb_batch_create(synth._h, ch.ctypes.data, self.nblocks, self.nch, delt, nsamp, flags,
+                                      C.byref(self._b)), "gpsbb_batch_create")
+
+    def close(self):
+        if self._b:
+            lib().gpsbb_batch_destroy(self._b)
+            self._b = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def iq_bytes(self):
+        return lib().gpsbb_batch_iq_bytes(self._b)
+
+    def run(self, d_iq=None):
+        """Enqueue seeding pre-pass + synthesis; d_iq = device pointer (int) or None for the internal buffer."""
+        _chk(lib().gpsbb_batch_run(self._b, d_iq), "gpsbb_batch_run")
+
+    def read(self, want_iq=True):
+        iq = np.empty((self.nblocks, self.nsamp, 2), np.int16) if want_iq else None
+        st = np.zeros((self.nblocks, self.nch), STATE_DTYPE)
+        _chk(lib().gpsbb_batch_read(self._b, iq.ctypes.data if want_iq else None, st.ctypes.data),
+             "gpsbb_batch_read")
+        return iq, st
+
+    def timing(self):
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        _chk(lib().gpsbb_batch_last_timing(self._b, C.byref(a), C.byref(b), C.byref(c)), "gpsbb_batch_last_timing")
+        return {"ms_seed": a.value, "ms_synth": b.value, "ms_total": c.value}
+
+    def timing_stats(self, reset=True):
+        n, a, b, c = C.c_int(), C.c_float(), C.c_float(), C.c_float()
+        _chk(lib().gpsbb_batch_timing_stats(self._b, C.byref(n), C.byref(a), C.byref(b), C.byref(c), int(reset)),
+             "gpsbb_batch_timing_stats")
+        return {"runs": n.value, "ms_seed_sum": a.value, "ms_synth_sum": b.value, "ms_total_sum": c.value}
+
+    def device_iq(self):
+        return lib().gpsbb_batch_device_iq(self._b)
+
+
+class Stream:
+    """Time-sharded streaming with pinned host gather (gpsbb_stream_*)."""
+
+    def __init__(self, synth, nch, delt, nsamp, blocks_per_slot, depth=3, flags=0):
+        self.synth = synth
+        self.nch, self.nsamp, self.bps = nch, nsamp, blocks_per_slot
+        self._s = C.c_void_p()
+        _chk(lib().gpsbb_stream_create(synth._h, nch, delt, nsamp, blocks_per_slot, depth, flags,
+                                       C.byref(self._s)), "gpsbb_stream_create")
+
+    def close(self):
+        if self._s:
+            lib().gpsbb_stream_destroy(self._s)
+            self._s = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push(self, ch):
+        ch = _as_chan(ch)
+        if ch.shape != (self.bps, self.nch):
+            raise ValueError("push expects [blocks_per_slot, nch] descriptors")
+        _chk(lib().gpsbb_stream_push(self._s, ch.ctypes.data), "gpsbb_stream_push")
+
+    def pop(self, copy=True):
+        p = C.c_void_p()
+        st = np.zeros((self.bps, self.nch), STATE_DTYPE)
+        _chk(lib().gpsbb_stream_pop(self._s, C.byref(p), st.ctypes.data), "gpsbb_stream_pop")
+        n = self.bps * self.nsamp * 2
+        view = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int16)), (n,)).reshape(self.bps, self.nsamp, 2)
+        return (view.copy() if copy else view), st
+
+    @property
+    def pending(self):
+        return lib().gpsbb_stream_pending(self._s)
+
+
+# ---- synthetic descriptors (BASELINE / SURVEY section 8d, workload M2) -------------------------------
+
+class SplitMix64:
+    """Counter-mode splitmix64: draw k (k = 1, 2, ...) is mix(seed + k*0x9E3779B97F4A7C15) — the sequence
+    the scalar generator produces, evaluated vectorised."""
+
+    def __init__(self, seed):
+        self.seed = np.uint64(seed)
+        self.k = 0
+
+    def take(self, n):
+        with np.errstate(over="ignore"):
+            idx = np.arange(self.k + 1, self.k + n + 1, dtype=np.uint64)
+            z = self.seed + idx * np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+        self.k += n
+        return z
+
+    def u01(self, shape):
+        n = int(np.prod(shape))
+        return ((self.take(n) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)).reshape(shape)
+
+    def u32(self, shape):
+        n = int(np.prod(shape))
+        return (self.take(n) >> np.uint64(32)).reshape(shape)
+
+
+def synth_descriptors(nblocks, nch=16, seed=0x5EED, max_doppler=5000.0):
+    """Seeded descriptor-level constellation: PRN 1..nch, f_carr ~ U(-max,max) Hz, f_code = 1.023e6 +
+    f_carr/1540, code_phase ~ U[0,1023), carr_phase ~ U[0,1), gain ~ U(0.30,0.80), random 30-bit nav
+    words, iword in [9,58], ibit in 0..29, icode in 0..19."""
+    g = SplitMix64(seed)
+    ch = np.zeros((nblocks, nch), CHAN_DTYPE)
+    ch["prn"] = np.arange(1, nch + 1, dtype=np.int32)[None, :]
+    ch["f_carr"] = (g.u01((nblocks, nch)) * 2.0 - 1.0) * max_doppler
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    ch["code_phase"] = g.u01((nblocks, nch)) * 1023.0
+    ch["carr_phase"] = g.u01((nblocks, nch))
+    ch["gain"] = 0.30 + 0.50 * g.u01((nblocks, nch))
+    ch["iword"] = 9 + (g.u32((nblocks, nch)) % np.uint64(50)).astype(np.int32)
+    ch["ibit"] = (g.u32((nblocks, nch)) % np.uint64(30)).astype(np.int32)
+    ch["icode"] = (g.u32((nblocks, nch)) % np.uint64(20)).astype(np.int32)
+    ch["dwrd"] = (g.u32((nblocks, nch, N_DWRD)) & np.uint64(0x3FFFFFFF)).astype(np.uint32)
+    return ch

@@ -1,0 +1,913 @@
+/*
+ * gpsbb.hip — host side of libgpsbb: the C ABI of include/gpsbb.h over the HIP kernels in
+ * gpsbb_kernels.hip.h.  Plain HIP runtime (streams, events, pinned memory); no torch, no CPU fallback:
+ * every fill entry point fails with GPSBB_E_NODEVICE / GPSBB_E_HIP when there is no gfx950 device.
+ *
+ * Reference interface replaced: the inline sample loop plutogpssim.c:2689-2759 and its producer/consumer
+ * contract with pluto_tx_thread_ep (plutogpssim.c:2146-2158).  See include/gpsbb.h.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "gpsbb.h"
+#include "gpsbb_kernels.hip.h"
+#include "gpsbb_nco.h"
+#include "gpsbb_testhooks.h"
+
+using namespace gpsbb_impl;
+
+/* ================================================================================================== */
+/* host-side tables                                                                                   */
+/* ================================================================================================== */
+
+namespace {
+
+/* sinTable512 / cosTable512 (plutogpssim.c:93-161) from their closed form trunc(511*f(2*pi*i/512)+1.0);
+ * guarded by a checksum of the 1024 values so that a libm that rounds differently fails loudly instead
+ * of silently changing the output. */
+constexpr uint64_t kSinCosFnv1a = 0x1c99a5cf84551314ull;
+
+bool make_sincos(int32_t sin512[512], int32_t cos512[512])
+{
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int i = 0; i < 512; i++) {
+        const double a = two_pi * (double)i / 512.0;
+        sin512[i] = (int32_t)(511.0 * std::sin(a) + 1.0);
+        cos512[i] = (int32_t)(511.0 * std::cos(a) + 1.0);
+    }
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto eat = [&h](const int32_t *t) {
+        for (int i = 0; i < 512; i++)
+            for (int k = 0; k < 4; k++) {
+                h ^= (uint8_t)((uint32_t)t[i] >> (8 * k));
+                h *= 0x100000001b3ull;
+            }
+    };
+    eat(sin512);
+    eat(cos512);
+    return h == kSinCosFnv1a;
+}
+
+/* C/A code of one PRN (the table codegen() builds, plutogpssim.c:207-244), generated the ICD way:
+ * two 10-stage LFSRs, G1 = 1+x^3+x^10, G2 = 1+x^2+x^3+x^6+x^8+x^9+x^10, both preset to all ones, and
+ * the PRN picked by XOR-ing two G2 stages (the "phase selector"), which is equivalent to the G2 delay
+ * table the reference uses (c:208-213). */
+const uint8_t kG2Taps[32][2] = {
+    {2, 6}, {3, 7}, {4, 8}, {5, 9}, {1, 9}, {2, 10}, {1, 8}, {2, 9}, {3, 10}, {2, 3}, {3, 4},
+    {5, 6}, {6, 7}, {7, 8}, {8, 9}, {9, 10}, {1, 4}, {2, 5}, {3, 6}, {4, 7}, {5, 8}, {6, 9},
+    {1, 3}, {4, 6}, {5, 7}, {6, 8}, {7, 9}, {8, 10}, {1, 6}, {2, 7}, {3, 8}, {4, 9}};
+
+void make_ca(int prn, uint8_t ca[GPSBB_CA_LEN])
+{
+    /* bit k-1 of g = stage k */
+    uint32_t g1 = 0x3ff, g2 = 0x3ff;
+    const int t1 = kG2Taps[prn - 1][0], t2 = kG2Taps[prn - 1][1];
+    for (int i = 0; i < GPSBB_CA_LEN; i++) {
+        const uint32_t o1 = (g1 >> 9) & 1u;
+        const uint32_t o2 = ((g2 >> (t1 - 1)) ^ (g2 >> (t2 - 1))) & 1u;
+        ca[i] = (uint8_t)(o1 ^ o2);
+        const uint32_t f1 = ((g1 >> 2) ^ (g1 >> 9)) & 1u;
+        const uint32_t f2 = ((g2 >> 1) ^ (g2 >> 2) ^ (g2 >> 5) ^ (g2 >> 7) ^ (g2 >> 8) ^ (g2 >> 9)) & 1u;
+        g1 = ((g1 << 1) | f1) & 0x3ff;
+        g2 = ((g2 << 1) | f2) & 0x3ff;
+    }
+}
+
+/* descriptor contract of gpsbb_chan_t (include/gpsbb.h) */
+bool chan_ok(const gpsbb_chan_t &c, double delt)
+{
+    if (c.prn == 0)
+        return true;
+    if (c.prn < 0 || c.prn > 32)
+        return false;
+    if (!std::isfinite(c.f_carr) || !std::isfinite(c.f_code) || !std::isfinite(c.carr_phase) ||
+        !std::isfinite(c.code_phase) || !std::isfinite(c.gain))
+        return false;
+    if (std::signbit(c.carr_phase) || c.carr_phase > 1.0)
+        return false;
+    if (std::signbit(c.code_phase) || !(c.code_phase < 1023.0))
+        return false;
+    const double sc = c.f_code * delt, sk = c.f_carr * delt;
+    if (!(sc > 0.0 && sc <= 1.5) || !(std::fabs(sk) <= 0.125))
+        return false;
+    if (!(std::fabs(c.gain) < 2097152.0))
+        return false;
+    if (c.iword < 0 || c.iword > 59 || c.ibit < 0 || c.ibit > 29 || c.icode < 0 || c.icode > 19)
+        return false;
+    for (int k = 0; k < GPSBB_N_DWRD; k++)
+        if (c.dwrd[k] >> 30)
+            return false;
+    return true;
+}
+
+/* Upper bound on the rows build_rows() emits for one chain (see the derivation in DESIGN.md):
+ * every lap (wrap to wrap) visits at most (top_e - e_s + 2) binades, each costing at most two rows,
+ * plus a handful of explicit steps around the wrap. */
+uint64_t row_bound(double s_abs, double range, int top_e, int nsamp)
+{
+    if (!(s_abs > 0.0))
+        return 4;
+    int es;
+    std::frexp(s_abs, &es); /* s_abs = m * 2^es, m in [0.5,1)  ->  binade exponent es-1 */
+    es -= 1;
+    const double laps = std::floor((double)nsamp * s_abs / range) + 2.0;
+    int binades = top_e - es + 3;
+    if (binades < 3)
+        binades = 3;
+    const double per_lap = 2.0 * binades + 6.0;
+    return (uint64_t)(laps * per_lap) + 16;
+}
+
+} /* namespace */
+
+/* ================================================================================================== */
+/* handle / batch                                                                                     */
+/* ================================================================================================== */
+
+struct gpsbb {
+    int device = 0;
+    hipStream_t s_compute = nullptr;
+    hipStream_t s_copy = nullptr;
+    int32_t *d_tabs = nullptr;
+    uint32_t *d_ca = nullptr;
+    uint32_t *d_status = nullptr;
+    unsigned long long *d_hz = nullptr;
+    int last_hip = 0;
+    gpsbb_batch *scratch = nullptr;
+    int sm_count = 0;
+};
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0; /* elements */
+    int reserve(size_t n)
+    {
+        if (n <= cap)
+            return hipSuccess;
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
+        if (e != hipSuccess)
+            return e;
+        cap = n;
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct gpsbb_batch {
+    gpsbb *h = nullptr;
+    int nblocks = 0, nch = 0, nsamp = 0, ntiles = 0;
+    double delt = 0.0;
+    unsigned flags = 0;
+    uint64_t total_rows = 0;
+    DevBuf<gpsbb_chan_t> d_ch;
+    DevBuf<uint64_t> d_row_off;
+    DevBuf<NcoRow> d_rows;
+    DevBuf<int32_t> d_tile_row;
+    DevBuf<gpsbb_chan_state_t> d_end;
+    DevBuf<int16_t> d_iq;
+    std::vector<uint64_t> row_off;
+    std::vector<gpsbb_chan_t> h_ch; /* library-owned copy: the caller's array may go away after the call */
+    const gpsbb_chan_t *prev_ch = nullptr;
+    const gpsbb_chan_state_t *prev_end = nullptr;
+    struct Ev3 { hipEvent_t e[3]; };
+    std::vector<Ev3> evs; /* one triple per run since the last timing reset */
+    size_t ev_used = 0;
+    bool ran = false;
+    int16_t *last_iq = nullptr;
+};
+
+#define HIPCHK(h, call)                                                                            \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            (h)->last_hip = (int)e__;                                                              \
+            return e__ == hipErrorOutOfMemory ? GPSBB_E_NOMEM : GPSBB_E_HIP;                       \
+        }                                                                                          \
+    } while (0)
+
+extern "C" int gpsbb_version(void) { return GPSBB_VERSION; }
+
+extern "C" const char *gpsbb_strerror(int err)
+{
+    switch (err) {
+    case GPSBB_OK: return "ok";
+    case GPSBB_E_BADARG: return "bad argument";
+    case GPSBB_E_BADCHAN: return "channel descriptor outside the contract";
+    case GPSBB_E_HIP: return "HIP runtime error";
+    case GPSBB_E_NOMEM: return "out of memory";
+    case GPSBB_E_INTERNAL: return "device self-check failed (row pool overflow)";
+    case GPSBB_E_NODEVICE: return "no usable HIP device";
+    case GPSBB_E_STATE: return "call sequence violation";
+    default: return "unknown error";
+    }
+}
+
+extern "C" int gpsbb_last_hip_error(const gpsbb_t *h) { return h ? h->last_hip : 0; }
+
+extern "C" int gpsbb_codegen(int prn, uint8_t ca[GPSBB_CA_LEN])
+{
+    if (!ca || prn < 1 || prn > 32)
+        return GPSBB_E_BADARG;
+    make_ca(prn, ca);
+    return GPSBB_OK;
+}
+
+extern "C" int gpsbb_sincos_tables(int32_t sin512[512], int32_t cos512[512])
+{
+    if (!sin512 || !cos512)
+        return GPSBB_E_BADARG;
+    return make_sincos(sin512, cos512) ? GPSBB_OK : GPSBB_E_INTERNAL;
+}
+
+extern "C" void gpsbb_destroy(gpsbb_t *h)
+{
+    if (!h)
+        return;
+    (void)hipSetDevice(h->device);
+    if (h->scratch)
+        gpsbb_batch_destroy(h->scratch);
+    if (h->s_compute)
+        (void)hipStreamSynchronize(h->s_compute);
+    if (h->s_copy)
+        (void)hipStreamSynchronize(h->s_copy);
+    if (h->d_tabs)
+        (void)hipFree(h->d_tabs);
+    if (h->d_ca)
+        (void)hipFree(h->d_ca);
+    if (h->d_status)
+        (void)hipFree(h->d_status);
+    if (h->d_hz)
+        (void)hipFree(h->d_hz);
+    if (h->s_compute)
+        (void)hipStreamDestroy(h->s_compute);
+    if (h->s_copy)
+        (void)hipStreamDestroy(h->s_copy);
+    delete h;
+}
+
+extern "C" int gpsbb_create(gpsbb_t **out, int device)
+{
+    if (!out)
+        return GPSBB_E_BADARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+        return GPSBB_E_NODEVICE;
+
+    int32_t tabs[1024];
+    if (!make_sincos(tabs + 512, tabs)) /* device layout: cos first, then sin */
+        return GPSBB_E_INTERNAL;
+    std::vector<uint32_t> ca(33 * 32, 0u);
+    for (int prn = 1; prn <= 32; prn++) {
+        uint8_t chips[GPSBB_CA_LEN];
+        make_ca(prn, chips);
+        for (int i = 0; i < GPSBB_CA_LEN; i++)
+            if (chips[i])
+                ca[prn * 32 + (i >> 5)] |= 1u << (i & 31);
+    }
+
+    gpsbb *h = new (std::nothrow) gpsbb;
+    if (!h)
+        return GPSBB_E_NOMEM;
+    h->device = device;
+    auto fail = [&](hipError_t e) {
+        h->last_hip = (int)e;
+        gpsbb_destroy(h);
+        return e == hipErrorOutOfMemory ? GPSBB_E_NOMEM : GPSBB_E_HIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail(e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail(e);
+    h->sm_count = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&h->s_compute, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+    if ((e = hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&h->d_tabs, sizeof tabs)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&h->d_ca, ca.size() * 4)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&h->d_status, 4)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&h->d_hz, 16)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(h->d_tabs, tabs, sizeof tabs, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(h->d_ca, ca.data(), ca.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(h->d_status, 0, 4)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(h->d_hz, 0, 16)) != hipSuccess) return fail(e);
+    *out = h;
+    return GPSBB_OK;
+}
+
+/* ---- batch planning -------------------------------------------------------------------------------- */
+
+static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int nch, double delt,
+                       int nsamp, unsigned flags, hipStream_t upload_stream)
+{
+    gpsbb *h = b->h;
+    if (!ch || nblocks < 1 || nblocks > 65535 || nch < 1 || nch > GPSBB_MAX_CHAN || nsamp < 1 ||
+        !(delt > 0.0) || !std::isfinite(delt) || (flags & ~GPSBB_CHAIN_CARRIER))
+        return GPSBB_E_BADARG;
+    const size_t nbc = (size_t)nblocks * nch;
+    for (size_t k = 0; k < nbc; k++)
+        if (!chan_ok(ch[k], delt))
+            return GPSBB_E_BADCHAN;
+
+    b->nblocks = nblocks;
+    b->nch = nch;
+    b->nsamp = nsamp;
+    b->delt = delt;
+    b->flags = flags;
+    b->ntiles = (nsamp + TILE - 1) / TILE;
+
+    /* row pool plan: chain id = kind*nbc + block*nch + channel */
+    b->row_off.assign(2 * nbc + 1, 0);
+    uint64_t off = 0;
+    for (int kind = 0; kind < 2; kind++)
+        for (size_t k = 0; k < nbc; k++) {
+            b->row_off[kind * nbc + k] = off;
+            if (ch[k].prn > 0) {
+                const double s = kind == 0 ? ch[k].f_code * delt : std::fabs(ch[k].f_carr * delt);
+                off += (kind == 0 ? row_bound(s, 1023.0, 9, nsamp) : row_bound(s, 1.0, -1, nsamp)) + 1;
+            } else {
+                off += 1;
+            }
+        }
+    b->row_off[2 * nbc] = off;
+    b->total_rows = off;
+
+    HIPCHK(h, (hipError_t)b->d_ch.reserve(nbc));
+    HIPCHK(h, (hipError_t)b->d_row_off.reserve(2 * nbc + 1));
+    HIPCHK(h, (hipError_t)b->d_rows.reserve(off));
+    HIPCHK(h, (hipError_t)b->d_tile_row.reserve(2 * nbc * (size_t)b->ntiles));
+    HIPCHK(h, (hipError_t)b->d_end.reserve(nbc));
+    b->h_ch.assign(ch, ch + nbc);
+    HIPCHK(h, hipMemcpyAsync(b->d_ch.p, b->h_ch.data(), nbc * sizeof(gpsbb_chan_t), hipMemcpyHostToDevice, upload_stream));
+    HIPCHK(h, hipMemcpyAsync(b->d_row_off.p, b->row_off.data(), (2 * nbc + 1) * 8, hipMemcpyHostToDevice, upload_stream));
+    b->ran = false;
+    return GPSBB_OK;
+}
+
+static gpsbb_batch *batch_new(gpsbb *h)
+{
+    gpsbb_batch *b = new (std::nothrow) gpsbb_batch;
+    if (!b)
+        return nullptr;
+    b->h = h;
+    return b;
+}
+
+extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
+{
+    if (!b)
+        return;
+    (void)hipSetDevice(b->h->device);
+    (void)hipStreamSynchronize(b->h->s_compute);
+    b->d_ch.release();
+    b->d_row_off.release();
+    b->d_rows.release();
+    b->d_tile_row.release();
+    b->d_end.release();
+    b->d_iq.release();
+    for (auto &t : b->evs)
+        for (auto &e : t.e)
+            if (e)
+                (void)hipEventDestroy(e);
+    delete b;
+}
+
+extern "C" int gpsbb_batch_create(gpsbb_t *h, const gpsbb_chan_t *ch, int nblocks, int nch, double delt,
+                                  int nsamp, unsigned flags, gpsbb_batch_t **out)
+{
+    if (!h || !out)
+        return GPSBB_E_BADARG;
+    *out = nullptr;
+    HIPCHK(h, hipSetDevice(h->device));
+    gpsbb_batch *b = batch_new(h);
+    if (!b)
+        return GPSBB_E_NOMEM;
+    int rc = batch_setup(b, ch, nblocks, nch, delt, nsamp, flags, h->s_compute);
+    if (rc != GPSBB_OK) {
+        gpsbb_batch_destroy(b);
+        return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->s_compute));
+    *out = b;
+    return GPSBB_OK;
+}
+
+extern "C" size_t gpsbb_batch_iq_bytes(const gpsbb_batch_t *b)
+{
+    return b ? (size_t)b->nblocks * (size_t)b->nsamp * 4 : 0;
+}
+
+static BatchDev batch_dev(const gpsbb_batch *b)
+{
+    BatchDev p;
+    p.ch = b->d_ch.p;
+    p.prev_ch = b->prev_ch;
+    p.prev_end = b->prev_end;
+    p.nblocks = b->nblocks;
+    p.nch = b->nch;
+    p.nsamp = b->nsamp;
+    p.ntiles = b->ntiles;
+    p.delt = b->delt;
+    p.flags = b->flags;
+    p.tabs = b->h->d_tabs;
+    p.ca_bits = b->h->d_ca;
+    p.rows = b->d_rows.p;
+    p.row_off = b->d_row_off.p;
+    p.tile_row = b->d_tile_row.p;
+    p.end = b->d_end.p;
+    p.status = b->h->d_status;
+    p.hazards = b->h->d_hz;
+    return p;
+}
+
+static int batch_launch(gpsbb_batch *b, int16_t *d_iq, hipStream_t st)
+{
+    gpsbb *h = b->h;
+    const BatchDev p = batch_dev(b);
+    const int nbc = b->nblocks * b->nch;
+    const int cbase = (nbc + 63) / 64 * 64;
+    const int ncarr = (b->flags & GPSBB_CHAIN_CARRIER) ? b->nch : nbc;
+    const int lanes = cbase + ncarr;
+    if (b->ev_used == b->evs.size()) {
+        if (b->evs.size() >= 4096) {
+            b->ev_used = 0; /* wrap: only the most recent runs are kept */
+        } else {
+            gpsbb_batch::Ev3 t = {{nullptr, nullptr, nullptr}};
+            for (auto &e : t.e)
+                HIPCHK(h, hipEventCreate(&e));
+            b->evs.push_back(t);
+        }
+    }
+    hipEvent_t *ev = b->evs[b->ev_used++].e;
+    HIPCHK(h, hipEventRecord(ev[0], st));
+    hipLaunchKernelGGL(k_seed, dim3((lanes + 63) / 64), dim3(64), 0, st, p, cbase);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(ev[1], st));
+    hipLaunchKernelGGL(k_synth, dim3(b->ntiles, b->nblocks), dim3(TILE_THREADS), 0, st, p, d_iq);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(ev[2], st));
+    b->ran = true;
+    return GPSBB_OK;
+}
+
+extern "C" int gpsbb_batch_run(gpsbb_batch_t *b, int16_t *d_iq)
+{
+    if (!b)
+        return GPSBB_E_BADARG;
+    gpsbb *h = b->h;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!d_iq) {
+        HIPCHK(h, (hipError_t)b->d_iq.reserve((size_t)b->nblocks * b->nsamp * 2));
+        d_iq = b->d_iq.p;
+        b->last_iq = d_iq;
+    } else {
+        b->last_iq = nullptr;
+    }
+    return batch_launch(b, d_iq, h->s_compute);
+}
+
+extern "C" int16_t *gpsbb_batch_device_iq(gpsbb_batch_t *b) { return b ? b->last_iq : nullptr; }
+
+extern "C" int gpsbb_sync(gpsbb_t *h)
+{
+    if (!h)
+        return GPSBB_E_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->s_compute));
+    HIPCHK(h, hipStreamSynchronize(h->s_copy));
+    uint32_t st = 0;
+    HIPCHK(h, hipMemcpy(&st, h->d_status, 4, hipMemcpyDeviceToHost));
+    if (st) {
+        HIPCHK(h, hipMemset(h->d_status, 0, 4));
+        return GPSBB_E_INTERNAL;
+    }
+    return GPSBB_OK;
+}
+
+extern "C" int gpsbb_batch_read(gpsbb_batch_t *b, int16_t *iq_out, gpsbb_chan_state_t *end_state)
+{
+    if (!b || !b->ran)
+        return GPSBB_E_STATE;
+    gpsbb *h = b->h;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (iq_out) {
+        if (!b->last_iq)
+            return GPSBB_E_STATE;
+        HIPCHK(h, hipMemcpy(iq_out, b->last_iq, gpsbb_batch_iq_bytes(b), hipMemcpyDeviceToHost));
+    }
+    if (end_state)
+        HIPCHK(h, hipMemcpy(end_state, b->d_end.p, (size_t)b->nblocks * b->nch * sizeof(gpsbb_chan_state_t),
+                            hipMemcpyDeviceToHost));
+    return GPSBB_OK;
+}
+
+extern "C" int gpsbb_get_hazards(gpsbb_t *h, gpsbb_hazards_t *out, int reset)
+{
+    if (!h || !out)
+        return GPSBB_E_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    unsigned long long v[2];
+    HIPCHK(h, hipMemcpy(v, h->d_hz, 16, hipMemcpyDeviceToHost));
+    out->itable_512 = v[0];
+    out->dwrd_oob = v[1];
+    if (reset)
+        HIPCHK(h, hipMemset(h->d_hz, 0, 16));
+    return GPSBB_OK;
+}
+
+extern "C" int gpsbb_batch_last_timing(gpsbb_batch_t *b, float *ms_seed, float *ms_synth, float *ms_total)
+{
+    if (!b || !b->ran || b->ev_used == 0)
+        return GPSBB_E_STATE;
+    gpsbb *h = b->h;
+    hipEvent_t *ev = b->evs[b->ev_used - 1].e;
+    float a = 0, c = 0, t = 0;
+    HIPCHK(h, hipEventElapsedTime(&a, ev[0], ev[1]));
+    HIPCHK(h, hipEventElapsedTime(&c, ev[1], ev[2]));
+    HIPCHK(h, hipEventElapsedTime(&t, ev[0], ev[2]));
+    if (ms_seed) *ms_seed = a;
+    if (ms_synth) *ms_synth = c;
+    if (ms_total) *ms_total = t;
+    return GPSBB_OK;
+}
+
+extern "C" int gpsbb_batch_timing_stats(gpsbb_batch_t *b, int *nruns, float *ms_seed_sum, float *ms_synth_sum,
+                                        float *ms_total_sum, int reset)
+{
+    if (!b)
+        return GPSBB_E_BADARG;
+    gpsbb *h = b->h;
+    float sa = 0, sc = 0, stt = 0;
+    for (size_t k = 0; k < b->ev_used; k++) {
+        hipEvent_t *ev = b->evs[k].e;
+        float a = 0, c = 0, t = 0;
+        HIPCHK(h, hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIPCHK(h, hipEventElapsedTime(&c, ev[1], ev[2]));
+        HIPCHK(h, hipEventElapsedTime(&t, ev[0], ev[2]));
+        sa += a;
+        sc += c;
+        stt += t;
+    }
+    if (nruns) *nruns = (int)b->ev_used;
+    if (ms_seed_sum) *ms_seed_sum = sa;
+    if (ms_synth_sum) *ms_synth_sum = sc;
+    if (ms_total_sum) *ms_total_sum = stt;
+    if (reset)
+        b->ev_used = 0;
+    return GPSBB_OK;
+}
+
+extern "C" int gpsbb_fill_ceiling(gpsbb_t *h, void *d_dst, size_t bytes, int iters, float *ms)
+{
+    if (!h || !d_dst || bytes < 16 || iters < 1 || !ms)
+        return GPSBB_E_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    const size_t n16 = bytes / 16;
+    const int grid = h->sm_count > 0 ? h->sm_count * 8 : 2048;
+    hipLaunchKernelGGL(k_fill_ceiling, dim3(grid), dim3(256), 0, h->s_compute, (uint4 *)d_dst, n16, 1u);
+    HIPCHK(h, hipEventRecord(e0, h->s_compute));
+    for (int i = 0; i < iters; i++)
+        hipLaunchKernelGGL(k_fill_ceiling, dim3(grid), dim3(256), 0, h->s_compute, (uint4 *)d_dst, n16, (uint32_t)i);
+    HIPCHK(h, hipEventRecord(e1, h->s_compute));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float t = 0;
+    HIPCHK(h, hipEventElapsedTime(&t, e0, e1));
+    *ms = t / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return GPSBB_OK;
+}
+
+/* ---- the synchronous single-block surface ------------------------------------------------------------ */
+
+extern "C" int gpsbb_fill_block(gpsbb_t *h, const gpsbb_chan_t *ch, int nch, double delt, int nsamp,
+                                int16_t *iq_out, gpsbb_chan_state_t *end_state)
+{
+    if (!h || !ch || !iq_out)
+        return GPSBB_E_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->scratch) {
+        h->scratch = batch_new(h);
+        if (!h->scratch)
+            return GPSBB_E_NOMEM;
+    }
+    gpsbb_batch *b = h->scratch;
+    b->prev_ch = nullptr;
+    b->prev_end = nullptr;
+    int rc = batch_setup(b, ch, 1, nch, delt, nsamp, 0, h->s_compute);
+    if (rc != GPSBB_OK)
+        return rc;
+    rc = gpsbb_batch_run(b, nullptr);
+    if (rc != GPSBB_OK)
+        return rc;
+    HIPCHK(h, hipMemcpyAsync(iq_out, b->last_iq, (size_t)nsamp * 4, hipMemcpyDeviceToHost, h->s_compute));
+    if (end_state)
+        HIPCHK(h, hipMemcpyAsync(end_state, b->d_end.p, (size_t)nch * sizeof(gpsbb_chan_state_t),
+                                 hipMemcpyDeviceToHost, h->s_compute));
+    return gpsbb_sync(h);
+}
+
+extern "C" int gpsbb_fill_block_ref(gpsbb_t *h, void *chan, const gpsbb_refchan_layout_t *L, int max_chan,
+                                    const double *gain, double delt, int nsamp, int16_t *iq_buff)
+{
+    if (!h || !chan || !L || !gain || !iq_buff || max_chan < 1 || max_chan > GPSBB_MAX_CHAN ||
+        (L->sizeof_dwrd_elem != 4 && L->sizeof_dwrd_elem != 8))
+        return GPSBB_E_BADARG;
+    gpsbb_chan_t d[GPSBB_MAX_CHAN];
+    gpsbb_chan_state_t st[GPSBB_MAX_CHAN];
+    char *base = static_cast<char *>(chan);
+    auto ld_i = [](const char *p) { int v; memcpy(&v, p, sizeof v); return v; };
+    auto ld_d = [](const char *p) { double v; memcpy(&v, p, sizeof v); return v; };
+    for (int i = 0; i < max_chan; i++) {
+        const char *c = base + (size_t)i * L->stride;
+        memset(&d[i], 0, sizeof d[i]);
+        d[i].prn = ld_i(c + L->off_prn);
+        if (d[i].prn <= 0) {
+            d[i].prn = 0;
+            continue;
+        }
+        d[i].f_carr = ld_d(c + L->off_f_carr);
+        d[i].f_code = ld_d(c + L->off_f_code);
+        d[i].carr_phase = ld_d(c + L->off_carr_phase);
+        d[i].code_phase = ld_d(c + L->off_code_phase);
+        d[i].iword = ld_i(c + L->off_iword);
+        d[i].ibit = ld_i(c + L->off_ibit);
+        d[i].icode = ld_i(c + L->off_icode);
+        d[i].gain = gain[i];
+        for (int k = 0; k < GPSBB_N_DWRD; k++) {
+            uint64_t w = 0;
+            memcpy(&w, c + L->off_dwrd + (size_t)k * L->sizeof_dwrd_elem, L->sizeof_dwrd_elem);
+            d[i].dwrd[k] = (uint32_t)w;
+        }
+    }
+    int rc = gpsbb_fill_block(h, d, max_chan, delt, nsamp, iq_buff, st);
+    if (rc != GPSBB_OK)
+        return rc;
+    for (int i = 0; i < max_chan; i++) {
+        if (d[i].prn <= 0)
+            continue;
+        char *c = base + (size_t)i * L->stride;
+        memcpy(c + L->off_carr_phase, &st[i].carr_phase, 8);
+        memcpy(c + L->off_code_phase, &st[i].code_phase, 8);
+        memcpy(c + L->off_iword, &st[i].iword, 4);
+        memcpy(c + L->off_ibit, &st[i].ibit, 4);
+        memcpy(c + L->off_icode, &st[i].icode, 4);
+        memcpy(c + L->off_dataBit, &st[i].dataBit, 4);
+        memcpy(c + L->off_codeCA, &st[i].codeCA, 4);
+    }
+    return GPSBB_OK;
+}
+
+/* ================================================================================================== */
+/* time-sharded streaming with pinned host gather                                                     */
+/* ================================================================================================== */
+
+struct gpsbb_stream {
+    gpsbb *h = nullptr;
+    int nch = 0, nsamp = 0, bps = 0, depth = 0;
+    double delt = 0.0;
+    unsigned flags = 0;
+    struct Slot {
+        gpsbb_batch *batch = nullptr;
+        int16_t *h_iq = nullptr;            /* pinned */
+        gpsbb_chan_state_t *h_end = nullptr; /* pinned */
+        hipEvent_t computed = nullptr, copied = nullptr;
+    };
+    std::vector<Slot> slots;
+    uint64_t head = 0, tail = 0; /* pushes / pops so far */
+};
+
+extern "C" void gpsbb_stream_destroy(gpsbb_stream_t *s)
+{
+    if (!s)
+        return;
+    (void)hipSetDevice(s->h->device);
+    (void)hipStreamSynchronize(s->h->s_compute);
+    (void)hipStreamSynchronize(s->h->s_copy);
+    for (auto &sl : s->slots) {
+        if (sl.batch) gpsbb_batch_destroy(sl.batch);
+        if (sl.h_iq) (void)hipHostFree(sl.h_iq);
+        if (sl.h_end) (void)hipHostFree(sl.h_end);
+        if (sl.computed) (void)hipEventDestroy(sl.computed);
+        if (sl.copied) (void)hipEventDestroy(sl.copied);
+    }
+    delete s;
+}
+
+extern "C" int gpsbb_stream_create(gpsbb_t *h, int nch, double delt, int nsamp, int blocks_per_slot,
+                                   int depth, unsigned flags, gpsbb_stream_t **out)
+{
+    if (!h || !out || nch < 1 || nch > GPSBB_MAX_CHAN || nsamp < 1 || blocks_per_slot < 1 || depth < 2 ||
+        depth > 64 || !(delt > 0.0) || (flags & ~GPSBB_CHAIN_CARRIER))
+        return GPSBB_E_BADARG;
+    *out = nullptr;
+    HIPCHK(h, hipSetDevice(h->device));
+    gpsbb_stream *s = new (std::nothrow) gpsbb_stream;
+    if (!s)
+        return GPSBB_E_NOMEM;
+    s->h = h;
+    s->nch = nch;
+    s->nsamp = nsamp;
+    s->bps = blocks_per_slot;
+    s->depth = depth;
+    s->delt = delt;
+    s->flags = flags;
+    s->slots.resize(depth);
+    const size_t iq_bytes = (size_t)blocks_per_slot * nsamp * 4;
+    const size_t end_bytes = (size_t)blocks_per_slot * nch * sizeof(gpsbb_chan_state_t);
+    for (auto &sl : s->slots) {
+        sl.batch = batch_new(h);
+        hipError_t e = sl.batch ? hipSuccess : hipErrorOutOfMemory;
+        if (e == hipSuccess) e = (hipError_t)sl.batch->d_iq.reserve(iq_bytes / 2);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_iq, iq_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_end, end_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.computed, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            h->last_hip = (int)e;
+            gpsbb_stream_destroy(s);
+            return e == hipErrorOutOfMemory ? GPSBB_E_NOMEM : GPSBB_E_HIP;
+        }
+    }
+    *out = s;
+    return GPSBB_OK;
+}
+
+extern "C" int gpsbb_stream_pending(const gpsbb_stream_t *s) { return s ? (int)(s->head - s->tail) : 0; }
+
+extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
+{
+    if (!s || !ch)
+        return GPSBB_E_BADARG;
+    if (s->head - s->tail >= (uint64_t)s->depth)
+        return GPSBB_E_STATE; /* ring full: pop first */
+    gpsbb *h = s->h;
+    HIPCHK(h, hipSetDevice(h->device));
+    auto &sl = s->slots[s->head % s->depth];
+    gpsbb_batch *b = sl.batch;
+    /* the slot's previous D2H copy was waited for by the pop that freed it */
+    int rc = batch_setup(b, ch, s->bps, s->nch, s->delt, s->nsamp, s->flags, h->s_compute);
+    if (rc != GPSBB_OK)
+        return rc;
+    b->prev_ch = nullptr;
+    b->prev_end = nullptr;
+    if ((s->flags & GPSBB_CHAIN_CARRIER) && s->head > 0) {
+        /* continue the carrier from the last block of the previous push (same compute stream, so its
+         * end state is complete before this push's seeding kernel runs) */
+        gpsbb_batch *pb = s->slots[(s->head - 1) % s->depth].batch;
+        b->prev_ch = pb->d_ch.p + (size_t)(pb->nblocks - 1) * pb->nch;
+        b->prev_end = pb->d_end.p + (size_t)(pb->nblocks - 1) * pb->nch;
+    }
+    b->last_iq = b->d_iq.p;
+    rc = batch_launch(b, b->d_iq.p, h->s_compute);
+    if (rc != GPSBB_OK)
+        return rc;
+    HIPCHK(h, hipEventRecord(sl.computed, h->s_compute));
+    /* gather on the side stream: pinned, asynchronous, overlaps the next push's kernels */
+    HIPCHK(h, hipStreamWaitEvent(h->s_copy, sl.computed, 0));
+    HIPCHK(h, hipMemcpyAsync(sl.h_iq, b->d_iq.p, (size_t)s->bps * s->nsamp * 4, hipMemcpyDeviceToHost, h->s_copy));
+    HIPCHK(h, hipMemcpyAsync(sl.h_end, b->d_end.p, (size_t)s->bps * s->nch * sizeof(gpsbb_chan_state_t),
+                             hipMemcpyDeviceToHost, h->s_copy));
+    HIPCHK(h, hipEventRecord(sl.copied, h->s_copy));
+    s->head++;
+    return GPSBB_OK;
+}
+
+extern "C" int gpsbb_stream_pop(gpsbb_stream_t *s, const int16_t **iq, gpsbb_chan_state_t *end_state)
+{
+    if (!s || !iq)
+        return GPSBB_E_BADARG;
+    if (s->head == s->tail)
+        return GPSBB_E_STATE;
+    gpsbb *h = s->h;
+    HIPCHK(h, hipSetDevice(h->device));
+    auto &sl = s->slots[s->tail % s->depth];
+    HIPCHK(h, hipEventSynchronize(sl.copied));
+    *iq = sl.h_iq;
+    if (end_state)
+        memcpy(end_state, sl.h_end, (size_t)s->bps * s->nch * sizeof(gpsbb_chan_state_t));
+    s->tail++;
+    uint32_t st = 0;
+    HIPCHK(h, hipMemcpy(&st, h->d_status, 4, hipMemcpyDeviceToHost));
+    if (st) {
+        HIPCHK(h, hipMemset(h->d_status, 0, 4));
+        return GPSBB_E_INTERNAL;
+    }
+    return GPSBB_OK;
+}
+
+/* ================================================================================================== */
+/* host helpers                                                                                       */
+/* ================================================================================================== */
+
+extern "C" int gpsbb_chain_carrier_host(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp,
+                                        double *seed, int nthreads)
+{
+    if (!ch || !seed || nblocks < 1 || nch < 1 || nch > GPSBB_MAX_CHAN || nsamp < 1 || !(delt > 0.0))
+        return GPSBB_E_BADARG;
+    for (size_t k = 0; k < (size_t)nblocks * nch; k++)
+        if (!chan_ok(ch[k], delt))
+            return GPSBB_E_BADCHAN;
+    auto work = [&](int i0, int i1) {
+        for (int i = i0; i < i1; i++) {
+            int prev_prn = 0;
+            double prev_x = 0.0;
+            for (int b = 0; b < nblocks; b++) {
+                const gpsbb_chan_t &c = ch[(size_t)b * nch + i];
+                double x0 = (c.prn > 0 && c.prn == prev_prn) ? prev_x : c.carr_phase;
+                seed[(size_t)b * nch + i] = c.prn > 0 ? x0 : 0.0;
+                if (c.prn > 0) {
+                    volatile double s = c.f_carr * delt; /* rounded on its own, as in the loop */
+                    prev_x = carr_jump(x0, s, nsamp);
+                }
+                prev_prn = c.prn > 0 ? c.prn : 0;
+            }
+        }
+    };
+    if (nthreads <= 0 || nthreads > nch)
+        nthreads = nch;
+    if (nthreads == 1) {
+        work(0, nch);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++) {
+            const int i0 = (int)((long)nch * t / nthreads), i1 = (int)((long)nch * (t + 1) / nthreads);
+            th.emplace_back(work, i0, i1);
+        }
+        for (auto &t : th)
+            t.join();
+    }
+    return GPSBB_OK;
+}
+
+/* ---- test hooks (gpsbb_testhooks.h): the shared NCO code, compiled for the host -------------------- */
+
+extern "C" double gpsbb_test_carr_jump(double x, double s, long long n) { return carr_jump(x, s, n); }
+
+extern "C" double gpsbb_test_code_jump(double x, double s, long long n, long long *wraps)
+{
+    int64_t w = 0;
+    double r = code_jump(x, s, n, &w);
+    if (wraps)
+        *wraps = w;
+    return r;
+}
+
+namespace {
+struct HostSink {
+    gpsbb_test_row_t *rows;
+    int cap, cnt;
+    unsigned long long fetches;
+    void row(int32_t n0, uint32_t nav, uint64_t xb, int64_t inc)
+    {
+        if (cnt < cap) {
+            rows[cnt].n0 = n0;
+            rows[cnt].nav = nav;
+            rows[cnt].xb = xb;
+            rows[cnt].inc = inc;
+        }
+        cnt++;
+    }
+    void nav_fetch(uint32_t) { fetches++; }
+};
+} /* namespace */
+
+extern "C" int gpsbb_test_build_rows(int kind, double x0, double s, unsigned nav0, int nsamp,
+                                     gpsbb_test_row_t *rows, int cap, double *x_end, unsigned *nav_end)
+{
+    HostSink sink{rows, cap, 0, 0};
+    uint32_t nav = nav0;
+    double x = kind == NCO_CODE ? build_rows<NCO_CODE>(x0, s, nav, nsamp, sink)
+                                : build_rows<NCO_CARR>(x0, s, nav, nsamp, sink);
+    if (x_end)
+        *x_end = x;
+    if (nav_end)
+        *nav_end = nav;
+    return sink.cnt;
+}
+
+extern "C" unsigned long long gpsbb_test_row_bound(int kind, double s_abs, int nsamp)
+{
+    return kind == NCO_CODE ? row_bound(s_abs, 1023.0, 9, nsamp) : row_bound(s_abs, 1.0, -1, nsamp);
+}

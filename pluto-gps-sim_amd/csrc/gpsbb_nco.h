@@ -1,0 +1,315 @@
+/*
+ * gpsbb_nco.h — exact jump-ahead for the reference's two sequential IEEE-double NCOs.
+ *
+ * Shared by the device seeding pre-pass (gpsbb_kernels.hip) and the host carrier chaining helper
+ * (gpsbb_host.cpp); it compiles as plain C++ too, which is how tests/test_nco_host.py checks it against
+ * brute-force stepping without a GPU.
+ *
+ * The recurrences (reference: plutogpssim.c:2709-2712 code, 2741-2746 carrier, FLOAT_CARR_PHASE on):
+ *     code   : x = fl(x + s);  if (x >= 1023.0) { x = fl(x - 1023.0); <advance nav counters> }
+ *     carrier: x = fl(x + s);  if (x >= 1.0) x = fl(x - 1.0); else if (x < 0.0) x = fl(x + 1.0);
+ * with s = fl(f * delt) computed once (no FMA: the reference is built -std=c11, Makefile:1-2).
+ * Sample n's chip / table index depend on n successive roundings, so x0 + n*s is NOT what the
+ * reference computes.  What makes the sequence jumpable:
+ *
+ *   While x stays inside one binade [2^e, 2^(e+1)) and no wrap fires, x = M * 2^(e-52) with an integer
+ *   mantissa M in [2^52, 2^53), and fl(x + s) = (M + inc) * 2^(e-52) where inc = RN(s / 2^(e-52)) is a
+ *   constant of (s, e): the exact sum is (M + sigma)*ulp with sigma = s/ulp real, M integer, so
+ *   round-to-nearest gives M + RN(sigma) unless sigma is exactly half-way, in which case ties-to-even
+ *   makes M even after one step and from then on the increment is the even one of {floor, ceil}.
+ *   Hence the raw bit pattern of x advances by the integer `inc` per step: bits(x_j) = bits(x_0) + j*inc,
+ *   for as many steps as M + j*inc provably stays inside the binade and below the wrap threshold
+ *   ("regular run").  Everything else — binade crossings, wraps, x below s's binade, x == 0 — is taken
+ *   as ONE explicit step with genuine IEEE adds, after which the next regular run starts.
+ *
+ * A block is thereby cut into "rows" {n0, bits(x_n0), inc}: row k covers samples n0_k .. n0_{k+1}-1 and
+ * the state at any sample n in it is bits(x_n0) + (n - n0)*inc, reinterpreted as a double.
+ */
+#ifndef GPSBB_NCO_H
+#define GPSBB_NCO_H
+
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GPSBB_HD __host__ __device__ __forceinline__
+#else
+#define GPSBB_HD inline
+#endif
+
+namespace gpsbb_impl {
+
+enum NcoKind { NCO_CODE = 0, NCO_CARR = 1 };
+
+static constexpr uint64_t F64_HID = 1ull << 52;          /* hidden bit            */
+static constexpr uint64_t F64_MANT = F64_HID - 1;         /* mantissa field        */
+static constexpr uint64_t F64_ABS = ~(1ull << 63);
+static constexpr uint64_t CODE_WRAP_M = 1023ull << 43;    /* 1023.0 = (1023*2^43) * 2^(9-52) */
+static constexpr int64_t NCO_KINF = INT64_MAX;
+
+GPSBB_HD uint64_t f64_bits(double x)
+{
+    uint64_t u;
+    memcpy(&u, &x, 8);
+    return u;
+}
+GPSBB_HD double bits_f64(uint64_t u)
+{
+    double x;
+    memcpy(&x, &u, 8);
+    return x;
+}
+
+/* individually rounded IEEE operations (never contracted into an FMA) */
+GPSBB_HD double add_rn(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __dadd_rn(a, b);
+#else
+    volatile double r = a + b; /* host: built with -ffp-contract=off as well; volatile pins the rounding */
+    return r;
+#endif
+}
+GPSBB_HD double mul_rn(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __dmul_rn(a, b);
+#else
+    volatile double r = a * b;
+    return r;
+#endif
+}
+
+/* One genuine step of the code NCO (plutogpssim.c:2709-2712).  Returns true when the 1023 wrap fired. */
+GPSBB_HD bool code_step(double &x, double s)
+{
+    x = add_rn(x, s);
+    if (x >= 1023.0) {
+        x = add_rn(x, -1023.0);
+        return true;
+    }
+    return false;
+}
+
+/* One genuine step of the carrier NCO (plutogpssim.c:2741-2746). */
+GPSBB_HD void carr_step(double &x, double s)
+{
+    x = add_rn(x, s);
+    if (x >= 1.0)
+        x = add_rn(x, -1.0);
+    else if (x < 0.0)
+        x = add_rn(x, 1.0);
+}
+
+/* Nav-message counters of one channel (plutogpssim.h:166-169) packed for the rows:
+ * bits 0-4 icode (0..19), 5-9 ibit (0..29), 10-25 iword. */
+GPSBB_HD uint32_t nav_pack(int icode, int ibit, int iword) { return (uint32_t)icode | ((uint32_t)ibit << 5) | ((uint32_t)iword << 10); }
+GPSBB_HD int nav_icode(uint32_t p) { return (int)(p & 31u); }
+GPSBB_HD int nav_ibit(uint32_t p) { return (int)((p >> 5) & 31u); }
+GPSBB_HD int nav_iword(uint32_t p) { return (int)(p >> 10); }
+
+/* One code-period roll-over (plutogpssim.c:2714-2733), on the packed counters. */
+GPSBB_HD uint32_t nav_advance(uint32_t p)
+{
+    int icode = nav_icode(p) + 1, ibit = nav_ibit(p), iword = nav_iword(p);
+    if (icode >= 20) {
+        icode = 0;
+        if (++ibit >= 30) {
+            ibit = 0;
+            iword++;
+        }
+    }
+    return nav_pack(icode, ibit, iword);
+}
+
+/*
+ * Regular run starting from state x (raw bits xb, x >= 0) with step s (raw bits sb).
+ * Returns k >= 0, the number of consecutive steps (capped at kcap) for which
+ *     bits(x_j) = xb + j*inc   (j = 0..k)   and no wrap fires,
+ * and sets inc.  k == 0 means "take one explicit step".
+ */
+template <int KIND>
+GPSBB_HD int64_t regular_run(uint64_t xb, uint64_t sb, int64_t kcap, int64_t &inc)
+{
+    inc = 0;
+    const int ex = (int)((xb >> 52) & 0x7ff);
+    if (ex == 0 || (xb >> 63))
+        return 0; /* zero / subnormal / negative: explicit step */
+    if (KIND == NCO_CARR) {
+        if (ex >= 1023)
+            return 0; /* x >= 1.0 (only the latent x == 1.0 case): the >= 1.0 wrap fires */
+    } else {
+        if (ex >= 1023 + 10)
+            return 0; /* x >= 1024: outside the contract */
+    }
+    const uint64_t sabs = sb & F64_ABS;
+    const bool sneg = (sb >> 63) != 0;
+    const uint64_t M = (xb & F64_MANT) | F64_HID;
+    if (sabs == 0)
+        return kcap; /* x + 0 == x for ever */
+
+    int es = (int)(sabs >> 52);
+    uint64_t Ms = sabs & F64_MANT;
+    if (es == 0)
+        es = 1; /* subnormal step: no hidden bit */
+    else
+        Ms |= F64_HID;
+
+    const int d = ex - es; /* sigma = s/ulp(x) = Ms / 2^d */
+    if (d <= 0)
+        return 0; /* x not above s's binade: the sum leaves x's binade at once */
+
+    uint64_t q;
+    bool tie = false;
+    if (d >= 64) {
+        q = 0; /* |sigma| < 2^-11 */
+    } else {
+        q = Ms >> d;
+        const uint64_t r = Ms & ((1ull << d) - 1);
+        const uint64_t half = 1ull << (d - 1);
+        if (r > half)
+            q++;
+        else if (r == half)
+            tie = true;
+    }
+    if (tie) {
+        if (M & 1)
+            return 0; /* odd mantissa on a tie: one explicit step makes it even */
+        q += (q & 1); /* even mantissa: ties-to-even keeps it even -> the even neighbour */
+    }
+    if (q == 0) {
+        if (sneg && M == F64_HID)
+            return 0; /* power of two and a negative step: spacing below is finer */
+        return kcap;  /* |s| < ulp/2: x + s rounds back to x for ever */
+    }
+
+    int64_t k;
+    if (!sneg) {
+        uint64_t Mlim = (F64_HID << 1) - 1;
+        if (KIND == NCO_CODE && ex == 1023 + 9)
+            Mlim = CODE_WRAP_M - 1; /* stay strictly below 1023.0 */
+        if (M + q > Mlim)
+            return 0;
+        inc = (int64_t)q;
+        k = (int64_t)((Mlim - M) / q);
+    } else {
+        const uint64_t Mmin = F64_HID + 1; /* stay strictly above the binade's lower edge */
+        if (M < Mmin + q)
+            return 0;
+        inc = -(int64_t)q;
+        k = (int64_t)((M - Mmin) / q);
+    }
+    return k < kcap ? k : kcap;
+}
+
+/*
+ * Advance a carrier NCO by n steps exactly (no rows emitted): used by the host chaining helper and by
+ * tests.  O(number of regular runs) instead of O(n).
+ */
+GPSBB_HD double carr_jump(double x, double s, int64_t n)
+{
+    const uint64_t sb = f64_bits(s);
+    while (n > 0) {
+        int64_t inc;
+        uint64_t xb = f64_bits(x);
+        int64_t k = regular_run<NCO_CARR>(xb, sb, n, inc);
+        if (k > 0) {
+            xb += (uint64_t)(k * inc);
+            x = bits_f64(xb);
+            n -= k;
+        } else {
+            const double before = x;
+            carr_step(x, s);
+            n -= 1;
+            if (x == before && f64_bits(x) == f64_bits(before)) {
+                /* x + s rounds back to x and no wrap fired: it will do so for ever */
+                break;
+            }
+        }
+    }
+    return x;
+}
+
+/* Same for the code NCO; *wraps receives the number of 1023 wraps (code periods completed). */
+GPSBB_HD double code_jump(double x, double s, int64_t n, int64_t *wraps)
+{
+    const uint64_t sb = f64_bits(s);
+    int64_t w = 0;
+    while (n > 0) {
+        int64_t inc;
+        uint64_t xb = f64_bits(x);
+        int64_t k = regular_run<NCO_CODE>(xb, sb, n, inc);
+        if (k > 0) {
+            xb += (uint64_t)(k * inc);
+            x = bits_f64(xb);
+            n -= k;
+        } else {
+            if (code_step(x, s))
+                w++;
+            n -= 1;
+        }
+    }
+    if (wraps)
+        *wraps = w;
+    return x;
+}
+
+/* One row of the per-block NCO segment table (see the file comment). 24 bytes. */
+struct NcoRow {
+    int32_t n0;   /* first sample of the row */
+    uint32_t nav; /* code NCO: packed nav counters valid for the whole row (they only change at a wrap,
+                     which is always an explicit step, i.e. a row boundary); carrier NCO: 0 */
+    uint64_t xb;  /* raw bits of the phase at sample n0 */
+    int64_t inc;  /* raw-bit increment per sample inside the row */
+};
+
+/*
+ * Cut nsamp steps of one NCO into rows.  `sink.row(n0, nav, xb, inc)` is called once per row in
+ * increasing n0 (first row at n0 = 0); `sink.nav_fetch(nav)` is called for the code NCO each time a
+ * data bit boundary is crossed (icode rolled over to 0), mirroring the reference's dataBit fetch at
+ * plutogpssim.c:2732.  Returns the state after nsamp steps.
+ */
+template <int KIND, class Sink>
+GPSBB_HD double build_rows(double x, double s, uint32_t &nav, int nsamp, Sink &sink)
+{
+    const uint64_t sb = f64_bits(s);
+    int64_t n = 0;
+    while (n < nsamp) {
+        int64_t inc;
+        uint64_t xb = f64_bits(x);
+        const int64_t k = regular_run<KIND>(xb, sb, (int64_t)nsamp - n, inc);
+        sink.row((int32_t)n, nav, xb, inc);
+        if (k > 0) {
+            xb += (uint64_t)(k * inc);
+            x = bits_f64(xb);
+            n += k;
+            if (n >= nsamp)
+                break;
+        }
+        /* one explicit step, sample n -> n+1 */
+        const uint64_t before = f64_bits(x);
+        bool wrapped = false;
+        if (KIND == NCO_CODE) {
+            wrapped = code_step(x, s);
+            if (wrapped) {
+                nav = nav_advance(nav);
+                if (nav_icode(nav) == 0)
+                    sink.nav_fetch(nav);
+            }
+        } else {
+            carr_step(x, s);
+        }
+        n += 1;
+        if (!wrapped && f64_bits(x) == before) {
+            /* x + s rounds back to x and nothing wrapped: constant from here on */
+            if (n < nsamp)
+                sink.row((int32_t)n, nav, before, 0);
+            break;
+        }
+    }
+    return x;
+}
+
+} /* namespace gpsbb_impl */
+#endif

@@ -1,0 +1,29 @@
+/*
+ * gpsbb_testhooks.h — exported only so that tests can exercise, on the host and without a GPU, the very
+ * same exact-jump-ahead code (gpsbb_nco.h) the device pre-pass runs.  Not part of the drop-in ABI.
+ */
+#ifndef GPSBB_TESTHOOKS_H
+#define GPSBB_TESTHOOKS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpsbb_test_row {
+    int32_t n0;
+    uint32_t nav;
+    uint64_t xb;
+    int64_t inc;
+} gpsbb_test_row_t;
+
+/* kind: 0 = code NCO, 1 = carrier NCO */
+double gpsbb_test_carr_jump(double x, double s, long long n);
+double gpsbb_test_code_jump(double x, double s, long long n, long long *wraps);
+int gpsbb_test_build_rows(int kind, double x0, double s, unsigned nav0, int nsamp, gpsbb_test_row_t *rows,
+                          int cap, double *x_end, unsigned *nav_end);
+unsigned long long gpsbb_test_row_bound(int kind, double s_abs, int nsamp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

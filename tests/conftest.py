@@ -1,0 +1,49 @@
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_package():
+    """Import pluto-gps-sim_amd/ (not a valid identifier, so by path) as `pluto_gps_sim_amd`."""
+    name = "pluto_gps_sim_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "pluto-gps-sim_amd", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    mod = load_package()
+    mod.build()
+    return mod
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_binding as ob
+    return ob.Oracle()
+
+
+@pytest.fixture(scope="session")
+def synth(pkg):
+    """One GPU handle for the whole session; the HIP path must load — no fallback."""
+    s = pkg.Synth(0)
+    yield s
+    s.close()
+
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")

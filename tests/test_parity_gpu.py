@@ -1,0 +1,263 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the committed golden vectors of the
+real reference.  Everything here is bit-exact: int16 IQ, end-of-block doubles compared by their bytes."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def assert_state_equal(got, want, active):
+    for f in ("carr_phase", "code_phase", "iword", "ibit", "icode", "dataBit", "codeCA"):
+        g, w = got[f][active], want[f][active]
+        assert g.tobytes() == w.tobytes(), f
+
+
+def test_native_library_is_what_runs(pkg, synth):
+    """The loaded shared object is the in-tree HIP build and it owns a device handle."""
+    maps = open("/proc/self/maps").read()
+    assert os.path.join("pluto-gps-sim_amd", "libgpsbb.so") in maps
+    assert synth._h
+
+
+@pytest.mark.parametrize("name", ["static_F", "motion_F", "dense_S", "loop_M2"])
+def test_golden_vectors_of_the_real_reference(pkg, synth, name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    fs, nsamp = float(z["fs"]), int(z["nsamp"])
+    desc = z["desc"].view(pkg.CHAN_DTYPE).reshape(z["desc"].shape[0], -1)
+    want_st = z["end_state"].view(pkg.STATE_DTYPE).reshape(desc.shape)
+    for k in range(desc.shape[0]):
+        iq, st = synth.fill_block(desc[k], 1.0 / fs, nsamp)
+        assert (iq[:z["iq_prefix"].shape[1]] == z["iq_prefix"][k]).all(), (name, k)
+        assert sha(iq) == str(z["iq_sha256"][k]), (name, k)
+        assert_state_equal(st, want_st[k], desc["prn"][k] > 0)
+    assert synth.hazards(reset=True) == {"itable_512": 0, "dwrd_oob": 0}
+
+
+@pytest.mark.parametrize("fs,nsamp,nch,seed", [
+    (25e6, 1, 16, 11), (25e6, 15, 16, 12), (25e6, 16, 16, 13), (25e6, 17, 3, 14), (2.6e6, 4095, 12, 15),
+    (2.6e6, 4096, 12, 16), (2.6e6, 4097, 12, 17), (1e6, 100003, 16, 18), (3e6, 300000, 12, 19),
+    (4.092e6, 65537, 1, 20), (25e6, 262146, 16, 21)])
+def test_single_block_vs_oracle(pkg, synth, oracle, fs, nsamp, nch, seed):
+    ch = pkg.synth_descriptors(1, nch=nch, seed=seed)[0]
+    want_iq, want_st, hz = oracle.fill_blocks(ch, 1.0 / fs, nsamp)
+    iq, st = synth.fill_block(ch, 1.0 / fs, nsamp)
+    assert (iq == want_iq[0]).all()
+    assert_state_equal(st, want_st[0], ch["prn"] > 0)
+
+
+def test_high_doppler_and_slow_channels(pkg, synth, oracle):
+    """Row-table stress: the largest carrier steps of the contract, tiny ones, zero, both signs, and a step
+    whose mantissa is a single bit (every addition is a rounding tie)."""
+    fs, nsamp = 1e6, 50000
+    ch = pkg.synth_descriptors(1, nch=10, seed=31)[0]
+    ch["f_carr"] = [124999.0, -124999.0, 0.0, 1e-7, -1e-7, fs * 2.0 ** -10, -fs * 2.0 ** -10, 5000.0, -5000.0, 0.3]
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    want_iq, want_st, _ = oracle.fill_blocks(ch, 1.0 / fs, nsamp)
+    iq, st = synth.fill_block(ch, 1.0 / fs, nsamp)
+    assert (iq == want_iq[0]).all()
+    assert_state_equal(st, want_st[0], ch["prn"] > 0)
+
+
+def test_inactive_and_empty_channels(pkg, synth, oracle):
+    ch = pkg.synth_descriptors(1, nch=8, seed=41)[0]
+    ch["prn"][[1, 4, 7]] = 0
+    want_iq, want_st, _ = oracle.fill_blocks(ch, 1 / 2.6e6, 20000)
+    iq, st = synth.fill_block(ch, 1 / 2.6e6, 20000)
+    assert (iq == want_iq[0]).all()
+    assert_state_equal(st, want_st[0], ch["prn"] > 0)
+    ch["prn"][:] = 0                      # nothing allocated: the reference writes zeros (c:2691-2692, 2754)
+    iq, _ = synth.fill_block(ch, 1 / 2.6e6, 5000)
+    assert not iq.any()
+
+
+def test_large_gain_wraps_like_the_short_cast(pkg, synth, oracle):
+    """(short)i_acc truncates modulo 2^16 (plutogpssim.c:2754-2755); gains far above the physical range
+    make the accumulators overflow int16 and must still match."""
+    ch = pkg.synth_descriptors(1, nch=16, seed=51)[0]
+    ch["gain"] = np.linspace(20.0, 900.0, 16)
+    ch["gain"][3] = -77.5
+    want_iq, _, _ = oracle.fill_blocks(ch, 1 / 25e6, 30000)
+    iq, _ = synth.fill_block(ch, 1 / 25e6, 30000)
+    assert (iq == want_iq[0]).all()
+
+
+def test_hazards_are_defined_and_counted_like_the_oracle(pkg, synth, oracle):
+    synth.hazards(reset=True)
+    ch = pkg.synth_descriptors(1, nch=2, seed=61)[0]
+    ch["carr_phase"][0] = 1.0
+    ch["f_carr"][0] = -100.0
+    ch["iword"][1], ch["ibit"][1], ch["icode"][1] = 59, 29, 19
+    want_iq, want_st, hz = oracle.fill_blocks(ch, 1 / 1e6, 100000)
+    iq, st = synth.fill_block(ch, 1 / 1e6, 100000)
+    assert (iq == want_iq[0]).all()
+    assert_state_equal(st, want_st[0], ch["prn"] > 0)
+    got = synth.hazards(reset=True)
+    assert got == {"itable_512": int(hz["itable_512"]), "dwrd_oob": int(hz["dwrd_oob"])}
+    assert got["itable_512"] == 1 and got["dwrd_oob"] == 5
+
+
+def test_contract_violations_return_badchan(pkg, synth):
+    ch = pkg.synth_descriptors(1, nch=2, seed=71)[0]
+    for field, val in [("code_phase", 1023.0), ("carr_phase", -0.1), ("carr_phase", 1.5), ("prn", 40),
+                       ("gain", float("inf")), ("iword", 60), ("f_code", 0.0), ("f_carr", 2e6)]:
+        bad = ch.copy()
+        bad[field][0] = val
+        with pytest.raises(pkg.GpsbbError) as e:
+            synth.fill_block(bad, 1 / 2.6e6, 100)
+        assert e.value.rc == -2, field
+
+
+def test_batch_independent_blocks(pkg, synth, oracle):
+    ch = pkg.synth_descriptors(5, nch=16, seed=81)
+    ch["prn"][2, 5] = 0
+    delt, nsamp = 1 / 25e6, 70001
+    want_iq, want_st, _ = oracle.fill_blocks(ch, delt, nsamp, chain=False)
+    b = synth.batch(ch, delt, nsamp)
+    assert b.iq_bytes == 5 * nsamp * 4
+    b.run()
+    synth.sync()
+    iq, st = b.read()
+    assert (iq == want_iq).all()
+    for k in range(5):
+        assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
+    t = b.timing()
+    assert t["ms_synth"] > 0 and t["ms_total"] >= t["ms_synth"]
+    b.run()                                 # a batch can be re-run
+    synth.sync()
+    assert (b.read()[0] == want_iq).all()
+    b.close()
+
+
+def test_batch_chained_carrier(pkg, synth, oracle):
+    """GPSBB_CHAIN_CARRIER: block b continues block b-1's carrier phase on the device, like iterating
+    plutogpssim.c:2655; a re-allocated channel restarts from its own descriptor."""
+    ch = pkg.synth_descriptors(6, nch=12, seed=91)
+    ch["prn"][3:, 4] = 30
+    ch["prn"][2, 7] = 0
+    delt, nsamp = 1 / 2.6e6, 300000
+    want_iq, want_st, _ = oracle.fill_blocks(ch, delt, nsamp, chain=True)
+    b = synth.batch(ch, delt, nsamp, flags=pkg.CHAIN_CARRIER)
+    b.run()
+    synth.sync()
+    iq, st = b.read()
+    assert (iq == want_iq).all()
+    for k in range(6):
+        assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
+    # the host chaining helper gives the same seeds, so time shards can start anywhere
+    seeds = pkg.chain_carrier_host(ch, delt, nsamp)
+    ch2 = ch.copy()
+    ch2["carr_phase"] = seeds
+    b2 = synth.batch(ch2[3:], delt, nsamp)  # "GPU 1" gets blocks 3..5 only
+    b2.run()
+    synth.sync()
+    assert (b2.read()[0] == want_iq[3:]).all()
+    b.close()
+    b2.close()
+
+
+def test_stream_ring_with_pinned_gather(pkg, synth, oracle):
+    nch, delt, nsamp, bps = 8, 1 / 4.092e6, 50000, 2
+    ch = pkg.synth_descriptors(10, nch=nch, seed=101)
+    want_iq, want_st, _ = oracle.fill_blocks(ch, delt, nsamp, chain=True)
+    s = synth.stream(nch, delt, nsamp, bps, depth=3, flags=pkg.CHAIN_CARRIER)
+    got = []
+    for k in range(5):
+        if s.pending == 3:
+            got.append(s.pop())
+        s.push(ch[2 * k:2 * k + 2])
+    with pytest.raises(pkg.GpsbbError):
+        while True:
+            s.push(ch[0:2])                 # ring full -> GPSBB_E_STATE
+    while s.pending:
+        got.append(s.pop())
+    got = got[:5]
+    iq = np.concatenate([g[0] for g in got])
+    st = np.concatenate([g[1] for g in got])
+    assert (iq == want_iq).all()
+    for k in range(10):
+        assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
+    s.close()
+
+
+def test_external_device_buffer(pkg, synth, oracle):
+    import torch
+    ch = pkg.synth_descriptors(2, nch=16, seed=111)
+    delt, nsamp = 1 / 25e6, 40000
+    out = torch.zeros(2 * nsamp * 2, dtype=torch.int16, device="cuda:0")
+    b = synth.batch(ch, delt, nsamp)
+    b.run(out.data_ptr())
+    synth.sync()
+    want_iq, _, _ = oracle.fill_blocks(ch, delt, nsamp)
+    assert (out.cpu().numpy().reshape(2, nsamp, 2) == want_iq).all()
+    b.close()
+
+
+def test_reference_struct_layout_entry_point(pkg, synth, oracle):
+    """gpsbb_fill_block_ref: the caller keeps the reference's channel_t (plutogpssim.h:152-174); build that
+    layout here (LP64: int prn; int ca[1023]; double f_carr, f_code, carr_phase, code_phase; gpstime_t g0;
+    unsigned long sbf[5][10]; unsigned long dwrd[60]; int iword, ibit, icode, dataBit, codeCA; ...)."""
+    import ctypes as C
+    chan_t = np.dtype([("prn", "<i4"), ("ca", "<i4", (1023,)), ("f_carr", "<f8"), ("f_code", "<f8"),
+                       ("carr_phase", "<f8"), ("code_phase", "<f8"), ("g0_week", "<i4"), ("_p0", "<i4"),
+                       ("g0_sec", "<f8"), ("sbf", "<u8", (50,)), ("dwrd", "<u8", (60,)), ("iword", "<i4"),
+                       ("ibit", "<i4"), ("icode", "<i4"), ("dataBit", "<i4"), ("codeCA", "<i4"), ("_p1", "<i4"),
+                       ("azel", "<f8", (2,)), ("rho0", "<f8", (8,))])
+    d = pkg.synth_descriptors(1, nch=12, seed=121)[0]
+    d["prn"][5] = 0
+    chan = np.zeros(12, chan_t)
+    for f in ("prn", "f_carr", "f_code", "carr_phase", "code_phase", "iword", "ibit", "icode"):
+        chan[f] = d[f]
+    chan["dwrd"] = d["dwrd"]
+    gain = np.ascontiguousarray(d["gain"])
+
+    class Layout(C.Structure):
+        _fields_ = [(n, C.c_size_t) for n in ("stride", "off_prn", "off_f_carr", "off_f_code", "off_carr_phase",
+                                              "off_code_phase", "off_dwrd", "sizeof_dwrd_elem", "off_iword",
+                                              "off_ibit", "off_icode", "off_dataBit", "off_codeCA")]
+    off = lambda n: chan_t.fields[n][1]
+    lay = Layout(chan_t.itemsize, off("prn"), off("f_carr"), off("f_code"), off("carr_phase"), off("code_phase"),
+                 off("dwrd"), 8, off("iword"), off("ibit"), off("icode"), off("dataBit"), off("codeCA"))
+    nsamp, delt = 300000, 1 / 2.6e6
+    iq = np.zeros((nsamp, 2), np.int16)
+    rc = pkg.lib().gpsbb_fill_block_ref(synth._h, chan.ctypes.data, C.byref(lay), 12, gain.ctypes.data, delt,
+                                        nsamp, iq.ctypes.data)
+    assert rc == 0
+    want_iq, want_st, _ = oracle.fill_blocks(d, delt, nsamp)
+    assert (iq == want_iq[0]).all()
+    act = d["prn"] > 0
+    for f in ("carr_phase", "code_phase", "iword", "ibit", "icode", "dataBit", "codeCA"):
+        assert chan[f][act].tobytes() == want_st[f][0][act].astype(chan[f].dtype).tobytes(), f
+
+
+def test_full_size_blocks_and_linearity(pkg, synth, oracle):
+    """BASELINE config 3 size (16 channels, 25 MS/s, 2.5 M samples per block): two blocks compared sample
+    for sample with the oracle, plus the size-independent property that the sum over channels is linear
+    modulo 2^16: all channels together == sum of each channel alone."""
+    delt, nsamp = 1 / 25e6, 2500000
+    ch = pkg.synth_descriptors(2, nch=16, seed=0x5EED)
+    b = synth.batch(ch, delt, nsamp)
+    b.run()
+    synth.sync()
+    iq, st = b.read()
+    b.close()
+    want_iq, want_st, _ = oracle.fill_blocks(ch, delt, nsamp)
+    assert (iq == want_iq).all()
+    for k in range(2):
+        assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
+    total = np.zeros((nsamp, 2), np.int16)
+    for i in range(16):
+        one = ch[0].copy()
+        one["prn"][np.arange(16) != i] = 0
+        part, _ = synth.fill_block(one, delt, nsamp)
+        total += part                        # int16 wrap-around addition
+    assert (total == iq[0]).all()

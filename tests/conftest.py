@@ -4,6 +4,11 @@ import sys
 
 import pytest
 
+try:  # torch bundles its own libamdhip64: import it BEFORE libgpsbb.so is loaded so both share one HIP runtime
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, ROOT)

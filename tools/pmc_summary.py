@@ -1,38 +1,87 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE counter CSVs into per-launch HBM bytes per kernel.
+"""Summarise one GPU round's rocprofv3 output (ROCm 7.2 writes rocpd SQLite .db files) into text/JSON
+that can be committed under profiles/.
 
-rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB-like units of 1024 bytes... calibrate: the pure fill
-kernel k_fill_ceiling writes a known byte count, so the WRITE_SIZE unit is derived from it rather than
-assumed (MI355X_MICROARCH.md: WRITE_SIZE is uncalibrated on gfx950; FETCH_SIZE under-reports wide reads 2x).
+  python tools/pmc_summary.py gpurun_out/<tag> [profiles/<name-prefix>]
+
+Reads <tag>/prof/*.db (--kernel-trace --stats run), <tag>/pmc_w/*.db (--pmc WRITE_SIZE run) and
+<tag>/pmc_r/*.db (--pmc FETCH_SIZE run).  HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md
+("HBM"): counters collected in their own passes; WRITE_SIZE / FETCH_SIZE are in KiB (x1024);
+FETCH_SIZE is doubled (gfx950 reports half the bytes of wide coalesced reads); WRITE_SIZE is calibrated
+on k_fill_ceiling, which writes a known byte count.
 """
-import csv
 import glob
 import json
 import os
+import sqlite3
 import sys
-from collections import defaultdict
 
 
-def collect(d):
-    per = defaultdict(lambda: defaultdict(list))
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        for row in csv.DictReader(open(f)):
-            per[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    return per
+def q(db, sql):
+    c = sqlite3.connect(db)
+    try:
+        return list(c.execute(sql))
+    finally:
+        c.close()
+
+
+def short(name):
+    for k in ("k_synth", "k_seed", "k_fill_ceiling"):
+        if k in name:
+            return k
+    return None
 
 
 def main():
-    out = sys.argv[1]
-    res = {}
-    for tag, name in (("pmc_w", "WRITE_SIZE"), ("pmc_r", "FETCH_SIZE")):
-        per = collect(os.path.join(out, tag))
-        for k, cs in per.items():
-            short = "k_synth" if "k_synth" in k else "k_seed" if "k_seed" in k else "k_fill_ceiling" if "k_fill" in k else None
-            if short and name in cs:
-                v = cs[name]
-                res.setdefault(short, {})[name + "_raw_per_launch"] = sum(v) / len(v)
-                res[short]["launches_" + name] = len(v)
+    tag = sys.argv[1]
+    prefix = sys.argv[2] if len(sys.argv) > 2 else None
+    res = {"kernels": {}}
+    lines = []
+    for db in glob.glob(os.path.join(tag, "prof", "*.db")):
+        rows = q(db, "select name,total_calls,total_duration,average,percentage from top_kernels")
+        lines.append("%-90s %6s %14s %12s %7s" % ("kernel (rocprofv3 --kernel-trace --stats)", "calls", "total_us", "avg_us", "pct"))
+        for n, calls, tot, avg, pct in rows:
+            lines.append("%-90s %6d %14.3f %12.3f %7.2f" % (n[:90], calls, tot, avg, pct))
+            if short(n):
+                res["kernels"].setdefault(short(n), {}).update(calls=calls, avg_us=avg, pct=pct)
+        for n, vg, sg, lds, gx, gy, wx in q(db, "select name,vgpr_count,sgpr_count,lds_size,grid_x,grid_y,workgroup_x from kernels group by name"):
+            if short(n):
+                res["kernels"][short(n)].update(vgpr=vg, sgpr=sg, lds=lds, grid=[gx, gy], wg=wx)
+    for sub, ctr in (("pmc_w", "WRITE_SIZE"), ("pmc_r", "FETCH_SIZE")):
+        for db in glob.glob(os.path.join(tag, sub, "*.db")):
+            for n, avg, cnt in q(db, "select kernel_name, avg(value), count(*) from counters_collection "
+                                     "where counter_name='%s' group by kernel_name" % ctr):
+                if short(n):
+                    res["kernels"].setdefault(short(n), {})[ctr + "_KiB_per_launch"] = avg
+                    res["kernels"][short(n)]["launches_" + ctr] = cnt
+    k = res["kernels"]
+    bench = None
+    bj = os.path.join(tag, "bench.json")
+    if os.path.exists(bj):
+        try:
+            bench = json.loads(open(bj).read().strip().splitlines()[-1])
+        except Exception:
+            bench = None
+    if "k_fill_ceiling" in k and "WRITE_SIZE_KiB_per_launch" in k["k_fill_ceiling"] and bench:
+        known = bench["roofline"]["algorithmic_bytes_per_launch"]  # the fill writes the same buffer
+        res["write_size_calibration"] = k["k_fill_ceiling"]["WRITE_SIZE_KiB_per_launch"] * 1024.0 / known
+    if "k_synth" in k and "WRITE_SIZE_KiB_per_launch" in k["k_synth"]:
+        cal = res.get("write_size_calibration", 1.0) or 1.0
+        w = k["k_synth"]["WRITE_SIZE_KiB_per_launch"] * 1024.0 / cal
+        r = 2.0 * k["k_synth"].get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024.0
+        res["k_synth_hbm_write_bytes_per_launch"] = w
+        res["k_synth_hbm_read_bytes_per_launch"] = r
+        res["k_synth_hbm_bytes_per_launch"] = w + r
+    if bench:
+        res["bench"] = {kk: bench[kk] for kk in ("value", "ms_per_step", "roofline", "seed_kernel_ms_per_launch") if kk in bench}
     print(json.dumps(res, indent=1))
+    if prefix:
+        with open(prefix + "_kernel_stats.txt", "w") as f:
+            f.write("\n".join(lines) + "\n")
+        with open(prefix + "_pmc.json", "w") as f:
+            json.dump(res, f, indent=1)
+        with open(os.path.join(os.path.dirname(prefix), "pmc_latest.json"), "w") as f:
+            json.dump({kk: res[kk] for kk in res if kk.startswith("k_synth_hbm")}, f, indent=1)
 
 
 if __name__ == "__main__":

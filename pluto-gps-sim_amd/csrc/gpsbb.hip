@@ -309,6 +309,9 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     if ((e = hipMemcpy(h->d_ca, ca.data(), ca.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemset(h->d_status, 0, 4)) != hipSuccess) return fail(e);
     if ((e = hipMemset(h->d_hz, 0, 16)) != hipSuccess) return fail(e);
+    /* k_synth carves ~76 KB of dynamic LDS per workgroup: above the 64 KB default limit */
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(SynthLds))) != hipSuccess) return fail(e);
     *out = h;
     return GPSBB_OK;
 }
@@ -353,7 +356,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     HIPCHK(h, (hipError_t)b->d_ch.reserve(nbc));
     HIPCHK(h, (hipError_t)b->d_row_off.reserve(2 * nbc + 1));
     HIPCHK(h, (hipError_t)b->d_rows.reserve(off));
-    HIPCHK(h, (hipError_t)b->d_tile_row.reserve(2 * nbc * (size_t)b->ntiles));
+    HIPCHK(h, (hipError_t)b->d_tile_row.reserve(2 * nbc * ((size_t)b->ntiles + 1)));
     HIPCHK(h, (hipError_t)b->d_end.reserve(nbc));
     b->h_ch.assign(ch, ch + nbc);
     HIPCHK(h, hipMemcpyAsync(b->d_ch.p, b->h_ch.data(), nbc * sizeof(gpsbb_chan_t), hipMemcpyHostToDevice, upload_stream));
@@ -461,7 +464,15 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq, hipStream_t st)
     hipLaunchKernelGGL(k_seed, dim3((lanes + 63) / 64), dim3(64), 0, st, p, cbase);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(ev[1], st));
-    hipLaunchKernelGGL(k_synth, dim3(b->ntiles, b->nblocks), dim3(TILE_THREADS), 0, st, p, d_iq);
+    {
+        /* several tiles per workgroup once the grid is large enough to fill the chip many times over:
+         * the per-block LDS tables (amplitude LUT, chips, nav words) are then built once per workgroup */
+        const long wg_slots = (long)(h->sm_count > 0 ? h->sm_count : 256) * 2;
+        long tpw = ((long)b->ntiles * b->nblocks) / (wg_slots * 6);
+        tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
+        const int gx = (int)((b->ntiles + tpw - 1) / tpw);
+        hipLaunchKernelGGL(k_synth, dim3(gx, b->nblocks), dim3(TILE_THREADS), sizeof(SynthLds), st, p, d_iq);
+    }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(ev[2], st));
     b->ran = true;

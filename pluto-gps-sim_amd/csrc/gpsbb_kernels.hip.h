@@ -35,9 +35,10 @@
 
 namespace gpsbb_impl {
 
-constexpr int TILE_THREADS = 256;           /* 4 wave64 per workgroup */
-constexpr int SPT = 16;                     /* consecutive samples per lane: 64 bytes of output */
-constexpr int TILE = TILE_THREADS * SPT;    /* samples per workgroup */
+constexpr int TILE_THREADS = 512;           /* 8 wave64 per workgroup */
+constexpr int SPT = 32;                     /* consecutive samples per lane: 128 bytes of output */
+constexpr int TILE = TILE_THREADS * SPT;    /* samples per tile (one workgroup pass) */
+constexpr int SYNTH_ROW_CAP = 1024;         /* rows of all chains of one tile staged in LDS (24 KB) */
 
 constexpr uint32_t ST_ROW_OVERFLOW = 1u;
 
@@ -53,7 +54,8 @@ struct BatchDev {
     const uint32_t *ca_bits;        /* [33][32] C/A chips per PRN, bit i of dword i>>5 = chip i      */
     NcoRow *rows;                   /* row pool                                                      */
     const uint64_t *row_off;        /* [2*nblocks*nch + 1] first row of each chain in the pool       */
-    int32_t *tile_row;              /* [2*nblocks*nch][ntiles] row holding each tile's first sample  */
+    int32_t *tile_row;              /* [2*nblocks*nch][ntiles+1] row holding each tile's first sample;
+                                       entry [ntiles] = the chain's last row                         */
     gpsbb_chan_state_t *end;        /* [nblocks*nch] end-of-block state                              */
     uint32_t *status;               /* self-check word                                               */
     unsigned long long *hazards;    /* [0] itable_512, [1] dwrd_oob                                  */
@@ -106,7 +108,7 @@ struct RowSink {
     }
     __device__ __forceinline__ void finish()
     {
-        while (next_tile < ntiles)
+        while (next_tile <= ntiles)
             tile_row[next_tile++] = (int32_t)cnt - 1;
         const uint32_t at = cnt < cap ? cnt : cap;
         NcoRow r;
@@ -125,7 +127,7 @@ __device__ __forceinline__ RowSink make_sink(const BatchDev &p, int chain)
     s.rows = p.rows + o0;
     s.cap = (uint32_t)(o1 - o0 - 1);
     s.cnt = 0;
-    s.tile_row = p.tile_row + (size_t)chain * p.ntiles;
+    s.tile_row = p.tile_row + (size_t)chain * (p.ntiles + 1);
     s.ntiles = p.ntiles;
     s.next_tile = 0;
     s.overflow = false;
@@ -235,42 +237,109 @@ __device__ __forceinline__ uint32_t v2s_u32(v2s v)
     return u;
 }
 
-/* state of one NCO at sample n, from the chain's row table */
-__device__ __forceinline__ uint64_t row_state(const NcoRow *__restrict__ rows, int r, int n, uint32_t *nav)
+/* LDS image of one workgroup (dynamic shared memory, 16-byte aligned carve) */
+struct SynthLds {
+    uint32_t amp[GPSBB_MAX_CHAN][512];          /* int16x2: lo = I (cos*gain), hi = Q (sin*gain)      */
+    int8_t chip[GPSBB_MAX_CHAN][1024];          /* codeCA as +1/-1 per chip (plutogpssim.c:2737)       */
+    uint32_t dwrd[GPSBB_MAX_CHAN][GPSBB_N_DWRD]; /* nav words                                          */
+    double sc[GPSBB_MAX_CHAN];                  /* f_code*delt                                         */
+    double sk512[GPSBB_MAX_CHAN];               /* f_carr*delt*512 (carrier phase is walked scaled by 512: exact) */
+    /* the tile's slice of the row tables, structure-of-arrays */
+    uint64_t rxb[SYNTH_ROW_CAP];
+    int64_t rinc[SYNTH_ROW_CAP];
+    int32_t rn0[SYNTH_ROW_CAP];
+    uint32_t rnav[SYNTH_ROW_CAP];
+    int32_t rbase[2 * GPSBB_MAX_CHAN];          /* first staged row of chain (a, kind)                 */
+    int32_t act[GPSBB_MAX_CHAN];
+    int32_t nact;
+    int32_t rows_in_lds;
+};
+
+/* state of one NCO at sample n, scanning forward from row r (global-memory fallback) */
+__device__ __forceinline__ uint64_t row_state_global(const NcoRow *__restrict__ rows, int r, int n, uint32_t *nav)
 {
     while (rows[r + 1].n0 <= n)
         r++;
     const NcoRow row = rows[r];
-    if (nav)
-        *nav = row.nav;
+    *nav = row.nav;
     return row.xb + (uint64_t)((int64_t)(n - row.n0) * row.inc);
 }
 
-__global__ __launch_bounds__(TILE_THREADS) void k_synth(BatchDev p, int16_t *__restrict__ iq)
+__device__ __forceinline__ uint64_t row_state_lds(const SynthLds &L, int r, int n, uint32_t *nav)
 {
-    __shared__ uint32_t s_amp[GPSBB_MAX_CHAN][512]; /* int16x2: lo = I (cos), hi = Q (sin) */
-    __shared__ uint32_t s_ca[GPSBB_MAX_CHAN][32];
-    __shared__ uint32_t s_dwrd[GPSBB_MAX_CHAN][GPSBB_N_DWRD];
-    __shared__ double s_sc[GPSBB_MAX_CHAN], s_sk[GPSBB_MAX_CHAN];
-    __shared__ int s_act[GPSBB_MAX_CHAN];
-    __shared__ int s_nact;
+    while (L.rn0[r + 1] <= n)
+        r++;
+    *nav = L.rnav[r];
+    return L.rxb[r] + (uint64_t)((int64_t)(n - L.rn0[r]) * L.rinc[r]);
+}
+
+__device__ __forceinline__ double hi_lo_f64(int hi, int lo) { return __hiloint2double(hi, lo); }
+
+/*
+ * SPT consecutive samples of one channel.  WRAPS = false is the straight-line version used when no lane
+ * of the wavefront can reach a code or carrier wrap inside its run (decided by the caller): the NCO
+ * updates are then single IEEE adds.  WRAPS = true is the reference's full update
+ * (plutogpssim.c:2709-2746) with the comparisons done on the high dword of the double.
+ */
+template <bool WRAPS>
+__device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc, double yk, uint32_t nav,
+                                             v2s (&acc)[SPT], int nvalid, unsigned long long &hz_itable)
+{
+    const double sc = L.sc[i], sk = L.sk512[i];
+    const uint32_t *__restrict__ amp = L.amp[i];
+    const int8_t *__restrict__ chip = L.chip[i];
+    /* codeCA*dataBit: chip sign (+1/-1) XOR-ed with 0xfffe when dataBit = -1 flips +-1 in 16 bits */
+    int dbx = nav_bit(L.dwrd[i], nav) < 0 ? 0xfffe : 0;
+#pragma unroll
+    for (int j = 0; j < SPT; j++) {
+        if ((j & 7) == 0)
+            __builtin_amdgcn_sched_barrier(0); /* keep at most 8 samples' lookups in flight: VGPR budget */
+        int it = (int)yk; /* floor(carr_phase*512), c:2697 (yk = carr_phase*512 >= 0) */
+        if (WRAPS && it > 511) { /* carr_phase == 1.0: latent OOB of the reference, defined as &511 */
+            it &= 511;
+            if (j < nvalid)
+                hz_itable++;
+        }
+        const int ci = (int)xc; /* c:2737 */
+        const short sg = (short)((int)chip[ci] ^ dbx);
+        acc[j] += u32_v2s(amp[it]) * v2s{sg, sg};
+
+        xc = add_rn(xc, sc); /* c:2709 */
+        yk = add_rn(yk, sk); /* c:2741, scaled by 512 */
+        if (WRAPS) {
+            if (__double2hiint(xc) >= 0x408FF800) { /* xc >= 1023.0 (xc >= 0) */
+                xc = add_rn(xc, -1023.0);
+                nav = nav_advance(nav);
+                if (nav_icode(nav) == 0)
+                    dbx = nav_bit(L.dwrd[i], nav) < 0 ? 0xfffe : 0;
+            }
+            const int h = __double2hiint(yk);
+            const int adj = h >= 0x40800000 ? (int)0xC0800000 : (h < 0 ? 0x40800000 : 0); /* -512 / +512 / 0 */
+            yk = add_rn(yk, hi_lo_f64(adj, 0)); /* c:2743-2746; adding +0.0 is exact */
+        }
+    }
+}
+
+__global__ __launch_bounds__(TILE_THREADS, 4) void k_synth(BatchDev p, int16_t *__restrict__ iq)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    SynthLds &L = *reinterpret_cast<SynthLds *>(smem_raw);
 
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x;
     const int b = blockIdx.y;
     const gpsbb_chan_t *__restrict__ cb = p.ch + (size_t)b * p.nch;
 
-    /* ---- stage the block's per-channel tables in LDS ---- */
+    /* ---- stage the block's per-channel tables in LDS (once per workgroup) ---- */
     if (tid == 0) {
         int na = 0;
         for (int i = 0; i < p.nch; i++)
             if (cb[i].prn > 0)
-                s_act[na++] = i;
-        s_nact = na;
+                L.act[na++] = i;
+        L.nact = na;
     }
     if (tid < p.nch) {
-        s_sc[tid] = mul_rn(cb[tid].f_code, p.delt);
-        s_sk[tid] = mul_rn(cb[tid].f_carr, p.delt);
+        L.sc[tid] = mul_rn(cb[tid].f_code, p.delt);
+        L.sk512[tid] = mul_rn(mul_rn(cb[tid].f_carr, p.delt), 512.0);
     }
     for (int e = tid; e < p.nch * 512; e += TILE_THREADS) {
         const int i = e >> 9, k = e & 511;
@@ -282,85 +351,118 @@ __global__ __launch_bounds__(TILE_THREADS) void k_synth(BatchDev p, int16_t *__r
             const int qp = (int)mul_rn((double)p.tabs[512 + k], g);
             v = ((uint32_t)ip & 0xffffu) | ((uint32_t)qp << 16);
         }
-        s_amp[i][k] = v;
+        L.amp[i][k] = v;
     }
-    for (int e = tid; e < p.nch * 32; e += TILE_THREADS) {
-        const int i = e >> 5, w = e & 31;
+    for (int e = tid; e < p.nch * 1024; e += TILE_THREADS) {
+        const int i = e >> 10, c = e & 1023;
         const int prn = cb[i].prn;
-        s_ca[i][w] = prn > 0 ? p.ca_bits[prn * 32 + w] : 0u;
+        const uint32_t w = prn > 0 ? p.ca_bits[prn * 32 + (c >> 5)] : 0u;
+        L.chip[i][c] = (int8_t)(((w >> (c & 31)) & 1u) ? 1 : -1);
     }
     for (int e = tid; e < p.nch * GPSBB_N_DWRD; e += TILE_THREADS) {
         const int i = e / GPSBB_N_DWRD, w = e % GPSBB_N_DWRD;
-        s_dwrd[i][w] = cb[i].dwrd[w];
+        L.dwrd[i][w] = cb[i].dwrd[w];
     }
     __syncthreads();
+    const int nact = L.nact;
 
-    const int n0 = tile * TILE + tid * SPT;
-    if (n0 >= p.nsamp)
-        return;
-
-    v2s acc[SPT];
-#pragma unroll
-    for (int j = 0; j < SPT; j++)
-        acc[j] = v2s{0, 0};
-
-    const int nact = s_nact;
-    unsigned long long hz_itable = 0;
-    for (int a = 0; a < nact; a++) {
-        const int i = s_act[a];
-        const int cc = chain_code(p, b, i), ck = chain_carr(p, b, i);
-        uint32_t nav;
-        double xc = bits_f64(row_state(p.rows + p.row_off[cc], p.tile_row[(size_t)cc * p.ntiles + tile], n0, &nav));
-        double xk = bits_f64(row_state(p.rows + p.row_off[ck], p.tile_row[(size_t)ck * p.ntiles + tile], n0, nullptr));
-        const double sc = s_sc[i], sk = s_sk[i];
-        int db = nav_bit(s_dwrd[i], nav);
-
-#pragma unroll
-        for (int j = 0; j < SPT; j++) {
-            /* carrier table index: floor(carr_phase*512) (c:2697); x*512 is exact, x >= 0 */
-            int it = (int)(xk * 512.0);
-            if (it > 511) { /* carr_phase == 1.0 exactly: latent OOB of the reference, defined as &511 */
-                it &= 511;
-                if (n0 + j < p.nsamp)
-                    hz_itable++;
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        /* ---- stage this tile's slice of the row tables: chain (a, kind) is copied by 16 lanes ---- */
+        __syncthreads(); /* previous tile's readers are done */
+        if (tid < 64) {
+            /* one wave: row counts of the 2*nact chains and their exclusive prefix sum */
+            int cnt = 0;
+            if (tid < 2 * nact) {
+                const int i = L.act[tid >> 1];
+                const int chain = (tid & 1) ? chain_carr(p, b, i) : chain_code(p, b, i);
+                const int32_t *tr = p.tile_row + (size_t)chain * (p.ntiles + 1);
+                cnt = tr[tile + 1] - tr[tile] + 2; /* rows r0..r1 plus the terminator of the scan */
             }
-            const int ci = (int)xc; /* chip index (c:2737) */
-            const int chip = (int)((s_ca[i][ci >> 5] >> (ci & 31)) & 1u);
-            const short sg = (short)((2 * chip - 1) * db); /* codeCA * dataBit */
-            acc[j] += u32_v2s(s_amp[i][it]) * v2s{sg, sg};
-
-            /* code NCO (c:2709-2734) */
-            xc = add_rn(xc, sc);
-            if (xc >= 1023.0) {
-                xc = add_rn(xc, -1023.0);
-                nav = nav_advance(nav);
-                if (nav_icode(nav) == 0)
-                    db = nav_bit(s_dwrd[i], nav);
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (tid >= o)
+                    incl += t;
             }
-            /* carrier NCO (c:2741-2746) */
-            xk = add_rn(xk, sk);
-            if (xk >= 1.0)
-                xk = add_rn(xk, -1.0);
-            else if (xk < 0.0)
-                xk = add_rn(xk, 1.0);
+            if (tid < 2 * nact)
+                L.rbase[tid] = incl - cnt;
+            if (tid == 63)
+                L.rows_in_lds = incl <= SYNTH_ROW_CAP ? 1 : 0;
         }
-    }
-    if (hz_itable)
-        atomicAdd(p.hazards, hz_itable);
+        __syncthreads();
+        const bool in_lds = L.rows_in_lds != 0;
+        if (in_lds) {
+            const int c = tid >> 4, sub = tid & 15; /* 32 chains x 16 lanes = 512 threads */
+            if (c < 2 * nact) {
+                const int i = L.act[c >> 1];
+                const int chain = (c & 1) ? chain_carr(p, b, i) : chain_code(p, b, i);
+                const int32_t *tr = p.tile_row + (size_t)chain * (p.ntiles + 1);
+                const int r0 = tr[tile], cnt = tr[tile + 1] - r0 + 2;
+                const NcoRow *__restrict__ rows = p.rows + p.row_off[chain] + r0;
+                const int base = L.rbase[c];
+                for (int r = sub; r < cnt; r += 16) {
+                    const NcoRow row = rows[r];
+                    L.rn0[base + r] = row.n0;
+                    L.rnav[base + r] = row.nav;
+                    L.rxb[base + r] = row.xb;
+                    L.rinc[base + r] = row.inc;
+                }
+            }
+        }
+        __syncthreads();
 
-    /* ---- store: int16 I,Q interleaved (c:2754-2755) ---- */
-    uint32_t *out = reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + n0;
-    const bool full = n0 + SPT <= p.nsamp;
-    if (full && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) {
-        uint4 *o4 = reinterpret_cast<uint4 *>(out);
+        const int n0 = tile * TILE + tid * SPT;
+        if (n0 < p.nsamp) {
+            v2s acc[SPT];
 #pragma unroll
-        for (int j = 0; j < SPT; j += 4)
-            o4[j >> 2] = make_uint4(v2s_u32(acc[j]), v2s_u32(acc[j + 1]), v2s_u32(acc[j + 2]), v2s_u32(acc[j + 3]));
-    } else {
+            for (int j = 0; j < SPT; j++)
+                acc[j] = v2s{0, 0};
+            const int nvalid = p.nsamp - n0 < SPT ? p.nsamp - n0 : SPT;
+            unsigned long long hz_itable = 0;
+
+            for (int a = 0; a < nact; a++) {
+                const int i = L.act[a];
+                uint32_t nav, nav_unused;
+                uint64_t xcb, xkb;
+                if (in_lds) {
+                    xcb = row_state_lds(L, L.rbase[2 * a], n0, &nav);
+                    xkb = row_state_lds(L, L.rbase[2 * a + 1], n0, &nav_unused);
+                } else {
+                    const int cc = chain_code(p, b, i), ck = chain_carr(p, b, i);
+                    xcb = row_state_global(p.rows + p.row_off[cc], p.tile_row[(size_t)cc * (p.ntiles + 1) + tile], n0, &nav);
+                    xkb = row_state_global(p.rows + p.row_off[ck], p.tile_row[(size_t)ck * (p.ntiles + 1) + tile], n0, &nav_unused);
+                }
+                const double xc = bits_f64(xcb);
+                const double yk = mul_rn(bits_f64(xkb), 512.0); /* exact */
+
+                /* can any lane of this wavefront wrap inside its run?  (SPT+2) steps of margin */
+                const double sc = L.sc[i], sk = L.sk512[i];
+                const double span = (double)(SPT + 2);
+                const double y_end = yk + span * sk;
+                const bool may_wrap = !(xc + span * sc < 1023.0) || !(y_end < 512.0) || !(y_end > 0.0) || !(yk < 512.0);
+                if (__any(may_wrap))
+                    walk_channel<true>(L, i, xc, yk, nav, acc, nvalid, hz_itable);
+                else
+                    walk_channel<false>(L, i, xc, yk, nav, acc, nvalid, hz_itable);
+            }
+            if (hz_itable)
+                atomicAdd(p.hazards, hz_itable);
+
+            /* ---- store: int16 I,Q interleaved (c:2754-2755) ---- */
+            uint32_t *out = reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + n0;
+            if (nvalid == SPT && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) {
+                uint4 *o4 = reinterpret_cast<uint4 *>(out);
 #pragma unroll
-        for (int j = 0; j < SPT; j++)
-            if (n0 + j < p.nsamp)
-                out[j] = v2s_u32(acc[j]);
+                for (int j = 0; j < SPT; j += 4)
+                    o4[j >> 2] = make_uint4(v2s_u32(acc[j]), v2s_u32(acc[j + 1]), v2s_u32(acc[j + 2]), v2s_u32(acc[j + 3]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < SPT; j++)
+                    if (j < nvalid)
+                        out[j] = v2s_u32(acc[j]);
+            }
+        }
     }
 }
 

@@ -123,6 +123,34 @@ GPSBB_HD uint32_t nav_advance(uint32_t p)
     return nav_pack(icode, ibit, iword);
 }
 
+/* floor(a / q) for 0 <= a < 2^53, 0 < q < 2^53, without a 64-bit integer division (which is a ~200
+ * instruction software routine on the GPU): reciprocal estimate, one Newton step, exact fix-up by the
+ * remainder.  Quotients >= 2^40 are only ever compared with a sample count, so they saturate. */
+GPSBB_HD uint64_t div_floor_53(uint64_t a, uint64_t q)
+{
+    const double qd = (double)q;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(qd);
+#else
+    double r = 1.0 / qd;
+#endif
+    r = r * (2.0 - qd * r); /* any rounding/contraction is fine here: the result is corrected below */
+    const double kd = (double)a * r;
+    if (kd >= 1099511627776.0)
+        return 1ull << 40;
+    uint64_t k = (uint64_t)kd;
+    int64_t rem = (int64_t)a - (int64_t)(k * q);
+    while (rem < 0) {
+        k--;
+        rem += (int64_t)q;
+    }
+    while (rem >= (int64_t)q) {
+        k++;
+        rem -= (int64_t)q;
+    }
+    return k;
+}
+
 /*
  * Regular run starting from state x (raw bits xb, x >= 0) with step s (raw bits sb).
  * Returns k >= 0, the number of consecutive steps (capped at kcap) for which
@@ -192,13 +220,13 @@ GPSBB_HD int64_t regular_run(uint64_t xb, uint64_t sb, int64_t kcap, int64_t &in
         if (M + q > Mlim)
             return 0;
         inc = (int64_t)q;
-        k = (int64_t)((Mlim - M) / q);
+        k = (int64_t)div_floor_53(Mlim - M, q);
     } else {
         const uint64_t Mmin = F64_HID + 1; /* stay strictly above the binade's lower edge */
         if (M < Mmin + q)
             return 0;
         inc = -(int64_t)q;
-        k = (int64_t)((M - Mmin) / q);
+        k = (int64_t)div_floor_53(M - Mmin, q);
     }
     return k < kcap ? k : kcap;
 }

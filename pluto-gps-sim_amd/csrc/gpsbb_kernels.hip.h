@@ -36,7 +36,7 @@
 namespace gpsbb_impl {
 
 constexpr int TILE_THREADS = 512;           /* 8 wave64 per workgroup */
-constexpr int SPT = 32;                     /* consecutive samples per lane: 128 bytes of output */
+constexpr int SPT = 16;                     /* consecutive samples per lane: 64 bytes of output */
 constexpr int TILE = TILE_THREADS * SPT;    /* samples per tile (one workgroup pass) */
 constexpr int SYNTH_ROW_CAP = 1024;         /* rows of all chains of one tile staged in LDS (24 KB) */
 
@@ -290,33 +290,52 @@ __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc
     const int8_t *__restrict__ chip = L.chip[i];
     /* codeCA*dataBit: chip sign (+1/-1) XOR-ed with 0xfffe when dataBit = -1 flips +-1 in 16 bits */
     int dbx = nav_bit(L.dwrd[i], nav) < 0 ? 0xfffe : 0;
+    constexpr int G = 8; /* samples whose LDS lookups are in flight together */
 #pragma unroll
-    for (int j = 0; j < SPT; j++) {
-        if ((j & 7) == 0)
-            __builtin_amdgcn_sched_barrier(0); /* keep at most 8 samples' lookups in flight: VGPR budget */
-        int it = (int)yk; /* floor(carr_phase*512), c:2697 (yk = carr_phase*512 >= 0) */
-        if (WRAPS && it > 511) { /* carr_phase == 1.0: latent OOB of the reference, defined as &511 */
-            it &= 511;
-            if (j < nvalid)
-                hz_itable++;
-        }
-        const int ci = (int)xc; /* c:2737 */
-        const short sg = (short)((int)chip[ci] ^ dbx);
-        acc[j] += u32_v2s(amp[it]) * v2s{sg, sg};
-
-        xc = add_rn(xc, sc); /* c:2709 */
-        yk = add_rn(yk, sk); /* c:2741, scaled by 512 */
-        if (WRAPS) {
-            if (__double2hiint(xc) >= 0x408FF800) { /* xc >= 1023.0 (xc >= 0) */
-                xc = add_rn(xc, -1023.0);
-                nav = nav_advance(nav);
-                if (nav_icode(nav) == 0)
-                    dbx = nav_bit(L.dwrd[i], nav) < 0 ? 0xfffe : 0;
+    for (int j0 = 0; j0 < SPT; j0 += G) {
+        int it[G], ci[G], dbs[G];
+        /* phase 1: table indices of G samples, NCOs advanced (two dependent chains of IEEE adds) */
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            it[u] = (int)yk; /* floor(carr_phase*512), c:2697 (yk = carr_phase*512 >= 0) */
+            if (WRAPS && it[u] > 511) { /* carr_phase == 1.0: latent OOB of the reference, defined as &511 */
+                it[u] &= 511;
+                if (j0 + u < nvalid)
+                    hz_itable++;
             }
-            const int h = __double2hiint(yk);
-            const int adj = h >= 0x40800000 ? (int)0xC0800000 : (h < 0 ? 0x40800000 : 0); /* -512 / +512 / 0 */
-            yk = add_rn(yk, hi_lo_f64(adj, 0)); /* c:2743-2746; adding +0.0 is exact */
+            ci[u] = (int)xc; /* c:2737 */
+            dbs[u] = dbx;
+            xc = add_rn(xc, sc); /* c:2709 */
+            yk = add_rn(yk, sk); /* c:2741, scaled by 512 */
+            if (WRAPS) {
+                if (__double2hiint(xc) >= 0x408FF800) { /* xc >= 1023.0 (xc >= 0) */
+                    xc = add_rn(xc, -1023.0);
+                    nav = nav_advance(nav);
+                    if (nav_icode(nav) == 0)
+                        dbx = nav_bit(L.dwrd[i], nav) < 0 ? 0xfffe : 0;
+                }
+                const int h = __double2hiint(yk);
+                const int adj = h >= 0x40800000 ? (int)0xC0800000 : (h < 0 ? 0x40800000 : 0); /* -512 / +512 / 0 */
+                yk = add_rn(yk, hi_lo_f64(adj, 0)); /* c:2743-2746; adding +0.0 is exact */
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        /* phase 2: 2*G LDS reads issued back to back */
+        uint32_t av[G];
+        int cv[G];
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            av[u] = amp[it[u]];
+            cv[u] = (int)chip[ci[u]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        /* phase 3: acc += amp * (codeCA*dataBit), packed int16x2 (c:2701-2706) */
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            const short sg = (short)(cv[u] ^ (WRAPS ? dbs[u] : dbx));
+            acc[j0 + u] += u32_v2s(av[u]) * v2s{sg, sg};
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 

@@ -134,8 +134,9 @@ uint64_t row_bound(double s_abs, double range, int top_e, int nsamp)
 
 struct gpsbb {
     int device = 0;
-    hipStream_t s_compute = nullptr;
-    hipStream_t s_copy = nullptr;
+    hipStream_t s_seed = nullptr;    /* NCO seeding pre-pass (k_seed) and descriptor uploads            */
+    hipStream_t s_compute = nullptr; /* synthesis kernel (k_synth)                                      */
+    hipStream_t s_copy = nullptr;    /* device-to-host gather                                            */
     int32_t *d_tabs = nullptr;
     uint32_t *d_ca = nullptr;
     uint32_t *d_status = nullptr;
@@ -180,16 +181,22 @@ struct gpsbb_batch {
     uint64_t total_rows = 0;
     DevBuf<gpsbb_chan_t> d_ch;
     DevBuf<uint64_t> d_row_off;
-    DevBuf<NcoRow> d_rows;
-    DevBuf<int32_t> d_tile_row;
-    DevBuf<gpsbb_chan_state_t> d_end;
+    /* row tables / tile index / end states exist twice: run k uses set k&1, so that the seeding
+     * pre-pass of run k+1 overlaps the synthesis kernel of run k (different streams) */
+    DevBuf<NcoRow> d_rows[2];
+    DevBuf<int32_t> d_tile_row[2];
+    DevBuf<gpsbb_chan_state_t> d_end[2];
+    hipEvent_t synth_done[2] = {nullptr, nullptr};
+    bool synth_pending[2] = {false, false};
+    unsigned run_count = 0;
+    int last_set = 0;
     DevBuf<int16_t> d_iq;
     std::vector<uint64_t> row_off;
     std::vector<gpsbb_chan_t> h_ch; /* library-owned copy: the caller's array may go away after the call */
     const gpsbb_chan_t *prev_ch = nullptr;
     const gpsbb_chan_state_t *prev_end = nullptr;
-    struct Ev3 { hipEvent_t e[3]; };
-    std::vector<Ev3> evs; /* one triple per run since the last timing reset */
+    struct Ev4 { hipEvent_t e[4]; }; /* seed start/end (seed stream), synth start/end (compute stream) */
+    std::vector<Ev4> evs; /* one set per run since the last timing reset */
     size_t ev_used = 0;
     bool ran = false;
     int16_t *last_iq = nullptr;
@@ -245,6 +252,8 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
     (void)hipSetDevice(h->device);
     if (h->scratch)
         gpsbb_batch_destroy(h->scratch);
+    if (h->s_seed)
+        (void)hipStreamSynchronize(h->s_seed);
     if (h->s_compute)
         (void)hipStreamSynchronize(h->s_compute);
     if (h->s_copy)
@@ -257,6 +266,8 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
         (void)hipFree(h->d_status);
     if (h->d_hz)
         (void)hipFree(h->d_hz);
+    if (h->s_seed)
+        (void)hipStreamDestroy(h->s_seed);
     if (h->s_compute)
         (void)hipStreamDestroy(h->s_compute);
     if (h->s_copy)
@@ -299,6 +310,7 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail(e);
     h->sm_count = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&h->s_seed, hipStreamNonBlocking)) != hipSuccess) return fail(e);
     if ((e = hipStreamCreateWithFlags(&h->s_compute, hipStreamNonBlocking)) != hipSuccess) return fail(e);
     if ((e = hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&h->d_tabs, sizeof tabs)) != hipSuccess) return fail(e);
@@ -355,9 +367,6 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
 
     HIPCHK(h, (hipError_t)b->d_ch.reserve(nbc));
     HIPCHK(h, (hipError_t)b->d_row_off.reserve(2 * nbc + 1));
-    HIPCHK(h, (hipError_t)b->d_rows.reserve(off));
-    HIPCHK(h, (hipError_t)b->d_tile_row.reserve(2 * nbc * ((size_t)b->ntiles + 1)));
-    HIPCHK(h, (hipError_t)b->d_end.reserve(nbc));
     b->h_ch.assign(ch, ch + nbc);
     HIPCHK(h, hipMemcpyAsync(b->d_ch.p, b->h_ch.data(), nbc * sizeof(gpsbb_chan_t), hipMemcpyHostToDevice, upload_stream));
     HIPCHK(h, hipMemcpyAsync(b->d_row_off.p, b->row_off.data(), (2 * nbc + 1) * 8, hipMemcpyHostToDevice, upload_stream));
@@ -379,12 +388,17 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
     if (!b)
         return;
     (void)hipSetDevice(b->h->device);
+    (void)hipStreamSynchronize(b->h->s_seed);
     (void)hipStreamSynchronize(b->h->s_compute);
     b->d_ch.release();
     b->d_row_off.release();
-    b->d_rows.release();
-    b->d_tile_row.release();
-    b->d_end.release();
+    for (int k = 0; k < 2; k++) {
+        b->d_rows[k].release();
+        b->d_tile_row[k].release();
+        b->d_end[k].release();
+        if (b->synth_done[k])
+            (void)hipEventDestroy(b->synth_done[k]);
+    }
     b->d_iq.release();
     for (auto &t : b->evs)
         for (auto &e : t.e)
@@ -403,12 +417,12 @@ extern "C" int gpsbb_batch_create(gpsbb_t *h, const gpsbb_chan_t *ch, int nblock
     gpsbb_batch *b = batch_new(h);
     if (!b)
         return GPSBB_E_NOMEM;
-    int rc = batch_setup(b, ch, nblocks, nch, delt, nsamp, flags, h->s_compute);
+    int rc = batch_setup(b, ch, nblocks, nch, delt, nsamp, flags, h->s_seed);
     if (rc != GPSBB_OK) {
         gpsbb_batch_destroy(b);
         return rc;
     }
-    HIPCHK(h, hipStreamSynchronize(h->s_compute));
+    HIPCHK(h, hipStreamSynchronize(h->s_seed));
     *out = b;
     return GPSBB_OK;
 }
@@ -418,7 +432,7 @@ extern "C" size_t gpsbb_batch_iq_bytes(const gpsbb_batch_t *b)
     return b ? (size_t)b->nblocks * (size_t)b->nsamp * 4 : 0;
 }
 
-static BatchDev batch_dev(const gpsbb_batch *b)
+static BatchDev batch_dev(const gpsbb_batch *b, int set)
 {
     BatchDev p;
     p.ch = b->d_ch.p;
@@ -432,38 +446,52 @@ static BatchDev batch_dev(const gpsbb_batch *b)
     p.flags = b->flags;
     p.tabs = b->h->d_tabs;
     p.ca_bits = b->h->d_ca;
-    p.rows = b->d_rows.p;
+    p.rows = b->d_rows[set].p;
     p.row_off = b->d_row_off.p;
-    p.tile_row = b->d_tile_row.p;
-    p.end = b->d_end.p;
+    p.tile_row = b->d_tile_row[set].p;
+    p.end = b->d_end[set].p;
     p.status = b->h->d_status;
     p.hazards = b->h->d_hz;
     return p;
 }
 
-static int batch_launch(gpsbb_batch *b, int16_t *d_iq, hipStream_t st)
+static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
 {
     gpsbb *h = b->h;
-    const BatchDev p = batch_dev(b);
-    const int nbc = b->nblocks * b->nch;
-    const int cbase = (nbc + 63) / 64 * 64;
-    const int ncarr = (b->flags & GPSBB_CHAIN_CARRIER) ? b->nch : nbc;
+    const int set = (int)(b->run_count & 1u);
+    const size_t nbc = (size_t)b->nblocks * b->nch;
+    HIPCHK(h, (hipError_t)b->d_rows[set].reserve(b->total_rows));
+    HIPCHK(h, (hipError_t)b->d_tile_row[set].reserve(2 * nbc * ((size_t)b->ntiles + 1)));
+    HIPCHK(h, (hipError_t)b->d_end[set].reserve(nbc));
+    if (!b->synth_done[set])
+        HIPCHK(h, hipEventCreateWithFlags(&b->synth_done[set], hipEventDisableTiming));
+    const BatchDev p = batch_dev(b, set);
+    const int cbase = ((int)nbc + 63) / 64 * 64;
+    const int ncarr = (b->flags & GPSBB_CHAIN_CARRIER) ? b->nch : (int)nbc;
     const int lanes = cbase + ncarr;
     if (b->ev_used == b->evs.size()) {
         if (b->evs.size() >= 4096) {
             b->ev_used = 0; /* wrap: only the most recent runs are kept */
         } else {
-            gpsbb_batch::Ev3 t = {{nullptr, nullptr, nullptr}};
+            gpsbb_batch::Ev4 t = {{nullptr, nullptr, nullptr, nullptr}};
             for (auto &e : t.e)
                 HIPCHK(h, hipEventCreate(&e));
             b->evs.push_back(t);
         }
     }
     hipEvent_t *ev = b->evs[b->ev_used++].e;
-    HIPCHK(h, hipEventRecord(ev[0], st));
-    hipLaunchKernelGGL(k_seed, dim3((lanes + 63) / 64), dim3(64), 0, st, p, cbase);
+
+    /* seeding pre-pass on its own stream: it may start as soon as the synthesis kernel that last read
+     * this buffer set (two runs ago) has finished, i.e. it overlaps the previous run's synthesis */
+    if (b->synth_pending[set])
+        HIPCHK(h, hipStreamWaitEvent(h->s_seed, b->synth_done[set], 0));
+    HIPCHK(h, hipEventRecord(ev[0], h->s_seed));
+    hipLaunchKernelGGL(k_seed, dim3((lanes + 63) / 64), dim3(64), 0, h->s_seed, p, cbase);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(ev[1], st));
+    HIPCHK(h, hipEventRecord(ev[1], h->s_seed));
+
+    HIPCHK(h, hipStreamWaitEvent(h->s_compute, ev[1], 0));
+    HIPCHK(h, hipEventRecord(ev[2], h->s_compute));
     {
         /* several tiles per workgroup once the grid is large enough to fill the chip many times over:
          * the per-block LDS tables (amplitude LUT, chips, nav words) are then built once per workgroup */
@@ -471,10 +499,14 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq, hipStream_t st)
         long tpw = ((long)b->ntiles * b->nblocks) / (wg_slots * 6);
         tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
         const int gx = (int)((b->ntiles + tpw - 1) / tpw);
-        hipLaunchKernelGGL(k_synth, dim3(gx, b->nblocks), dim3(TILE_THREADS), sizeof(SynthLds), st, p, d_iq);
+        hipLaunchKernelGGL(k_synth, dim3(gx, b->nblocks), dim3(TILE_THREADS), sizeof(SynthLds), h->s_compute, p, d_iq);
     }
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(ev[2], st));
+    HIPCHK(h, hipEventRecord(ev[3], h->s_compute));
+    HIPCHK(h, hipEventRecord(b->synth_done[set], h->s_compute));
+    b->synth_pending[set] = true;
+    b->last_set = set;
+    b->run_count++;
     b->ran = true;
     return GPSBB_OK;
 }
@@ -492,7 +524,7 @@ extern "C" int gpsbb_batch_run(gpsbb_batch_t *b, int16_t *d_iq)
     } else {
         b->last_iq = nullptr;
     }
-    return batch_launch(b, d_iq, h->s_compute);
+    return batch_launch(b, d_iq);
 }
 
 extern "C" int16_t *gpsbb_batch_device_iq(gpsbb_batch_t *b) { return b ? b->last_iq : nullptr; }
@@ -502,6 +534,7 @@ extern "C" int gpsbb_sync(gpsbb_t *h)
     if (!h)
         return GPSBB_E_BADARG;
     HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->s_seed));
     HIPCHK(h, hipStreamSynchronize(h->s_compute));
     HIPCHK(h, hipStreamSynchronize(h->s_copy));
     uint32_t st = 0;
@@ -525,7 +558,7 @@ extern "C" int gpsbb_batch_read(gpsbb_batch_t *b, int16_t *iq_out, gpsbb_chan_st
         HIPCHK(h, hipMemcpy(iq_out, b->last_iq, gpsbb_batch_iq_bytes(b), hipMemcpyDeviceToHost));
     }
     if (end_state)
-        HIPCHK(h, hipMemcpy(end_state, b->d_end.p, (size_t)b->nblocks * b->nch * sizeof(gpsbb_chan_state_t),
+        HIPCHK(h, hipMemcpy(end_state, b->d_end[b->last_set].p, (size_t)b->nblocks * b->nch * sizeof(gpsbb_chan_state_t),
                             hipMemcpyDeviceToHost));
     return GPSBB_OK;
 }
@@ -552,8 +585,8 @@ extern "C" int gpsbb_batch_last_timing(gpsbb_batch_t *b, float *ms_seed, float *
     hipEvent_t *ev = b->evs[b->ev_used - 1].e;
     float a = 0, c = 0, t = 0;
     HIPCHK(h, hipEventElapsedTime(&a, ev[0], ev[1]));
-    HIPCHK(h, hipEventElapsedTime(&c, ev[1], ev[2]));
-    HIPCHK(h, hipEventElapsedTime(&t, ev[0], ev[2]));
+    HIPCHK(h, hipEventElapsedTime(&c, ev[2], ev[3]));
+    HIPCHK(h, hipEventElapsedTime(&t, ev[0], ev[3]));
     if (ms_seed) *ms_seed = a;
     if (ms_synth) *ms_synth = c;
     if (ms_total) *ms_total = t;
@@ -571,8 +604,8 @@ extern "C" int gpsbb_batch_timing_stats(gpsbb_batch_t *b, int *nruns, float *ms_
         hipEvent_t *ev = b->evs[k].e;
         float a = 0, c = 0, t = 0;
         HIPCHK(h, hipEventElapsedTime(&a, ev[0], ev[1]));
-        HIPCHK(h, hipEventElapsedTime(&c, ev[1], ev[2]));
-        HIPCHK(h, hipEventElapsedTime(&t, ev[0], ev[2]));
+        HIPCHK(h, hipEventElapsedTime(&c, ev[2], ev[3]));
+        HIPCHK(h, hipEventElapsedTime(&t, ev[0], ev[3]));
         sa += a;
         sc += c;
         stt += t;
@@ -626,7 +659,7 @@ extern "C" int gpsbb_fill_block(gpsbb_t *h, const gpsbb_chan_t *ch, int nch, dou
     gpsbb_batch *b = h->scratch;
     b->prev_ch = nullptr;
     b->prev_end = nullptr;
-    int rc = batch_setup(b, ch, 1, nch, delt, nsamp, 0, h->s_compute);
+    int rc = batch_setup(b, ch, 1, nch, delt, nsamp, 0, h->s_seed);
     if (rc != GPSBB_OK)
         return rc;
     rc = gpsbb_batch_run(b, nullptr);
@@ -634,7 +667,7 @@ extern "C" int gpsbb_fill_block(gpsbb_t *h, const gpsbb_chan_t *ch, int nch, dou
         return rc;
     HIPCHK(h, hipMemcpyAsync(iq_out, b->last_iq, (size_t)nsamp * 4, hipMemcpyDeviceToHost, h->s_compute));
     if (end_state)
-        HIPCHK(h, hipMemcpyAsync(end_state, b->d_end.p, (size_t)nch * sizeof(gpsbb_chan_state_t),
+        HIPCHK(h, hipMemcpyAsync(end_state, b->d_end[b->last_set].p, (size_t)nch * sizeof(gpsbb_chan_state_t),
                                  hipMemcpyDeviceToHost, h->s_compute));
     return gpsbb_sync(h);
 }
@@ -714,6 +747,7 @@ extern "C" void gpsbb_stream_destroy(gpsbb_stream_t *s)
     if (!s)
         return;
     (void)hipSetDevice(s->h->device);
+    (void)hipStreamSynchronize(s->h->s_seed);
     (void)hipStreamSynchronize(s->h->s_compute);
     (void)hipStreamSynchronize(s->h->s_copy);
     for (auto &sl : s->slots) {
@@ -778,7 +812,7 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     auto &sl = s->slots[s->head % s->depth];
     gpsbb_batch *b = sl.batch;
     /* the slot's previous D2H copy was waited for by the pop that freed it */
-    int rc = batch_setup(b, ch, s->bps, s->nch, s->delt, s->nsamp, s->flags, h->s_compute);
+    int rc = batch_setup(b, ch, s->bps, s->nch, s->delt, s->nsamp, s->flags, h->s_seed);
     if (rc != GPSBB_OK)
         return rc;
     b->prev_ch = nullptr;
@@ -788,17 +822,17 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
          * end state is complete before this push's seeding kernel runs) */
         gpsbb_batch *pb = s->slots[(s->head - 1) % s->depth].batch;
         b->prev_ch = pb->d_ch.p + (size_t)(pb->nblocks - 1) * pb->nch;
-        b->prev_end = pb->d_end.p + (size_t)(pb->nblocks - 1) * pb->nch;
+        b->prev_end = pb->d_end[pb->last_set].p + (size_t)(pb->nblocks - 1) * pb->nch;
     }
     b->last_iq = b->d_iq.p;
-    rc = batch_launch(b, b->d_iq.p, h->s_compute);
+    rc = batch_launch(b, b->d_iq.p);
     if (rc != GPSBB_OK)
         return rc;
     HIPCHK(h, hipEventRecord(sl.computed, h->s_compute));
     /* gather on the side stream: pinned, asynchronous, overlaps the next push's kernels */
     HIPCHK(h, hipStreamWaitEvent(h->s_copy, sl.computed, 0));
     HIPCHK(h, hipMemcpyAsync(sl.h_iq, b->d_iq.p, (size_t)s->bps * s->nsamp * 4, hipMemcpyDeviceToHost, h->s_copy));
-    HIPCHK(h, hipMemcpyAsync(sl.h_end, b->d_end.p, (size_t)s->bps * s->nch * sizeof(gpsbb_chan_state_t),
+    HIPCHK(h, hipMemcpyAsync(sl.h_end, b->d_end[b->last_set].p, (size_t)s->bps * s->nch * sizeof(gpsbb_chan_state_t),
                              hipMemcpyDeviceToHost, h->s_copy));
     HIPCHK(h, hipEventRecord(sl.copied, h->s_copy));
     s->head++;

@@ -497,7 +497,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
          * the per-block LDS tables (amplitude LUT, chips, nav words) are then built once per workgroup */
         const long wg_slots = (long)(h->sm_count > 0 ? h->sm_count : 256) * 2;
         long tpw = ((long)b->ntiles * b->nblocks) / (wg_slots * 6);
-        tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
+        tpw = tpw < 1 ? 1 : (tpw > 16 ? 16 : tpw);
         const int gx = (int)((b->ntiles + tpw - 1) / tpw);
         hipLaunchKernelGGL(k_synth, dim3(gx, b->nblocks), dim3(TILE_THREADS), sizeof(SynthLds), h->s_compute, p, d_iq);
     }

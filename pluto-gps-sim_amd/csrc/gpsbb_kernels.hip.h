@@ -36,7 +36,10 @@
 namespace gpsbb_impl {
 
 constexpr int TILE_THREADS = 512;           /* 8 wave64 per workgroup */
-constexpr int SPT = 16;                     /* consecutive samples per lane: 64 bytes of output */
+#ifndef GPSBB_SPT
+#define GPSBB_SPT 16
+#endif
+constexpr int SPT = GPSBB_SPT;              /* consecutive samples per lane (128 bytes of output at 32) */
 constexpr int TILE = TILE_THREADS * SPT;    /* samples per tile (one workgroup pass) */
 constexpr int SYNTH_ROW_CAP = 1024;         /* rows of all chains of one tile staged in LDS (24 KB) */
 
@@ -244,6 +247,8 @@ struct SynthLds {
     uint32_t dwrd[GPSBB_MAX_CHAN][GPSBB_N_DWRD]; /* nav words                                          */
     double sc[GPSBB_MAX_CHAN];                  /* f_code*delt                                         */
     double sk512[GPSBB_MAX_CHAN];               /* f_carr*delt*512 (carrier phase is walked scaled by 512: exact) */
+    double xlim[GPSBB_MAX_CHAN];                /* a run starting below this code phase cannot reach 1023     */
+    double ylo[GPSBB_MAX_CHAN], yhi[GPSBB_MAX_CHAN]; /* ... strictly inside (ylo, yhi): no carrier wrap       */
     /* the tile's slice of the row tables, structure-of-arrays */
     uint64_t rxb[SYNTH_ROW_CAP];
     int64_t rinc[SYNTH_ROW_CAP];
@@ -267,8 +272,11 @@ __device__ __forceinline__ uint64_t row_state_global(const NcoRow *__restrict__ 
 
 __device__ __forceinline__ uint64_t row_state_lds(const SynthLds &L, int r, int n, uint32_t *nav)
 {
-    while (L.rn0[r + 1] <= n)
+    if (L.rn0[r + 1] <= n) { /* most tiles hold a single row of a chain: the scan is the rare path */
         r++;
+        while (L.rn0[r + 1] <= n)
+            r++;
+    }
     *nav = L.rnav[r];
     return L.rxb[r] + (uint64_t)((int64_t)(n - L.rn0[r]) * L.rinc[r]);
 }
@@ -281,44 +289,74 @@ __device__ __forceinline__ double hi_lo_f64(int hi, int lo) { return __hiloint2d
  * updates are then single IEEE adds.  WRAPS = true is the reference's full update
  * (plutogpssim.c:2709-2746) with the comparisons done on the high dword of the double.
  */
+constexpr int WALK_G = 8; /* samples whose LDS lookups are in flight together */
+
+/* dataBit handling inside one run: a run of SPT samples crosses at most one code-period boundary
+ * (a period is >= 666 samples under the contract f_code*delt <= 1.5), hence at most one data-bit change:
+ * samples j < jw use dbx0, the others dbx1 (XOR masks, see walk_channel). */
+struct RunNav {
+    uint32_t nav;
+    int dbx0, dbx1, jw;
+};
+
+/* phase 1 of a group: table indices of WALK_G samples, both NCOs advanced (two chains of IEEE adds) */
+template <bool WRAPS>
+__device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc, double sk, double &xc, double &yk,
+                                             RunNav &rn, int (&it)[WALK_G], int (&ci)[WALK_G], int jbase, int nvalid,
+                                             unsigned long long &hz_itable)
+{
+#pragma unroll
+    for (int u = 0; u < WALK_G; u++) {
+        it[u] = (int)yk; /* floor(carr_phase*512), c:2697 (yk = carr_phase*512 >= 0) */
+        if (WRAPS && it[u] > 511) { /* carr_phase == 1.0: latent OOB of the reference, defined as &511 */
+            it[u] &= 511;
+            if (jbase + u < nvalid)
+                hz_itable++;
+        }
+        ci[u] = (int)xc; /* c:2737 */
+        xc = add_rn(xc, sc); /* c:2709 */
+        yk = add_rn(yk, sk); /* c:2741, scaled by 512 */
+        if (WRAPS) {
+            if (__double2hiint(xc) >= 0x408FF800) { /* xc >= 1023.0 (xc >= 0) */
+                xc = add_rn(xc, -1023.0);
+                rn.nav = nav_advance(rn.nav);
+                if (nav_icode(rn.nav) == 0) { /* c:2717-2733: new data bit from the next sample on */
+                    rn.dbx1 = nav_bit(L.dwrd[i], rn.nav) < 0 ? 0xfffe : 0;
+                    rn.jw = jbase + u + 1;
+                }
+            }
+            const int h = __double2hiint(yk);
+            const int adj = h >= 0x40800000 ? (int)0xC0800000 : (h < 0 ? 0x40800000 : 0); /* -512 / +512 / 0 */
+            yk = add_rn(yk, hi_lo_f64(adj, 0)); /* c:2743-2746; adding +0.0 is exact */
+        }
+    }
+}
+
+/*
+ * SPT consecutive samples of one channel.  WRAPS = false is the straight-line version used when no lane
+ * of the wavefront can reach a code or carrier wrap inside its run (decided by the caller): the NCO
+ * updates are then single IEEE adds.  WRAPS = true is the reference's full update
+ * (plutogpssim.c:2709-2746) with the comparisons done on the high dword of the double.
+ * Software-pipelined by hand: the LDS reads of group k are issued, then the indices of group k+1 are
+ * computed (pure VALU, covers the LDS latency), then group k is accumulated.
+ */
 template <bool WRAPS>
 __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc, double yk, uint32_t nav,
                                              v2s (&acc)[SPT], int nvalid, unsigned long long &hz_itable)
 {
+    constexpr int G = WALK_G;
     const double sc = L.sc[i], sk = L.sk512[i];
     const uint32_t *__restrict__ amp = L.amp[i];
     const int8_t *__restrict__ chip = L.chip[i];
     /* codeCA*dataBit: chip sign (+1/-1) XOR-ed with 0xfffe when dataBit = -1 flips +-1 in 16 bits */
-    int dbx = nav_bit(L.dwrd[i], nav) < 0 ? 0xfffe : 0;
-    constexpr int G = 8; /* samples whose LDS lookups are in flight together */
+    RunNav rn;
+    rn.nav = nav;
+    rn.dbx0 = rn.dbx1 = nav_bit(L.dwrd[i], nav) < 0 ? 0xfffe : 0;
+    rn.jw = SPT;
+    int it[G], ci[G];
+    walk_indices<WRAPS>(L, i, sc, sk, xc, yk, rn, it, ci, 0, nvalid, hz_itable);
 #pragma unroll
     for (int j0 = 0; j0 < SPT; j0 += G) {
-        int it[G], ci[G], dbs[G];
-        /* phase 1: table indices of G samples, NCOs advanced (two dependent chains of IEEE adds) */
-#pragma unroll
-        for (int u = 0; u < G; u++) {
-            it[u] = (int)yk; /* floor(carr_phase*512), c:2697 (yk = carr_phase*512 >= 0) */
-            if (WRAPS && it[u] > 511) { /* carr_phase == 1.0: latent OOB of the reference, defined as &511 */
-                it[u] &= 511;
-                if (j0 + u < nvalid)
-                    hz_itable++;
-            }
-            ci[u] = (int)xc; /* c:2737 */
-            dbs[u] = dbx;
-            xc = add_rn(xc, sc); /* c:2709 */
-            yk = add_rn(yk, sk); /* c:2741, scaled by 512 */
-            if (WRAPS) {
-                if (__double2hiint(xc) >= 0x408FF800) { /* xc >= 1023.0 (xc >= 0) */
-                    xc = add_rn(xc, -1023.0);
-                    nav = nav_advance(nav);
-                    if (nav_icode(nav) == 0)
-                        dbx = nav_bit(L.dwrd[i], nav) < 0 ? 0xfffe : 0;
-                }
-                const int h = __double2hiint(yk);
-                const int adj = h >= 0x40800000 ? (int)0xC0800000 : (h < 0 ? 0x40800000 : 0); /* -512 / +512 / 0 */
-                yk = add_rn(yk, hi_lo_f64(adj, 0)); /* c:2743-2746; adding +0.0 is exact */
-            }
-        }
         __builtin_amdgcn_sched_barrier(0);
         /* phase 2: 2*G LDS reads issued back to back */
         uint32_t av[G];
@@ -329,13 +367,17 @@ __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc
             cv[u] = (int)chip[ci[u]];
         }
         __builtin_amdgcn_sched_barrier(0);
+        /* phase 1 of the next group while the reads are in flight */
+        if (j0 + G < SPT)
+            walk_indices<WRAPS>(L, i, sc, sk, xc, yk, rn, it, ci, j0 + G, nvalid, hz_itable);
+        __builtin_amdgcn_sched_barrier(0);
         /* phase 3: acc += amp * (codeCA*dataBit), packed int16x2 (c:2701-2706) */
 #pragma unroll
         for (int u = 0; u < G; u++) {
-            const short sg = (short)(cv[u] ^ (WRAPS ? dbs[u] : dbx));
+            const int dbx = WRAPS ? (j0 + u < rn.jw ? rn.dbx0 : rn.dbx1) : rn.dbx0;
+            const short sg = (short)(cv[u] ^ dbx);
             acc[j0 + u] += u32_v2s(av[u]) * v2s{sg, sg};
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -357,8 +399,15 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void k_synth(BatchDev p, int16_t *
         L.nact = na;
     }
     if (tid < p.nch) {
-        L.sc[tid] = mul_rn(cb[tid].f_code, p.delt);
-        L.sk512[tid] = mul_rn(mul_rn(cb[tid].f_carr, p.delt), 512.0);
+        const double sc = mul_rn(cb[tid].f_code, p.delt);
+        const double sk = mul_rn(mul_rn(cb[tid].f_carr, p.delt), 512.0);
+        L.sc[tid] = sc;
+        L.sk512[tid] = sk;
+        /* (SPT+2) steps of margin: the accumulated rounding of SPT adds is far below one step */
+        const double span = (double)(SPT + 2);
+        L.xlim[tid] = 1023.0 - span * sc;
+        L.yhi[tid] = sk > 0.0 ? 512.0 - span * sk : 512.0;
+        L.ylo[tid] = sk < 0.0 ? -span * sk : -1.0;
     }
     for (int e = tid; e < p.nch * 512; e += TILE_THREADS) {
         const int i = e >> 9, k = e & 511;
@@ -455,11 +504,8 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void k_synth(BatchDev p, int16_t *
                 const double xc = bits_f64(xcb);
                 const double yk = mul_rn(bits_f64(xkb), 512.0); /* exact */
 
-                /* can any lane of this wavefront wrap inside its run?  (SPT+2) steps of margin */
-                const double sc = L.sc[i], sk = L.sk512[i];
-                const double span = (double)(SPT + 2);
-                const double y_end = yk + span * sk;
-                const bool may_wrap = !(xc + span * sc < 1023.0) || !(y_end < 512.0) || !(y_end > 0.0) || !(yk < 512.0);
+                /* can any lane of this wavefront wrap inside its run? */
+                const bool may_wrap = !(xc < L.xlim[i]) || !(yk < L.yhi[i]) || !(yk > L.ylo[i]);
                 if (__any(may_wrap))
                     walk_channel<true>(L, i, xc, yk, nav, acc, nvalid, hz_itable);
                 else

@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--blocks", type=int, default=40, help="0.1 s blocks per step and GPU")
+    ap.add_argument("--blocks", type=int, default=400, help="0.1 s blocks per step and GPU")
     ap.add_argument("--nch", type=int, default=16)
     ap.add_argument("--fs", type=float, default=25e6)
     ap.add_argument("--nsamp", type=int, default=2500000)

@@ -12,7 +12,7 @@ tail -5 "$OUT/pytest_gpu.log"
 timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 3000 "$OUT/bench.json"
 # per-kernel time (same command as the bench, fewer steps, no CPU leg)
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o trace -- python "$OLDPWD/bench.py" --steps 5 --warmup 1 --no-cpu > "$OLDPWD/$OUT/prof_stdout.log" 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o trace -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu > "$OLDPWD/$OUT/prof_stdout.log" 2>&1 )
 find "$OUT/prof" -name "*kernel_stats*" | head -3
 f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cat "$f"
 # HBM write bytes: counters in their own pass, kernel-trace only

@@ -351,3 +351,20 @@ def synth_descriptors(nblocks, nch=16, seed=0x5EED, max_doppler=5000.0):
     ch["icode"] = (g.u32((nblocks, nch)) % np.uint64(20)).astype(np.int32)
     ch["dwrd"] = (g.u32((nblocks, nch, N_DWRD)) & np.uint64(0x3FFFFFFF)).astype(np.uint32)
     return ch
+
+
+# ---- time sharding (one process per GPU, no data-path collective) ------------------------------------
+
+def shard_blocks(nblocks, rank, world):
+    """Contiguous block range [b0, b1) of rank `rank` out of `world` (BASELINE configs[4]: GPU g gets blocks
+    [g*B/G, (g+1)*B/G))."""
+    return (nblocks * rank) // world, (nblocks * (rank + 1)) // world
+
+
+def shard_descriptors(ch, rank, world, delt, nsamp, nthreads=0):
+    """Descriptors of this rank's time shard with the exact carrier phase seeded at every block start, so
+    the shard can be synthesised without the preceding blocks (gpsbb_chain_carrier_host)."""
+    ch = _as_chan(ch).copy()
+    ch["carr_phase"] = chain_carrier_host(ch, delt, nsamp, nthreads)
+    b0, b1 = shard_blocks(ch.shape[0], rank, world)
+    return ch[b0:b1]

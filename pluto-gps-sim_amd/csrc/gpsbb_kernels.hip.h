@@ -283,10 +283,18 @@ __device__ __forceinline__ uint64_t row_state_lds(const SynthLds &L, int r, int 
 
 __device__ __forceinline__ double hi_lo_f64(int hi, int lo) { return __hiloint2double(hi, lo); }
 
+/* a 64-bit value known to be equal in all lanes, moved to scalar registers */
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 /*
- * SPT consecutive samples of one channel.  WRAPS = false is the straight-line version used when no lane
- * of the wavefront can reach a code or carrier wrap inside its run (decided by the caller): the NCO
- * updates are then single IEEE adds.  WRAPS = true is the reference's full update
+ * SPT consecutive samples of one channel.  CODEW / CARRW = false are the straight-line versions used when
+ * no lane of the wavefront can reach a code / carrier wrap inside its run (decided by the caller): that
+ * NCO's update is then a single IEEE add.  With the flag set it is the reference's full update
  * (plutogpssim.c:2709-2746) with the comparisons done on the high dword of the double.
  */
 constexpr int WALK_G = 8; /* samples whose LDS lookups are in flight together */
@@ -300,7 +308,7 @@ struct RunNav {
 };
 
 /* phase 1 of a group: table indices of WALK_G samples, both NCOs advanced (two chains of IEEE adds) */
-template <bool WRAPS>
+template <bool CODEW, bool CARRW>
 __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc, double sk, double &xc, double &yk,
                                              RunNav &rn, int (&it)[WALK_G], int (&ci)[WALK_G], int jbase, int nvalid,
                                              unsigned long long &hz_itable)
@@ -308,7 +316,7 @@ __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc
 #pragma unroll
     for (int u = 0; u < WALK_G; u++) {
         it[u] = (int)yk; /* floor(carr_phase*512), c:2697 (yk = carr_phase*512 >= 0) */
-        if (WRAPS && it[u] > 511) { /* carr_phase == 1.0: latent OOB of the reference, defined as &511 */
+        if (CARRW && it[u] > 511) { /* carr_phase == 1.0: latent OOB of the reference, defined as &511 */
             it[u] &= 511;
             if (jbase + u < nvalid)
                 hz_itable++;
@@ -316,7 +324,7 @@ __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc
         ci[u] = (int)xc; /* c:2737 */
         xc = add_rn(xc, sc); /* c:2709 */
         yk = add_rn(yk, sk); /* c:2741, scaled by 512 */
-        if (WRAPS) {
+        if (CODEW) {
             if (__double2hiint(xc) >= 0x408FF800) { /* xc >= 1023.0 (xc >= 0) */
                 xc = add_rn(xc, -1023.0);
                 rn.nav = nav_advance(rn.nav);
@@ -325,6 +333,8 @@ __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc
                     rn.jw = jbase + u + 1;
                 }
             }
+        }
+        if (CARRW) {
             const int h = __double2hiint(yk);
             const int adj = h >= 0x40800000 ? (int)0xC0800000 : (h < 0 ? 0x40800000 : 0); /* -512 / +512 / 0 */
             yk = add_rn(yk, hi_lo_f64(adj, 0)); /* c:2743-2746; adding +0.0 is exact */
@@ -333,14 +343,14 @@ __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc
 }
 
 /*
- * SPT consecutive samples of one channel.  WRAPS = false is the straight-line version used when no lane
- * of the wavefront can reach a code or carrier wrap inside its run (decided by the caller): the NCO
- * updates are then single IEEE adds.  WRAPS = true is the reference's full update
+ * SPT consecutive samples of one channel.  CODEW / CARRW = false are the straight-line versions used when
+ * no lane of the wavefront can reach a code / carrier wrap inside its run (decided by the caller): that
+ * NCO's update is then a single IEEE add.  With the flag set it is the reference's full update
  * (plutogpssim.c:2709-2746) with the comparisons done on the high dword of the double.
  * Software-pipelined by hand: the LDS reads of group k are issued, then the indices of group k+1 are
  * computed (pure VALU, covers the LDS latency), then group k is accumulated.
  */
-template <bool WRAPS>
+template <bool CODEW, bool CARRW>
 __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc, double yk, uint32_t nav,
                                              v2s (&acc)[SPT], int nvalid, unsigned long long &hz_itable)
 {
@@ -354,7 +364,7 @@ __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc
     rn.dbx0 = rn.dbx1 = nav_bit(L.dwrd[i], nav) < 0 ? 0xfffe : 0;
     rn.jw = SPT;
     int it[G], ci[G];
-    walk_indices<WRAPS>(L, i, sc, sk, xc, yk, rn, it, ci, 0, nvalid, hz_itable);
+    walk_indices<CODEW, CARRW>(L, i, sc, sk, xc, yk, rn, it, ci, 0, nvalid, hz_itable);
 #pragma unroll
     for (int j0 = 0; j0 < SPT; j0 += G) {
         __builtin_amdgcn_sched_barrier(0);
@@ -369,12 +379,12 @@ __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc
         __builtin_amdgcn_sched_barrier(0);
         /* phase 1 of the next group while the reads are in flight */
         if (j0 + G < SPT)
-            walk_indices<WRAPS>(L, i, sc, sk, xc, yk, rn, it, ci, j0 + G, nvalid, hz_itable);
+            walk_indices<CODEW, CARRW>(L, i, sc, sk, xc, yk, rn, it, ci, j0 + G, nvalid, hz_itable);
         __builtin_amdgcn_sched_barrier(0);
         /* phase 3: acc += amp * (codeCA*dataBit), packed int16x2 (c:2701-2706) */
 #pragma unroll
         for (int u = 0; u < G; u++) {
-            const int dbx = WRAPS ? (j0 + u < rn.jw ? rn.dbx0 : rn.dbx1) : rn.dbx0;
+            const int dbx = CODEW ? (j0 + u < rn.jw ? rn.dbx0 : rn.dbx1) : rn.dbx0;
             const short sg = (short)(cv[u] ^ dbx);
             acc[j0 + u] += u32_v2s(av[u]) * v2s{sg, sg};
         }
@@ -421,11 +431,19 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void k_synth(BatchDev p, int16_t *
         }
         L.amp[i][k] = v;
     }
-    for (int e = tid; e < p.nch * 1024; e += TILE_THREADS) {
-        const int i = e >> 10, c = e & 1023;
+    for (int e = tid; e < p.nch * 32; e += TILE_THREADS) { /* one dword of 32 chips per lane */
+        const int i = e >> 5, wd = e & 31;
         const int prn = cb[i].prn;
-        const uint32_t w = prn > 0 ? p.ca_bits[prn * 32 + (c >> 5)] : 0u;
-        L.chip[i][c] = (int8_t)(((w >> (c & 31)) & 1u) ? 1 : -1);
+        const uint32_t w = prn > 0 ? p.ca_bits[prn * 32 + wd] : 0u;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&L.chip[i][wd * 32]);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                v |= (((w >> (4 * q + k)) & 1u) ? 0x01u : 0xffu) << (8 * k);
+            dst[q] = v;
+        }
     }
     for (int e = tid; e < p.nch * GPSBB_N_DWRD; e += TILE_THREADS) {
         const int i = e / GPSBB_N_DWRD, w = e % GPSBB_N_DWRD;
@@ -489,13 +507,44 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void k_synth(BatchDev p, int16_t *
             const int nvalid = p.nsamp - n0 < SPT ? p.nsamp - n0 : SPT;
             unsigned long long hz_itable = 0;
 
+            /* first and last run start of this wavefront (wave-uniform) */
+            const int wn0 = __builtin_amdgcn_readfirstlane(n0);
+            const int wnl = wn0 + 63 * SPT;
+            const int lane = (n0 - wn0) / SPT;
+
             for (int a = 0; a < nact; a++) {
                 const int i = L.act[a];
                 uint32_t nav, nav_unused;
                 uint64_t xcb, xkb;
                 if (in_lds) {
-                    xcb = row_state_lds(L, L.rbase[2 * a], n0, &nav);
-                    xkb = row_state_lds(L, L.rbase[2 * a + 1], n0, &nav_unused);
+                    /* Rows are thousands of samples long, so all 64 runs of a wavefront normally sit in the
+                     * same row of a chain: find that row once per wavefront with wave-uniform values and
+                     * derive each lane's state as base + lane*(SPT*inc). */
+                    int rc = __builtin_amdgcn_readfirstlane(L.rbase[2 * a]);
+                    int rk = __builtin_amdgcn_readfirstlane(L.rbase[2 * a + 1]);
+                    int nxc = __builtin_amdgcn_readfirstlane(L.rn0[rc + 1]);
+                    while (nxc <= wn0) {
+                        rc++;
+                        nxc = __builtin_amdgcn_readfirstlane(L.rn0[rc + 1]);
+                    }
+                    int nxk = __builtin_amdgcn_readfirstlane(L.rn0[rk + 1]);
+                    while (nxk <= wn0) {
+                        rk++;
+                        nxk = __builtin_amdgcn_readfirstlane(L.rn0[rk + 1]);
+                    }
+                    if (nxc > wnl && nxk > wnl) {
+                        const uint64_t cb = uniform_u64(L.rxb[rc]), kb = uniform_u64(L.rxb[rk]);
+                        const int64_t cinc = (int64_t)uniform_u64((uint64_t)L.rinc[rc]);
+                        const int64_t kinc = (int64_t)uniform_u64((uint64_t)L.rinc[rk]);
+                        const int dc = wn0 - __builtin_amdgcn_readfirstlane(L.rn0[rc]);
+                        const int dk = wn0 - __builtin_amdgcn_readfirstlane(L.rn0[rk]);
+                        nav = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.rnav[rc]);
+                        xcb = (cb + (uint64_t)((int64_t)dc * cinc)) + (uint64_t)lane * (uint64_t)(cinc * SPT);
+                        xkb = (kb + (uint64_t)((int64_t)dk * kinc)) + (uint64_t)lane * (uint64_t)(kinc * SPT);
+                    } else {
+                        xcb = row_state_lds(L, rc, n0, &nav);
+                        xkb = row_state_lds(L, rk, n0, &nav_unused);
+                    }
                 } else {
                     const int cc = chain_code(p, b, i), ck = chain_carr(p, b, i);
                     xcb = row_state_global(p.rows + p.row_off[cc], p.tile_row[(size_t)cc * (p.ntiles + 1) + tile], n0, &nav);
@@ -505,11 +554,16 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void k_synth(BatchDev p, int16_t *
                 const double yk = mul_rn(bits_f64(xkb), 512.0); /* exact */
 
                 /* can any lane of this wavefront wrap inside its run? */
-                const bool may_wrap = !(xc < L.xlim[i]) || !(yk < L.yhi[i]) || !(yk > L.ylo[i]);
-                if (__any(may_wrap))
-                    walk_channel<true>(L, i, xc, yk, nav, acc, nvalid, hz_itable);
+                const bool code_w = __any(!(xc < L.xlim[i]));
+                const bool carr_w = __any(!(yk < L.yhi[i]) || !(yk > L.ylo[i]));
+                if (!code_w && !carr_w)
+                    walk_channel<false, false>(L, i, xc, yk, nav, acc, nvalid, hz_itable);
+                else if (!code_w)
+                    walk_channel<false, true>(L, i, xc, yk, nav, acc, nvalid, hz_itable);
+                else if (!carr_w)
+                    walk_channel<true, false>(L, i, xc, yk, nav, acc, nvalid, hz_itable);
                 else
-                    walk_channel<false>(L, i, xc, yk, nav, acc, nvalid, hz_itable);
+                    walk_channel<true, true>(L, i, xc, yk, nav, acc, nvalid, hz_itable);
             }
             if (hz_itable)
                 atomicAdd(p.hazards, hz_itable);

@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--fs", type=float, default=25e6)
     ap.add_argument("--nsamp", type=int, default=2500000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--synth-only", action="store_true",
+                    help="measurement aid: after warm-up re-run only k_synth on the tables already built")
     args = ap.parse_args()
 
     import torch  # first: it brings the HIP runtime the library then shares
@@ -104,6 +106,9 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if args.synth_only:
+        pkg.lib().gpsbb_test_skip_seed(1)
+        args.warmup = max(args.warmup, 2)
     for _ in range(args.warmup):
         batch.run(out.data_ptr())
     barrier()

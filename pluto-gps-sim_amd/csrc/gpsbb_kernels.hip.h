@@ -40,8 +40,9 @@ constexpr int TILE_THREADS = 512;           /* 8 wave64 per workgroup */
 #define GPSBB_SPT 16
 #endif
 constexpr int SPT = GPSBB_SPT;              /* consecutive samples per lane (128 bytes of output at 32) */
-constexpr int TILE = TILE_THREADS * SPT;    /* samples per tile (one workgroup pass) */
-constexpr int SYNTH_ROW_CAP = 1024;         /* rows of all chains of one tile staged in LDS (24 KB) */
+constexpr int TILE = 64 * SPT;              /* samples per tile = one pass of one wavefront (the row-index granule) */
+constexpr int WAVES_PER_WG = TILE_THREADS / 64;
+constexpr int WAVE_ROW_CAP = 128;           /* rows of all chains of one tile staged in a wavefront's LDS slice */
 
 constexpr uint32_t ST_ROW_OVERFLOW = 1u;
 
@@ -240,6 +241,14 @@ __device__ __forceinline__ uint32_t v2s_u32(v2s v)
     return u;
 }
 
+/* a wavefront's private slice of LDS: the rows of every chain that overlap its current tile (SoA) */
+struct WaveRows {
+    uint64_t xb[WAVE_ROW_CAP];
+    int64_t inc[WAVE_ROW_CAP];
+    int32_t n0[WAVE_ROW_CAP];
+    uint32_t nav[WAVE_ROW_CAP];
+};
+
 /* LDS image of one workgroup (dynamic shared memory, 16-byte aligned carve) */
 struct SynthLds {
     uint32_t amp[GPSBB_MAX_CHAN][512];          /* int16x2: lo = I (cos*gain), hi = Q (sin*gain)      */
@@ -249,15 +258,10 @@ struct SynthLds {
     double sk512[GPSBB_MAX_CHAN];               /* f_carr*delt*512 (carrier phase is walked scaled by 512: exact) */
     double xlim[GPSBB_MAX_CHAN];                /* a run starting below this code phase cannot reach 1023     */
     double ylo[GPSBB_MAX_CHAN], yhi[GPSBB_MAX_CHAN]; /* ... strictly inside (ylo, yhi): no carrier wrap       */
-    /* the tile's slice of the row tables, structure-of-arrays */
-    uint64_t rxb[SYNTH_ROW_CAP];
-    int64_t rinc[SYNTH_ROW_CAP];
-    int32_t rn0[SYNTH_ROW_CAP];
-    uint32_t rnav[SYNTH_ROW_CAP];
-    int32_t rbase[2 * GPSBB_MAX_CHAN];          /* first staged row of chain (a, kind)                 */
+    WaveRows wr[WAVES_PER_WG];
+    uint64_t roff[2 * GPSBB_MAX_CHAN];          /* first pool row of chain (a, kind) of this block     */
     int32_t act[GPSBB_MAX_CHAN];
     int32_t nact;
-    int32_t rows_in_lds;
 };
 
 /* state of one NCO at sample n, scanning forward from row r (global-memory fallback) */
@@ -270,15 +274,12 @@ __device__ __forceinline__ uint64_t row_state_global(const NcoRow *__restrict__ 
     return row.xb + (uint64_t)((int64_t)(n - row.n0) * row.inc);
 }
 
-__device__ __forceinline__ uint64_t row_state_lds(const SynthLds &L, int r, int n, uint32_t *nav)
+__device__ __forceinline__ uint64_t row_state_lds(const WaveRows &W, int r, int n, uint32_t *nav)
 {
-    if (L.rn0[r + 1] <= n) { /* most tiles hold a single row of a chain: the scan is the rare path */
+    while (W.n0[r + 1] <= n)
         r++;
-        while (L.rn0[r + 1] <= n)
-            r++;
-    }
-    *nav = L.rnav[r];
-    return L.rxb[r] + (uint64_t)((int64_t)(n - L.rn0[r]) * L.rinc[r]);
+    *nav = W.nav[r];
+    return W.xb[r] + (uint64_t)((int64_t)(n - W.n0[r]) * W.inc[r]);
 }
 
 __device__ __forceinline__ double hi_lo_f64(int hi, int lo) { return __hiloint2double(hi, lo); }
@@ -399,7 +400,6 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void k_synth(BatchDev p, int16_t *
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const gpsbb_chan_t *__restrict__ cb = p.ch + (size_t)b * p.nch;
-
     /* ---- stage the block's per-channel tables in LDS (once per workgroup) ---- */
     if (tid == 0) {
         int na = 0;
@@ -449,56 +449,61 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void k_synth(BatchDev p, int16_t *
         const int i = e / GPSBB_N_DWRD, w = e % GPSBB_N_DWRD;
         L.dwrd[i][w] = cb[i].dwrd[w];
     }
+    if (tid < 2 * p.nch) {
+        const int i = tid >> 1;
+        L.roff[tid] = p.row_off[(tid & 1) ? chain_carr(p, b, i) : chain_code(p, b, i)];
+    }
     __syncthreads();
     const int nact = L.nact;
 
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-        /* ---- stage this tile's slice of the row tables: chain (a, kind) is copied by 16 lanes ---- */
-        __syncthreads(); /* previous tile's readers are done */
-        if (tid < 64) {
-            /* one wave: row counts of the 2*nact chains and their exclusive prefix sum */
-            int cnt = 0;
-            if (tid < 2 * nact) {
-                const int i = L.act[tid >> 1];
-                const int chain = (tid & 1) ? chain_carr(p, b, i) : chain_code(p, b, i);
-                const int32_t *tr = p.tile_row + (size_t)chain * (p.ntiles + 1);
-                cnt = tr[tile + 1] - tr[tile] + 2; /* rows r0..r1 plus the terminator of the scan */
-            }
-            int incl = cnt;
+    /* ---- from here on every wavefront works alone: tile after tile, no workgroup barrier ---- */
+    const int wave = tid >> 6, lane = tid & 63;
+    WaveRows &W = L.wr[wave];
+    const int ntw = p.ntiles;
+    for (int wt = blockIdx.x * WAVES_PER_WG + wave; wt < ntw; wt += gridDim.x * WAVES_PER_WG) {
+        /* -- stage the rows that overlap this tile: lane c copies chain c = (channel c>>1, kind c&1) -- */
+        int cnt = 0, r0 = 0;
+        const NcoRow *__restrict__ src = nullptr;
+        if (lane < 2 * nact) {
+            const int i = L.act[lane >> 1];
+            const int chain = (lane & 1) ? chain_carr(p, b, i) : chain_code(p, b, i);
+            const int32_t *__restrict__ tr = p.tile_row + (size_t)chain * (ntw + 1);
+            r0 = tr[wt];
+            cnt = tr[wt + 1] - r0 + 2; /* rows r0..r1 plus the terminator of the scan */
+            src = p.rows + L.roff[2 * i + (lane & 1)] + r0;
+        }
+        int incl = cnt;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_up(incl, o);
-                if (tid >= o)
-                    incl += t;
-            }
-            if (tid < 2 * nact)
-                L.rbase[tid] = incl - cnt;
-            if (tid == 63)
-                L.rows_in_lds = incl <= SYNTH_ROW_CAP ? 1 : 0;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o)
+                incl += t;
         }
-        __syncthreads();
-        const bool in_lds = L.rows_in_lds != 0;
+        const int base = incl - cnt;
+        const bool in_lds = __shfl(incl, 63) <= WAVE_ROW_CAP;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* the previous tile's readers are done */
         if (in_lds) {
-            const int c = tid >> 4, sub = tid & 15; /* 32 chains x 16 lanes = 512 threads */
-            if (c < 2 * nact) {
-                const int i = L.act[c >> 1];
-                const int chain = (c & 1) ? chain_carr(p, b, i) : chain_code(p, b, i);
-                const int32_t *tr = p.tile_row + (size_t)chain * (p.ntiles + 1);
-                const int r0 = tr[tile], cnt = tr[tile + 1] - r0 + 2;
-                const NcoRow *__restrict__ rows = p.rows + p.row_off[chain] + r0;
-                const int base = L.rbase[c];
-                for (int r = sub; r < cnt; r += 16) {
-                    const NcoRow row = rows[r];
-                    L.rn0[base + r] = row.n0;
-                    L.rnav[base + r] = row.nav;
-                    L.rxb[base + r] = row.xb;
-                    L.rinc[base + r] = row.inc;
-                }
+            for (int r = 0; r < cnt; r += 4) { /* 4 independent 24-byte loads in flight */
+                NcoRow row[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (r + q < cnt)
+                        row[q] = src[r + q];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (r + q < cnt) {
+                        W.n0[base + r + q] = row[q].n0;
+                        W.nav[base + r + q] = row[q].nav;
+                        W.xb[base + r + q] = row[q].xb;
+                        W.inc[base + r + q] = row[q].inc;
+                    }
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* LDS is in order within a wavefront */
 
-        const int n0 = tile * TILE + tid * SPT;
+        const int wn0 = wt * TILE;            /* first run start of this tile (wave-uniform) */
+        const int wnl = wn0 + 63 * SPT;       /* last run start */
+        const int n0 = wn0 + lane * SPT;
         if (n0 < p.nsamp) {
             v2s acc[SPT];
 #pragma unroll
@@ -507,48 +512,36 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void k_synth(BatchDev p, int16_t *
             const int nvalid = p.nsamp - n0 < SPT ? p.nsamp - n0 : SPT;
             unsigned long long hz_itable = 0;
 
-            /* first and last run start of this wavefront (wave-uniform) */
-            const int wn0 = __builtin_amdgcn_readfirstlane(n0);
-            const int wnl = wn0 + 63 * SPT;
-            const int lane = (n0 - wn0) / SPT;
-
             for (int a = 0; a < nact; a++) {
                 const int i = L.act[a];
                 uint32_t nav, nav_unused;
                 uint64_t xcb, xkb;
                 if (in_lds) {
-                    /* Rows are thousands of samples long, so all 64 runs of a wavefront normally sit in the
-                     * same row of a chain: find that row once per wavefront with wave-uniform values and
-                     * derive each lane's state as base + lane*(SPT*inc). */
-                    int rc = __builtin_amdgcn_readfirstlane(L.rbase[2 * a]);
-                    int rk = __builtin_amdgcn_readfirstlane(L.rbase[2 * a + 1]);
-                    int nxc = __builtin_amdgcn_readfirstlane(L.rn0[rc + 1]);
-                    while (nxc <= wn0) {
-                        rc++;
-                        nxc = __builtin_amdgcn_readfirstlane(L.rn0[rc + 1]);
-                    }
-                    int nxk = __builtin_amdgcn_readfirstlane(L.rn0[rk + 1]);
-                    while (nxk <= wn0) {
-                        rk++;
-                        nxk = __builtin_amdgcn_readfirstlane(L.rn0[rk + 1]);
-                    }
+                    /* Rows are thousands of samples long, so the 64 runs of a wavefront often sit in one
+                     * row of a chain: then every lane's state is base + lane*(SPT*inc) from wave-uniform
+                     * values; otherwise each lane scans the few staged rows. */
+                    const int rc = __builtin_amdgcn_readlane(base, 2 * a);
+                    const int rk = __builtin_amdgcn_readlane(base, 2 * a + 1);
+                    const int nxc = __builtin_amdgcn_readfirstlane(W.n0[rc + 1]);
+                    const int nxk = __builtin_amdgcn_readfirstlane(W.n0[rk + 1]);
                     if (nxc > wnl && nxk > wnl) {
-                        const uint64_t cb = uniform_u64(L.rxb[rc]), kb = uniform_u64(L.rxb[rk]);
-                        const int64_t cinc = (int64_t)uniform_u64((uint64_t)L.rinc[rc]);
-                        const int64_t kinc = (int64_t)uniform_u64((uint64_t)L.rinc[rk]);
-                        const int dc = wn0 - __builtin_amdgcn_readfirstlane(L.rn0[rc]);
-                        const int dk = wn0 - __builtin_amdgcn_readfirstlane(L.rn0[rk]);
-                        nav = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.rnav[rc]);
+                        const uint64_t cb = uniform_u64(W.xb[rc]), kb = uniform_u64(W.xb[rk]);
+                        const int64_t cinc = (int64_t)uniform_u64((uint64_t)W.inc[rc]);
+                        const int64_t kinc = (int64_t)uniform_u64((uint64_t)W.inc[rk]);
+                        const int dc = wn0 - __builtin_amdgcn_readfirstlane(W.n0[rc]);
+                        const int dk = wn0 - __builtin_amdgcn_readfirstlane(W.n0[rk]);
+                        nav = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.nav[rc]);
                         xcb = (cb + (uint64_t)((int64_t)dc * cinc)) + (uint64_t)lane * (uint64_t)(cinc * SPT);
                         xkb = (kb + (uint64_t)((int64_t)dk * kinc)) + (uint64_t)lane * (uint64_t)(kinc * SPT);
                     } else {
-                        xcb = row_state_lds(L, rc, n0, &nav);
-                        xkb = row_state_lds(L, rk, n0, &nav_unused);
+                        xcb = row_state_lds(W, rc, n0, &nav);
+                        xkb = row_state_lds(W, rk, n0, &nav_unused);
                     }
                 } else {
+                    /* more rows than the LDS slice holds (very high Doppler / low sample rate): scan in HBM */
                     const int cc = chain_code(p, b, i), ck = chain_carr(p, b, i);
-                    xcb = row_state_global(p.rows + p.row_off[cc], p.tile_row[(size_t)cc * (p.ntiles + 1) + tile], n0, &nav);
-                    xkb = row_state_global(p.rows + p.row_off[ck], p.tile_row[(size_t)ck * (p.ntiles + 1) + tile], n0, &nav_unused);
+                    xcb = row_state_global(p.rows + L.roff[2 * i], p.tile_row[(size_t)cc * (ntw + 1) + wt], n0, &nav);
+                    xkb = row_state_global(p.rows + L.roff[2 * i + 1], p.tile_row[(size_t)ck * (ntw + 1) + wt], n0, &nav_unused);
                 }
                 const double xc = bits_f64(xcb);
                 const double yk = mul_rn(bits_f64(xkb), 512.0); /* exact */

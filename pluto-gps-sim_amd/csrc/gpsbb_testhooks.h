@@ -21,6 +21,9 @@ double gpsbb_test_carr_jump(double x, double s, long long n);
 double gpsbb_test_code_jump(double x, double s, long long n, long long *wraps);
 int gpsbb_test_build_rows(int kind, double x0, double s, unsigned nav0, int nsamp, gpsbb_test_row_t *rows,
                           int cap, double *x_end, unsigned *nav_end);
+/* measurement only: after the first two runs of a batch (both table sets built) skip k_seed, so that
+ * k_synth can be timed alone on unchanged tables */
+void gpsbb_test_skip_seed(int on);
 unsigned long long gpsbb_test_row_bound(int kind, double s_abs, int nsamp);
 
 #ifdef __cplusplus

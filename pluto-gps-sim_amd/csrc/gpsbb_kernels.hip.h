@@ -247,6 +247,8 @@ struct WaveRows {
     int64_t inc[WAVE_ROW_CAP];
     int32_t n0[WAVE_ROW_CAP];
     uint32_t nav[WAVE_ROW_CAP];
+    int32_t cbase[2 * GPSBB_MAX_CHAN]; /* first staged row of chain c (rows that change inside the tile) */
+    int32_t cr0[2 * GPSBB_MAX_CHAN];   /* pool row holding the tile's first sample, for the HBM fallback */
 };
 
 /* LDS image of one workgroup (dynamic shared memory, 16-byte aligned carve) */
@@ -283,6 +285,14 @@ __device__ __forceinline__ uint64_t row_state_lds(const WaveRows &W, int r, int 
 }
 
 __device__ __forceinline__ double hi_lo_f64(int hi, int lo) { return __hiloint2double(hi, lo); }
+
+/* lane `src`'s 64-bit value, broadcast through scalar registers (src is wave-uniform) */
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
 
 /* a 64-bit value known to be equal in all lanes, moved to scalar registers */
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
@@ -456,22 +466,48 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void k_synth(BatchDev p, int16_t *
     __syncthreads();
     const int nact = L.nact;
 
-    /* ---- from here on every wavefront works alone: tile after tile, no workgroup barrier ---- */
+    /* ---- from here on every wavefront works alone: a contiguous range of tiles, no workgroup barrier ---- */
     const int wave = tid >> 6, lane = tid & 63;
     WaveRows &W = L.wr[wave];
     const int ntw = p.ntiles;
-    for (int wt = blockIdx.x * WAVES_PER_WG + wave; wt < ntw; wt += gridDim.x * WAVES_PER_WG) {
-        /* -- stage the rows that overlap this tile: lane c copies chain c = (channel c>>1, kind c&1) -- */
-        int cnt = 0, r0 = 0;
-        const NcoRow *__restrict__ src = nullptr;
-        if (lane < 2 * nact) {
-            const int i = L.act[lane >> 1];
-            const int chain = (lane & 1) ? chain_carr(p, b, i) : chain_code(p, b, i);
-            const int32_t *__restrict__ tr = p.tile_row + (size_t)chain * (ntw + 1);
-            r0 = tr[wt];
-            cnt = tr[wt + 1] - r0 + 2; /* rows r0..r1 plus the terminator of the scan */
-            src = p.rows + L.roff[2 * i + (lane & 1)] + r0;
-        }
+    const int nwaves = gridDim.x * WAVES_PER_WG;
+    const int per_wave = (ntw + nwaves - 1) / nwaves;
+    const int wt_begin = (blockIdx.x * WAVES_PER_WG + wave) * per_wave;
+    const int wt_end = wt_begin + per_wave < ntw ? wt_begin + per_wave : ntw;
+
+    /* lane c serves chain c = (channel c>>1, kind c&1) of this block */
+    const bool has_chain = lane < 2 * nact;
+    int r_first = 0, r_next = 0; /* row holding the first sample of tile wt / wt+1 */
+    if (has_chain && wt_begin < wt_end) {
+        const int i = L.act[lane >> 1];
+        const int32_t *__restrict__ tr =
+            p.tile_row + (size_t)((lane & 1) ? chain_carr(p, b, i) : chain_code(p, b, i)) * (ntw + 1);
+        r_first = tr[wt_begin];
+        r_next = tr[wt_begin + 1];
+    }
+
+    for (int wt = wt_begin; wt < wt_end; wt++) {
+        const int wn0 = wt * TILE;      /* first run start of this tile (wave-uniform) */
+        const int wnl = wn0 + 63 * SPT; /* last run start */
+
+        /* -- the rows of chain `lane` that overlap this tile: r_first..r_next plus the scan terminator -- */
+        const int r0 = r_first;
+        const int cnt = has_chain ? r_next - r0 + 2 : 0;
+        const int ci_ = has_chain ? L.act[lane >> 1] : 0;
+        const NcoRow *__restrict__ src = p.rows + L.roff[2 * ci_ + (lane & 1)] + r0;
+        /* prefetch the row index of the tile after next: a contiguous range per wavefront makes this
+         * tile's r_next the next tile's r_first */
+        int r_after = r_next;
+        if (has_chain && wt + 2 <= ntw)
+            r_after = p.tile_row[(size_t)((lane & 1) ? chain_carr(p, b, ci_) : chain_code(p, b, ci_)) * (ntw + 1) + wt + 2];
+
+        /* first four rows straight into registers (unconditional loads: lanes without a chain and rows
+         * past the end re-read row 0 of a valid region) */
+        NcoRow row[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            row[q] = src[q < cnt ? q : 0];
+
         int incl = cnt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -481,28 +517,47 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void k_synth(BatchDev p, int16_t *
         }
         const int base = incl - cnt;
         const bool in_lds = __shfl(incl, 63) <= WAVE_ROW_CAP;
+
+        /* A chain whose first row covers all 64 run starts of the tile ("uniform", the usual case: rows
+         * are thousands of samples long) needs no table at all: its lanes' states are
+         * ubase + lane*ustep.  Computed here by the chain's lane, broadcast later with v_readlane. */
+        int uni = 0;
+        uint64_t ubase = 0, ustep = 0;
+        uint32_t unav = 0;
+        if (cnt > 0) {
+            uni = row[1].n0 > wnl;
+            ubase = row[0].xb + (uint64_t)((int64_t)(wn0 - row[0].n0) * row[0].inc);
+            ustep = (uint64_t)(row[0].inc * SPT);
+            unav = row[0].nav;
+        }
+
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* the previous tile's readers are done */
-        if (in_lds) {
-            for (int r = 0; r < cnt; r += 4) { /* 4 independent 24-byte loads in flight */
-                NcoRow row[4];
+        if (has_chain) {
+            W.cbase[lane] = base;
+            W.cr0[lane] = r0;
+        }
+        if (in_lds && !__all(uni || cnt == 0)) {
+            /* some chain changes row inside the tile: stage the rows in this wavefront's LDS slice */
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (r + q < cnt)
-                        row[q] = src[r + q];
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (r + q < cnt) {
-                        W.n0[base + r + q] = row[q].n0;
-                        W.nav[base + r + q] = row[q].nav;
-                        W.xb[base + r + q] = row[q].xb;
-                        W.inc[base + r + q] = row[q].inc;
-                    }
+            for (int q = 0; q < 4; q++)
+                if (q < cnt) {
+                    W.n0[base + q] = row[q].n0;
+                    W.nav[base + q] = row[q].nav;
+                    W.xb[base + q] = row[q].xb;
+                    W.inc[base + q] = row[q].inc;
+                }
+            for (int r = 4; r < cnt; r++) {
+                const NcoRow rw = src[r];
+                W.n0[base + r] = rw.n0;
+                W.nav[base + r] = rw.nav;
+                W.xb[base + r] = rw.xb;
+                W.inc[base + r] = rw.inc;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* LDS is in order within a wavefront */
+        r_first = r_next;
+        r_next = r_after;
 
-        const int wn0 = wt * TILE;            /* first run start of this tile (wave-uniform) */
-        const int wnl = wn0 + 63 * SPT;       /* last run start */
         const int n0 = wn0 + lane * SPT;
         if (n0 < p.nsamp) {
             v2s acc[SPT];
@@ -516,32 +571,22 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void k_synth(BatchDev p, int16_t *
                 const int i = L.act[a];
                 uint32_t nav, nav_unused;
                 uint64_t xcb, xkb;
-                if (in_lds) {
-                    /* Rows are thousands of samples long, so the 64 runs of a wavefront often sit in one
-                     * row of a chain: then every lane's state is base + lane*(SPT*inc) from wave-uniform
-                     * values; otherwise each lane scans the few staged rows. */
-                    const int rc = __builtin_amdgcn_readlane(base, 2 * a);
-                    const int rk = __builtin_amdgcn_readlane(base, 2 * a + 1);
-                    const int nxc = __builtin_amdgcn_readfirstlane(W.n0[rc + 1]);
-                    const int nxk = __builtin_amdgcn_readfirstlane(W.n0[rk + 1]);
-                    if (nxc > wnl && nxk > wnl) {
-                        const uint64_t cb = uniform_u64(W.xb[rc]), kb = uniform_u64(W.xb[rk]);
-                        const int64_t cinc = (int64_t)uniform_u64((uint64_t)W.inc[rc]);
-                        const int64_t kinc = (int64_t)uniform_u64((uint64_t)W.inc[rk]);
-                        const int dc = wn0 - __builtin_amdgcn_readfirstlane(W.n0[rc]);
-                        const int dk = wn0 - __builtin_amdgcn_readfirstlane(W.n0[rk]);
-                        nav = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.nav[rc]);
-                        xcb = (cb + (uint64_t)((int64_t)dc * cinc)) + (uint64_t)lane * (uint64_t)(cinc * SPT);
-                        xkb = (kb + (uint64_t)((int64_t)dk * kinc)) + (uint64_t)lane * (uint64_t)(kinc * SPT);
-                    } else {
-                        xcb = row_state_lds(W, rc, n0, &nav);
-                        xkb = row_state_lds(W, rk, n0, &nav_unused);
-                    }
+                const int uc = __builtin_amdgcn_readlane(uni, 2 * a);
+                const int uk = __builtin_amdgcn_readlane(uni, 2 * a + 1);
+                if (uc) {
+                    xcb = readlane_u64(ubase, 2 * a) + (uint64_t)lane * readlane_u64(ustep, 2 * a);
+                    nav = (uint32_t)__builtin_amdgcn_readlane((int)unav, 2 * a);
+                } else if (in_lds) {
+                    xcb = row_state_lds(W, W.cbase[2 * a], n0, &nav);
+                } else { /* more rows than the LDS slice holds (very high Doppler / low sample rate): scan in HBM */
+                    xcb = row_state_global(p.rows + L.roff[2 * i], W.cr0[2 * a], n0, &nav);
+                }
+                if (uk) {
+                    xkb = readlane_u64(ubase, 2 * a + 1) + (uint64_t)lane * readlane_u64(ustep, 2 * a + 1);
+                } else if (in_lds) {
+                    xkb = row_state_lds(W, W.cbase[2 * a + 1], n0, &nav_unused);
                 } else {
-                    /* more rows than the LDS slice holds (very high Doppler / low sample rate): scan in HBM */
-                    const int cc = chain_code(p, b, i), ck = chain_carr(p, b, i);
-                    xcb = row_state_global(p.rows + L.roff[2 * i], p.tile_row[(size_t)cc * (ntw + 1) + wt], n0, &nav);
-                    xkb = row_state_global(p.rows + L.roff[2 * i + 1], p.tile_row[(size_t)ck * (ntw + 1) + wt], n0, &nav_unused);
+                    xkb = row_state_global(p.rows + L.roff[2 * i + 1], W.cr0[2 * a + 1], n0, &nav_unused);
                 }
                 const double xc = bits_f64(xcb);
                 const double yk = mul_rn(bits_f64(xkb), 512.0); /* exact */

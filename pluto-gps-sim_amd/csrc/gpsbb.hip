@@ -948,15 +948,8 @@ extern "C" int gpsbb_test_build_rows(int kind, double x0, double s, unsigned nav
 {
     HostSink sink{rows, cap, 0, 0};
     uint32_t nav = nav0;
-    double x;
-    if (kind & 2) { /* bit 1: the tabulated variant the device pre-pass uses */
-        NcoTabHost tab;
-        x = (kind & 1) == NCO_CODE ? build_rows_tab<NCO_CODE>(x0, s, nav, nsamp, sink, tab)
-                                   : build_rows_tab<NCO_CARR>(x0, s, nav, nsamp, sink, tab);
-    } else {
-        x = kind == NCO_CODE ? build_rows<NCO_CODE>(x0, s, nav, nsamp, sink)
-                             : build_rows<NCO_CARR>(x0, s, nav, nsamp, sink);
-    }
+    double x = kind == NCO_CODE ? build_rows<NCO_CODE>(x0, s, nav, nsamp, sink)
+                                : build_rows<NCO_CARR>(x0, s, nav, nsamp, sink);
     if (x_end)
         *x_end = x;
     if (nav_end)
@@ -966,5 +959,5 @@ extern "C" int gpsbb_test_build_rows(int kind, double x0, double s, unsigned nav
 
 extern "C" unsigned long long gpsbb_test_row_bound(int kind, double s_abs, int nsamp)
 {
-    return (kind & 1) == NCO_CODE ? row_bound(s_abs, 1023.0, 9, nsamp) : row_bound(s_abs, 1.0, -1, nsamp);
+    return kind == NCO_CODE ? row_bound(s_abs, 1023.0, 9, nsamp) : row_bound(s_abs, 1.0, -1, nsamp);
 }

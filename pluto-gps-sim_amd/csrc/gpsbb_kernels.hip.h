@@ -139,27 +139,7 @@ __device__ __forceinline__ RowSink make_sink(const BatchDev &p, int chain)
     return s;
 }
 
-/* regular_run()'s per-binade constants of one chain: one LDS column per lane of the (single-wave) workgroup */
-struct SeedTabLds {
-    uint64_t q_[NCO_TAB_D + 1][64];
-    double r_[NCO_TAB_D + 1][64];
-    uint32_t t_[NCO_TAB_D + 1][64];
-};
-struct SeedTab {
-    SeedTabLds *m;
-    int lane;
-    __device__ __forceinline__ uint64_t q(int d) const { return m->q_[d][lane]; }
-    __device__ __forceinline__ double rcp(int d) const { return m->r_[d][lane]; }
-    __device__ __forceinline__ uint32_t tie(int d) const { return m->t_[d][lane]; }
-    __device__ __forceinline__ void set(int d, uint64_t q, double r, uint32_t t)
-    {
-        m->q_[d][lane] = q;
-        m->r_[d][lane] = r;
-        m->t_[d][lane] = t;
-    }
-};
-
-__device__ inline void seed_code_chain(const BatchDev &p, int b, int i, SeedTab &tab)
+__device__ inline void seed_code_chain(const BatchDev &p, int b, int i)
 {
     const gpsbb_chan_t &c = p.ch[(size_t)b * p.nch + i];
     gpsbb_chan_state_t &e = p.end[(size_t)b * p.nch + i];
@@ -172,7 +152,7 @@ __device__ inline void seed_code_chain(const BatchDev &p, int b, int i, SeedTab 
     RowSink sink = make_sink(p, chain_code(p, b, i));
     uint32_t nav = nav_pack(c.icode, c.ibit, c.iword);
     const double s = mul_rn(c.f_code, p.delt); /* plutogpssim.c:2709: f_code * delt, rounded on its own */
-    const double x = build_rows_tab<NCO_CODE>(c.code_phase, s, nav, p.nsamp, sink, tab);
+    const double x = build_rows<NCO_CODE>(c.code_phase, s, nav, p.nsamp, sink);
     sink.finish();
     if (sink.overflow)
         atomicOr(p.status, ST_ROW_OVERFLOW);
@@ -186,7 +166,7 @@ __device__ inline void seed_code_chain(const BatchDev &p, int b, int i, SeedTab 
     e._pad = 0;
 }
 
-__device__ inline double seed_carr_chain(const BatchDev &p, int b, int i, double x0, SeedTab &tab)
+__device__ inline double seed_carr_chain(const BatchDev &p, int b, int i, double x0)
 {
     const gpsbb_chan_t &c = p.ch[(size_t)b * p.nch + i];
     gpsbb_chan_state_t &e = p.end[(size_t)b * p.nch + i];
@@ -197,7 +177,7 @@ __device__ inline double seed_carr_chain(const BatchDev &p, int b, int i, double
     RowSink sink = make_sink(p, chain_carr(p, b, i));
     uint32_t nav = 0;
     const double s = mul_rn(c.f_carr, p.delt); /* plutogpssim.c:2741 */
-    const double x = build_rows_tab<NCO_CARR>(x0, s, nav, p.nsamp, sink, tab);
+    const double x = build_rows<NCO_CARR>(x0, s, nav, p.nsamp, sink);
     sink.finish();
     if (sink.overflow)
         atomicOr(p.status, ST_ROW_OVERFLOW);
@@ -209,14 +189,10 @@ __device__ inline double seed_carr_chain(const BatchDev &p, int b, int i, double
  * wave so that the two kinds of chain never share a wavefront). */
 __global__ __launch_bounds__(64) void k_seed(BatchDev p, int cbase)
 {
-    __shared__ SeedTabLds tab_lds;
-    SeedTab tab;
-    tab.m = &tab_lds;
-    tab.lane = threadIdx.x;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nbc = p.nblocks * p.nch;
     if (gid < nbc) {
-        seed_code_chain(p, gid / p.nch, gid % p.nch, tab);
+        seed_code_chain(p, gid / p.nch, gid % p.nch);
         return;
     }
     const int g = gid - cbase;
@@ -237,14 +213,14 @@ __global__ __launch_bounds__(64) void k_seed(BatchDev p, int cbase)
         for (int b = 0; b < p.nblocks; b++) {
             const gpsbb_chan_t &c = p.ch[(size_t)b * p.nch + g];
             const double x0 = (c.prn > 0 && c.prn == prev_prn) ? prev_x : c.carr_phase;
-            prev_x = seed_carr_chain(p, b, g, x0, tab);
+            prev_x = seed_carr_chain(p, b, g, x0);
             prev_prn = c.prn > 0 ? c.prn : 0;
         }
     } else {
         if (g >= nbc)
             return;
         const int b = g / p.nch, i = g % p.nch;
-        seed_carr_chain(p, b, i, p.ch[(size_t)b * p.nch + i].carr_phase, tab);
+        seed_carr_chain(p, b, i, p.ch[(size_t)b * p.nch + i].carr_phase);
     }
 }
 

@@ -232,142 +232,6 @@ GPSBB_HD int64_t regular_run(uint64_t xb, uint64_t sb, int64_t kcap, int64_t &in
 }
 
 /*
- * Per-chain table of regular_run()'s binade constants.  The increment of a regular run depends only on
- * the step s and on d = (x's binade) - (s's binade); a chain revisits the same ~15 binades on every lap,
- * so q (ties already resolved to the even neighbour) and 1/q are tabulated once per chain for
- * d = 1..NCO_TAB_D and the per-row work shrinks to a lookup, a multiply and a remainder fix-up.
- * `Tab` provides q(d), rcp(d), tie(d) (read) and set(d, q, rcp, tie) — plain arrays on the host, one
- * LDS column per lane on the device.
- */
-constexpr int NCO_TAB_D = 24;
-
-template <class Tab>
-GPSBB_HD void nco_table_build(uint64_t sb, Tab &tab)
-{
-    const uint64_t sabs = sb & F64_ABS;
-    int es = (int)(sabs >> 52);
-    uint64_t Ms = sabs & F64_MANT;
-    if (es == 0)
-        es = 1;
-    else
-        Ms |= F64_HID;
-    for (int d = 1; d <= NCO_TAB_D; d++) {
-        uint64_t q = Ms >> d;
-        const uint64_t r = Ms & ((1ull << d) - 1);
-        const uint64_t half = 1ull << (d - 1);
-        uint32_t tie = 0;
-        if (r > half)
-            q++;
-        else if (r == half) {
-            tie = 1;
-            q += (q & 1); /* even mantissa + tie: the even neighbour (odd mantissas take an explicit step) */
-        }
-        tab.set(d, q, q ? 1.0 / (double)q : 0.0, tie);
-    }
-}
-
-/* floor(a / q) given rcp ~ 1/q (any accuracy better than ~2^-30 is enough: the remainder fix-up makes the
- * result exact); saturates at 2^40 like div_floor_53 */
-GPSBB_HD uint64_t div_floor_rcp(uint64_t a, uint64_t q, double rcp)
-{
-    const double kd = (double)a * rcp;
-    if (kd >= 1099511627776.0)
-        return 1ull << 40;
-    uint64_t k = (uint64_t)kd;
-    int64_t rem = (int64_t)a - (int64_t)(k * q);
-    while (rem < 0) {
-        k--;
-        rem += (int64_t)q;
-    }
-    while (rem >= (int64_t)q) {
-        k++;
-        rem -= (int64_t)q;
-    }
-    return k;
-}
-
-/* regular_run() with the binade constants taken from `tab`; identical results (tests compare them) */
-template <int KIND, class Tab>
-GPSBB_HD int64_t regular_run_tab(uint64_t xb, uint64_t sb, int64_t kcap, int64_t &inc, const Tab &tab)
-{
-    const uint64_t sabs = sb & F64_ABS;
-    int es = (int)(sabs >> 52);
-    if (es == 0)
-        es = 1;
-    const int ex = (int)((xb >> 52) & 0x7ff);
-    const int d = ex - es;
-    if (sabs == 0 || d > NCO_TAB_D || ex == 0 || (xb >> 63))
-        return regular_run<KIND>(xb, sb, kcap, inc); /* rare shapes: the untabulated path */
-    inc = 0;
-    if (KIND == NCO_CARR ? ex >= 1023 : ex >= 1023 + 10)
-        return 0;
-    if (d <= 0)
-        return 0;
-    const uint64_t M = (xb & F64_MANT) | F64_HID;
-    if (tab.tie(d) && (M & 1))
-        return 0;
-    const uint64_t q = tab.q(d);
-    const bool sneg = (sb >> 63) != 0;
-    if (q == 0) {
-        if (sneg && M == F64_HID)
-            return 0;
-        return kcap;
-    }
-    int64_t k;
-    if (!sneg) {
-        uint64_t Mlim = (F64_HID << 1) - 1;
-        if (KIND == NCO_CODE && ex == 1023 + 9)
-            Mlim = CODE_WRAP_M - 1;
-        if (M + q > Mlim)
-            return 0;
-        inc = (int64_t)q;
-        k = (int64_t)div_floor_rcp(Mlim - M, q, tab.rcp(d));
-    } else {
-        const uint64_t Mmin = F64_HID + 1;
-        if (M < Mmin + q)
-            return 0;
-        inc = -(int64_t)q;
-        k = (int64_t)div_floor_rcp(M - Mmin, q, tab.rcp(d));
-    }
-    return k < kcap ? k : kcap;
-}
-
-/* host-side table */
-struct NcoTabHost {
-    uint64_t q_[NCO_TAB_D + 1];
-    double r_[NCO_TAB_D + 1];
-    uint32_t t_[NCO_TAB_D + 1];
-    GPSBB_HD uint64_t q(int d) const { return q_[d]; }
-    GPSBB_HD double rcp(int d) const { return r_[d]; }
-    GPSBB_HD uint32_t tie(int d) const { return t_[d]; }
-    GPSBB_HD void set(int d, uint64_t q, double r, uint32_t t)
-    {
-        q_[d] = q;
-        r_[d] = r;
-        t_[d] = t;
-    }
-};
-
-struct RunPlain { /* run functor: no table */
-    uint64_t sb;
-    template <int KIND>
-    GPSBB_HD int64_t run(uint64_t xb, int64_t kcap, int64_t &inc) const
-    {
-        return regular_run<KIND>(xb, sb, kcap, inc);
-    }
-};
-template <class Tab>
-struct RunTab { /* run functor: tabulated */
-    uint64_t sb;
-    const Tab *tab;
-    template <int KIND>
-    GPSBB_HD int64_t run(uint64_t xb, int64_t kcap, int64_t &inc) const
-    {
-        return regular_run_tab<KIND>(xb, sb, kcap, inc, *tab);
-    }
-};
-
-/*
  * Advance a carrier NCO by n steps exactly (no rows emitted): used by the host chaining helper and by
  * tests.  O(number of regular runs) instead of O(n).
  */
@@ -434,14 +298,15 @@ struct NcoRow {
  * data bit boundary is crossed (icode rolled over to 0), mirroring the reference's dataBit fetch at
  * plutogpssim.c:2732.  Returns the state after nsamp steps.
  */
-template <int KIND, class Sink, class Run>
-GPSBB_HD double build_rows_with(double x, double s, uint32_t &nav, int nsamp, Sink &sink, const Run &runner)
+template <int KIND, class Sink>
+GPSBB_HD double build_rows(double x, double s, uint32_t &nav, int nsamp, Sink &sink)
 {
+    const uint64_t sb = f64_bits(s);
     int64_t n = 0;
     while (n < nsamp) {
         int64_t inc;
         uint64_t xb = f64_bits(x);
-        const int64_t k = runner.template run<KIND>(xb, (int64_t)nsamp - n, inc);
+        const int64_t k = regular_run<KIND>(xb, sb, (int64_t)nsamp - n, inc);
         sink.row((int32_t)n, nav, xb, inc);
         if (k > 0) {
             xb += (uint64_t)(k * inc);
@@ -472,24 +337,6 @@ GPSBB_HD double build_rows_with(double x, double s, uint32_t &nav, int nsamp, Si
         }
     }
     return x;
-}
-
-template <int KIND, class Sink>
-GPSBB_HD double build_rows(double x, double s, uint32_t &nav, int nsamp, Sink &sink)
-{
-    RunPlain r;
-    r.sb = f64_bits(s);
-    return build_rows_with<KIND>(x, s, nav, nsamp, sink, r);
-}
-
-template <int KIND, class Sink, class Tab>
-GPSBB_HD double build_rows_tab(double x, double s, uint32_t &nav, int nsamp, Sink &sink, Tab &tab)
-{
-    RunTab<Tab> r;
-    r.sb = f64_bits(s);
-    r.tab = &tab;
-    nco_table_build(r.sb, tab);
-    return build_rows_with<KIND>(x, s, nav, nsamp, sink, r);
 }
 
 } /* namespace gpsbb_impl */

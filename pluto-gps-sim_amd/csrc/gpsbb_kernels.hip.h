@@ -77,22 +77,25 @@ __device__ __forceinline__ int nav_bit(const P dwrd, uint32_t nav)
     return (int)((dwrd[w] >> (29 - nav_ibit(nav))) & 1u) * 2 - 1;
 }
 
+/* lane `src`'s 64-bit value, broadcast through scalar registers (src is wave-uniform) */
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 /* ---- k_seed -------------------------------------------------------------------------------------- */
 
 struct RowSink {
     NcoRow *rows;
-    uint32_t cap;  /* rows available, not counting the sentinel slot */
+    uint32_t cap; /* rows available, not counting the sentinel slot */
     uint32_t cnt;
-    int32_t *tile_row;
-    int ntiles, next_tile;
     bool overflow;
     unsigned long long *hz;
 
     __device__ __forceinline__ void row(int32_t n0, uint32_t nav, uint64_t xb, int64_t inc)
     {
-        /* tiles that start before this row belong to the previous one */
-        while (next_tile < ntiles && (int64_t)next_tile * TILE < (int64_t)n0)
-            tile_row[next_tile++] = (int32_t)cnt - 1;
         if (cnt < cap) {
             NcoRow r;
             r.n0 = n0;
@@ -112,16 +115,22 @@ struct RowSink {
     }
     __device__ __forceinline__ void finish()
     {
-        while (next_tile <= ntiles)
-            tile_row[next_tile++] = (int32_t)cnt - 1;
-        const uint32_t at = cnt < cap ? cnt : cap;
+        if (cnt > cap)
+            cnt = cap;
         NcoRow r;
         r.n0 = INT32_MAX; /* sentinel: terminates every forward scan */
         r.nav = 0;
         r.xb = 0;
         r.inc = 0;
-        rows[at] = r;
+        rows[cnt] = r;
     }
+};
+
+/* what phase 2 of k_seed needs to know about the chain a lane has just built */
+struct ChainDone {
+    const NcoRow *rows;
+    int32_t *tile_row;
+    int cnt; /* 0 = this lane built nothing */
 };
 
 __device__ __forceinline__ RowSink make_sink(const BatchDev &p, int chain)
@@ -131,25 +140,24 @@ __device__ __forceinline__ RowSink make_sink(const BatchDev &p, int chain)
     s.rows = p.rows + o0;
     s.cap = (uint32_t)(o1 - o0 - 1);
     s.cnt = 0;
-    s.tile_row = p.tile_row + (size_t)chain * (p.ntiles + 1);
-    s.ntiles = p.ntiles;
-    s.next_tile = 0;
     s.overflow = false;
     s.hz = p.hazards;
     return s;
 }
 
-__device__ inline void seed_code_chain(const BatchDev &p, int b, int i)
+__device__ inline ChainDone seed_code_chain(const BatchDev &p, int b, int i)
 {
     const gpsbb_chan_t &c = p.ch[(size_t)b * p.nch + i];
     gpsbb_chan_state_t &e = p.end[(size_t)b * p.nch + i];
+    ChainDone d = {nullptr, nullptr, 0};
     if (c.prn <= 0) {
         e.code_phase = 0.0;
         e.iword = e.ibit = e.icode = e.dataBit = e.codeCA = 0;
         e._pad = 0;
-        return;
+        return d;
     }
-    RowSink sink = make_sink(p, chain_code(p, b, i));
+    const int chain = chain_code(p, b, i);
+    RowSink sink = make_sink(p, chain);
     uint32_t nav = nav_pack(c.icode, c.ibit, c.iword);
     const double s = mul_rn(c.f_code, p.delt); /* plutogpssim.c:2709: f_code * delt, rounded on its own */
     const double x = build_rows<NCO_CODE>(c.code_phase, s, nav, p.nsamp, sink);
@@ -164,17 +172,24 @@ __device__ inline void seed_code_chain(const BatchDev &p, int b, int i)
     const int ci = (int)x;
     e.codeCA = (int)((p.ca_bits[c.prn * 32 + (ci >> 5)] >> (ci & 31)) & 1u) * 2 - 1; /* c:2737 */
     e._pad = 0;
+    d.rows = sink.rows;
+    d.tile_row = p.tile_row + (size_t)chain * (p.ntiles + 1);
+    d.cnt = (int)sink.cnt;
+    return d;
 }
 
-__device__ inline double seed_carr_chain(const BatchDev &p, int b, int i, double x0)
+__device__ inline ChainDone seed_carr_chain(const BatchDev &p, int b, int i, double x0, double *x_end)
 {
     const gpsbb_chan_t &c = p.ch[(size_t)b * p.nch + i];
     gpsbb_chan_state_t &e = p.end[(size_t)b * p.nch + i];
+    ChainDone d = {nullptr, nullptr, 0};
     if (c.prn <= 0) {
         e.carr_phase = 0.0;
-        return 0.0;
+        *x_end = 0.0;
+        return d;
     }
-    RowSink sink = make_sink(p, chain_carr(p, b, i));
+    const int chain = chain_carr(p, b, i);
+    RowSink sink = make_sink(p, chain);
     uint32_t nav = 0;
     const double s = mul_rn(c.f_carr, p.delt); /* plutogpssim.c:2741 */
     const double x = build_rows<NCO_CARR>(x0, s, nav, p.nsamp, sink);
@@ -182,7 +197,59 @@ __device__ inline double seed_carr_chain(const BatchDev &p, int b, int i, double
     if (sink.overflow)
         atomicOr(p.status, ST_ROW_OVERFLOW);
     e.carr_phase = x;
-    return x;
+    *x_end = x;
+    d.rows = sink.rows;
+    d.tile_row = p.tile_row + (size_t)chain * (p.ntiles + 1);
+    d.cnt = (int)sink.cnt;
+    return d;
+}
+
+/*
+ * Phase 2 of k_seed, wave-cooperative: for each chain a lane of this wavefront has just built, fill
+ * tile_row[t] = index of the row holding sample t*TILE (t = 0..ntiles-1) and tile_row[ntiles] = last row.
+ * The 64 lanes split the tiles of one chain evenly (a binary search for the first tile, then a forward
+ * walk), so the cost does not depend on how the rows are distributed.
+ */
+__device__ inline void seed_tile_index(const ChainDone &mine, int ntiles)
+{
+    __threadfence(); /* the rows were written by other lanes of this wavefront */
+    const int lane = threadIdx.x & 63;
+    const int per = (ntiles + 1 + 63) / 64;
+    for (int c = 0; c < 64; c++) {
+        const int cnt = __builtin_amdgcn_readlane(mine.cnt, c);
+        if (cnt == 0)
+            continue;
+        const NcoRow *__restrict__ rows = reinterpret_cast<const NcoRow *>(readlane_u64(reinterpret_cast<uint64_t>(mine.rows), c));
+        int32_t *__restrict__ tr = reinterpret_cast<int32_t *>(readlane_u64(reinterpret_cast<uint64_t>(mine.tile_row), c));
+        const int t0 = lane * per;
+        const int t1 = t0 + per < ntiles + 1 ? t0 + per : ntiles + 1;
+        if (t0 >= t1)
+            continue;
+        /* largest r with rows[r].n0 <= t0*TILE (rows[0].n0 == 0) */
+        const long long s0 = (long long)t0 * TILE;
+        int lo = 0, hi = cnt - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((long long)rows[mid].n0 <= s0)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        int r = lo;
+        int nxt = rows[r + 1].n0; /* the sentinel row terminates the walk */
+        for (int t = t0; t < t1; t++) {
+            if (t == ntiles) {
+                tr[t] = cnt - 1;
+                break;
+            }
+            const int st = t * TILE;
+            while (nxt <= st) {
+                r++;
+                nxt = rows[r + 1].n0;
+            }
+            tr[t] = r;
+        }
+    }
 }
 
 /* grid: lanes [0, nbc) = code chains; lanes [cbase, ...) = carrier chains (cbase = nbc rounded up to a
@@ -191,36 +258,42 @@ __global__ __launch_bounds__(64) void k_seed(BatchDev p, int cbase)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nbc = p.nblocks * p.nch;
-    if (gid < nbc) {
-        seed_code_chain(p, gid / p.nch, gid % p.nch);
+    if (gid < cbase) { /* a wavefront of code chains */
+        ChainDone d = {nullptr, nullptr, 0};
+        if (gid < nbc)
+            d = seed_code_chain(p, gid / p.nch, gid % p.nch);
+        seed_tile_index(d, p.ntiles);
         return;
     }
     const int g = gid - cbase;
-    if (g < 0)
-        return;
     if (p.flags & GPSBB_CHAIN_CARRIER) {
         /* one lane per channel walks the blocks in time order: block b starts where b-1 ended, unless
          * the channel was (re)allocated, in which case the descriptor's own carr_phase applies
          * (allocateChannel, plutogpssim.c:1956-1964) */
-        if (g >= p.nch)
-            return;
         int prev_prn = 0;
         double prev_x = 0.0;
-        if (p.prev_ch && p.prev_end) {
+        if (g < p.nch && p.prev_ch && p.prev_end) {
             prev_prn = p.prev_ch[g].prn;
             prev_x = p.prev_end[g].carr_phase;
         }
         for (int b = 0; b < p.nblocks; b++) {
-            const gpsbb_chan_t &c = p.ch[(size_t)b * p.nch + g];
-            const double x0 = (c.prn > 0 && c.prn == prev_prn) ? prev_x : c.carr_phase;
-            prev_x = seed_carr_chain(p, b, g, x0);
-            prev_prn = c.prn > 0 ? c.prn : 0;
+            ChainDone d = {nullptr, nullptr, 0};
+            if (g < p.nch) {
+                const gpsbb_chan_t &c = p.ch[(size_t)b * p.nch + g];
+                const double x0 = (c.prn > 0 && c.prn == prev_prn) ? prev_x : c.carr_phase;
+                d = seed_carr_chain(p, b, g, x0, &prev_x);
+                prev_prn = c.prn > 0 ? c.prn : 0;
+            }
+            seed_tile_index(d, p.ntiles);
         }
     } else {
-        if (g >= nbc)
-            return;
-        const int b = g / p.nch, i = g % p.nch;
-        seed_carr_chain(p, b, i, p.ch[(size_t)b * p.nch + i].carr_phase);
+        ChainDone d = {nullptr, nullptr, 0};
+        if (g < nbc) {
+            const int b = g / p.nch, i = g % p.nch;
+            double unused;
+            d = seed_carr_chain(p, b, i, p.ch[(size_t)b * p.nch + i].carr_phase, &unused);
+        }
+        seed_tile_index(d, p.ntiles);
     }
 }
 
@@ -285,14 +358,6 @@ __device__ __forceinline__ uint64_t row_state_lds(const WaveRows &W, int r, int 
 }
 
 __device__ __forceinline__ double hi_lo_f64(int hi, int lo) { return __hiloint2double(hi, lo); }
-
-/* lane `src`'s 64-bit value, broadcast through scalar registers (src is wave-uniform) */
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src)
-{
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
-    return ((uint64_t)hi << 32) | lo;
-}
 
 /* a 64-bit value known to be equal in all lanes, moved to scalar registers */
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t v)

@@ -212,22 +212,17 @@ GPSBB_HD int64_t regular_run(uint64_t xb, uint64_t sb, int64_t kcap, int64_t &in
         return kcap;  /* |s| < ulp/2: x + s rounds back to x for ever */
     }
 
-    int64_t k;
-    if (!sneg) {
-        uint64_t Mlim = (F64_HID << 1) - 1;
-        if (KIND == NCO_CODE && ex == 1023 + 9)
-            Mlim = CODE_WRAP_M - 1; /* stay strictly below 1023.0 */
-        if (M + q > Mlim)
-            return 0;
-        inc = (int64_t)q;
-        k = (int64_t)div_floor_53(Mlim - M, q);
-    } else {
-        const uint64_t Mmin = F64_HID + 1; /* stay strictly above the binade's lower edge */
-        if (M < Mmin + q)
-            return 0;
-        inc = -(int64_t)q;
-        k = (int64_t)div_floor_53(M - Mmin, q);
-    }
+    /* distance (in mantissa units) to the edge the run moves towards, written without a branch on the
+     * sign of s: lanes with opposite Doppler signs then stay convergent on the GPU */
+    uint64_t Mlim = (F64_HID << 1) - 1;
+    if (KIND == NCO_CODE && ex == 1023 + 9)
+        Mlim = CODE_WRAP_M - 1; /* stay strictly below 1023.0 */
+    const uint64_t Mmin = F64_HID + 1; /* stay strictly above the binade's lower edge */
+    const uint64_t room = sneg ? (M >= Mmin ? M - Mmin : 0) : (Mlim >= M ? Mlim - M : 0);
+    if ((sneg && M < Mmin) || (!sneg && M > Mlim) || room < q)
+        return 0;
+    inc = sneg ? -(int64_t)q : (int64_t)q;
+    const int64_t k = (int64_t)div_floor_53(room, q);
     return k < kcap ? k : kcap;
 }
 

@@ -185,6 +185,7 @@ struct gpsbb_batch {
      * pre-pass of run k+1 overlaps the synthesis kernel of run k (different streams) */
     DevBuf<NcoRow> d_rows[2];
     DevBuf<int32_t> d_tile_row[2];
+    DevBuf<int32_t> d_row_cnt[2];
     DevBuf<gpsbb_chan_state_t> d_end[2];
     hipEvent_t synth_done[2] = {nullptr, nullptr};
     bool synth_pending[2] = {false, false};
@@ -395,6 +396,7 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
     for (int k = 0; k < 2; k++) {
         b->d_rows[k].release();
         b->d_tile_row[k].release();
+        b->d_row_cnt[k].release();
         b->d_end[k].release();
         if (b->synth_done[k])
             (void)hipEventDestroy(b->synth_done[k]);
@@ -452,6 +454,7 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.rows = b->d_rows[set].p;
     p.row_off = b->d_row_off.p;
     p.tile_row = b->d_tile_row[set].p;
+    p.row_cnt = b->d_row_cnt[set].p;
     p.end = b->d_end[set].p;
     p.status = b->h->d_status;
     p.hazards = b->h->d_hz;
@@ -466,6 +469,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     HIPCHK(h, (hipError_t)b->d_rows[set].reserve(b->total_rows));
     HIPCHK(h, (hipError_t)b->d_tile_row[set].reserve(2 * nbc * ((size_t)b->ntiles + 1)));
     HIPCHK(h, (hipError_t)b->d_end[set].reserve(nbc));
+    HIPCHK(h, (hipError_t)b->d_row_cnt[set].reserve(2 * nbc));
     if (!b->synth_done[set])
         HIPCHK(h, hipEventCreateWithFlags(&b->synth_done[set], hipEventDisableTiming));
     const BatchDev p = batch_dev(b, set);
@@ -490,7 +494,11 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         HIPCHK(h, hipStreamWaitEvent(h->s_seed, b->synth_done[set], 0));
     HIPCHK(h, hipEventRecord(ev[0], h->s_seed));
     if (!(g_test_skip_seed && b->run_count >= 2)) /* measurement hook: time k_synth alone on tables already built */
+    {
         hipLaunchKernelGGL(k_seed, dim3((lanes + 63) / 64), dim3(64), 0, h->s_seed, p, cbase);
+        const long long nthr = 2ll * (long long)nbc * TIDX_PARTS;
+        hipLaunchKernelGGL(k_tile_index, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, h->s_seed, p);
+    }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(ev[1], h->s_seed));
 

@@ -60,6 +60,7 @@ struct BatchDev {
     const uint64_t *row_off;        /* [2*nblocks*nch + 1] first row of each chain in the pool       */
     int32_t *tile_row;              /* [2*nblocks*nch][ntiles+1] row holding each tile's first sample;
                                        entry [ntiles] = the chain's last row                         */
+    int32_t *row_cnt;               /* [2*nblocks*nch] rows each chain produced (0 = inactive)       */
     gpsbb_chan_state_t *end;        /* [nblocks*nch] end-of-block state                              */
     uint32_t *status;               /* self-check word                                               */
     unsigned long long *hazards;    /* [0] itable_512, [1] dwrd_oob                                  */
@@ -204,96 +205,95 @@ __device__ inline ChainDone seed_carr_chain(const BatchDev &p, int b, int i, dou
     return d;
 }
 
-/*
- * Phase 2 of k_seed, wave-cooperative: for each chain a lane of this wavefront has just built, fill
- * tile_row[t] = index of the row holding sample t*TILE (t = 0..ntiles-1) and tile_row[ntiles] = last row.
- * The 64 lanes split the tiles of one chain evenly (a binary search for the first tile, then a forward
- * walk), so the cost does not depend on how the rows are distributed.
- */
-__device__ inline void seed_tile_index(const ChainDone &mine, int ntiles)
-{
-    __threadfence(); /* the rows were written by other lanes of this wavefront */
-    const int lane = threadIdx.x & 63;
-    const int per = (ntiles + 1 + 63) / 64;
-    for (int c = 0; c < 64; c++) {
-        const int cnt = __builtin_amdgcn_readlane(mine.cnt, c);
-        if (cnt == 0)
-            continue;
-        const NcoRow *__restrict__ rows = reinterpret_cast<const NcoRow *>(readlane_u64(reinterpret_cast<uint64_t>(mine.rows), c));
-        int32_t *__restrict__ tr = reinterpret_cast<int32_t *>(readlane_u64(reinterpret_cast<uint64_t>(mine.tile_row), c));
-        const int t0 = lane * per;
-        const int t1 = t0 + per < ntiles + 1 ? t0 + per : ntiles + 1;
-        if (t0 >= t1)
-            continue;
-        /* largest r with rows[r].n0 <= t0*TILE (rows[0].n0 == 0) */
-        const long long s0 = (long long)t0 * TILE;
-        int lo = 0, hi = cnt - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if ((long long)rows[mid].n0 <= s0)
-                lo = mid;
-            else
-                hi = mid - 1;
-        }
-        int r = lo;
-        int nxt = rows[r + 1].n0; /* the sentinel row terminates the walk */
-        for (int t = t0; t < t1; t++) {
-            if (t == ntiles) {
-                tr[t] = cnt - 1;
-                break;
-            }
-            const int st = t * TILE;
-            while (nxt <= st) {
-                r++;
-                nxt = rows[r + 1].n0;
-            }
-            tr[t] = r;
-        }
-    }
-}
-
 /* grid: lanes [0, nbc) = code chains; lanes [cbase, ...) = carrier chains (cbase = nbc rounded up to a
- * wave so that the two kinds of chain never share a wavefront). */
+ * wave so that the two kinds of chain never share a wavefront).  Writes each chain's rows, end state and
+ * row count; the tile index is filled by k_tile_index, massively parallel, afterwards. */
 __global__ __launch_bounds__(64) void k_seed(BatchDev p, int cbase)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nbc = p.nblocks * p.nch;
-    if (gid < cbase) { /* a wavefront of code chains */
-        ChainDone d = {nullptr, nullptr, 0};
-        if (gid < nbc)
-            d = seed_code_chain(p, gid / p.nch, gid % p.nch);
-        seed_tile_index(d, p.ntiles);
+    if (gid < nbc) {
+        const ChainDone d = seed_code_chain(p, gid / p.nch, gid % p.nch);
+        p.row_cnt[chain_code(p, gid / p.nch, gid % p.nch)] = d.cnt;
         return;
     }
     const int g = gid - cbase;
+    if (g < 0)
+        return;
     if (p.flags & GPSBB_CHAIN_CARRIER) {
         /* one lane per channel walks the blocks in time order: block b starts where b-1 ended, unless
          * the channel was (re)allocated, in which case the descriptor's own carr_phase applies
          * (allocateChannel, plutogpssim.c:1956-1964) */
+        if (g >= p.nch)
+            return;
         int prev_prn = 0;
         double prev_x = 0.0;
-        if (g < p.nch && p.prev_ch && p.prev_end) {
+        if (p.prev_ch && p.prev_end) {
             prev_prn = p.prev_ch[g].prn;
             prev_x = p.prev_end[g].carr_phase;
         }
         for (int b = 0; b < p.nblocks; b++) {
-            ChainDone d = {nullptr, nullptr, 0};
-            if (g < p.nch) {
-                const gpsbb_chan_t &c = p.ch[(size_t)b * p.nch + g];
-                const double x0 = (c.prn > 0 && c.prn == prev_prn) ? prev_x : c.carr_phase;
-                d = seed_carr_chain(p, b, g, x0, &prev_x);
-                prev_prn = c.prn > 0 ? c.prn : 0;
-            }
-            seed_tile_index(d, p.ntiles);
+            const gpsbb_chan_t &c = p.ch[(size_t)b * p.nch + g];
+            const double x0 = (c.prn > 0 && c.prn == prev_prn) ? prev_x : c.carr_phase;
+            const ChainDone d = seed_carr_chain(p, b, g, x0, &prev_x);
+            p.row_cnt[chain_carr(p, b, g)] = d.cnt;
+            prev_prn = c.prn > 0 ? c.prn : 0;
         }
     } else {
-        ChainDone d = {nullptr, nullptr, 0};
-        if (g < nbc) {
-            const int b = g / p.nch, i = g % p.nch;
-            double unused;
-            d = seed_carr_chain(p, b, i, p.ch[(size_t)b * p.nch + i].carr_phase, &unused);
+        if (g >= nbc)
+            return;
+        const int b = g / p.nch, i = g % p.nch;
+        double unused;
+        const ChainDone d = seed_carr_chain(p, b, i, p.ch[(size_t)b * p.nch + i].carr_phase, &unused);
+        p.row_cnt[chain_carr(p, b, i)] = d.cnt;
+    }
+}
+
+/*
+ * tile_row[chain][t] = index of the row holding sample t*TILE (t = 0..ntiles-1), [ntiles] = last row.
+ * 64 lanes per chain, each a contiguous slice of the tiles: binary search for the first one, then a
+ * forward walk.  One thread per (chain, slice): ~2 M independent threads for the headline batch.
+ */
+constexpr int TIDX_PARTS = 64;
+__global__ __launch_bounds__(256) void k_tile_index(BatchDev p)
+{
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int chain = (int)(id / TIDX_PARTS), part = (int)(id % TIDX_PARTS);
+    if (chain >= 2 * p.nblocks * p.nch)
+        return;
+    const int cnt = p.row_cnt[chain];
+    if (cnt == 0)
+        return;
+    const NcoRow *__restrict__ rows = p.rows + p.row_off[chain];
+    int32_t *__restrict__ tr = p.tile_row + (size_t)chain * (p.ntiles + 1);
+    const int per = (p.ntiles + 1 + TIDX_PARTS - 1) / TIDX_PARTS;
+    const int t0 = part * per;
+    const int t1 = t0 + per < p.ntiles + 1 ? t0 + per : p.ntiles + 1;
+    if (t0 >= t1)
+        return;
+    /* largest r with rows[r].n0 <= t0*TILE (rows[0].n0 == 0) */
+    const long long s0 = (long long)t0 * TILE;
+    int lo = 0, hi = cnt - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((long long)rows[mid].n0 <= s0)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    int r = lo;
+    int nxt = rows[r + 1].n0; /* the sentinel row terminates the walk */
+    for (int t = t0; t < t1; t++) {
+        if (t == p.ntiles) {
+            tr[t] = cnt - 1;
+            break;
         }
-        seed_tile_index(d, p.ntiles);
+        const int st = t * TILE;
+        while (nxt <= st) {
+            r++;
+            nxt = rows[r + 1].n0;
+        }
+        tr[t] = r;
     }
 }
 

@@ -566,11 +566,11 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void k_synth(BatchDev p, int16_t *
         if (has_chain && wt + 2 <= ntw)
             r_after = p.tile_row[(size_t)((lane & 1) ? chain_carr(p, b, ci_) : chain_code(p, b, ci_)) * (ntw + 1) + wt + 2];
 
-        /* first four rows straight into registers (unconditional loads: lanes without a chain and rows
-         * past the end re-read row 0 of a valid region) */
-        NcoRow row[4];
+        /* the first two rows straight into registers (unconditional loads: lanes without a chain re-read
+         * row 0 of a valid region); they decide whether the chain is uniform over this tile */
+        NcoRow row[2];
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int q = 0; q < 2; q++)
             row[q] = src[q < cnt ? q : 0];
 
         int incl = cnt;
@@ -604,14 +604,14 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void k_synth(BatchDev p, int16_t *
         if (in_lds && !__all(uni || cnt == 0)) {
             /* some chain changes row inside the tile: stage the rows in this wavefront's LDS slice */
 #pragma unroll
-            for (int q = 0; q < 4; q++)
+            for (int q = 0; q < 2; q++)
                 if (q < cnt) {
                     W.n0[base + q] = row[q].n0;
                     W.nav[base + q] = row[q].nav;
                     W.xb[base + q] = row[q].xb;
                     W.inc[base + q] = row[q].inc;
                 }
-            for (int r = 4; r < cnt; r++) {
+            for (int r = 2; r < cnt; r++) {
                 const NcoRow rw = src[r];
                 W.n0[base + r] = rw.n0;
                 W.nav[base + r] = rw.nav;

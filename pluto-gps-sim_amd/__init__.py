@@ -368,3 +368,107 @@ def shard_descriptors(ch, rank, world, delt, nsamp, nthreads=0):
     ch["carr_phase"] = chain_carrier_host(ch, delt, nsamp, nthreads)
     b0, b1 = shard_blocks(ch.shape[0], rank, world)
     return ch[b0:b1]
+
+
+# ---- host front end (include/gpsfe.h): RINEX-2 + position/motion -> per-block descriptors -------------
+
+FE_LIB_PATH = os.path.join(HERE, "libgpsfe.so")
+_fe_lib = None
+
+
+class _FeConfig(C.Structure):
+    _fields_ = [("navfile", C.c_char_p), ("motion_file", C.c_char_p), ("use_ecef", C.c_int),
+                ("pos", C.c_double * 3), ("have_start", C.c_int), ("y", C.c_int), ("m", C.c_int),
+                ("d", C.c_int), ("hh", C.c_int), ("mm", C.c_int), ("sec", C.c_double),
+                ("time_overwrite", C.c_int), ("iono_disable", C.c_int), ("max_chan", C.c_int)]
+
+
+def build_frontend(force=False):
+    src = os.path.join(HERE, "host", "gpsfe.c")
+    if force or not os.path.exists(FE_LIB_PATH) or os.path.getmtime(src) > os.path.getmtime(FE_LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "host")])
+    return FE_LIB_PATH
+
+
+def fe_lib():
+    global _fe_lib
+    if _fe_lib is None:
+        if not os.path.exists(FE_LIB_PATH):
+            raise RuntimeError("libgpsfe.so is not built (make -C %s/host)" % HERE)
+        L = C.CDLL(FE_LIB_PATH)
+        L.gpsfe_open.argtypes = [C.POINTER(_FeConfig), C.POINTER(C.c_void_p)]
+        L.gpsfe_close.argtypes = [C.c_void_p]
+        L.gpsfe_close.restype = None
+        L.gpsfe_strerror.argtypes = [C.c_int]
+        L.gpsfe_strerror.restype = C.c_char_p
+        L.gpsfe_max_chan.argtypes = [C.c_void_p]
+        L.gpsfe_next_block.argtypes = [C.c_void_p, C.c_void_p]
+        L.gpsfe_feed_back.argtypes = [C.c_void_p, C.c_void_p]
+        L.gpsfe_generate.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.gpsfe_time.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.gpsfe_channel_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)] + [C.POINTER(C.c_double)] * 4
+        _fe_lib = L
+    return _fe_lib
+
+
+class FrontEnd:
+    """gpsfe_open / gpsfe_generate: the scenario the reference's main() runs, as descriptor blocks."""
+
+    def __init__(self, navfile, llh=None, ecef=None, motion=None, start=None, time_overwrite=False,
+                 iono=True, max_chan=12):
+        cfg = _FeConfig()
+        cfg.navfile = os.fsencode(navfile)
+        cfg.motion_file = os.fsencode(motion) if motion else None
+        if ecef is not None:
+            cfg.use_ecef = 1
+            cfg.pos = (C.c_double * 3)(*ecef)
+        else:
+            cfg.pos = (C.c_double * 3)(*(llh if llh is not None else (35.681298, 139.766247, 10.0)))
+        if start is not None:  # (y, m, d, hh, mm, sec)
+            cfg.have_start = 1
+            cfg.y, cfg.m, cfg.d, cfg.hh, cfg.mm = [int(v) for v in start[:5]]
+            cfg.sec = float(start[5])
+        cfg.time_overwrite = int(time_overwrite)
+        cfg.iono_disable = int(not iono)
+        cfg.max_chan = max_chan
+        self.max_chan = max_chan
+        self._fe = C.c_void_p()
+        rc = fe_lib().gpsfe_open(C.byref(cfg), C.byref(self._fe))
+        if rc != 0:
+            raise RuntimeError("gpsfe_open: %s (%d)" % (fe_lib().gpsfe_strerror(rc).decode(), rc))
+
+    def close(self):
+        if self._fe:
+            fe_lib().gpsfe_close(self._fe)
+            self._fe = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def generate(self, nblocks):
+        ch = np.zeros((nblocks, self.max_chan), CHAN_DTYPE)
+        rc = fe_lib().gpsfe_generate(self._fe, nblocks, ch.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("gpsfe_generate: %d" % rc)
+        return ch
+
+    def next_block(self):
+        ch = np.zeros(self.max_chan, CHAN_DTYPE)
+        rc = fe_lib().gpsfe_next_block(self._fe, ch.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("gpsfe_next_block: %d" % rc)
+        return ch
+
+    def feed_back(self, end_state):
+        st = np.ascontiguousarray(end_state, dtype=STATE_DTYPE)
+        rc = fe_lib().gpsfe_feed_back(self._fe, st.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("gpsfe_feed_back: %d" % rc)
+
+    def time(self):
+        w, s = C.c_int(), C.c_double()
+        fe_lib().gpsfe_time(self._fe, C.byref(w), C.byref(s))
+        return w.value, s.value

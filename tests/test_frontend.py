@@ -1,0 +1,98 @@
+"""The from-scratch host front end (pluto-gps-sim_amd/host/gpsfe.c) against descriptor dumps of the
+reference's own code: every field of every channel of every kept block must be bit-identical.  carr_phase
+(which the reference carries in the sample loop) is reconstructed with gpsbb_chain_carrier_host.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from conftest import GOLDEN
+
+SITE = (30.286502, 120.032669, 100.0)
+FIELDS = ("prn", "iword", "ibit", "icode", "f_carr", "f_code", "code_phase", "gain", "dwrd", "carr_phase")
+
+
+@pytest.fixture(scope="module")
+def fe_pkg(pkg):
+    pkg.build_frontend()
+    return pkg
+
+
+def chained(pkg, ch, fs, nsamp):
+    out = ch.copy()
+    out["carr_phase"] = pkg.chain_carrier_host(ch, 1.0 / fs, nsamp)
+    out["carr_phase"][ch["prn"] <= 0] = 0.0
+    return out
+
+
+def assert_desc_equal(got, want, what):
+    for f in FIELDS:
+        a, b = np.ascontiguousarray(got[f]), np.ascontiguousarray(want[f])
+        assert a.tobytes() == b.tobytes(), "%s: field %s differs" % (what, f)
+
+
+@pytest.mark.parametrize("name,nav,motion,max_chan", [
+    ("static_F", "synth3540.14n", None, 12),
+    ("motion_F", "synth3540.14n", "circle_motion.csv", 12),
+    ("dense_S", "dense3540.14n", None, 16)])
+def test_descriptors_match_the_reference_dumps(fe_pkg, name, nav, motion, max_chan):
+    pkg = fe_pkg
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    fs, nsamp = float(z["fs"]), int(z["nsamp"])
+    blocks = [int(b) for b in z["blocks"]]
+    want = z["desc"].view(pkg.CHAN_DTYPE).reshape(len(blocks), -1)
+    fe = pkg.FrontEnd(os.path.join(GOLDEN, nav), llh=SITE, motion=os.path.join(GOLDEN, motion) if motion else None,
+                      max_chan=max_chan)
+    ch = chained(pkg, fe.generate(max(blocks) + 1), fs, nsamp)
+    fe.close()
+    for k, b in enumerate(blocks):
+        assert_desc_equal(ch[b], want[k], "%s block %d" % (name, b))
+
+
+@pytest.mark.skipif(not ob.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+@pytest.mark.parametrize("extra,kw", [
+    ((), {}),
+    (("-i",), {"iono": False}),
+    (("-t", "2014/12/20,01:30:17"), {"start": (2014, 12, 20, 1, 30, 17.0)}),
+    (("-t", "2014/12/21,10:00:00", "-T"), {"start": (2014, 12, 21, 10, 0, 0.0), "time_overwrite": True}),
+])
+def test_every_block_against_a_live_reference_run(fe_pkg, extra, kw):
+    """All blocks of a 65 s run (two nav-frame refreshes) against the reference slices run right now,
+    for the option combinations that change the front end's arithmetic."""
+    pkg = fe_pkg
+    nav = os.path.join(GOLDEN, "synth3540.14n")
+    nblocks, nsamp, fs = 650, 2000, 2600000
+    _, want, _ = ob.run_ref_sim(nav, nblocks, nsamp, fs, llh=tuple(str(v) for v in SITE), max_chan=12, opt="",
+                                extra=extra)
+    fe = pkg.FrontEnd(nav, llh=SITE, max_chan=12, **kw)
+    ch = chained(pkg, fe.generate(nblocks), fs, nsamp)
+    fe.close()
+    assert_desc_equal(ch, want, "live run %r" % (extra,))
+
+
+@pytest.mark.skipif(not ob.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+def test_ecef_position_and_ephemeris_rollover(fe_pkg):
+    """-c ECEF input, and a start 20 s before the 02:00 set becomes current so the roll-over at c:2776-2790
+    (ieph++ and fresh subframes) happens inside the run."""
+    pkg = fe_pkg
+    nav = os.path.join(GOLDEN, "synth3540.14n")
+    xyz = (-2758918.636, 4772301.120, 3197889.437)
+    nblocks, nsamp, fs = 700, 1000, 2600000
+    extra = ("-c", "%r,%r,%r" % xyz, "-t", "2014/12/20,00:59:40")
+    _, want, _ = ob.run_ref_sim(nav, nblocks, nsamp, fs, max_chan=12, extra=extra)
+    fe = pkg.FrontEnd(nav, ecef=xyz, start=(2014, 12, 20, 0, 59, 40.0), max_chan=12)
+    ch = chained(pkg, fe.generate(nblocks), fs, nsamp)
+    fe.close()
+    assert_desc_equal(ch, want, "rollover run")
+    assert (want["dwrd"][0] != want["dwrd"][-1]).any()
+
+
+def test_front_end_errors(fe_pkg):
+    pkg = fe_pkg
+    with pytest.raises(RuntimeError):
+        pkg.FrontEnd("/nonexistent.14n", llh=SITE)
+    with pytest.raises(RuntimeError):  # start outside the window (c:2555-2564)
+        pkg.FrontEnd(os.path.join(GOLDEN, "synth3540.14n"), llh=SITE, start=(2015, 1, 1, 0, 0, 0.0))
+    with pytest.raises(RuntimeError):
+        pkg.FrontEnd(os.path.join(GOLDEN, "synth3540.14n"), llh=SITE, motion="/nonexistent.csv")

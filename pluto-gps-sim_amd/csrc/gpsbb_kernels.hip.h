@@ -35,7 +35,13 @@
 
 namespace gpsbb_impl {
 
-constexpr int TILE_THREADS = 512;           /* 8 wave64 per workgroup */
+#ifndef GPSBB_WG
+#define GPSBB_WG 512
+#endif
+#ifndef GPSBB_WAVES_PER_SIMD
+#define GPSBB_WAVES_PER_SIMD 4
+#endif
+constexpr int TILE_THREADS = GPSBB_WG;      /* wave64 x (GPSBB_WG/64) per workgroup */
 #ifndef GPSBB_SPT
 #define GPSBB_SPT 16
 #endif
@@ -467,7 +473,7 @@ __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc
     }
 }
 
-__global__ __launch_bounds__(TILE_THREADS, 4) void k_synth(BatchDev p, int16_t *__restrict__ iq)
+__global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(BatchDev p, int16_t *__restrict__ iq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     SynthLds &L = *reinterpret_cast<SynthLds *>(smem_raw);

@@ -384,9 +384,11 @@ class _FeConfig(C.Structure):
 
 
 def build_frontend(force=False):
-    src = os.path.join(HERE, "host", "gpsfe.c")
-    if force or not os.path.exists(FE_LIB_PATH) or os.path.getmtime(src) > os.path.getmtime(FE_LIB_PATH):
-        subprocess.check_call(["make", "-C", os.path.join(HERE, "host")])
+    hostdir = os.path.join(HERE, "host")
+    sim = os.path.join(HERE, "gpsbb-sim")
+    newest = max(os.path.getmtime(os.path.join(hostdir, f)) for f in os.listdir(hostdir))
+    if force or not os.path.exists(FE_LIB_PATH) or not os.path.exists(sim) or newest > os.path.getmtime(FE_LIB_PATH):
+        subprocess.check_call(["make", "-C", hostdir])
     return FE_LIB_PATH
 
 

@@ -1,0 +1,138 @@
+/*
+ * gpsbb-sim — end-to-end generator: RINEX-2 navigation file + position/motion -> int16 I/Q file, with the
+ * reference's own program structure (front end -> fill -> TX hand-off) and the fill done on an MI355X.
+ *
+ *   gpsbb-sim -e nav.14n [-l lat,lon,h | -c x,y,z | -u motion.csv] [-t Y/M/D,h:m:s] [-T] [-i]
+ *             [-s fs_hz] [-d seconds] [-n samples_per_block] [-N channels] [-g gpu] -o out.bin
+ *
+ * Options mirror the reference's (plutogpssim.c:1991-2012, 2296-2390) where they concern the signal; the
+ * Pluto-specific ones (-A -B -U -N host) have no meaning here.  -n defaults to 300000, the reference's
+ * fixed block (plutogpssim.c:43-44); "-n 0" means fs/10 (time-continuous blocks, gps-sdr-sim semantics).
+ * The main loop below is the reference's (c:2655-2806) with the inline sample loop replaced by
+ * gpsbb_fill_block(): same mutex/condvar hand-off, same per-block front-end update, carrier phase fed back.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "gpsbb.h"
+#include "gpsbb_tx.h"
+#include "gpsfe.h"
+
+static void usage(void)
+{
+    fprintf(stderr, "usage: gpsbb-sim -e nav [-l lat,lon,h|-c x,y,z|-u motion.csv] [-t Y/M/D,h:m:s] [-T] [-i]\n"
+                    "                 [-s fs_hz] [-d seconds] [-n samples_per_block] [-N channels] [-g gpu] -o out.bin\n");
+}
+
+int main(int argc, char **argv)
+{
+    gpsfe_config_t cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.pos[0] = 35.681298; /* default static location: Tokyo (c:2266-2268) */
+    cfg.pos[1] = 139.766247;
+    cfg.pos[2] = 10.0;
+    cfg.max_chan = 12; /* MAX_CHAN h:21 */
+    long fs_hz = 3000000; /* TX_SAMPLE_FREQ c:43 */
+    long nsamp = 300000;  /* NUM_SAMPLES c:44 */
+    double duration = 1.0;
+    int gpu = 0, opt;
+    const char *out_path = NULL;
+
+    while ((opt = getopt(argc, argv, "e:u:c:l:s:Tt:in:N:d:o:g:")) != -1) {
+        switch (opt) {
+        case 'e': cfg.navfile = optarg; break;
+        case 'u': cfg.motion_file = optarg; break;
+        case 'c': cfg.use_ecef = 1; sscanf(optarg, "%lf,%lf,%lf", &cfg.pos[0], &cfg.pos[1], &cfg.pos[2]); break;
+        case 'l': cfg.use_ecef = 0; sscanf(optarg, "%lf,%lf,%lf", &cfg.pos[0], &cfg.pos[1], &cfg.pos[2]); break;
+        case 's':
+            fs_hz = atol(optarg);
+            if (fs_hz < 1000000) { /* c:2326 */
+                fprintf(stderr, "ERROR: Invalid sampling frequency.\n");
+                return 1;
+            }
+            break;
+        case 'T': cfg.time_overwrite = 1; break;
+        case 't':
+            cfg.have_start = 1;
+            sscanf(optarg, "%d/%d/%d,%d:%d:%lf", &cfg.y, &cfg.m, &cfg.d, &cfg.hh, &cfg.mm, &cfg.sec);
+            break;
+        case 'i': cfg.iono_disable = 1; break;
+        case 'n': nsamp = atol(optarg); break;
+        case 'N': cfg.max_chan = atoi(optarg); break;
+        case 'd': duration = atof(optarg); break;
+        case 'o': out_path = optarg; break;
+        case 'g': gpu = atoi(optarg); break;
+        default: usage(); return 1;
+        }
+    }
+    if (!cfg.navfile || !out_path) {
+        usage();
+        return 1;
+    }
+    if (nsamp == 0)
+        nsamp = fs_hz / 10;
+    const double delt = 1.0 / (double)fs_hz; /* c:2397 */
+    const long nblocks = (long)(duration * 10.0 + 0.5);
+
+    gpsfe_t *fe = NULL;
+    int rc = gpsfe_open(&cfg, &fe);
+    if (rc != GPSFE_OK) {
+        fprintf(stderr, "ERROR: %s\n", gpsfe_strerror(rc));
+        return 1;
+    }
+    gpsbb_t *bb = NULL;
+    rc = gpsbb_create(&bb, gpu);
+    if (rc != GPSBB_OK) {
+        fprintf(stderr, "ERROR: gpsbb_create: %s\n", gpsbb_strerror(rc));
+        return 1;
+    }
+    FILE *fout = strcmp(out_path, "-") ? fopen(out_path, "wb") : stdout;
+    if (!fout) {
+        fprintf(stderr, "ERROR: cannot open %s\n", out_path);
+        return 1;
+    }
+    gpsbb_tx_t *tx = NULL;
+    if (gpsbb_tx_create(&tx, (size_t)nsamp, gpsbb_tx_push_to_file, fout) != 0) {
+        fprintf(stderr, "ERROR: cannot start the TX surface\n");
+        return 1;
+    }
+
+    fprintf(stderr, "PRN   Az    El     Range     Iono\n"); /* the table the reference prints, c:2634-2639 */
+    for (int i = 0; i < cfg.max_chan; i++) {
+        int prn;
+        double az, el, range, iono;
+        gpsfe_channel_info(fe, i, &prn, &az, &el, &range, &iono);
+        if (prn > 0)
+            fprintf(stderr, "%02d %6.1f %5.1f %11.1f %5.1f\n", prn, az, el, range, iono);
+    }
+
+    gpsbb_chan_t ch[GPSBB_MAX_CHAN];
+    gpsbb_chan_state_t st[GPSBB_MAX_CHAN];
+    long blk;
+    for (blk = 0; blk < nblocks; blk++) { /* while (!plutotx.exit), c:2655 */
+        gpsfe_next_block(fe, ch);                                   /* c:2656-2687 (+ c:2764-2805) */
+        int16_t *iq = gpsbb_tx_begin(tx);                           /* c:2689 */
+        rc = gpsbb_fill_block(bb, ch, cfg.max_chan, delt, (int)nsamp, iq, st); /* replaces c:2690-2756 */
+        const int stopped = gpsbb_tx_end(tx);                       /* c:2757-2759 */
+        if (rc != GPSBB_OK) {
+            fprintf(stderr, "ERROR: gpsbb_fill_block: %s\n", gpsbb_strerror(rc));
+            break;
+        }
+        gpsfe_feed_back(fe, st); /* the loop's in-place update of chan[i].carr_phase */
+        if (stopped)
+            break;
+    }
+    gpsbb_tx_destroy(tx);
+    if (fout != stdout)
+        fclose(fout);
+    gpsbb_hazards_t hz;
+    if (gpsbb_get_hazards(bb, &hz, 0) == GPSBB_OK && (hz.itable_512 || hz.dwrd_oob))
+        fprintf(stderr, "note: latent out-of-bounds cases of the reference hit: table %llu, nav words %llu\n",
+                (unsigned long long)hz.itable_512, (unsigned long long)hz.dwrd_oob);
+    gpsbb_destroy(bb);
+    gpsfe_close(fe);
+    fprintf(stderr, "%ld blocks of %ld samples written\n", blk, nsamp);
+    return rc == GPSBB_OK ? 0 : 1;
+}

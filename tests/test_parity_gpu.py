@@ -304,3 +304,19 @@ def test_single_block_feedback_loop_like_the_reference(pkg, synth):
         fe.feed_back(st)
         assert sha(iq) == str(z["iq_sha256"][blk]), blk
     fe.close()
+
+
+def test_gpsbb_sim_end_to_end_file(pkg, tmp_path):
+    """The C program with the reference's structure (front end -> gpsbb_fill_block -> mutex/condvar TX
+    surface -> file): its output file must be the golden blocks, byte for byte."""
+    import subprocess
+    pkg.build_frontend()
+    exe = os.path.join(os.path.dirname(pkg.LIB_PATH), "gpsbb-sim")
+    z = np.load(os.path.join(GOLDEN, "static_F.npz"))
+    nsamp = int(z["nsamp"])
+    out = str(tmp_path / "iq.bin")
+    subprocess.run([exe, "-e", os.path.join(GOLDEN, "synth3540.14n"), "-l", "30.286502,120.032669,100",
+                    "-s", "2600000", "-d", "0.3", "-o", out], check=True, stderr=subprocess.DEVNULL)
+    iq = np.fromfile(out, np.int16).reshape(3, nsamp, 2)
+    for blk in range(3):
+        assert sha(iq[blk]) == str(z["iq_sha256"][blk]), blk

@@ -1,0 +1,88 @@
+"""The TX hand-off surface (pluto-gps-sim_amd/host/gpsbb_tx.c): the reference's one-buffer mutex/condvar
+protocol (plutogpssim.c:2146-2158, 2689, 2757-2759) with a pluggable sink.  CPU only."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+PUSH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int16), C.c_size_t)
+
+
+@pytest.fixture(scope="module")
+def tx(pkg):
+    pkg.build_frontend()
+    L = pkg.fe_lib()
+    L.gpsbb_tx_create.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, PUSH_FN, C.c_void_p]
+    L.gpsbb_tx_begin.argtypes = [C.c_void_p]
+    L.gpsbb_tx_begin.restype = C.POINTER(C.c_int16)
+    L.gpsbb_tx_end.argtypes = [C.c_void_p]
+    L.gpsbb_tx_destroy.argtypes = [C.c_void_p]
+    L.gpsbb_tx_destroy.restype = None
+    L.gpsbb_tx_delivered.argtypes = [C.c_void_p]
+    L.gpsbb_tx_delivered.restype = C.c_ulong
+    return L
+
+
+def test_every_block_is_delivered_once_and_in_order(tx):
+    nsamp, nblocks = 1000, 50
+    got = []
+
+    @PUSH_FN
+    def push(user, iq, n):
+        got.append(np.ctypeslib.as_array(iq, (2 * n,)).copy())
+        return 0
+
+    h = C.c_void_p()
+    assert tx.gpsbb_tx_create(C.byref(h), nsamp, push, None) == 0
+    for b in range(nblocks):
+        buf = tx.gpsbb_tx_begin(h)                      # generator holds the mutex while it fills (c:2689)
+        np.ctypeslib.as_array(buf, (2 * nsamp,))[:] = b
+        assert tx.gpsbb_tx_end(h) == 0                  # signal + wait until the TX thread has copied it
+    tx.gpsbb_tx_destroy(h)
+    assert len(got) == nblocks
+    for b, blk in enumerate(got):
+        assert (blk == b).all()
+
+
+def test_sink_error_stops_the_generator(tx):
+    """A negative return of the sink plays iio_buffer_push failing (c:2153-2157): the generator sees `exit`."""
+    calls = []
+
+    @PUSH_FN
+    def push(user, iq, n):
+        calls.append(1)
+        return -1 if len(calls) == 3 else 0
+
+    h = C.c_void_p()
+    assert tx.gpsbb_tx_create(C.byref(h), 16, push, None) == 0
+    stopped_at = None
+    for b in range(10):
+        tx.gpsbb_tx_begin(h)
+        if tx.gpsbb_tx_end(h) == 1:
+            stopped_at = b
+            break
+    tx.gpsbb_tx_destroy(h)
+    assert stopped_at is not None and stopped_at <= 4 and len(calls) == 3
+
+
+def test_file_sink_writes_gps_sdr_sim_format(tx, tmp_path):
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    path = str(tmp_path / "iq.bin")
+    f = libc.fopen(path.encode(), b"wb")
+    push = C.cast(tx.gpsbb_tx_push_to_file, PUSH_FN)
+    h = C.c_void_p()
+    assert tx.gpsbb_tx_create(C.byref(h), 64, push, f) == 0
+    want = []
+    for b in range(5):
+        buf = tx.gpsbb_tx_begin(h)
+        blk = (np.arange(128) + 1000 * b).astype(np.int16)
+        np.ctypeslib.as_array(buf, (128,))[:] = blk
+        want.append(blk)
+        tx.gpsbb_tx_end(h)
+    tx.gpsbb_tx_destroy(h)
+    libc.fclose(f)
+    assert (np.fromfile(path, np.int16) == np.concatenate(want)).all()

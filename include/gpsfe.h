@@ -4,7 +4,7 @@
  *
  * This is the part of the reference that stays on the host.  It reproduces,
  * bit for bit, what the reference's main() leaves in chan[] / gain[] before every run of the sample loop:
- *   ephemeris reader           readRinex2            plutogpssim.c:874-1233
+ *   ephemeris reader           readRinex2 / readRinex3   plutogpssim.c:874-1233, 1241-1610
  *   scenario start / eph set   main()                plutogpssim.c:2497-2597
  *   orbit + clock              satpos                plutogpssim.c:443-546
  *   range, az/el, Klobuchar    computeRange          plutogpssim.c:1691-1747, 1612-1683
@@ -35,7 +35,8 @@ extern "C" {
 typedef struct gpsfe gpsfe_t;
 
 typedef struct gpsfe_config {
-    const char *navfile;     /* -e : RINEX-2 navigation file (plain or gzip)                        */
+    const char *navfile;     /* -e : RINEX navigation file (plain or gzip)                          */
+    int rinex3;              /* -3 : the file is RINEX 3 (readRinex3 c:1241-1610) instead of 2      */
     const char *motion_file; /* -u : "t,x,y,z" ECEF at 10 Hz; NULL = static position               */
     int use_ecef;            /* static position given as ECEF (-c) instead of lat,lon,height (-l)  */
     double pos[3];           /* -l: degrees, degrees, metres   /   -c: metres ECEF                  */

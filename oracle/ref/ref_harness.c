@@ -203,7 +203,7 @@ int main(int argc, char *argv[])
 
     /* harness-only */
     long long fs_hz = 3000000; /* TX_SAMPLE_FREQ, c:43, 2271 */
-    int nblocks = 1, result, blk;
+    int nblocks = 1, result, blk, use_rinex3 = 0;
     const char *iq_path = NULL, *desc_path = NULL, *state_path = NULL;
     FILE *fiq = NULL, *fdesc = NULL, *fstate = NULL;
 
@@ -219,7 +219,7 @@ int main(int argc, char *argv[])
     llh[2] = 10.0;
     llh2xyz(llh, xyz[0]);
 
-    while ((result = getopt(argc, argv, "e:u:c:l:s:Tt:in:b:o:d:S:")) != -1) {
+    while ((result = getopt(argc, argv, "e:u:c:l:s:Tt:in:b:o:d:S:3")) != -1) {
         switch (result) {
         case 'e':
             navfile = optarg;
@@ -252,6 +252,9 @@ int main(int argc, char *argv[])
                 die("invalid date and time");
             t0.sec = floor(t0.sec);
             date2gps(&t0, &g0);
+            break;
+        case '3': /* c:2305-2308 (the reference's getopt string gives -3 an argument; a flag here) */
+            use_rinex3 = 1;
             break;
         case 'i': /* c:2360-2362 */
             ionoutc.enable = false;
@@ -289,7 +292,7 @@ int main(int argc, char *argv[])
             die("failed to read user motion data");
     }
 
-    neph = readRinex2(eph, &ionoutc, navfile); /* c:2479 */
+    neph = use_rinex3 ? readRinex3(eph, &ionoutc, navfile) : readRinex2(eph, &ionoutc, navfile); /* c:2476-2480 */
     if (neph == 0)
         die("no ephemeris available");
 

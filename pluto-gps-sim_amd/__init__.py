@@ -377,7 +377,7 @@ _fe_lib = None
 
 
 class _FeConfig(C.Structure):
-    _fields_ = [("navfile", C.c_char_p), ("motion_file", C.c_char_p), ("use_ecef", C.c_int),
+    _fields_ = [("navfile", C.c_char_p), ("rinex3", C.c_int), ("motion_file", C.c_char_p), ("use_ecef", C.c_int),
                 ("pos", C.c_double * 3), ("have_start", C.c_int), ("y", C.c_int), ("m", C.c_int),
                 ("d", C.c_int), ("hh", C.c_int), ("mm", C.c_int), ("sec", C.c_double),
                 ("time_overwrite", C.c_int), ("iono_disable", C.c_int), ("max_chan", C.c_int)]
@@ -417,9 +417,10 @@ class FrontEnd:
     """gpsfe_open / gpsfe_generate: the scenario the reference's main() runs, as descriptor blocks."""
 
     def __init__(self, navfile, llh=None, ecef=None, motion=None, start=None, time_overwrite=False,
-                 iono=True, max_chan=12):
+                 iono=True, max_chan=12, rinex3=False):
         cfg = _FeConfig()
         cfg.navfile = os.fsencode(navfile)
+        cfg.rinex3 = int(rinex3)
         cfg.motion_file = os.fsencode(motion) if motion else None
         if ecef is not None:
             cfg.use_ecef = 1

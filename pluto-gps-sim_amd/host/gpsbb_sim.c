@@ -22,7 +22,7 @@
 
 static void usage(void)
 {
-    fprintf(stderr, "usage: gpsbb-sim -e nav [-l lat,lon,h|-c x,y,z|-u motion.csv] [-t Y/M/D,h:m:s] [-T] [-i]\n"
+    fprintf(stderr, "usage: gpsbb-sim -e nav [-l lat,lon,h|-c x,y,z|-u motion.csv] [-t Y/M/D,h:m:s] [-T] [-i] [-3]\n"
                     "                 [-s fs_hz] [-d seconds] [-n samples_per_block] [-N channels] [-g gpu] -o out.bin\n");
 }
 
@@ -40,7 +40,7 @@ int main(int argc, char **argv)
     int gpu = 0, opt;
     const char *out_path = NULL;
 
-    while ((opt = getopt(argc, argv, "e:u:c:l:s:Tt:in:N:d:o:g:")) != -1) {
+    while ((opt = getopt(argc, argv, "e:u:c:l:s:Tt:in:N:d:o:g:3")) != -1) {
         switch (opt) {
         case 'e': cfg.navfile = optarg; break;
         case 'u': cfg.motion_file = optarg; break;
@@ -59,6 +59,7 @@ int main(int argc, char **argv)
             sscanf(optarg, "%d/%d/%d,%d:%d:%lf", &cfg.y, &cfg.m, &cfg.d, &cfg.hh, &cfg.mm, &cfg.sec);
             break;
         case 'i': cfg.iono_disable = 1; break;
+        case '3': cfg.rinex3 = 1; break; /* the reference declares -3 with an argument (c:2296); here it is a flag */
         case 'n': nsamp = atol(optarg); break;
         case 'N': cfg.max_chan = atoi(optarg); break;
         case 'd': duration = atof(optarg); break;

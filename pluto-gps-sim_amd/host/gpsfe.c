@@ -634,13 +634,26 @@ static int field_int(const char *line, size_t len, int col, int width)
     return atoi(tmp);
 }
 
+/* the v3 reader runs the D->E replacement over this integer field before atoi (c:1345-1348) */
+static long strtol_field(const char *line, size_t len, int col, int width)
+{
+    char tmp[24];
+    int n = 0;
+    for (int k = 0; k < width && (size_t)(col + k) < len && line[col + k] != 0; k++)
+        tmp[n++] = (line[col + k] == 'D' || line[col + k] == 'd') ? 'E' : line[col + k];
+    tmp[n] = 0;
+    return atoi(tmp);
+}
+
 static int label_is(const char *line, size_t len, const char *label)
 {
     const size_t l = strlen(label);
     return len >= 60 + l && strncmp(line + 60, label, l) == 0;
 }
 
-static int read_rinex2(gpsfe_t *fe, const char *path)
+/* RINEX-2 (readRinex2 c:874-1233) and RINEX-3 (readRinex3 c:1241-1610) GPS navigation files: same
+ * content, the v3 columns are shifted by one and the header carries the iono/UTC terms under other labels */
+static int read_rinex(gpsfe_t *fe, const char *path, int v3)
 {
     gzFile fp = gzopen(path, "rt");
     if (!fp)
@@ -652,7 +665,7 @@ static int read_rinex2(gpsfe_t *fe, const char *path)
         for (int sv = 0; sv < N_SAT; sv++)
             fe->eph[s][sv].valid = 0;
 
-    /* header: labels start at column 60 (c:899-1000) */
+    /* header: labels start at column 60 (c:899-1000 / c:1266-1362) */
     while (gzgets(fp, line, sizeof line)) {
         const size_t len = strlen(line);
         if (label_is(line, len, "COMMENT"))
@@ -660,23 +673,42 @@ static int read_rinex2(gpsfe_t *fe, const char *path)
         if (label_is(line, len, "END OF HEADER"))
             break;
         if (label_is(line, len, "RINEX VERSION / TYPE")) {
-            if (field(line, len, 0, 9) > 3.0 || line[20] != 'N') {
+            const double ver = field(line, len, 0, 9);
+            const int bad = v3 ? (ver < 3.0 || (line[20] != 'N' && line[40] != 'G')) : (ver > 3.0 || line[20] != 'N');
+            if (bad) {
                 gzclose(fp);
                 return -2;
             }
-        } else if (label_is(line, len, "ION ALPHA")) {
+        } else if (!v3 && label_is(line, len, "ION ALPHA")) {
             for (int k = 0; k < 4; k++)
                 io->alpha[k] = field(line, len, 2 + 12 * k, 12);
             flags |= 1;
-        } else if (label_is(line, len, "ION BETA")) {
+        } else if (!v3 && label_is(line, len, "ION BETA")) {
             for (int k = 0; k < 4; k++)
                 io->beta[k] = field(line, len, 2 + 12 * k, 12);
             flags |= 2;
-        } else if (label_is(line, len, "DELTA-UTC")) {
+        } else if (!v3 && label_is(line, len, "DELTA-UTC")) {
             io->A0 = field(line, len, 3, 19);
             io->A1 = field(line, len, 22, 19);
             io->tot = field_int(line, len, 41, 9);
             io->wnt = field_int(line, len, 50, 9);
+            if (io->tot % 4096 == 0)
+                flags |= 4;
+        } else if (v3 && label_is(line, len, "IONOSPHERIC CORR")) {
+            if (strncmp(line, "GPSA", 4) == 0) {
+                for (int k = 0; k < 4; k++)
+                    io->alpha[k] = field(line, len, 5 + 12 * k, 12);
+                flags |= 1;
+            } else if (strncmp(line, "GPSB", 4) == 0) {
+                for (int k = 0; k < 4; k++)
+                    io->beta[k] = field(line, len, 5 + 12 * k, 12);
+                flags |= 2;
+            }
+        } else if (v3 && label_is(line, len, "TIME SYSTEM CORR") && strncmp(line, "GPUT", 4) == 0) {
+            io->A0 = field(line, len, 5, 17);
+            io->A1 = field(line, len, 22, 16);
+            io->tot = (int)strtol_field(line, len, 38, 7);
+            io->wnt = field_int(line, len, 45, 6);
             if (io->tot % 4096 == 0)
                 flags |= 4;
         } else if (label_is(line, len, "LEAP SECONDS")) {
@@ -687,18 +719,32 @@ static int read_rinex2(gpsfe_t *fe, const char *path)
     io->valid = (flags == 0xF);
 
     /* records: 8 lines per satellite; a new set starts when TOC jumps by more than an hour (c:1046-1054) */
+    const int o = v3 ? 1 : 0; /* column shift of the four 19-character fields */
     gtime_t g_set = {-1, 0.0};
     int ieph = 0;
     while (gzgets(fp, line, sizeof line)) {
         size_t len = strlen(line);
-        const int sv = field_int(line, len, 0, 2) - 1;
+        int sv;
         caltime_t t;
-        t.y = field_int(line, len, 3, 2) + 2000;
-        t.m = field_int(line, len, 6, 2);
-        t.d = field_int(line, len, 9, 2);
-        t.hh = field_int(line, len, 12, 2);
-        t.mm = field_int(line, len, 15, 2);
-        t.sec = field(line, len, 18, 2); /* the reference parses two characters of the seconds field (c:1036-1038) */
+        if (v3) {
+            if (line[0] != 'G') /* other constellations (c:1380-1382) */
+                continue;
+            sv = field_int(line, len, 1, 2) - 1;
+            t.y = field_int(line, len, 4, 4);
+            t.m = field_int(line, len, 9, 2);
+            t.d = field_int(line, len, 12, 2);
+            t.hh = field_int(line, len, 15, 2);
+            t.mm = field_int(line, len, 18, 2);
+            t.sec = (double)field_int(line, len, 21, 2);
+        } else {
+            sv = field_int(line, len, 0, 2) - 1;
+            t.y = field_int(line, len, 3, 2) + 2000;
+            t.m = field_int(line, len, 6, 2);
+            t.d = field_int(line, len, 9, 2);
+            t.hh = field_int(line, len, 12, 2);
+            t.mm = field_int(line, len, 15, 2);
+            t.sec = field(line, len, 18, 2); /* two characters of the seconds field (c:1036-1038) */
+        }
         const gtime_t g = cal_to_gps(&t);
         if (g_set.week == -1)
             g_set = g;
@@ -712,43 +758,43 @@ static int read_rinex2(gpsfe_t *fe, const char *path)
         eph_t *e = &fe->eph[ieph][sv];
         e->t = t;
         e->toc = g;
-        e->af0 = field(line, len, 22, 19);
-        e->af1 = field(line, len, 41, 19);
-        e->af2 = field(line, len, 60, 19);
+        e->af0 = field(line, len, 22 + o, 19);
+        e->af1 = field(line, len, 41 + o, 19);
+        e->af2 = field(line, len, 60 + o, 19);
 #define NEXT_LINE()                                  \
     if (!gzgets(fp, line, sizeof line))              \
         break;                                       \
     len = strlen(line)
         NEXT_LINE(); /* orbit 1 */
-        e->iode = (int)field(line, len, 3, 19);
-        e->crs = field(line, len, 22, 19);
-        e->deltan = field(line, len, 41, 19);
-        e->m0 = field(line, len, 60, 19);
+        e->iode = (int)field(line, len, 3 + o, 19);
+        e->crs = field(line, len, 22 + o, 19);
+        e->deltan = field(line, len, 41 + o, 19);
+        e->m0 = field(line, len, 60 + o, 19);
         NEXT_LINE(); /* orbit 2 */
-        e->cuc = field(line, len, 3, 19);
-        e->ecc = field(line, len, 22, 19);
-        e->cus = field(line, len, 41, 19);
-        e->sqrta = field(line, len, 60, 19);
+        e->cuc = field(line, len, 3 + o, 19);
+        e->ecc = field(line, len, 22 + o, 19);
+        e->cus = field(line, len, 41 + o, 19);
+        e->sqrta = field(line, len, 60 + o, 19);
         NEXT_LINE(); /* orbit 3 */
-        e->toe.sec = field(line, len, 3, 19);
-        e->cic = field(line, len, 22, 19);
-        e->omg0 = field(line, len, 41, 19);
-        e->cis = field(line, len, 60, 19);
+        e->toe.sec = field(line, len, 3 + o, 19);
+        e->cic = field(line, len, 22 + o, 19);
+        e->omg0 = field(line, len, 41 + o, 19);
+        e->cis = field(line, len, 60 + o, 19);
         NEXT_LINE(); /* orbit 4 */
-        e->inc0 = field(line, len, 3, 19);
-        e->crc = field(line, len, 22, 19);
-        e->aop = field(line, len, 41, 19);
-        e->omgdot = field(line, len, 60, 19);
+        e->inc0 = field(line, len, 3 + o, 19);
+        e->crc = field(line, len, 22 + o, 19);
+        e->aop = field(line, len, 41 + o, 19);
+        e->omgdot = field(line, len, 60 + o, 19);
         NEXT_LINE(); /* orbit 5 */
-        e->idot = field(line, len, 3, 19);
-        e->codeL2 = (int)field(line, len, 22, 19);
-        e->toe.week = (int)field(line, len, 41, 19);
+        e->idot = field(line, len, 3 + o, 19);
+        e->codeL2 = (int)field(line, len, 22 + o, 19);
+        e->toe.week = (int)field(line, len, 41 + o, 19);
         NEXT_LINE(); /* orbit 6 */
-        e->svhlth = (int)field(line, len, 22, 19);
+        e->svhlth = (int)field(line, len, 22 + o, 19);
         if (e->svhlth > 0 && e->svhlth < 32)
             e->svhlth += 32;
-        e->tgd = field(line, len, 41, 19);
-        e->iodc = (int)field(line, len, 60, 19);
+        e->tgd = field(line, len, 41 + o, 19);
+        e->iodc = (int)field(line, len, 60 + o, 19);
         NEXT_LINE(); /* orbit 7: not used */
 #undef NEXT_LINE
         e->valid = 1;
@@ -842,7 +888,7 @@ int gpsfe_open(const gpsfe_config_t *cfg, gpsfe_t **out)
         llh_to_ecef(llh, fe->xyz[0]);
     }
 
-    fe->neph = read_rinex2(fe, cfg->navfile);
+    fe->neph = read_rinex(fe, cfg->navfile, cfg->rinex3);
     if (fe->neph <= 0) {
         gpsfe_close(fe);
         return GPSFE_E_NAVFILE;

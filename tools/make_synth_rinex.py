@@ -136,6 +136,55 @@ def record(prn, hour, el, iode):
     return "".join(l)
 
 
+def header3():
+    def line(body, label):
+        return "%-60s%-20s\n" % (body, label)
+    out = []
+    out.append(line("     3.02           N: GNSS NAV DATA    G: GPS", "RINEX VERSION / TYPE"))
+    out.append(line("gpsbb-synth         gpsbb               20141220 000000 UTC", "PGM / RUN BY / DATE"))
+    out.append(line("synthetic broadcast ephemeris, not real data", "COMMENT"))
+    out.append(line("GPSA %12s%12s%12s%12s" % ("1.1176D-08", "7.4506D-09", "-5.9605D-08", "-5.9605D-08"),
+                    "IONOSPHERIC CORR"))
+    out.append(line("GPSB %12s%12s%12s%12s" % ("9.0112D+04", "0.0000D+00", "-1.9661D+05", "-6.5536D+04"),
+                    "IONOSPHERIC CORR"))
+    out.append(line("GPUT %17s%16s%7d%5d" % ("%17.10E" % -1.862645149231e-09, "%16.9E" % -1.687538997e-14, 503808, WEEK),
+                    "TIME SYSTEM CORR"))
+    out.append(line("%6d" % 16, "LEAP SECONDS"))
+    out.append(line("", "END OF HEADER"))
+    return "".join(out)
+
+
+def record3(prn, hour, el, iode):
+    l = []
+    l.append("G%02d %4d %02d %02d %02d %02d %02d%s%s%s\n" % (prn, 2014, 12, 20, hour, 0, 0, fmt(el["af0"]),
+                                                          fmt(el["af1"]), fmt(el["af2"])))
+    rows = [
+        (float(iode), el["crs"], el["deltan"], el["m0"]),
+        (el["cuc"], el["ecc"], el["cus"], el["sqrta"]),
+        (el["toe"], el["cic"], el["omg0"], el["cis"]),
+        (el["inc0"], el["crc"], el["aop"], el["omgdot"]),
+        (el["idot"], 1.0, float(WEEK), 0.0),
+        (2.0, 0.0, el["tgd"], float(iode)),
+        (el["toe"] - 7200.0, 4.0, 0.0, 0.0),
+    ]
+    for r in rows:
+        l.append("    " + "".join(fmt(v) for v in r) + "\n")
+    return "".join(l)
+
+
+def write_file3(path, sats, hours=(0, 2, 4)):
+    """The same ephemerides in RINEX 3.02 layout (readRinex3, plutogpssim.c:1241-1610), plus two records of
+    another constellation that the reader must skip (c:1380-1382)."""
+    with open(path, "w") as f:
+        f.write(header3())
+        for k, hour in enumerate(hours):
+            for prn in sorted(sats):
+                el = advance(sats[prn], 3600.0 * hour)
+                f.write(record3(prn, hour, el, 10 + 3 * k + (prn % 3)))
+                if prn == 5:
+                    f.write(record3(prn, hour, el, 1).replace("G05", "R05", 1))
+
+
 def write_file(path, sats, hours=(0, 2, 4)):
     with open(path, "w") as f:
         f.write(header())
@@ -187,4 +236,5 @@ if __name__ == "__main__":
     os.makedirs(gold, exist_ok=True)
     write_file(os.path.join(gold, "synth3540.14n"), full_constellation(3582))
     write_file(os.path.join(gold, "dense3540.14n"), dense_constellation(35401))
+    write_file3(os.path.join(gold, "synth3540_v3.rnx"), full_constellation(3582))
     print("wrote", os.path.normpath(os.path.join(gold, "synth3540.14n")), "and dense3540.14n")

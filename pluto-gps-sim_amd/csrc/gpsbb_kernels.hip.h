@@ -433,7 +433,7 @@ __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc
  * computed (pure VALU, covers the LDS latency), then group k is accumulated.
  */
 template <bool CODEW, bool CARRW>
-__device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc, double yk, uint32_t nav,
+__device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc, double yk, uint32_t nav, int dbx0,
                                              v2s (&acc)[SPT], int nvalid, unsigned long long &hz_itable)
 {
     constexpr int G = WALK_G;
@@ -443,7 +443,7 @@ __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc
     /* codeCA*dataBit: chip sign (+1/-1) XOR-ed with 0xfffe when dataBit = -1 flips +-1 in 16 bits */
     RunNav rn;
     rn.nav = nav;
-    rn.dbx0 = rn.dbx1 = nav_bit(L.dwrd[i], nav) < 0 ? 0xfffe : 0;
+    rn.dbx0 = rn.dbx1 = dbx0;
     rn.jw = SPT;
     int it[G], ci[G];
     walk_indices<CODEW, CARRW>(L, i, sc, sk, xc, yk, rn, it, ci, 0, nvalid, hz_itable);
@@ -592,14 +592,27 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         /* A chain whose first row covers all 64 run starts of the tile ("uniform", the usual case: rows
          * are thousands of samples long) needs no table at all: its lanes' states are
          * ubase + lane*ustep.  Computed here by the chain's lane, broadcast later with v_readlane. */
-        int uni = 0;
+        int uni = 0;      /* bit 0: uniform; bit 1: additionally no wrap anywhere in the tile */
         uint64_t ubase = 0, ustep = 0;
-        uint32_t unav = 0;
+        uint32_t unav = 0; /* code chains: nav counters, bit 31 = data bit is -1 */
         if (cnt > 0) {
             uni = row[1].n0 > wnl;
+            /* a row is a regular run: no wrap and no binade change between its samples.  If it reaches
+             * past the tile, no lane can wrap inside its run and the wrap tests are not needed at all */
+            if (row[1].n0 >= wn0 + TILE)
+                uni |= 2;
             ubase = row[0].xb + (uint64_t)((int64_t)(wn0 - row[0].n0) * row[0].inc);
             ustep = (uint64_t)(row[0].inc * SPT);
-            unav = row[0].nav;
+            if (lane & 1) {
+                /* carrier: the walk uses the phase scaled by 512 = the same mantissa, exponent + 9 */
+                const uint32_t ex = (uint32_t)(ubase >> 52) & 0x7ffu;
+                if (ex != 0)
+                    ubase += 9ull << 52;
+                else if (ubase != 0)
+                    uni = 0; /* subnormal phase: leave it to the generic path */
+            } else {
+                unav = row[0].nav | (nav_bit(L.dwrd[ci_], row[0].nav) < 0 ? 0x80000000u : 0u); /* bit 31: dataBit = -1 */
+            }
         }
 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* the previous tile's readers are done */
@@ -607,7 +620,7 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
             W.cbase[lane] = base;
             W.cr0[lane] = r0;
         }
-        if (in_lds && !__all(uni || cnt == 0)) {
+        if (in_lds && !__all((uni & 1) || cnt == 0)) {
             /* some chain changes row inside the tile: stage the rows in this wavefront's LDS slice */
 #pragma unroll
             for (int q = 0; q < 2; q++)
@@ -644,35 +657,43 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                 uint64_t xcb, xkb;
                 const int uc = __builtin_amdgcn_readlane(uni, 2 * a);
                 const int uk = __builtin_amdgcn_readlane(uni, 2 * a + 1);
-                if (uc) {
+                int dbx;
+                if (uc & 1) {
                     xcb = readlane_u64(ubase, 2 * a) + (uint64_t)lane * readlane_u64(ustep, 2 * a);
                     nav = (uint32_t)__builtin_amdgcn_readlane((int)unav, 2 * a);
-                } else if (in_lds) {
-                    xcb = row_state_lds(W, W.cbase[2 * a], n0, &nav);
-                } else { /* more rows than the LDS slice holds (very high Doppler / low sample rate): scan in HBM */
-                    xcb = row_state_global(p.rows + L.roff[2 * i], W.cr0[2 * a], n0, &nav);
-                }
-                if (uk) {
-                    xkb = readlane_u64(ubase, 2 * a + 1) + (uint64_t)lane * readlane_u64(ustep, 2 * a + 1);
-                } else if (in_lds) {
-                    xkb = row_state_lds(W, W.cbase[2 * a + 1], n0, &nav_unused);
+                    dbx = (nav >> 31) ? 0xfffe : 0;
+                    nav &= 0x7fffffffu;
                 } else {
-                    xkb = row_state_global(p.rows + L.roff[2 * i + 1], W.cr0[2 * a + 1], n0, &nav_unused);
+                    if (in_lds)
+                        xcb = row_state_lds(W, W.cbase[2 * a], n0, &nav);
+                    else /* more rows than the LDS slice holds (very high Doppler / low sample rate): scan in HBM */
+                        xcb = row_state_global(p.rows + L.roff[2 * i], W.cr0[2 * a], n0, &nav);
+                    dbx = nav_bit(L.dwrd[i], nav) < 0 ? 0xfffe : 0;
+                }
+                double yk;
+                if (uk & 1) {
+                    yk = bits_f64(readlane_u64(ubase, 2 * a + 1) + (uint64_t)lane * readlane_u64(ustep, 2 * a + 1));
+                } else {
+                    if (in_lds)
+                        xkb = row_state_lds(W, W.cbase[2 * a + 1], n0, &nav_unused);
+                    else
+                        xkb = row_state_global(p.rows + L.roff[2 * i + 1], W.cr0[2 * a + 1], n0, &nav_unused);
+                    yk = mul_rn(bits_f64(xkb), 512.0); /* exact */
                 }
                 const double xc = bits_f64(xcb);
-                const double yk = mul_rn(bits_f64(xkb), 512.0); /* exact */
 
-                /* can any lane of this wavefront wrap inside its run? */
-                const bool code_w = __any(!(xc < L.xlim[i]));
-                const bool carr_w = __any(!(yk < L.yhi[i]) || !(yk > L.ylo[i]));
+                /* can any lane of this wavefront wrap inside its run?  Known to be impossible when the
+                 * chain's row reaches past the tile; otherwise compare with the per-channel limits */
+                const bool code_w = (uc & 2) ? false : (bool)__any(!(xc < L.xlim[i]));
+                const bool carr_w = (uk & 2) ? false : (bool)__any(!(yk < L.yhi[i]) || !(yk > L.ylo[i]));
                 if (!code_w && !carr_w)
-                    walk_channel<false, false>(L, i, xc, yk, nav, acc, nvalid, hz_itable);
+                    walk_channel<false, false>(L, i, xc, yk, nav, dbx, acc, nvalid, hz_itable);
                 else if (!code_w)
-                    walk_channel<false, true>(L, i, xc, yk, nav, acc, nvalid, hz_itable);
+                    walk_channel<false, true>(L, i, xc, yk, nav, dbx, acc, nvalid, hz_itable);
                 else if (!carr_w)
-                    walk_channel<true, false>(L, i, xc, yk, nav, acc, nvalid, hz_itable);
+                    walk_channel<true, false>(L, i, xc, yk, nav, dbx, acc, nvalid, hz_itable);
                 else
-                    walk_channel<true, true>(L, i, xc, yk, nav, acc, nvalid, hz_itable);
+                    walk_channel<true, true>(L, i, xc, yk, nav, dbx, acc, nvalid, hz_itable);
             }
             if (hz_itable)
                 atomicAdd(p.hazards, hz_itable);

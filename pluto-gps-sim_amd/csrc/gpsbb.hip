@@ -466,7 +466,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     gpsbb *h = b->h;
     const int set = (int)(b->run_count & 1u);
     const size_t nbc = (size_t)b->nblocks * b->nch;
-    HIPCHK(h, (hipError_t)b->d_rows[set].reserve(b->total_rows));
+    HIPCHK(h, (hipError_t)b->d_rows[set].reserve(b->total_rows + 4)); /* + slack: k_synth prefetches one row past a chain */
     HIPCHK(h, (hipError_t)b->d_tile_row[set].reserve(2 * nbc * ((size_t)b->ntiles + 1)));
     HIPCHK(h, (hipError_t)b->d_end[set].reserve(nbc));
     HIPCHK(h, (hipError_t)b->d_row_cnt[set].reserve(2 * nbc));

@@ -556,8 +556,23 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         r_first = tr[wt_begin];
         r_next = tr[wt_begin + 1];
     }
+    /* rows are fetched one tile ahead: row 0 of the chain for the tile and the start of row 1 */
+    const NcoRow *__restrict__ lane_rows = p.rows + L.roff[has_chain ? 2 * L.act[lane >> 1] + (lane & 1) : 0];
+    NcoRow pre_row0 = lane_rows[r_first];
+    int pre_n1 = lane_rows[r_first + 1].n0;
 
     for (int wt = wt_begin; wt < wt_end; wt++) {
+#if defined(GPSBB_EXPERIMENT) && GPSBB_EXPERIMENT == 4 /* timing only: stores + workgroup prologue */
+        {
+            const int n0e = wt * TILE + lane * SPT;
+            if (n0e + SPT <= p.nsamp) {
+                uint4 *o4 = reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + n0e);
+                for (int j = 0; j < SPT / 4; j++)
+                    o4[j] = make_uint4(tid, wt, j, b);
+            }
+            continue;
+        }
+#endif
         const int wn0 = wt * TILE;      /* first run start of this tile (wave-uniform) */
         const int wnl = wn0 + 63 * SPT; /* last run start */
 
@@ -572,12 +587,14 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         if (has_chain && wt + 2 <= ntw)
             r_after = p.tile_row[(size_t)((lane & 1) ? chain_carr(p, b, ci_) : chain_code(p, b, ci_)) * (ntw + 1) + wt + 2];
 
-        /* the first two rows straight into registers (unconditional loads: lanes without a chain re-read
-         * row 0 of a valid region); they decide whether the chain is uniform over this tile */
+        /* this tile's first row (and where the second starts) were fetched during the previous tile; they
+         * decide whether the chain is uniform over this tile.  Issue the next tile's now (lanes without a
+         * chain re-read row 0 of a valid region). */
         NcoRow row[2];
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-            row[q] = src[q < cnt ? q : 0];
+        row[0] = pre_row0;
+        row[1].n0 = pre_n1;
+        pre_row0 = lane_rows[r_next];
+        pre_n1 = lane_rows[r_next + 1].n0;
 
         int incl = cnt;
 #pragma unroll
@@ -622,15 +639,13 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         }
         if (in_lds && !__all((uni & 1) || cnt == 0)) {
             /* some chain changes row inside the tile: stage the rows in this wavefront's LDS slice */
-#pragma unroll
-            for (int q = 0; q < 2; q++)
-                if (q < cnt) {
-                    W.n0[base + q] = row[q].n0;
-                    W.nav[base + q] = row[q].nav;
-                    W.xb[base + q] = row[q].xb;
-                    W.inc[base + q] = row[q].inc;
-                }
-            for (int r = 2; r < cnt; r++) {
+            if (cnt > 0) {
+                W.n0[base] = row[0].n0;
+                W.nav[base] = row[0].nav;
+                W.xb[base] = row[0].xb;
+                W.inc[base] = row[0].inc;
+            }
+            for (int r = 1; r < cnt; r++) {
                 const NcoRow rw = src[r];
                 W.n0[base + r] = rw.n0;
                 W.nav[base + r] = rw.nav;
@@ -651,7 +666,13 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
             const int nvalid = p.nsamp - n0 < SPT ? p.nsamp - n0 : SPT;
             unsigned long long hz_itable = 0;
 
+#if defined(GPSBB_EXPERIMENT) && GPSBB_EXPERIMENT >= 3 /* timing only: no channel loop */
+            acc[0] += v2s{(short)ubase, (short)ustep};
+            acc[1] += v2s{(short)unav, (short)uni};
+            for (int a = 0; a < 0; a++) {
+#else
             for (int a = 0; a < nact; a++) {
+#endif
                 const int i = L.act[a];
                 uint32_t nav, nav_unused;
                 uint64_t xcb, xkb;
@@ -681,6 +702,11 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                     yk = mul_rn(bits_f64(xkb), 512.0); /* exact */
                 }
                 const double xc = bits_f64(xcb);
+#if defined(GPSBB_EXPERIMENT) && GPSBB_EXPERIMENT == 2 /* timing only: everything but the walk */
+                acc[0] += v2s{(short)xcb, (short)dbx};
+                acc[1] += v2s{(short)nav, (short)(xc + yk)};
+                continue;
+#endif
 
                 /* can any lane of this wavefront wrap inside its run?  Known to be impossible when the
                  * chain's row reaches past the tile; otherwise compare with the per-channel limits */

@@ -596,16 +596,6 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         pre_row0 = lane_rows[r_next];
         pre_n1 = lane_rows[r_next + 1].n0;
 
-        int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o);
-            if (lane >= o)
-                incl += t;
-        }
-        const int base = incl - cnt;
-        const bool in_lds = __shfl(incl, 63) <= WAVE_ROW_CAP;
-
         /* A chain whose first row covers all 64 run starts of the tile ("uniform", the usual case: rows
          * are thousands of samples long) needs no table at all: its lanes' states are
          * ubase + lane*ustep.  Computed here by the chain's lane, broadcast later with v_readlane. */
@@ -632,12 +622,29 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
             }
         }
 
+        /* only when some chain changes row inside the tile are its rows staged in LDS: then (and only then)
+         * the chains' slots in the wavefront's slice are laid out with a prefix sum over the lanes */
+        const bool all_uniform = __all((uni & 1) || cnt == 0);
+        int base = 0;
+        bool in_lds = true;
+        if (!all_uniform) {
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o)
+                    incl += t;
+            }
+            base = incl - cnt;
+            in_lds = __shfl(incl, 63) <= WAVE_ROW_CAP;
+        }
+
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* the previous tile's readers are done */
         if (has_chain) {
             W.cbase[lane] = base;
             W.cr0[lane] = r0;
         }
-        if (in_lds && !__all((uni & 1) || cnt == 0)) {
+        if (in_lds && !all_uniform) {
             /* some chain changes row inside the tile: stage the rows in this wavefront's LDS slice */
             if (cnt > 0) {
                 W.n0[base] = row[0].n0;

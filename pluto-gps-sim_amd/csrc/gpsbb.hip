@@ -186,6 +186,7 @@ struct gpsbb_batch {
     DevBuf<NcoRow> d_rows[2];
     DevBuf<int32_t> d_tile_row[2];
     DevBuf<int32_t> d_row_cnt[2];
+    DevBuf<int32_t> d_tile_ctr;
     DevBuf<gpsbb_chan_state_t> d_end[2];
     hipEvent_t synth_done[2] = {nullptr, nullptr};
     bool synth_pending[2] = {false, false};
@@ -397,6 +398,7 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         b->d_rows[k].release();
         b->d_tile_row[k].release();
         b->d_row_cnt[k].release();
+        b->d_tile_ctr.release();
         b->d_end[k].release();
         if (b->synth_done[k])
             (void)hipEventDestroy(b->synth_done[k]);
@@ -455,6 +457,7 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.row_off = b->d_row_off.p;
     p.tile_row = b->d_tile_row[set].p;
     p.row_cnt = b->d_row_cnt[set].p;
+    p.tile_ctr = b->d_tile_ctr.p;
     p.end = b->d_end[set].p;
     p.status = b->h->d_status;
     p.hazards = b->h->d_hz;
@@ -470,6 +473,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     HIPCHK(h, (hipError_t)b->d_tile_row[set].reserve(2 * nbc * ((size_t)b->ntiles + 1)));
     HIPCHK(h, (hipError_t)b->d_end[set].reserve(nbc));
     HIPCHK(h, (hipError_t)b->d_row_cnt[set].reserve(2 * nbc));
+    HIPCHK(h, (hipError_t)b->d_tile_ctr.reserve((size_t)b->nblocks));
     if (!b->synth_done[set])
         HIPCHK(h, hipEventCreateWithFlags(&b->synth_done[set], hipEventDisableTiming));
     const BatchDev p = batch_dev(b, set);
@@ -503,15 +507,18 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     HIPCHK(h, hipEventRecord(ev[1], h->s_seed));
 
     HIPCHK(h, hipStreamWaitEvent(h->s_compute, ev[1], 0));
+    HIPCHK(h, hipMemsetAsync(b->d_tile_ctr.p, 0, (size_t)b->nblocks * sizeof(int32_t), h->s_compute));
     HIPCHK(h, hipEventRecord(ev[2], h->s_compute));
     {
-        /* several tiles per workgroup once the grid is large enough to fill the chip many times over:
-         * the per-block LDS tables (amplitude LUT, chips, nav words) are then built once per workgroup */
+        /* Workgroups per block: enough of them to oversubscribe the chip ~3x (tiles are handed out
+         * dynamically in chunks, so the tail is short), never more than there are chunks; the per-block
+         * LDS tables (amplitude LUT, chips, nav words) are then built few times per block. */
         const long wg_slots = (long)(h->sm_count > 0 ? h->sm_count : 256) * 2;
-        const long wg_tiles = ((long)b->ntiles + WAVES_PER_WG - 1) / WAVES_PER_WG; /* one tile per wavefront per pass */
-        long tpw = (wg_tiles * b->nblocks) / (wg_slots * 6);
-        tpw = tpw < 1 ? 1 : (tpw > 16 ? 16 : tpw);
-        const int gx = (int)((wg_tiles + tpw - 1) / tpw);
+        const long chunks = ((long)b->ntiles + TILE_CHUNK - 1) / TILE_CHUNK;
+        const long max_useful = (chunks + WAVES_PER_WG - 1) / WAVES_PER_WG;
+        long want = (wg_slots * 3 + b->nblocks - 1) / b->nblocks;
+        want = want < 1 ? 1 : (want > max_useful ? max_useful : want);
+        const int gx = (int)want;
         hipLaunchKernelGGL(k_synth, dim3(gx, b->nblocks), dim3(TILE_THREADS), sizeof(SynthLds), h->s_compute, p, d_iq);
     }
     HIPCHK(h, hipGetLastError());

@@ -48,6 +48,7 @@ constexpr int TILE_THREADS = GPSBB_WG;      /* wave64 x (GPSBB_WG/64) per workgr
 constexpr int SPT = GPSBB_SPT;              /* consecutive samples per lane (128 bytes of output at 32) */
 constexpr int TILE = 64 * SPT;              /* samples per tile = one pass of one wavefront (the row-index granule) */
 constexpr int WAVES_PER_WG = TILE_THREADS / 64;
+constexpr int TILE_CHUNK = 8;               /* consecutive tiles a wavefront takes at a time */
 constexpr int WAVE_ROW_CAP = 128;           /* rows of all chains of one tile staged in a wavefront's LDS slice */
 
 constexpr uint32_t ST_ROW_OVERFLOW = 1u;
@@ -68,6 +69,7 @@ struct BatchDev {
                                        entry [ntiles] = the chain's last row                         */
     int32_t *row_cnt;               /* [2*nblocks*nch] rows each chain produced (0 = inactive)       */
     gpsbb_chan_state_t *end;        /* [nblocks*nch] end-of-block state                              */
+    int32_t *tile_ctr;              /* [nblocks] next tile to hand out (zeroed before every k_synth)  */
     uint32_t *status;               /* self-check word                                               */
     unsigned long long *hazards;    /* [0] itable_512, [1] dwrd_oob                                  */
 };
@@ -541,23 +543,26 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
     const int wave = tid >> 6, lane = tid & 63;
     WaveRows &W = L.wr[wave];
     const int ntw = p.ntiles;
-    const int nwaves = gridDim.x * WAVES_PER_WG;
-    const int per_wave = (ntw + nwaves - 1) / nwaves;
-    const int wt_begin = (blockIdx.x * WAVES_PER_WG + wave) * per_wave;
-    const int wt_end = wt_begin + per_wave < ntw ? wt_begin + per_wave : ntw;
-
     /* lane c serves chain c = (channel c>>1, kind c&1) of this block */
     const bool has_chain = lane < 2 * nact;
-    int r_first = 0, r_next = 0; /* row holding the first sample of tile wt / wt+1 */
-    if (has_chain && wt_begin < wt_end) {
-        const int i = L.act[lane >> 1];
-        const int32_t *__restrict__ tr =
-            p.tile_row + (size_t)((lane & 1) ? chain_carr(p, b, i) : chain_code(p, b, i)) * (ntw + 1);
-        r_first = tr[wt_begin];
-        r_next = tr[wt_begin + 1];
-    }
-    /* rows are fetched one tile ahead: row 0 of the chain for the tile and the start of row 1 */
+    const int32_t *__restrict__ lane_tr =
+        p.tile_row + (size_t)(has_chain ? ((lane & 1) ? chain_carr(p, b, L.act[lane >> 1]) : chain_code(p, b, L.act[lane >> 1])) : 0) * (ntw + 1);
     const NcoRow *__restrict__ lane_rows = p.rows + L.roff[has_chain ? 2 * L.act[lane >> 1] + (lane & 1) : 0];
+
+    /* Tiles are handed out dynamically in chunks of TILE_CHUNK consecutive tiles from a per-block counter:
+     * a wavefront that shares its SIMD with another kernel (the next run's seeding pre-pass runs
+     * concurrently) simply takes fewer chunks instead of stretching the whole launch. */
+  for (;;) {
+    int chunk = 0;
+    if (lane == 0)
+        chunk = atomicAdd(&p.tile_ctr[b], TILE_CHUNK);
+    const int wt_begin = __builtin_amdgcn_readfirstlane(chunk);
+    if (wt_begin >= ntw)
+        break;
+    const int wt_end = wt_begin + TILE_CHUNK < ntw ? wt_begin + TILE_CHUNK : ntw;
+
+    int r_first = lane_tr[wt_begin], r_next = lane_tr[wt_begin + 1]; /* row holding the first sample of tile wt / wt+1 */
+    /* rows are fetched one tile ahead: row 0 of the chain for the tile and the start of row 1 */
     NcoRow pre_row0 = lane_rows[r_first];
     int pre_n1 = lane_rows[r_first + 1].n0;
 
@@ -584,8 +589,8 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         /* prefetch the row index of the tile after next: a contiguous range per wavefront makes this
          * tile's r_next the next tile's r_first */
         int r_after = r_next;
-        if (has_chain && wt + 2 <= ntw)
-            r_after = p.tile_row[(size_t)((lane & 1) ? chain_carr(p, b, ci_) : chain_code(p, b, ci_)) * (ntw + 1) + wt + 2];
+        if (wt + 2 <= ntw)
+            r_after = lane_tr[wt + 2];
 
         /* this tile's first row (and where the second starts) were fetched during the previous tile; they
          * decide whether the chain is uniform over this tile.  Issue the next tile's now (lanes without a
@@ -746,6 +751,7 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
             }
         }
     }
+  } /* chunk loop */
 }
 
 /* pure write stream of the same shape as k_synth's output: the empirical int16x2 write ceiling */

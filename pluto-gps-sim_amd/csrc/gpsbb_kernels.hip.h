@@ -598,8 +598,10 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         NcoRow row[2];
         row[0] = pre_row0;
         row[1].n0 = pre_n1;
-        pre_row0 = lane_rows[r_next];
-        pre_n1 = lane_rows[r_next + 1].n0;
+        if (r_next != r_first) { /* rows span many tiles: usually the next tile starts in the same row */
+            pre_row0 = lane_rows[r_next];
+            pre_n1 = lane_rows[r_next + 1].n0;
+        }
 
         /* A chain whose first row covers all 64 run starts of the tile ("uniform", the usual case: rows
          * are thousands of samples long) needs no table at all: its lanes' states are

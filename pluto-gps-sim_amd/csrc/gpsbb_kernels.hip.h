@@ -48,7 +48,7 @@ constexpr int TILE_THREADS = GPSBB_WG;      /* wave64 x (GPSBB_WG/64) per workgr
 constexpr int SPT = GPSBB_SPT;              /* consecutive samples per lane (128 bytes of output at 32) */
 constexpr int TILE = 64 * SPT;              /* samples per tile = one pass of one wavefront (the row-index granule) */
 constexpr int WAVES_PER_WG = TILE_THREADS / 64;
-constexpr int TILE_CHUNK = 8;               /* consecutive tiles a wavefront takes at a time */
+constexpr int TILE_CHUNK = 4;               /* consecutive tiles a wavefront takes at a time */
 constexpr int WAVE_ROW_CAP = 128;           /* rows of all chains of one tile staged in a wavefront's LDS slice */
 
 constexpr uint32_t ST_ROW_OVERFLOW = 1u;
@@ -65,8 +65,9 @@ struct BatchDev {
     const uint32_t *ca_bits;        /* [33][32] C/A chips per PRN, bit i of dword i>>5 = chip i      */
     NcoRow *rows;                   /* row pool                                                      */
     const uint64_t *row_off;        /* [2*nblocks*nch + 1] first row of each chain in the pool       */
-    int32_t *tile_row;              /* [2*nblocks*nch][ntiles+1] row holding each tile's first sample;
-                                       entry [ntiles] = the chain's last row                         */
+    int32_t *tile_row;              /* [nblocks][ntiles+1][2*nch]: row (relative to its chain) holding each
+                                       tile's first sample, column 2*channel + kind; the 2*nch entries of
+                                       one tile share a cache line; entry [ntiles] = the chain's last row */
     int32_t *row_cnt;               /* [2*nblocks*nch] rows each chain produced (0 = inactive)       */
     gpsbb_chan_state_t *end;        /* [nblocks*nch] end-of-block state                              */
     int32_t *tile_ctr;              /* [nblocks] next tile to hand out (zeroed before every k_synth)  */
@@ -74,6 +75,10 @@ struct BatchDev {
     unsigned long long *hazards;    /* [0] itable_512, [1] dwrd_oob                                  */
 };
 
+__device__ __forceinline__ size_t tile_row_at(const BatchDev &p, int b, int t, int i, int kind)
+{
+    return ((size_t)b * (p.ntiles + 1) + t) * (2 * p.nch) + 2 * i + kind;
+}
 __device__ __forceinline__ int chain_code(const BatchDev &p, int b, int i) { return b * p.nch + i; }
 __device__ __forceinline__ int chain_carr(const BatchDev &p, int b, int i) { return p.nblocks * p.nch + b * p.nch + i; }
 
@@ -138,7 +143,6 @@ struct RowSink {
 /* what phase 2 of k_seed needs to know about the chain a lane has just built */
 struct ChainDone {
     const NcoRow *rows;
-    int32_t *tile_row;
     int cnt; /* 0 = this lane built nothing */
 };
 
@@ -158,7 +162,7 @@ __device__ inline ChainDone seed_code_chain(const BatchDev &p, int b, int i)
 {
     const gpsbb_chan_t &c = p.ch[(size_t)b * p.nch + i];
     gpsbb_chan_state_t &e = p.end[(size_t)b * p.nch + i];
-    ChainDone d = {nullptr, nullptr, 0};
+    ChainDone d = {nullptr, 0};
     if (c.prn <= 0) {
         e.code_phase = 0.0;
         e.iword = e.ibit = e.icode = e.dataBit = e.codeCA = 0;
@@ -182,7 +186,6 @@ __device__ inline ChainDone seed_code_chain(const BatchDev &p, int b, int i)
     e.codeCA = (int)((p.ca_bits[c.prn * 32 + (ci >> 5)] >> (ci & 31)) & 1u) * 2 - 1; /* c:2737 */
     e._pad = 0;
     d.rows = sink.rows;
-    d.tile_row = p.tile_row + (size_t)chain * (p.ntiles + 1);
     d.cnt = (int)sink.cnt;
     return d;
 }
@@ -191,7 +194,7 @@ __device__ inline ChainDone seed_carr_chain(const BatchDev &p, int b, int i, dou
 {
     const gpsbb_chan_t &c = p.ch[(size_t)b * p.nch + i];
     gpsbb_chan_state_t &e = p.end[(size_t)b * p.nch + i];
-    ChainDone d = {nullptr, nullptr, 0};
+    ChainDone d = {nullptr, 0};
     if (c.prn <= 0) {
         e.carr_phase = 0.0;
         *x_end = 0.0;
@@ -208,7 +211,6 @@ __device__ inline ChainDone seed_carr_chain(const BatchDev &p, int b, int i, dou
     e.carr_phase = x;
     *x_end = x;
     d.rows = sink.rows;
-    d.tile_row = p.tile_row + (size_t)chain * (p.ntiles + 1);
     d.cnt = (int)sink.cnt;
     return d;
 }
@@ -273,7 +275,10 @@ __global__ __launch_bounds__(256) void k_tile_index(BatchDev p)
     if (cnt == 0)
         return;
     const NcoRow *__restrict__ rows = p.rows + p.row_off[chain];
-    int32_t *__restrict__ tr = p.tile_row + (size_t)chain * (p.ntiles + 1);
+    const int nbc = p.nblocks * p.nch;
+    const int kind = chain >= nbc ? 1 : 0, bi = chain - kind * nbc;
+    int32_t *__restrict__ tr = p.tile_row + tile_row_at(p, bi / p.nch, 0, bi % p.nch, kind);
+    const size_t tstride = 2 * (size_t)p.nch;
     const int per = (p.ntiles + 1 + TIDX_PARTS - 1) / TIDX_PARTS;
     const int t0 = part * per;
     const int t1 = t0 + per < p.ntiles + 1 ? t0 + per : p.ntiles + 1;
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(256) void k_tile_index(BatchDev p)
     int nxt = rows[r + 1].n0; /* the sentinel row terminates the walk */
     for (int t = t0; t < t1; t++) {
         if (t == p.ntiles) {
-            tr[t] = cnt - 1;
+            tr[t * tstride] = cnt - 1;
             break;
         }
         const int st = t * TILE;
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256) void k_tile_index(BatchDev p)
             r++;
             nxt = rows[r + 1].n0;
         }
-        tr[t] = r;
+        tr[t * tstride] = r;
     }
 }
 
@@ -545,8 +550,8 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
     const int ntw = p.ntiles;
     /* lane c serves chain c = (channel c>>1, kind c&1) of this block */
     const bool has_chain = lane < 2 * nact;
-    const int32_t *__restrict__ lane_tr =
-        p.tile_row + (size_t)(has_chain ? ((lane & 1) ? chain_carr(p, b, L.act[lane >> 1]) : chain_code(p, b, L.act[lane >> 1])) : 0) * (ntw + 1);
+    const int32_t *__restrict__ lane_tr = p.tile_row + tile_row_at(p, b, 0, has_chain ? L.act[lane >> 1] : 0, lane & 1);
+    const size_t tstride = 2 * (size_t)p.nch; /* the 2*nch entries of one tile are contiguous: one cache line */
     const NcoRow *__restrict__ lane_rows = p.rows + L.roff[has_chain ? 2 * L.act[lane >> 1] + (lane & 1) : 0];
 
     /* Tiles are handed out dynamically in chunks of TILE_CHUNK consecutive tiles from a per-block counter:
@@ -561,7 +566,11 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         break;
     const int wt_end = wt_begin + TILE_CHUNK < ntw ? wt_begin + TILE_CHUNK : ntw;
 
-    int r_first = lane_tr[wt_begin], r_next = lane_tr[wt_begin + 1]; /* row holding the first sample of tile wt / wt+1 */
+    int r_first = 0, r_next = 0;
+    if (has_chain) { /* lanes without a chain keep re-reading row 0 of a valid region */
+        r_first = lane_tr[wt_begin * tstride];
+        r_next = lane_tr[(wt_begin + 1) * tstride];
+    } /* row holding the first sample of tile wt / wt+1 */
     /* rows are fetched one tile ahead: row 0 of the chain for the tile and the start of row 1 */
     NcoRow pre_row0 = lane_rows[r_first];
     int pre_n1 = lane_rows[r_first + 1].n0;
@@ -589,8 +598,8 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         /* prefetch the row index of the tile after next: a contiguous range per wavefront makes this
          * tile's r_next the next tile's r_first */
         int r_after = r_next;
-        if (wt + 2 <= ntw)
-            r_after = lane_tr[wt + 2];
+        if (has_chain && wt + 2 <= ntw)
+            r_after = lane_tr[(wt + 2) * tstride];
 
         /* this tile's first row (and where the second starts) were fetched during the previous tile; they
          * decide whether the chain is uniform over this tile.  Issue the next tile's now (lanes without a

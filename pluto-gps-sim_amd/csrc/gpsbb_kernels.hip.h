@@ -49,7 +49,10 @@ constexpr int SPT = GPSBB_SPT;              /* consecutive samples per lane (128
 constexpr int TILE = 64 * SPT;              /* samples per tile = one pass of one wavefront (the row-index granule) */
 constexpr int WAVES_PER_WG = TILE_THREADS / 64;
 constexpr int TILE_CHUNK = 4;               /* consecutive tiles a wavefront takes at a time */
-constexpr int WAVE_ROW_CAP = 128;           /* rows of all chains of one tile staged in a wavefront's LDS slice */
+#ifndef GPSBB_ROW_CAP
+#define GPSBB_ROW_CAP 128
+#endif
+constexpr int WAVE_ROW_CAP = GPSBB_ROW_CAP;           /* rows of all chains of one tile staged in a wavefront's LDS slice */
 
 constexpr uint32_t ST_ROW_OVERFLOW = 1u;
 
@@ -386,7 +389,10 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
  * NCO's update is then a single IEEE add.  With the flag set it is the reference's full update
  * (plutogpssim.c:2709-2746) with the comparisons done on the high dword of the double.
  */
-constexpr int WALK_G = 8; /* samples whose LDS lookups are in flight together */
+#ifndef GPSBB_WALK_G
+#define GPSBB_WALK_G 8
+#endif
+constexpr int WALK_G = GPSBB_WALK_G; /* samples whose LDS lookups are in flight together */
 
 /* dataBit handling inside one run: a run of SPT samples crosses at most one code-period boundary
  * (a period is >= 666 samples under the contract f_code*delt <= 1.5), hence at most one data-bit change:

@@ -46,6 +46,8 @@ typedef struct gpsfe_config {
     int time_overwrite;      /* -T : overwrite TOC/TOE to the scenario start time                   */
     int iono_disable;        /* -i                                                                  */
     int max_chan;            /* channels to allocate: 12 in the reference (h:21), up to 16 here     */
+    int fixed_carrier;       /* descriptors for GPSBB_FIXED_CARRIER: carr_phase is the 32-bit accumulator
+                                value the `#ifndef FLOAT_CARR_PHASE` code initialises at c:1966-1967 */
 } gpsfe_config_t;
 
 int gpsfe_open(const gpsfe_config_t *cfg, gpsfe_t **out);

@@ -63,7 +63,7 @@ void gpsbb_oracle_codegen(int *ca, int prn)
 
 /* ---- descriptor contract (include/gpsbb.h, gpsbb_chan_t) ---------------------------------------- */
 
-static int chan_ok(const gpsbb_chan_t *c, double delt)
+static int chan_ok(const gpsbb_chan_t *c, double delt, int fixed)
 {
     if (c->prn == 0)
         return 1;
@@ -72,8 +72,10 @@ static int chan_ok(const gpsbb_chan_t *c, double delt)
     if (!isfinite(c->f_carr) || !isfinite(c->f_code) || !isfinite(c->carr_phase) ||
         !isfinite(c->code_phase) || !isfinite(c->gain))
         return 0;
-    if (signbit(c->carr_phase) || c->carr_phase > 1.0)
+    if (!fixed && (signbit(c->carr_phase) || c->carr_phase > 1.0))
         return 0;
+    if (fixed && (signbit(c->carr_phase) || c->carr_phase >= 4294967296.0 || c->carr_phase != floor(c->carr_phase)))
+        return 0; /* fixed-point variant: the 32-bit accumulator's value (h:160) */
     if (signbit(c->code_phase) || !(c->code_phase < 1023.0))
         return 0;
     double sc = c->f_code * delt, sk = c->f_carr * delt;
@@ -96,6 +98,8 @@ typedef struct {
     double f_carr, f_code, carr_phase, code_phase, gain;
     const uint32_t *dwrd;
     int iword, ibit, icode, dataBit, codeCA;
+    unsigned int carr_acc; /* fixed-point variant: unsigned int carr_phase (h:160) */
+    int carr_step;         /* int carr_phasestep (h:161) */
 } ochan_t;
 
 static int nav_bit(const ochan_t *c, gpsbb_hazards_t *hz)
@@ -130,7 +134,7 @@ static void load_chan(ochan_t *o, const gpsbb_chan_t *c, gpsbb_hazards_t *hz)
 }
 
 static void fill_core(ochan_t *oc, int nch, double delt, int nsamp, int16_t *iq, const int *sinT,
-                      const int *cosT, gpsbb_hazards_t *hz)
+                      const int *cosT, gpsbb_hazards_t *hz, int fixed)
 {
     for (int n = 0; n < nsamp; n++) {
         int64_t i_acc = 0, q_acc = 0; /* c:2691-2692 */
@@ -139,12 +143,17 @@ static void fill_core(ochan_t *oc, int nch, double delt, int nsamp, int16_t *iq,
             if (c->prn <= 0) /* c:2695 */
                 continue;
 
-            /* carrier table index (c:2697); ==512 only if carr_phase==1.0 exactly (latent OOB) */
-            int it = (int)floor(c->carr_phase * 512.0);
-            if (it > 511) {
-                it &= 511;
-                if (hz)
-                    hz->itable_512++;
+            int it;
+            if (fixed) {
+                it = (c->carr_acc >> 16) & 0x1ff; /* 9-bit index, c:2699 */
+            } else {
+                /* carrier table index (c:2697); ==512 only if carr_phase==1.0 exactly (latent OOB) */
+                it = (int)floor(c->carr_phase * 512.0);
+                if (it > 511) {
+                    it &= 511;
+                    if (hz)
+                        hz->itable_512++;
+                }
             }
 
             /* int*int*int -> double product with gain -> truncation toward zero (c:2701-2702) */
@@ -168,12 +177,16 @@ static void fill_core(ochan_t *oc, int nch, double delt, int nsamp, int16_t *iq,
             }
             c->codeCA = c->ca[(int)c->code_phase] * 2 - 1; /* c:2737 */
 
-            /* carrier NCO, FLOAT_CARR_PHASE variant (c:2741-2746) */
-            c->carr_phase += c->f_carr * delt;
-            if (c->carr_phase >= 1.0)
-                c->carr_phase -= 1.0;
-            else if (c->carr_phase < 0.0)
-                c->carr_phase += 1.0;
+            if (fixed) {
+                c->carr_acc += (unsigned int)c->carr_step; /* c:2748 */
+            } else {
+                /* carrier NCO, FLOAT_CARR_PHASE variant (c:2741-2746) */
+                c->carr_phase += c->f_carr * delt;
+                if (c->carr_phase >= 1.0)
+                    c->carr_phase -= 1.0;
+                else if (c->carr_phase < 0.0)
+                    c->carr_phase += 1.0;
+            }
         }
         if (iq) {
             iq[2 * n] = (int16_t)i_acc; /* (short) cast, c:2754-2755 */
@@ -196,16 +209,15 @@ static void store_state(gpsbb_chan_state_t *s, const ochan_t *c)
     s->codeCA = c->codeCA;
 }
 
-int gpsbb_oracle_fill_blocks(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp,
-                             int chain, int16_t *iq, gpsbb_chan_state_t *end_state,
-                             gpsbb_hazards_t *hz)
+static int fill_blocks(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp, int chain,
+                       int16_t *iq, gpsbb_chan_state_t *end_state, gpsbb_hazards_t *hz, int fixed)
 {
     static int sinT[512], cosT[512];
     static int have_tables;
     if (!ch || nblocks < 0 || nch < 0 || nch > GPSBB_MAX_CHAN || nsamp < 0 || !(delt > 0.0))
         return -1;
     for (int k = 0; k < nblocks * nch; k++)
-        if (!chan_ok(&ch[k], delt))
+        if (!chan_ok(&ch[k], delt, fixed))
             return -1;
     if (!have_tables) {
         gpsbb_oracle_tables(sinT, cosT);
@@ -225,9 +237,16 @@ int gpsbb_oracle_fill_blocks(const gpsbb_chan_t *ch, int nblocks, int nch, doubl
             /* carr_phase is never re-seeded while a channel stays allocated (c:2741-2746; born c:1964) */
             if (chain && b > 0 && oc[i].prn > 0 && prev_prn[i] == oc[i].prn)
                 oc[i].carr_phase = prev_phase[i];
+            if (fixed && oc[i].prn > 0) {
+                oc[i].carr_acc = (unsigned int)oc[i].carr_phase;
+                /* per-block phase step of the fixed-point variant (c:2675) */
+                oc[i].carr_step = (int)round(512.0 * 65536.0 * oc[i].f_carr * delt);
+            }
         }
-        fill_core(oc, nch, delt, nsamp, iq ? iq + (size_t)b * 2 * nsamp : NULL, sinT, cosT, hz);
+        fill_core(oc, nch, delt, nsamp, iq ? iq + (size_t)b * 2 * nsamp : NULL, sinT, cosT, hz, fixed);
         for (int i = 0; i < nch; i++) {
+            if (fixed && oc[i].prn > 0)
+                oc[i].carr_phase = (double)oc[i].carr_acc;
             prev_prn[i] = oc[i].prn > 0 ? oc[i].prn : 0;
             prev_phase[i] = oc[i].carr_phase;
             if (end_state)
@@ -235,6 +254,20 @@ int gpsbb_oracle_fill_blocks(const gpsbb_chan_t *ch, int nblocks, int nch, doubl
         }
     }
     return 0;
+}
+
+int gpsbb_oracle_fill_blocks(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp,
+                             int chain, int16_t *iq, gpsbb_chan_state_t *end_state,
+                             gpsbb_hazards_t *hz)
+{
+    return fill_blocks(ch, nblocks, nch, delt, nsamp, chain, iq, end_state, hz, 0);
+}
+
+int gpsbb_oracle_fill_blocks_fixed(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp,
+                                   int chain, int16_t *iq, gpsbb_chan_state_t *end_state,
+                                   gpsbb_hazards_t *hz)
+{
+    return fill_blocks(ch, nblocks, nch, delt, nsamp, chain, iq, end_state, hz, 1);
 }
 
 int gpsbb_oracle_fill(const gpsbb_chan_t *ch, int nch, double delt, int nsamp, int16_t *iq,

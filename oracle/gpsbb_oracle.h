@@ -45,6 +45,14 @@ int gpsbb_oracle_fill_blocks(const gpsbb_chan_t *ch, int nblocks, int nch, doubl
                              int chain, int16_t *iq, gpsbb_chan_state_t *end_state,
                              gpsbb_hazards_t *hz);
 
+/* The reference's other carrier NCO (the `#ifndef FLOAT_CARR_PHASE` code, compiled out as shipped:
+ * h:12, 157-162; c:1966-1967, 2675, 2699, 2748): a 32-bit accumulator, step
+ * (int)round(2^25 * f_carr * delt) per block, table index (phase >> 16) & 0x1ff.  ch[].carr_phase holds
+ * the accumulator's value (an integer in [0, 2^32)); end_state[].carr_phase likewise. */
+int gpsbb_oracle_fill_blocks_fixed(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp,
+                                   int chain, int16_t *iq, gpsbb_chan_state_t *end_state,
+                                   gpsbb_hazards_t *hz);
+
 #ifdef __cplusplus
 }
 #endif

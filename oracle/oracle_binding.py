@@ -36,6 +36,8 @@ class Oracle:
         L.gpsbb_oracle_fill_blocks.restype = C.c_int
         L.gpsbb_oracle_fill_blocks.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int,
                                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gpsbb_oracle_fill_blocks_fixed.restype = C.c_int
+        L.gpsbb_oracle_fill_blocks_fixed.argtypes = L.gpsbb_oracle_fill_blocks.argtypes
         L.gpsbb_oracle_tables.argtypes = [C.c_void_p, C.c_void_p]
         L.gpsbb_oracle_codegen.argtypes = [C.c_void_p, C.c_int]
 
@@ -50,8 +52,9 @@ class Oracle:
         self.lib.gpsbb_oracle_codegen(ca.ctypes.data, prn)
         return ca
 
-    def fill_blocks(self, ch, delt, nsamp, chain=False, want_iq=True):
-        """ch: CHAN_DTYPE array [nblocks, nch] -> (iq int16 [nblocks, nsamp, 2], end_state, hazards)"""
+    def fill_blocks(self, ch, delt, nsamp, chain=False, want_iq=True, fixed=False):
+        """ch: CHAN_DTYPE array [nblocks, nch] -> (iq int16 [nblocks, nsamp, 2], end_state, hazards).
+        fixed=True: the reference's fixed-point carrier variant (carr_phase = 32-bit accumulator value)."""
         ch = np.ascontiguousarray(ch, dtype=CHAN_DTYPE)
         if ch.ndim == 1:
             ch = ch[None, :]
@@ -59,7 +62,8 @@ class Oracle:
         iq = np.zeros((nb, nsamp, 2), np.int16) if want_iq else None
         st = np.zeros((nb, nch), STATE_DTYPE)
         hz = np.zeros(1, HAZ_DTYPE)
-        rc = self.lib.gpsbb_oracle_fill_blocks(ch.ctypes.data, nb, nch, delt, nsamp, int(chain),
+        fn = self.lib.gpsbb_oracle_fill_blocks_fixed if fixed else self.lib.gpsbb_oracle_fill_blocks
+        rc = fn(ch.ctypes.data, nb, nch, delt, nsamp, int(chain),
                                                iq.ctypes.data if want_iq else None, st.ctypes.data,
                                                hz.ctypes.data)
         if rc != 0:
@@ -71,7 +75,8 @@ REF_DIR = os.path.join(HERE, "_ref")
 
 
 def have_ref():
-    return os.path.exists(os.path.join(REF_DIR, "libplutoref.so"))
+    return os.path.exists(os.path.join(REF_DIR, "libplutoref.so")) and \
+        os.path.exists(os.path.join(REF_DIR, "libplutoref_fixed.so"))
 
 
 class RefLoop:

@@ -62,4 +62,14 @@ done
 $CC $REFFLAGS $INC -DREF_MAX_CHAN=16 -shared -fPIC "$HERE/ref_harness.c" -o "$OUT/libplutoref.so" -lm -lz
 $CC $FASTFLAGS $INC -DREF_MAX_CHAN=16 -shared -fPIC "$HERE/ref_harness.c" -o "$OUT/libplutoref_O2.so" -lm -lz
 $CC $FASTFLAGS $INC -DREF_MAX_CHAN=16 -DREF_BUILD_MAIN "$HERE/ref_harness.c" -o "$OUT/ref_sim16_O2" -lm -lz
+# The reference's other carrier NCO (the `#ifndef FLOAT_CARR_PHASE` code: 32-bit phase accumulator).  The
+# header defines FLOAT_CARR_PHASE unconditionally (h:12), so this variant is compiled against a temporary
+# copy of the header with exactly that one line removed; everything else is as above.
+HFIX="$TMP/hfixed"
+mkdir -p "$HFIX"
+sed -n '12p' "$HDR" | grep -q '^#define FLOAT_CARR_PHASE'
+sed '12d' "$HDR" > "$HFIX/plutogpssim.h"
+INCF="-I$TMP -I$HFIX -I$HERE/../../include"
+$CC $REFFLAGS $INCF -DREF_MAX_CHAN=16 -shared -fPIC "$HERE/ref_harness.c" -o "$OUT/libplutoref_fixed.so" -lm -lz
+$CC $REFFLAGS $INCF -DREF_MAX_CHAN=12 -DREF_BUILD_MAIN "$HERE/ref_harness.c" -o "$OUT/ref_sim12_fixed" -lm -lz
 echo "build_ref: built $(ls "$OUT" | tr '\n' ' ')"

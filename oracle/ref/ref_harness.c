@@ -142,6 +142,9 @@ int ref_loop_fill(const gpsbb_chan_t *ch, int nch, double delt_in, int nsamp, in
         chan[i].codeCA = chan[i].ca[(int)chan[i].code_phase] * 2 - 1;
         chan[i].dataBit = (int)((chan[i].dwrd[chan[i].iword] >> (29 - chan[i].ibit)) & 0x1UL) * 2 - 1;
         gain[i] = ch[i].gain;
+#ifndef FLOAT_CARR_PHASE /* built against the header copy without h:12: the step main() sets at c:2675 */
+        chan[i].carr_phasestep = (int)round(512.0 * 65536.0 * chan[i].f_carr * delt);
+#endif
     }
     ref_nsamp = nsamp;
 

@@ -34,6 +34,7 @@ ROW_DTYPE = np.dtype([("n0", "<i4"), ("nav", "<u4"), ("xb", "<u8"), ("inc", "<i8
 assert CHAN_DTYPE.itemsize == 296 and STATE_DTYPE.itemsize == 40 and ROW_DTYPE.itemsize == 24
 
 CHAIN_CARRIER = 1
+FIXED_CARRIER = 2
 
 ERRORS = {0: "GPSBB_OK", -1: "GPSBB_E_BADARG", -2: "GPSBB_E_BADCHAN", -3: "GPSBB_E_HIP", -4: "GPSBB_E_NOMEM",
           -5: "GPSBB_E_INTERNAL", -6: "GPSBB_E_NODEVICE", -7: "GPSBB_E_STATE"}
@@ -41,7 +42,7 @@ ERRORS = {0: "GPSBB_OK", -1: "GPSBB_E_BADARG", -2: "GPSBB_E_BADCHAN", -3: "GPSBB
 # every symbol include/gpsbb.h declares
 API_SYMBOLS = [
     "gpsbb_create", "gpsbb_destroy", "gpsbb_strerror", "gpsbb_last_hip_error", "gpsbb_version",
-    "gpsbb_fill_block", "gpsbb_fill_block_ref", "gpsbb_batch_create", "gpsbb_batch_destroy",
+    "gpsbb_fill_block", "gpsbb_fill_block_ex", "gpsbb_fill_block_ref", "gpsbb_batch_create", "gpsbb_batch_destroy",
     "gpsbb_batch_iq_bytes", "gpsbb_batch_run", "gpsbb_sync", "gpsbb_batch_read", "gpsbb_batch_device_iq",
     "gpsbb_get_hazards", "gpsbb_batch_last_timing", "gpsbb_batch_timing_stats", "gpsbb_fill_ceiling", "gpsbb_stream_create",
     "gpsbb_stream_destroy", "gpsbb_stream_push", "gpsbb_stream_pop", "gpsbb_stream_pending",
@@ -82,6 +83,7 @@ def lib():
         L.gpsbb_strerror.restype = C.c_char_p
         L.gpsbb_last_hip_error.argtypes = [vp]
         L.gpsbb_fill_block.argtypes = [vp, vp, i, d, i, vp, vp]
+        L.gpsbb_fill_block_ex.argtypes = [vp, vp, i, d, i, u, vp, vp]
         L.gpsbb_fill_block_ref.argtypes = [vp, vp, vp, i, vp, d, i, vp]
         L.gpsbb_batch_create.argtypes = [vp, vp, i, i, d, i, u, C.POINTER(vp)]
         L.gpsbb_batch_destroy.argtypes = [vp]
@@ -183,13 +185,13 @@ class Synth:
     def __exit__(self, *a):
         self.close()
 
-    def fill_block(self, ch, delt, nsamp):
-        """gpsbb_fill_block: ch = CHAN_DTYPE[nch] -> (int16 [nsamp,2], STATE_DTYPE[nch])"""
+    def fill_block(self, ch, delt, nsamp, flags=0):
+        """gpsbb_fill_block(_ex): ch = CHAN_DTYPE[nch] -> (int16 [nsamp,2], STATE_DTYPE[nch])"""
         ch = np.ascontiguousarray(ch, dtype=CHAN_DTYPE)
         iq = np.empty((nsamp, 2), np.int16)
         st = np.zeros(ch.shape[0], STATE_DTYPE)
-        _chk(lib().gpsbb_fill_block(self._h, ch.ctypes.data, ch.shape[0], delt, nsamp, iq.ctypes.data,
-                                    st.ctypes.data), "gpsbb_fill_block")
+        _chk(lib().gpsbb_fill_block_ex(self._h, ch.ctypes.data, ch.shape[0], delt, nsamp, flags, iq.ctypes.data,
+                                       st.ctypes.data), "gpsbb_fill_block_ex")
         return iq, st
 
     def batch(self, ch, delt, nsamp, flags=0):
@@ -380,7 +382,8 @@ class _FeConfig(C.Structure):
     _fields_ = [("navfile", C.c_char_p), ("rinex3", C.c_int), ("motion_file", C.c_char_p), ("use_ecef", C.c_int),
                 ("pos", C.c_double * 3), ("have_start", C.c_int), ("y", C.c_int), ("m", C.c_int),
                 ("d", C.c_int), ("hh", C.c_int), ("mm", C.c_int), ("sec", C.c_double),
-                ("time_overwrite", C.c_int), ("iono_disable", C.c_int), ("max_chan", C.c_int)]
+                ("time_overwrite", C.c_int), ("iono_disable", C.c_int), ("max_chan", C.c_int),
+                ("fixed_carrier", C.c_int)]
 
 
 def build_frontend(force=False):
@@ -417,7 +420,7 @@ class FrontEnd:
     """gpsfe_open / gpsfe_generate: the scenario the reference's main() runs, as descriptor blocks."""
 
     def __init__(self, navfile, llh=None, ecef=None, motion=None, start=None, time_overwrite=False,
-                 iono=True, max_chan=12, rinex3=False):
+                 iono=True, max_chan=12, rinex3=False, fixed_carrier=False):
         cfg = _FeConfig()
         cfg.navfile = os.fsencode(navfile)
         cfg.rinex3 = int(rinex3)
@@ -434,6 +437,7 @@ class FrontEnd:
         cfg.time_overwrite = int(time_overwrite)
         cfg.iono_disable = int(not iono)
         cfg.max_chan = max_chan
+        cfg.fixed_carrier = int(fixed_carrier)
         self.max_chan = max_chan
         self._fe = C.c_void_p()
         rc = fe_lib().gpsfe_open(C.byref(cfg), C.byref(self._fe))

@@ -82,7 +82,7 @@ void make_ca(int prn, uint8_t ca[GPSBB_CA_LEN])
 }
 
 /* descriptor contract of gpsbb_chan_t (include/gpsbb.h) */
-bool chan_ok(const gpsbb_chan_t &c, double delt)
+bool chan_ok(const gpsbb_chan_t &c, double delt, bool fixed = false)
 {
     if (c.prn == 0)
         return true;
@@ -91,8 +91,10 @@ bool chan_ok(const gpsbb_chan_t &c, double delt)
     if (!std::isfinite(c.f_carr) || !std::isfinite(c.f_code) || !std::isfinite(c.carr_phase) ||
         !std::isfinite(c.code_phase) || !std::isfinite(c.gain))
         return false;
-    if (std::signbit(c.carr_phase) || c.carr_phase > 1.0)
+    if (!fixed && (std::signbit(c.carr_phase) || c.carr_phase > 1.0))
         return false;
+    if (fixed && (std::signbit(c.carr_phase) || c.carr_phase >= 4294967296.0 || c.carr_phase != std::floor(c.carr_phase)))
+        return false; /* fixed-point variant: the value of the 32-bit accumulator */
     if (std::signbit(c.code_phase) || !(c.code_phase < 1023.0))
         return false;
     const double sc = c.f_code * delt, sk = c.f_carr * delt;
@@ -187,6 +189,12 @@ struct gpsbb_batch {
     DevBuf<int32_t> d_tile_row[2];
     DevBuf<int32_t> d_row_cnt[2];
     DevBuf<int32_t> d_tile_ctr;
+    DevBuf<uint32_t> d_kph0; /* fixed-point carrier variant: start phase and step per (block, channel) */
+    DevBuf<int32_t> d_kstep;
+    std::vector<uint32_t> h_kph0;
+    std::vector<int32_t> h_kstep;
+    const int *fixed_prev_prn = nullptr;      /* stream chaining of the fixed-point carrier (host side) */
+    const uint32_t *fixed_prev_phase = nullptr;
     DevBuf<gpsbb_chan_state_t> d_end[2];
     hipEvent_t synth_done[2] = {nullptr, nullptr};
     bool synth_pending[2] = {false, false};
@@ -337,11 +345,12 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
 {
     gpsbb *h = b->h;
     if (!ch || nblocks < 1 || nblocks > 65535 || nch < 1 || nch > GPSBB_MAX_CHAN || nsamp < 1 ||
-        !(delt > 0.0) || !std::isfinite(delt) || (flags & ~GPSBB_CHAIN_CARRIER))
+        !(delt > 0.0) || !std::isfinite(delt) || (flags & ~(GPSBB_CHAIN_CARRIER | GPSBB_FIXED_CARRIER)))
         return GPSBB_E_BADARG;
     const size_t nbc = (size_t)nblocks * nch;
+    const bool fixed = (flags & GPSBB_FIXED_CARRIER) != 0;
     for (size_t k = 0; k < nbc; k++)
-        if (!chan_ok(ch[k], delt))
+        if (!chan_ok(ch[k], delt, fixed))
             return GPSBB_E_BADCHAN;
 
     b->nblocks = nblocks;
@@ -357,7 +366,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     for (int kind = 0; kind < 2; kind++)
         for (size_t k = 0; k < nbc; k++) {
             b->row_off[kind * nbc + k] = off;
-            if (ch[k].prn > 0) {
+            if (ch[k].prn > 0 && !(kind == 1 && fixed)) {
                 const double s = kind == 0 ? ch[k].f_code * delt : std::fabs(ch[k].f_carr * delt);
                 off += (kind == 0 ? row_bound(s, 1023.0, 9, nsamp) : row_bound(s, 1.0, -1, nsamp)) + 1;
             } else {
@@ -369,6 +378,34 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
 
     HIPCHK(h, (hipError_t)b->d_ch.reserve(nbc));
     HIPCHK(h, (hipError_t)b->d_row_off.reserve(2 * nbc + 1));
+    if (fixed) {
+        /* start phase and step of the 32-bit accumulator per (block, channel); the chain across blocks is
+         * plain modular arithmetic, resolved here (c:2675, 2748) */
+        b->h_kph0.assign(nbc, 0u);
+        b->h_kstep.assign(nbc, 0);
+        for (int i = 0; i < nch; i++) {
+            int prev_prn = b->fixed_prev_prn ? b->fixed_prev_prn[i] : 0;
+            uint32_t prev_ph = b->fixed_prev_phase ? b->fixed_prev_phase[i] : 0u;
+            for (int blk = 0; blk < nblocks; blk++) {
+                const gpsbb_chan_t &c = ch[(size_t)blk * nch + i];
+                const size_t k = (size_t)blk * nch + i;
+                if (c.prn <= 0) {
+                    prev_prn = 0;
+                    continue;
+                }
+                const volatile double scaled = 512.0 * 65536.0 * c.f_carr * delt;
+                b->h_kstep[k] = (int)std::round(scaled);
+                const bool cont = (flags & GPSBB_CHAIN_CARRIER) && c.prn == prev_prn;
+                b->h_kph0[k] = cont ? prev_ph : (uint32_t)c.carr_phase;
+                prev_ph = b->h_kph0[k] + (uint32_t)nsamp * (uint32_t)b->h_kstep[k];
+                prev_prn = c.prn;
+            }
+        }
+        HIPCHK(h, (hipError_t)b->d_kph0.reserve(nbc));
+        HIPCHK(h, (hipError_t)b->d_kstep.reserve(nbc));
+        HIPCHK(h, hipMemcpyAsync(b->d_kph0.p, b->h_kph0.data(), nbc * 4, hipMemcpyHostToDevice, upload_stream));
+        HIPCHK(h, hipMemcpyAsync(b->d_kstep.p, b->h_kstep.data(), nbc * 4, hipMemcpyHostToDevice, upload_stream));
+    }
     b->h_ch.assign(ch, ch + nbc);
     HIPCHK(h, hipMemcpyAsync(b->d_ch.p, b->h_ch.data(), nbc * sizeof(gpsbb_chan_t), hipMemcpyHostToDevice, upload_stream));
     HIPCHK(h, hipMemcpyAsync(b->d_row_off.p, b->row_off.data(), (2 * nbc + 1) * 8, hipMemcpyHostToDevice, upload_stream));
@@ -399,6 +436,8 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         b->d_tile_row[k].release();
         b->d_row_cnt[k].release();
         b->d_tile_ctr.release();
+        b->d_kph0.release();
+        b->d_kstep.release();
         b->d_end[k].release();
         if (b->synth_done[k])
             (void)hipEventDestroy(b->synth_done[k]);
@@ -458,6 +497,8 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.tile_row = b->d_tile_row[set].p;
     p.row_cnt = b->d_row_cnt[set].p;
     p.tile_ctr = b->d_tile_ctr.p;
+    p.kph0 = (b->flags & GPSBB_FIXED_CARRIER) ? b->d_kph0.p : nullptr;
+    p.kstep = (b->flags & GPSBB_FIXED_CARRIER) ? b->d_kstep.p : nullptr;
     p.end = b->d_end[set].p;
     p.status = b->h->d_status;
     p.hazards = b->h->d_hz;
@@ -668,6 +709,12 @@ extern "C" int gpsbb_fill_ceiling(gpsbb_t *h, void *d_dst, size_t bytes, int ite
 extern "C" int gpsbb_fill_block(gpsbb_t *h, const gpsbb_chan_t *ch, int nch, double delt, int nsamp,
                                 int16_t *iq_out, gpsbb_chan_state_t *end_state)
 {
+    return gpsbb_fill_block_ex(h, ch, nch, delt, nsamp, 0u, iq_out, end_state);
+}
+
+extern "C" int gpsbb_fill_block_ex(gpsbb_t *h, const gpsbb_chan_t *ch, int nch, double delt, int nsamp, unsigned flags,
+                                   int16_t *iq_out, gpsbb_chan_state_t *end_state)
+{
     if (!h || !ch || !iq_out)
         return GPSBB_E_BADARG;
     HIPCHK(h, hipSetDevice(h->device));
@@ -679,7 +726,9 @@ extern "C" int gpsbb_fill_block(gpsbb_t *h, const gpsbb_chan_t *ch, int nch, dou
     gpsbb_batch *b = h->scratch;
     b->prev_ch = nullptr;
     b->prev_end = nullptr;
-    int rc = batch_setup(b, ch, 1, nch, delt, nsamp, 0, h->s_seed);
+    if (flags & ~GPSBB_FIXED_CARRIER & ~GPSBB_CHAIN_CARRIER)
+        return GPSBB_E_BADARG;
+    int rc = batch_setup(b, ch, 1, nch, delt, nsamp, flags & GPSBB_FIXED_CARRIER, h->s_seed);
     if (rc != GPSBB_OK)
         return rc;
     rc = gpsbb_batch_run(b, nullptr);
@@ -760,6 +809,8 @@ struct gpsbb_stream {
     };
     std::vector<Slot> slots;
     uint64_t head = 0, tail = 0; /* pushes / pops so far */
+    int fx_prn[GPSBB_MAX_CHAN] = {0};          /* fixed-point carrier: channel state after the last push */
+    uint32_t fx_phase[GPSBB_MAX_CHAN] = {0};
 };
 
 extern "C" void gpsbb_stream_destroy(gpsbb_stream_t *s)
@@ -784,7 +835,7 @@ extern "C" int gpsbb_stream_create(gpsbb_t *h, int nch, double delt, int nsamp, 
                                    int depth, unsigned flags, gpsbb_stream_t **out)
 {
     if (!h || !out || nch < 1 || nch > GPSBB_MAX_CHAN || nsamp < 1 || blocks_per_slot < 1 || depth < 2 ||
-        depth > 64 || !(delt > 0.0) || (flags & ~GPSBB_CHAIN_CARRIER))
+        depth > 64 || !(delt > 0.0) || (flags & ~(GPSBB_CHAIN_CARRIER | GPSBB_FIXED_CARRIER)))
         return GPSBB_E_BADARG;
     *out = nullptr;
     HIPCHK(h, hipSetDevice(h->device));
@@ -832,9 +883,20 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     auto &sl = s->slots[s->head % s->depth];
     gpsbb_batch *b = sl.batch;
     /* the slot's previous D2H copy was waited for by the pop that freed it */
+    const bool fx_chain = (s->flags & GPSBB_FIXED_CARRIER) && (s->flags & GPSBB_CHAIN_CARRIER) && s->head > 0;
+    b->fixed_prev_prn = fx_chain ? s->fx_prn : nullptr;
+    b->fixed_prev_phase = fx_chain ? s->fx_phase : nullptr;
     int rc = batch_setup(b, ch, s->bps, s->nch, s->delt, s->nsamp, s->flags, h->s_seed);
+    b->fixed_prev_prn = nullptr;
+    b->fixed_prev_phase = nullptr;
     if (rc != GPSBB_OK)
         return rc;
+    if (s->flags & GPSBB_FIXED_CARRIER)
+        for (int i = 0; i < s->nch; i++) {
+            const size_t k = (size_t)(s->bps - 1) * s->nch + i;
+            s->fx_prn[i] = ch[k].prn > 0 ? ch[k].prn : 0;
+            s->fx_phase[i] = b->h_kph0[k] + (uint32_t)s->nsamp * (uint32_t)b->h_kstep[k];
+        }
     b->prev_ch = nullptr;
     b->prev_end = nullptr;
     if ((s->flags & GPSBB_CHAIN_CARRIER) && s->head > 0) {

@@ -74,6 +74,9 @@ struct BatchDev {
     int32_t *row_cnt;               /* [2*nblocks*nch] rows each chain produced (0 = inactive)       */
     gpsbb_chan_state_t *end;        /* [nblocks*nch] end-of-block state                              */
     int32_t *tile_ctr;              /* [nblocks] next tile to hand out (zeroed before every k_synth)  */
+    const uint32_t *kph0;           /* fixed-point carrier variant (GPSBB_FIXED_CARRIER): [nblocks*nch] 32-bit
+                                       phase accumulator at the start of each block, else NULL          */
+    const int32_t *kstep;           /* ... and its per-sample step (int)round(2^25*f_carr*delt), c:2675 */
     uint32_t *status;               /* self-check word                                               */
     unsigned long long *hazards;    /* [0] itable_512, [1] dwrd_oob                                  */
 };
@@ -218,6 +221,14 @@ __device__ inline ChainDone seed_carr_chain(const BatchDev &p, int b, int i, dou
     return d;
 }
 
+/* fixed-point carrier variant: the phase after the block is start + nsamp*step modulo 2^32 (c:2748) */
+__device__ inline void seed_carr_fixed(const BatchDev &p, int b, int i)
+{
+    const size_t k = (size_t)b * p.nch + i;
+    p.row_cnt[chain_carr(p, b, i)] = 0;
+    p.end[k].carr_phase = p.ch[k].prn > 0 ? (double)(uint32_t)(p.kph0[k] + (uint32_t)p.nsamp * (uint32_t)p.kstep[k]) : 0.0;
+}
+
 /* grid: lanes [0, nbc) = code chains; lanes [cbase, ...) = carrier chains (cbase = nbc rounded up to a
  * wave so that the two kinds of chain never share a wavefront).  Writes each chain's rows, end state and
  * row count; the tile index is filled by k_tile_index, massively parallel, afterwards. */
@@ -247,6 +258,10 @@ __global__ __launch_bounds__(64) void k_seed(BatchDev p, int cbase)
         }
         for (int b = 0; b < p.nblocks; b++) {
             const gpsbb_chan_t &c = p.ch[(size_t)b * p.nch + g];
+            if (p.kph0) { /* fixed-point carrier: no rows; the host has already chained the start phases */
+                seed_carr_fixed(p, b, g);
+                continue;
+            }
             const double x0 = (c.prn > 0 && c.prn == prev_prn) ? prev_x : c.carr_phase;
             const ChainDone d = seed_carr_chain(p, b, g, x0, &prev_x);
             p.row_cnt[chain_carr(p, b, g)] = d.cnt;
@@ -256,6 +271,10 @@ __global__ __launch_bounds__(64) void k_seed(BatchDev p, int cbase)
         if (g >= nbc)
             return;
         const int b = g / p.nch, i = g % p.nch;
+        if (p.kph0) {
+            seed_carr_fixed(p, b, i);
+            return;
+        }
         double unused;
         const ChainDone d = seed_carr_chain(p, b, i, p.ch[(size_t)b * p.nch + i].carr_phase, &unused);
         p.row_cnt[chain_carr(p, b, i)] = d.cnt;
@@ -384,10 +403,11 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
 }
 
 /*
- * SPT consecutive samples of one channel.  CODEW / CARRW = false are the straight-line versions used when
+ * SPT consecutive samples of one channel.  CODEW = false / CARR = 0 are the straight-line versions used when
  * no lane of the wavefront can reach a code / carrier wrap inside its run (decided by the caller): that
- * NCO's update is then a single IEEE add.  With the flag set it is the reference's full update
- * (plutogpssim.c:2709-2746) with the comparisons done on the high dword of the double.
+ * NCO's update is then a single IEEE add.  With CODEW / CARR = 1 it is the reference's full update
+ * (plutogpssim.c:2709-2746) with the comparisons done on the high dword of the double.  CARR = 2 is the
+ * reference's fixed-point carrier (32-bit accumulator, c:2699/2748).
  */
 #ifndef GPSBB_WALK_G
 #define GPSBB_WALK_G 8
@@ -403,14 +423,20 @@ struct RunNav {
 };
 
 /* phase 1 of a group: table indices of WALK_G samples, both NCOs advanced (two chains of IEEE adds) */
-template <bool CODEW, bool CARRW>
+template <bool CODEW, int CARR>
 __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc, double sk, double &xc, double &yk,
-                                             RunNav &rn, int (&it)[WALK_G], int (&ci)[WALK_G], int jbase, int nvalid,
-                                             unsigned long long &hz_itable)
+                                             uint32_t &ph, uint32_t kstep, RunNav &rn, int (&it)[WALK_G],
+                                             int (&ci)[WALK_G], int jbase, int nvalid, unsigned long long &hz_itable)
 {
+    constexpr bool CARRW = CARR == 1;
 #pragma unroll
     for (int u = 0; u < WALK_G; u++) {
-        it[u] = (int)yk; /* floor(carr_phase*512), c:2697 (yk = carr_phase*512 >= 0) */
+        if (CARR == 2) {
+            it[u] = (int)((ph >> 16) & 0x1ffu); /* fixed-point variant: 9-bit index, c:2699 */
+            ph += kstep;                       /* c:2748 */
+        } else {
+            it[u] = (int)yk; /* floor(carr_phase*512), c:2697 (yk = carr_phase*512 >= 0) */
+        }
         if (CARRW && it[u] > 511) { /* carr_phase == 1.0: latent OOB of the reference, defined as &511 */
             it[u] &= 511;
             if (jbase + u < nvalid)
@@ -418,7 +444,8 @@ __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc
         }
         ci[u] = (int)xc; /* c:2737 */
         xc = add_rn(xc, sc); /* c:2709 */
-        yk = add_rn(yk, sk); /* c:2741, scaled by 512 */
+        if (CARR != 2)
+            yk = add_rn(yk, sk); /* c:2741, scaled by 512 */
         if (CODEW) {
             if (__double2hiint(xc) >= 0x408FF800) { /* xc >= 1023.0 (xc >= 0) */
                 xc = add_rn(xc, -1023.0);
@@ -438,16 +465,18 @@ __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc
 }
 
 /*
- * SPT consecutive samples of one channel.  CODEW / CARRW = false are the straight-line versions used when
+ * SPT consecutive samples of one channel.  CODEW = false / CARR = 0 are the straight-line versions used when
  * no lane of the wavefront can reach a code / carrier wrap inside its run (decided by the caller): that
- * NCO's update is then a single IEEE add.  With the flag set it is the reference's full update
- * (plutogpssim.c:2709-2746) with the comparisons done on the high dword of the double.
+ * NCO's update is then a single IEEE add.  With CODEW / CARR = 1 it is the reference's full update
+ * (plutogpssim.c:2709-2746) with the comparisons done on the high dword of the double.  CARR = 2 is the
+ * reference's fixed-point carrier (32-bit accumulator, c:2699/2748).
  * Software-pipelined by hand: the LDS reads of group k are issued, then the indices of group k+1 are
  * computed (pure VALU, covers the LDS latency), then group k is accumulated.
  */
-template <bool CODEW, bool CARRW>
-__device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc, double yk, uint32_t nav, int dbx0,
-                                             v2s (&acc)[SPT], int nvalid, unsigned long long &hz_itable)
+template <bool CODEW, int CARR>
+__device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc, double yk, uint32_t ph, uint32_t kstep,
+                                             uint32_t nav, int dbx0, v2s (&acc)[SPT], int nvalid,
+                                             unsigned long long &hz_itable)
 {
     constexpr int G = WALK_G;
     const double sc = L.sc[i], sk = L.sk512[i];
@@ -459,7 +488,7 @@ __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc
     rn.dbx0 = rn.dbx1 = dbx0;
     rn.jw = SPT;
     int it[G], ci[G];
-    walk_indices<CODEW, CARRW>(L, i, sc, sk, xc, yk, rn, it, ci, 0, nvalid, hz_itable);
+    walk_indices<CODEW, CARR>(L, i, sc, sk, xc, yk, ph, kstep, rn, it, ci, 0, nvalid, hz_itable);
 #pragma unroll
     for (int j0 = 0; j0 < SPT; j0 += G) {
         __builtin_amdgcn_sched_barrier(0);
@@ -474,7 +503,7 @@ __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc
         __builtin_amdgcn_sched_barrier(0);
         /* phase 1 of the next group while the reads are in flight */
         if (j0 + G < SPT)
-            walk_indices<CODEW, CARRW>(L, i, sc, sk, xc, yk, rn, it, ci, j0 + G, nvalid, hz_itable);
+            walk_indices<CODEW, CARR>(L, i, sc, sk, xc, yk, ph, kstep, rn, it, ci, j0 + G, nvalid, hz_itable);
         __builtin_amdgcn_sched_barrier(0);
         /* phase 3: acc += amp * (codeCA*dataBit), packed int16x2 (c:2701-2706) */
 #pragma unroll
@@ -555,7 +584,8 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
     WaveRows &W = L.wr[wave];
     const int ntw = p.ntiles;
     /* lane c serves chain c = (channel c>>1, kind c&1) of this block */
-    const bool has_chain = lane < 2 * nact;
+    const bool fixed_carr = p.kph0 != nullptr; /* fixed-point carrier variant: carrier chains have no rows */
+    const bool has_chain = lane < 2 * nact && !(fixed_carr && (lane & 1));
     const int32_t *__restrict__ lane_tr = p.tile_row + tile_row_at(p, b, 0, has_chain ? L.act[lane >> 1] : 0, lane & 1);
     const size_t tstride = 2 * (size_t)p.nch; /* the 2*nch entries of one tile are contiguous: one cache line */
     const NcoRow *__restrict__ lane_rows = p.rows + L.roff[has_chain ? 2 * L.act[lane >> 1] + (lane & 1) : 0];
@@ -720,6 +750,19 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                         xcb = row_state_global(p.rows + L.roff[2 * i], W.cr0[2 * a], n0, &nav);
                     dbx = nav_bit(L.dwrd[i], nav) < 0 ? 0xfffe : 0;
                 }
+                const double xc = bits_f64(xcb);
+                /* can any lane of this wavefront wrap inside its run?  Known to be impossible when the
+                 * chain's row reaches past the tile; otherwise compare with the per-channel limits */
+                const bool code_w = (uc & 2) ? false : (bool)__any(!(xc < L.xlim[i]));
+                if (fixed_carr) {
+                    const uint32_t kstep = (uint32_t)p.kstep[(size_t)b * p.nch + i];
+                    const uint32_t ph = p.kph0[(size_t)b * p.nch + i] + (uint32_t)n0 * kstep;
+                    if (!code_w)
+                        walk_channel<false, 2>(L, i, xc, 0.0, ph, kstep, nav, dbx, acc, nvalid, hz_itable);
+                    else
+                        walk_channel<true, 2>(L, i, xc, 0.0, ph, kstep, nav, dbx, acc, nvalid, hz_itable);
+                    continue;
+                }
                 double yk;
                 if (uk & 1) {
                     yk = bits_f64(readlane_u64(ubase, 2 * a + 1) + (uint64_t)lane * readlane_u64(ustep, 2 * a + 1));
@@ -730,25 +773,15 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                         xkb = row_state_global(p.rows + L.roff[2 * i + 1], W.cr0[2 * a + 1], n0, &nav_unused);
                     yk = mul_rn(bits_f64(xkb), 512.0); /* exact */
                 }
-                const double xc = bits_f64(xcb);
-#if defined(GPSBB_EXPERIMENT) && GPSBB_EXPERIMENT == 2 /* timing only: everything but the walk */
-                acc[0] += v2s{(short)xcb, (short)dbx};
-                acc[1] += v2s{(short)nav, (short)(xc + yk)};
-                continue;
-#endif
-
-                /* can any lane of this wavefront wrap inside its run?  Known to be impossible when the
-                 * chain's row reaches past the tile; otherwise compare with the per-channel limits */
-                const bool code_w = (uc & 2) ? false : (bool)__any(!(xc < L.xlim[i]));
                 const bool carr_w = (uk & 2) ? false : (bool)__any(!(yk < L.yhi[i]) || !(yk > L.ylo[i]));
                 if (!code_w && !carr_w)
-                    walk_channel<false, false>(L, i, xc, yk, nav, dbx, acc, nvalid, hz_itable);
+                    walk_channel<false, 0>(L, i, xc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
                 else if (!code_w)
-                    walk_channel<false, true>(L, i, xc, yk, nav, dbx, acc, nvalid, hz_itable);
+                    walk_channel<false, 1>(L, i, xc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
                 else if (!carr_w)
-                    walk_channel<true, false>(L, i, xc, yk, nav, dbx, acc, nvalid, hz_itable);
+                    walk_channel<true, 0>(L, i, xc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
                 else
-                    walk_channel<true, true>(L, i, xc, yk, nav, dbx, acc, nvalid, hz_itable);
+                    walk_channel<true, 1>(L, i, xc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
             }
             if (hz_itable)
                 atomicAdd(p.hazards, hz_itable);

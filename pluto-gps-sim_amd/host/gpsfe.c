@@ -85,6 +85,7 @@ typedef struct {  /* the host-side part of channel_t h:152-174 */
 
 struct gpsfe {
     int max_chan;
+    int fixed_carrier; /* the reference's `#ifndef FLOAT_CARR_PHASE` variant: 32-bit phase accumulator */
     eph_t eph[N_EPH_SETS + 1][N_SAT]; /* one spare, always-invalid set: the reference peeks at set ieph+1 (c:2777) */
     int neph, ieph;
     iono_t iono;
@@ -579,8 +580,13 @@ static int allocate_channels(gpsfe_t *fe, const eph_t *eph, gtime_t grx, const d
                     const double r_xyz = rho.range;
                     pseudorange(&rho, &eph[sv], &fe->iono, grx, origin);
                     const double r_ref = rho.range;
-                    const double phase_ini = (2.0 * r_ref - r_xyz) / K_LAMBDA;
-                    c->carr_phase = phase_ini - floor(phase_ini);
+                    double phase_ini = (2.0 * r_ref - r_xyz) / K_LAMBDA;
+                    if (!fe->fixed_carrier) {
+                        c->carr_phase = phase_ini - floor(phase_ini);
+                    } else { /* c:1966-1967: the accumulator's value, kept here as a double */
+                        phase_ini -= floor(phase_ini);
+                        c->carr_phase = (double)(unsigned int)(512.0 * 65536.0 * phase_ini);
+                    }
                     break;
                 }
                 if (i < fe->max_chan)
@@ -871,6 +877,7 @@ int gpsfe_open(const gpsfe_config_t *cfg, gpsfe_t **out)
         return GPSFE_E_NOMEM;
     }
     fe->max_chan = cfg->max_chan;
+    fe->fixed_carrier = cfg->fixed_carrier;
     fe->iono.enable = !cfg->iono_disable;
 
     /* receiver position (c:2312-2322, 2403-2415) */

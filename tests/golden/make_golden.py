@@ -11,6 +11,7 @@ are committed and are what the tests use on the GPU box, where /root/reference d
   motion_F.npz   config 4: user motion (circle_motion.csv, 10 Hz), otherwise as above; blocks 0,1,2,299,300
   dense_S.npz    config 3 geometry through the real front end: dense3540.14n, MAX_CHAN 16, fs 25 MS/s,
                  2.5 M-sample blocks 0,1
+  static_F_fixed.npz  as static_F with the reference's fixed-point carrier NCO (`#ifndef FLOAT_CARR_PHASE`)
   loop_M2.npz    the verbatim sample loop (plutogpssim.c:2690-2756) on the seeded M2 descriptor set
                  (16 channels, fs 25 MS/s), 3 blocks of 100000 samples
 
@@ -63,6 +64,12 @@ def main():
     np.savez_compressed(os.path.join(HERE, "dense_S.npz"), fs=25000000, nsamp=2500000,
                         **keep(iq, desc, st, [0, 1]))
     print("dense_S: prns", desc["prn"][0])
+
+    # the reference's fixed-point carrier variant (built against the header without h:12)
+    iq, desc, st = ob.run_ref_sim(nav, 301, 300000, 2600000, llh=SITE, max_chan=12, opt="_fixed")
+    np.savez_compressed(os.path.join(HERE, "static_F_fixed.npz"), fs=2600000, nsamp=300000,
+                        **keep(iq, desc, st, [0, 1, 2, 300]))
+    print("static_F_fixed: carr_phase", desc["carr_phase"][0][:3])
 
     pkg = load_package()
     ch = pkg.synth_descriptors(3, nch=16, seed=0x5EED)

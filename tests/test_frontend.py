@@ -123,3 +123,25 @@ def test_rinex3_and_rinex2_files_give_the_same_orbits(fe_pkg):
         assert a[f].tobytes() == b[f].tobytes(), f
     with pytest.raises(RuntimeError):   # a v2 file through the v3 reader is rejected (c:1279-1282)
         pkg.FrontEnd(os.path.join(GOLDEN, "synth3540.14n"), llh=SITE, rinex3=True)
+
+
+def test_fixed_carrier_descriptors(fe_pkg):
+    """Front end in the fixed-point carrier variant: the accumulator's initial value (c:1966-1967) and its
+    chain (start + nsamp*step mod 2^32) against the dumps of the reference built without FLOAT_CARR_PHASE."""
+    pkg = fe_pkg
+    z = np.load(os.path.join(GOLDEN, "static_F_fixed.npz"))
+    fs, nsamp = float(z["fs"]), int(z["nsamp"])
+    blocks = [int(b) for b in z["blocks"]]
+    want = z["desc"].view(pkg.CHAN_DTYPE).reshape(len(blocks), -1)
+    fe = pkg.FrontEnd(os.path.join(GOLDEN, "synth3540.14n"), llh=SITE, max_chan=12, fixed_carrier=True)
+    ch = fe.generate(max(blocks) + 1)
+    fe.close()
+    # chain the 32-bit accumulator on the host the way the loop does (c:2675, 2748)
+    step = np.round(512.0 * 65536.0 * ch["f_carr"] * (1.0 / fs)).astype(np.int64)
+    ph = ch["carr_phase"].astype(np.int64)
+    for b in range(1, ch.shape[0]):
+        same = (ch["prn"][b] == ch["prn"][b - 1]) & (ch["prn"][b] > 0)
+        ph[b][same] = (ph[b - 1][same] + nsamp * step[b - 1][same]) % (1 << 32)
+    ch["carr_phase"] = ph.astype(np.float64)
+    for k, b in enumerate(blocks):
+        assert_desc_equal(ch[b], want[k], "fixed block %d" % b)

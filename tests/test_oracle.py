@@ -111,3 +111,31 @@ def test_oracle_hazards_are_defined_and_counted(oracle, pkg):
     ch["iword"][0, 0], ch["ibit"][0, 0], ch["icode"][0, 0] = 59, 29, 19
     _, st, hz = oracle.fill_blocks(ch, 1 / 1e6, 100000)   # 0.1 s: 100 code periods -> 5 bit fetches in word 60
     assert hz["dwrd_oob"] == 5 and st["iword"][0, 0] == 60
+
+
+# ---- the reference's fixed-point carrier variant (`#ifndef FLOAT_CARR_PHASE`) ----------------------------
+
+def test_fixed_carrier_oracle_reproduces_golden_blocks(oracle):
+    z, fs, nsamp = load("static_F_fixed")
+    desc = z["desc"].view(ob.CHAN_DTYPE).reshape(z["desc"].shape[0], -1)
+    iq, st, _ = oracle.fill_blocks(desc, 1.0 / fs, nsamp, fixed=True)
+    want_st = z["end_state"].view(ob.STATE_DTYPE).reshape(st.shape)
+    for k in range(desc.shape[0]):
+        assert sha(iq[k]) == str(z["iq_sha256"][k]), k
+        assert st[k].tobytes() == want_st[k].tobytes()
+    # and it is a different signal from the floating-point variant
+    zf, _, _ = load("static_F")
+    assert str(z["iq_sha256"][0]) != str(zf["iq_sha256"][0])
+
+
+@pytest.mark.skipif(not ob.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+def test_fixed_carrier_oracle_against_the_reference_build(oracle, pkg):
+    r = ob.RefLoop("_fixed")
+    ch = pkg.synth_descriptors(3, nch=16, seed=77)
+    ch["carr_phase"] = np.floor(ch["carr_phase"] * 2.0 ** 32)
+    ch["f_carr"][0, :4] = [0.0, 124999.0, -124999.0, 1e-3]
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    for b in range(3):
+        want_iq, want_st = r.fill(ch[b], 1.0 / 1e6, 40001)
+        iq, st, _ = oracle.fill_blocks(ch[b], 1.0 / 1e6, 40001, fixed=True)
+        assert (iq[0] == want_iq).all() and st[0].tobytes() == want_st.tobytes()

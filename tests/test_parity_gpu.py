@@ -320,3 +320,70 @@ def test_gpsbb_sim_end_to_end_file(pkg, tmp_path):
     iq = np.fromfile(out, np.int16).reshape(3, nsamp, 2)
     for blk in range(3):
         assert sha(iq[blk]) == str(z["iq_sha256"][blk]), blk
+
+
+# ---- GPSBB_FIXED_CARRIER: the reference's `#ifndef FLOAT_CARR_PHASE` carrier NCO -------------------------
+
+def _fixed_desc(pkg, nblocks, nch, seed):
+    ch = pkg.synth_descriptors(nblocks, nch=nch, seed=seed)
+    ch["carr_phase"] = np.floor(ch["carr_phase"] * 2.0 ** 32)
+    return ch
+
+
+@pytest.mark.parametrize("fs,nsamp,nch,seed", [(25e6, 100000, 16, 201), (2.6e6, 300000, 12, 202), (1e6, 4097, 3, 203)])
+def test_fixed_carrier_single_block(pkg, synth, oracle, fs, nsamp, nch, seed):
+    ch = _fixed_desc(pkg, 1, nch, seed)[0]
+    want_iq, want_st, _ = oracle.fill_blocks(ch, 1.0 / fs, nsamp, fixed=True)
+    iq, st = synth.fill_block(ch, 1.0 / fs, nsamp, flags=pkg.FIXED_CARRIER)
+    assert (iq == want_iq[0]).all()
+    assert_state_equal(st, want_st[0], ch["prn"] > 0)
+
+
+def test_fixed_carrier_chained_batch_and_stream(pkg, synth, oracle):
+    ch = _fixed_desc(pkg, 8, 10, 211)
+    ch["prn"][5:, 3] = 29
+    ch["prn"][2, 6] = 0
+    delt, nsamp = 1 / 4.092e6, 60000
+    want_iq, want_st, _ = oracle.fill_blocks(ch, delt, nsamp, chain=True, fixed=True)
+    b = synth.batch(ch, delt, nsamp, flags=pkg.CHAIN_CARRIER | pkg.FIXED_CARRIER)
+    b.run()
+    synth.sync()
+    iq, st = b.read()
+    b.close()
+    assert (iq == want_iq).all()
+    for k in range(8):
+        assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
+    s = synth.stream(10, delt, nsamp, 2, depth=2, flags=pkg.CHAIN_CARRIER | pkg.FIXED_CARRIER)
+    got = []
+    for k in range(4):
+        if s.pending == 2:
+            got.append(s.pop())
+        s.push(ch[2 * k:2 * k + 2])
+    while s.pending:
+        got.append(s.pop())
+    s.close()
+    assert (np.concatenate([g[0] for g in got]) == want_iq).all()
+
+
+def test_fixed_carrier_golden_and_end_to_end(pkg, synth):
+    """Golden vectors of the reference built without FLOAT_CARR_PHASE, from captured descriptors and from
+    the RINEX file through the front end."""
+    pkg.build_frontend()
+    z = np.load(os.path.join(GOLDEN, "static_F_fixed.npz"))
+    fs, nsamp = float(z["fs"]), int(z["nsamp"])
+    blocks = [int(b) for b in z["blocks"]]
+    desc = z["desc"].view(pkg.CHAN_DTYPE).reshape(len(blocks), -1)
+    for k in range(len(blocks)):
+        iq, _ = synth.fill_block(desc[k], 1.0 / fs, nsamp, flags=pkg.FIXED_CARRIER)
+        assert sha(iq) == str(z["iq_sha256"][k]), k
+    fe = pkg.FrontEnd(os.path.join(GOLDEN, "synth3540.14n"), llh=(30.286502, 120.032669, 100.0), max_chan=12,
+                      fixed_carrier=True)
+    ch = fe.generate(3)
+    fe.close()
+    b = synth.batch(ch, 1.0 / fs, nsamp, flags=pkg.CHAIN_CARRIER | pkg.FIXED_CARRIER)
+    b.run()
+    synth.sync()
+    iq, _ = b.read()
+    b.close()
+    for blk in range(3):
+        assert sha(iq[blk]) == str(z["iq_sha256"][blk]), blk

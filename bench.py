@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--fs", type=float, default=25e6)
     ap.add_argument("--nsamp", type=int, default=2500000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--fixed-carrier", action="store_true",
+                    help="the reference's fixed-point carrier variant (GPSBB_FIXED_CARRIER); not the headline config")
     ap.add_argument("--synth-only", action="store_true",
                     help="measurement aid: after warm-up re-run only k_synth on the tables already built")
     args = ap.parse_args()
@@ -96,8 +98,13 @@ def main():
     ch_all = pkg.synth_descriptors(B * world, nch=args.nch, seed=0x5EED)
     ch = ch_all[rank * B:(rank + 1) * B]
 
+    flags = 0
+    if args.fixed_carrier:
+        ch = ch.copy()
+        ch["carr_phase"] = np.floor(ch["carr_phase"] * 2.0 ** 32)
+        flags = pkg.FIXED_CARRIER
     synth = pkg.Synth(local)
-    batch = synth.batch(ch, delt, args.nsamp)
+    batch = synth.batch(ch, delt, args.nsamp, flags=flags)
     out = torch.empty(B * args.nsamp * 2, dtype=torch.int16, device="cuda:%d" % local)
 
     def barrier():
@@ -153,7 +160,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 NCO + int16x2 accumulate", "data": "synthetic",
-            "config": {"workload": "synth16-S: %d ch, fs %.3g S/s, %d-sample blocks, %d blocks per step per GPU, "
+            "config": {"carrier_nco": "fixed-point 32-bit (variant)" if args.fixed_carrier else "IEEE double (reference default)",
+                       "workload": "synth16-S: %d ch, fs %.3g S/s, %d-sample blocks, %d blocks per step per GPU, "
                                    "seeded descriptors (splitmix64 0x5EED), time-sharded by rank" %
                                    (args.nch, args.fs, args.nsamp, B),
                        "global_samples_per_step": world * samples_per_step, "parallelism": "time-shard x%d" % world},

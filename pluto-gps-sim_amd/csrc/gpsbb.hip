@@ -540,7 +540,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     HIPCHK(h, hipEventRecord(ev[0], h->s_seed));
     if (!(g_test_skip_seed && b->run_count >= 2)) /* measurement hook: time k_synth alone on tables already built */
     {
-        hipLaunchKernelGGL(k_seed, dim3((lanes + 63) / 64), dim3(64), 0, h->s_seed, p, cbase);
+        hipLaunchKernelGGL(k_seed, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, h->s_seed, p, cbase);
         const long long nthr = 2ll * (long long)nbc * TIDX_PARTS;
         hipLaunchKernelGGL(k_tile_index, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, h->s_seed, p);
     }

@@ -232,8 +232,17 @@ __device__ inline void seed_carr_fixed(const BatchDev &p, int b, int i)
 /* grid: lanes [0, nbc) = code chains; lanes [cbase, ...) = carrier chains (cbase = nbc rounded up to a
  * wave so that the two kinds of chain never share a wavefront).  Writes each chain's rows, end state and
  * row count; the tile index is filled by k_tile_index, massively parallel, afterwards. */
-__global__ __launch_bounds__(64) void k_seed(BatchDev p, int cbase)
+#ifndef GPSBB_SEED_WG
+#define GPSBB_SEED_WG 256
+#endif
+/* Four wavefronts per workgroup (one per SIMD of a CU): measured best trade between the pre-pass's own
+ * speed (chains sharing a SIMD slow each other by ~1/3) and how many CUs it takes away from the previous
+ * run's k_synth, which it overlaps (64: step 9.39 ms, 256: 9.18 ms, 1024: 10.6 ms per 1e9 samples). */
+__global__ __launch_bounds__(GPSBB_SEED_WG) void k_seed(BatchDev p, int cbase)
 {
+    /* the chain walk is a long dependent instruction stream: let it issue whenever it is ready (it uses a
+     * small fraction of the issue slots, so the co-resident synthesis wavefronts hardly notice) */
+    __builtin_amdgcn_s_setprio(3);
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nbc = p.nblocks * p.nch;
     if (gid < nbc) {

@@ -1,28 +1,34 @@
 /*
  * gpsbb_kernels.hip.h — the device side of libgpsbb: hand-written HIP for gfx950 (CDNA4).
  *
- * Two kernels per batch of blocks:
+ * Three kernels per batch of blocks:
  *
- *   k_seed   NCO seeding pre-pass.  One lane per NCO chain (block x channel x {code, carrier}).  Walks
- *            the chain with the exact jump-ahead of gpsbb_nco.h — O(#binade crossings + #wraps), not
- *            O(#samples) — and writes the chain's row table {n0, bits(x), inc}, the row index of every
- *            tile start, and the end-of-block state (the reference's live-out, plutogpssim.c:2741-2746).
- *            This replaces the sample-to-sample dependency of plutogpssim.c:2709/2741 with a table any
- *            lane can index.
+ *   k_seed        NCO seeding pre-pass.  One lane per NCO chain (block x channel x {code, carrier}).
+ *                 Walks the chain with the exact jump-ahead of gpsbb_nco.h — O(#binade crossings +
+ *                 #wraps), not O(#samples) — and writes the chain's row table {n0, bits(x), inc, nav} and
+ *                 the end-of-block state (the reference's live-out, plutogpssim.c:2741-2746).  This
+ *                 replaces the sample-to-sample dependency of plutogpssim.c:2709/2741 with a table any
+ *                 lane can index.  Sequential per chain, so it runs on its own stream into double-buffered
+ *                 tables and overlaps the previous run's k_synth.
  *
- *   k_synth  The sample loop itself (plutogpssim.c:2690-2756), one lane per run of SPT consecutive
- *            output samples.  Per workgroup the per-channel tables are staged in LDS: the amplitude LUT
- *            (int)(cosTable512[k]*gain), (int)(sinTable512[k]*gain) packed as int16x2 — the product
- *            dataBit*codeCA*table*gain of c:2701-2702 factorises into sign * that LUT because IEEE
- *            multiply and truncation are odd-symmetric — the 1023 C/A chips bit-packed (32 dwords per
- *            PRN) and the 60 nav words.  A lane looks up its start state in the row tables, then steps
- *            both NCOs with genuine IEEE double adds (__dadd_rn, never an FMA), accumulates all
- *            channels in packed int16x2 (wrap-around == the reference's (short) cast, c:2754-2755) and
- *            stores 16-byte vectors.
+ *   k_tile_index  One thread per (chain, 1/64 of the tiles): which row holds the first sample of every
+ *                 1024-sample tile.  Laid out [block][tile][chain] so one tile's 32 entries share a line.
+ *
+ *   k_synth       The sample loop itself (plutogpssim.c:2690-2756), one lane per run of SPT consecutive
+ *                 output samples, one wavefront per tile.  Per workgroup the per-channel tables are staged
+ *                 in LDS once: the amplitude LUT (int)(cosTable512[k]*gain), (int)(sinTable512[k]*gain)
+ *                 packed as int16x2 — the product dataBit*codeCA*table*gain of c:2701-2702 factorises into
+ *                 sign * that LUT because IEEE multiply and truncation are odd-symmetric — the 1023 C/A
+ *                 chips as +-1 bytes and the 60 nav words.  After that every wavefront works alone: it
+ *                 takes chunks of tiles from a per-block counter, fetches the rows one tile ahead, derives
+ *                 each lane's start state (usually base + lane*step broadcast with v_readlane), steps both
+ *                 NCOs with genuine IEEE double adds (__dadd_rn, never an FMA), accumulates all channels in
+ *                 packed int16x2 (wrap-around == the reference's (short) cast, c:2754-2755) and stores
+ *                 16-byte vectors.
  *
  * No MFMA anywhere: this is table-driven fixed-point work.  The roofline that bounds the output is the
- * HBM write stream (4 bytes per IQ sample); the unit that actually saturates is the VALU (two FP64 adds
- * and ~25 integer ops per channel-sample).
+ * HBM write stream (4 bytes per IQ sample); the unit that actually saturates is the VALU (per
+ * channel-sample: 2 FP64 adds, 2 FP64->int conversions, 4 integer/packed ops, 2 LDS reads).
  */
 #ifndef GPSBB_KERNELS_HIP_H
 #define GPSBB_KERNELS_HIP_H
@@ -45,7 +51,7 @@ constexpr int TILE_THREADS = GPSBB_WG;      /* wave64 x (GPSBB_WG/64) per workgr
 #ifndef GPSBB_SPT
 #define GPSBB_SPT 16
 #endif
-constexpr int SPT = GPSBB_SPT;              /* consecutive samples per lane (128 bytes of output at 32) */
+constexpr int SPT = GPSBB_SPT;              /* consecutive samples per lane (16 -> 64 bytes of output) */
 constexpr int TILE = 64 * SPT;              /* samples per tile = one pass of one wavefront (the row-index granule) */
 constexpr int WAVES_PER_WG = TILE_THREADS / 64;
 constexpr int TILE_CHUNK = 4;               /* consecutive tiles a wavefront takes at a time */
@@ -621,17 +627,6 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
     int pre_n1 = lane_rows[r_first + 1].n0;
 
     for (int wt = wt_begin; wt < wt_end; wt++) {
-#if defined(GPSBB_EXPERIMENT) && GPSBB_EXPERIMENT == 4 /* timing only: stores + workgroup prologue */
-        {
-            const int n0e = wt * TILE + lane * SPT;
-            if (n0e + SPT <= p.nsamp) {
-                uint4 *o4 = reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + n0e);
-                for (int j = 0; j < SPT / 4; j++)
-                    o4[j] = make_uint4(tid, wt, j, b);
-            }
-            continue;
-        }
-#endif
         const int wn0 = wt * TILE;      /* first run start of this tile (wave-uniform) */
         const int wnl = wn0 + 63 * SPT; /* last run start */
 
@@ -734,13 +729,7 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
             const int nvalid = p.nsamp - n0 < SPT ? p.nsamp - n0 : SPT;
             unsigned long long hz_itable = 0;
 
-#if defined(GPSBB_EXPERIMENT) && GPSBB_EXPERIMENT >= 3 /* timing only: no channel loop */
-            acc[0] += v2s{(short)ubase, (short)ustep};
-            acc[1] += v2s{(short)unav, (short)uni};
-            for (int a = 0; a < 0; a++) {
-#else
             for (int a = 0; a < nact; a++) {
-#endif
                 const int i = L.act[a];
                 uint32_t nav, nav_unused;
                 uint64_t xcb, xkb;

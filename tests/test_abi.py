@@ -64,3 +64,16 @@ def test_no_cpu_fallback(pkg):
         pytest.skip("GPU present")
     h = C.c_void_p()
     assert pkg.lib().gpsbb_create(C.byref(h), 0) == -6
+
+
+def test_host_library_exports_its_headers(pkg):
+    """libgpsfe.so exports every function include/gpsfe.h and include/gpsbb_tx.h declare."""
+    pkg.build_frontend()
+    L = pkg.fe_lib()
+    for hdr in ("gpsfe.h", "gpsbb_tx.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names = sorted(set(re.findall(r"\b(gps(?:fe|bb_tx)_[a-z_0-9]+)\s*\(", txt)))
+        assert len(names) >= 6, hdr
+        for n in names:
+            assert hasattr(L, n), "libgpsfe.so does not export %s" % n

@@ -683,15 +683,16 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         const bool all_uniform = __all((uni & 1) || cnt == 0);
         int base = 0;
         bool in_lds = true;
+        const int scnt = (uni & 1) ? 0 : cnt; /* uniform chains need no slot */
         if (!all_uniform) {
-            int incl = cnt;
+            int incl = scnt;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const int t = __shfl_up(incl, o);
                 if (lane >= o)
                     incl += t;
             }
-            base = incl - cnt;
+            base = incl - scnt;
             in_lds = __shfl(incl, 63) <= WAVE_ROW_CAP;
         }
 
@@ -702,13 +703,13 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         }
         if (in_lds && !all_uniform) {
             /* some chain changes row inside the tile: stage the rows in this wavefront's LDS slice */
-            if (cnt > 0) {
+            if (scnt > 0) {
                 W.n0[base] = row[0].n0;
                 W.nav[base] = row[0].nav;
                 W.xb[base] = row[0].xb;
                 W.inc[base] = row[0].inc;
             }
-            for (int r = 1; r < cnt; r++) {
+            for (int r = 1; r < scnt; r++) {
                 const NcoRow rw = src[r];
                 W.n0[base + r] = rw.n0;
                 W.nav[base + r] = rw.nav;

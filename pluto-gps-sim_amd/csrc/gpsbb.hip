@@ -203,8 +203,6 @@ struct gpsbb_batch {
     DevBuf<int16_t> d_iq;
     std::vector<uint64_t> row_off;
     std::vector<gpsbb_chan_t> h_ch; /* library-owned copy: the caller's array may go away after the call */
-    const gpsbb_chan_t *prev_ch = nullptr;
-    const gpsbb_chan_state_t *prev_end = nullptr;
     struct Ev4 { hipEvent_t e[4]; }; /* seed start/end (seed stream), synth start/end (compute stream) */
     std::vector<Ev4> evs; /* one set per run since the last timing reset */
     size_t ev_used = 0;
@@ -482,8 +480,6 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
 {
     BatchDev p;
     p.ch = b->d_ch.p;
-    p.prev_ch = b->prev_ch;
-    p.prev_end = b->prev_end;
     p.nblocks = b->nblocks;
     p.nch = b->nch;
     p.nsamp = b->nsamp;
@@ -724,8 +720,6 @@ extern "C" int gpsbb_fill_block_ex(gpsbb_t *h, const gpsbb_chan_t *ch, int nch, 
             return GPSBB_E_NOMEM;
     }
     gpsbb_batch *b = h->scratch;
-    b->prev_ch = nullptr;
-    b->prev_end = nullptr;
     if (flags & ~GPSBB_FIXED_CARRIER & ~GPSBB_CHAIN_CARRIER)
         return GPSBB_E_BADARG;
     int rc = batch_setup(b, ch, 1, nch, delt, nsamp, flags & GPSBB_FIXED_CARRIER, h->s_seed);
@@ -796,6 +790,15 @@ extern "C" int gpsbb_fill_block_ref(gpsbb_t *h, void *chan, const gpsbb_refchan_
 /* time-sharded streaming with pinned host gather                                                     */
 /* ================================================================================================== */
 
+/* carry[i] = {prn, phase} of channel i after the previous call (in) / after this one (out); may be NULL */
+struct ChainCarry {
+    int prn[GPSBB_MAX_CHAN];
+    double phase[GPSBB_MAX_CHAN];
+};
+
+static void chain_carrier_host(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp, double *seed,
+                               int nthreads, ChainCarry *carry);
+
 struct gpsbb_stream {
     gpsbb *h = nullptr;
     int nch = 0, nsamp = 0, bps = 0, depth = 0;
@@ -809,6 +812,9 @@ struct gpsbb_stream {
     };
     std::vector<Slot> slots;
     uint64_t head = 0, tail = 0; /* pushes / pops so far */
+    ChainCarry *carry = nullptr;               /* IEEE carrier chained on the host across pushes */
+    std::vector<gpsbb_chan_t> seeded;
+    std::vector<double> seeds;
     int fx_prn[GPSBB_MAX_CHAN] = {0};          /* fixed-point carrier: channel state after the last push */
     uint32_t fx_phase[GPSBB_MAX_CHAN] = {0};
 };
@@ -821,6 +827,7 @@ extern "C" void gpsbb_stream_destroy(gpsbb_stream_t *s)
     (void)hipStreamSynchronize(s->h->s_seed);
     (void)hipStreamSynchronize(s->h->s_compute);
     (void)hipStreamSynchronize(s->h->s_copy);
+    delete s->carry;
     for (auto &sl : s->slots) {
         if (sl.batch) gpsbb_batch_destroy(sl.batch);
         if (sl.h_iq) (void)hipHostFree(sl.h_iq);
@@ -882,11 +889,35 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     HIPCHK(h, hipSetDevice(h->device));
     auto &sl = s->slots[s->head % s->depth];
     gpsbb_batch *b = sl.batch;
+    /* Blocks consecutive in time with the IEEE carrier: the exact phase at the start of every block is
+     * computed here on host threads with the same jump-ahead the device uses (it depends on descriptors
+     * only), so the device sees independent blocks and the pre-pass stays fully parallel.  Chaining on the
+     * device (one lane per channel walking the slot's blocks in order) is ~12x slower for a 16-block slot. */
+    unsigned run_flags = s->flags;
+    if ((s->flags & GPSBB_CHAIN_CARRIER) && !(s->flags & GPSBB_FIXED_CARRIER)) {
+        const size_t nbc = (size_t)s->bps * s->nch;
+        for (size_t k = 0; k < nbc; k++)
+            if (!chan_ok(ch[k], s->delt))
+                return GPSBB_E_BADCHAN;
+        if (!s->carry) {
+            s->carry = new (std::nothrow) ChainCarry();
+            if (!s->carry)
+                return GPSBB_E_NOMEM;
+            memset(s->carry, 0, sizeof *s->carry);
+        }
+        s->seeded.assign(ch, ch + nbc);
+        s->seeds.resize(nbc);
+        chain_carrier_host(ch, s->bps, s->nch, s->delt, s->nsamp, s->seeds.data(), 0, s->carry);
+        for (size_t k = 0; k < nbc; k++)
+            s->seeded[k].carr_phase = s->seeds[k];
+        ch = s->seeded.data();
+        run_flags &= ~GPSBB_CHAIN_CARRIER;
+    }
     /* the slot's previous D2H copy was waited for by the pop that freed it */
     const bool fx_chain = (s->flags & GPSBB_FIXED_CARRIER) && (s->flags & GPSBB_CHAIN_CARRIER) && s->head > 0;
     b->fixed_prev_prn = fx_chain ? s->fx_prn : nullptr;
     b->fixed_prev_phase = fx_chain ? s->fx_phase : nullptr;
-    int rc = batch_setup(b, ch, s->bps, s->nch, s->delt, s->nsamp, s->flags, h->s_seed);
+    int rc = batch_setup(b, ch, s->bps, s->nch, s->delt, s->nsamp, run_flags, h->s_seed);
     b->fixed_prev_prn = nullptr;
     b->fixed_prev_phase = nullptr;
     if (rc != GPSBB_OK)
@@ -897,15 +928,6 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
             s->fx_prn[i] = ch[k].prn > 0 ? ch[k].prn : 0;
             s->fx_phase[i] = b->h_kph0[k] + (uint32_t)s->nsamp * (uint32_t)b->h_kstep[k];
         }
-    b->prev_ch = nullptr;
-    b->prev_end = nullptr;
-    if ((s->flags & GPSBB_CHAIN_CARRIER) && s->head > 0) {
-        /* continue the carrier from the last block of the previous push (same compute stream, so its
-         * end state is complete before this push's seeding kernel runs) */
-        gpsbb_batch *pb = s->slots[(s->head - 1) % s->depth].batch;
-        b->prev_ch = pb->d_ch.p + (size_t)(pb->nblocks - 1) * pb->nch;
-        b->prev_end = pb->d_end[pb->last_set].p + (size_t)(pb->nblocks - 1) * pb->nch;
-    }
     b->last_iq = b->d_iq.p;
     rc = batch_launch(b, b->d_iq.p);
     if (rc != GPSBB_OK)
@@ -948,18 +970,13 @@ extern "C" int gpsbb_stream_pop(gpsbb_stream_t *s, const int16_t **iq, gpsbb_cha
 /* host helpers                                                                                       */
 /* ================================================================================================== */
 
-extern "C" int gpsbb_chain_carrier_host(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp,
-                                        double *seed, int nthreads)
+static void chain_carrier_host(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp, double *seed,
+                               int nthreads, ChainCarry *carry)
 {
-    if (!ch || !seed || nblocks < 1 || nch < 1 || nch > GPSBB_MAX_CHAN || nsamp < 1 || !(delt > 0.0))
-        return GPSBB_E_BADARG;
-    for (size_t k = 0; k < (size_t)nblocks * nch; k++)
-        if (!chan_ok(ch[k], delt))
-            return GPSBB_E_BADCHAN;
     auto work = [&](int i0, int i1) {
         for (int i = i0; i < i1; i++) {
-            int prev_prn = 0;
-            double prev_x = 0.0;
+            int prev_prn = carry ? carry->prn[i] : 0;
+            double prev_x = carry ? carry->phase[i] : 0.0;
             for (int b = 0; b < nblocks; b++) {
                 const gpsbb_chan_t &c = ch[(size_t)b * nch + i];
                 double x0 = (c.prn > 0 && c.prn == prev_prn) ? prev_x : c.carr_phase;
@@ -969,6 +986,10 @@ extern "C" int gpsbb_chain_carrier_host(const gpsbb_chan_t *ch, int nblocks, int
                     prev_x = carr_jump(x0, s, nsamp);
                 }
                 prev_prn = c.prn > 0 ? c.prn : 0;
+            }
+            if (carry) {
+                carry->prn[i] = prev_prn;
+                carry->phase[i] = prev_x;
             }
         }
     };
@@ -985,6 +1006,17 @@ extern "C" int gpsbb_chain_carrier_host(const gpsbb_chan_t *ch, int nblocks, int
         for (auto &t : th)
             t.join();
     }
+}
+
+extern "C" int gpsbb_chain_carrier_host(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp,
+                                        double *seed, int nthreads)
+{
+    if (!ch || !seed || nblocks < 1 || nch < 1 || nch > GPSBB_MAX_CHAN || nsamp < 1 || !(delt > 0.0))
+        return GPSBB_E_BADARG;
+    for (size_t k = 0; k < (size_t)nblocks * nch; k++)
+        if (!chan_ok(ch[k], delt))
+            return GPSBB_E_BADCHAN;
+    chain_carrier_host(ch, nblocks, nch, delt, nsamp, seed, nthreads, nullptr);
     return GPSBB_OK;
 }
 

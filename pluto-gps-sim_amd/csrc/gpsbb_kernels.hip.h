@@ -65,8 +65,6 @@ constexpr uint32_t ST_ROW_OVERFLOW = 1u;
 /* Everything the kernels need about one batch; passed by value as the kernel argument. */
 struct BatchDev {
     const gpsbb_chan_t *ch;         /* [nblocks*nch] descriptors, block-major                        */
-    const gpsbb_chan_t *prev_ch;    /* [nch] last block of the previous push of a stream, or NULL   */
-    const gpsbb_chan_state_t *prev_end; /* [nch] its end state, or NULL                              */
     int nblocks, nch, nsamp, ntiles;
     double delt;
     unsigned flags;
@@ -267,10 +265,6 @@ __global__ __launch_bounds__(GPSBB_SEED_WG) void k_seed(BatchDev p, int cbase)
             return;
         int prev_prn = 0;
         double prev_x = 0.0;
-        if (p.prev_ch && p.prev_end) {
-            prev_prn = p.prev_ch[g].prn;
-            prev_x = p.prev_end[g].carr_phase;
-        }
         for (int b = 0; b < p.nblocks; b++) {
             const gpsbb_chan_t &c = p.ch[(size_t)b * p.nch + g];
             if (p.kph0) { /* fixed-point carrier: no rows; the host has already chained the start phases */

@@ -36,7 +36,7 @@ def main():
         st.close()
     samples = nslots * bps * nsamp
     print(json.dumps({"stream_samples_per_s": samples / dt, "GBps_to_host": samples * 4 / dt / 1e9,
-                      "device_chained_carrier": bool(flags), "slot_blocks": bps, "depth": depth, "slots": nslots, "seconds": dt}))
+                      "chained_carrier": bool(flags), "slot_blocks": bps, "depth": depth, "slots": nslots, "seconds": dt}))
 
 
 if __name__ == "__main__":

@@ -336,6 +336,14 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     return GPSBB_OK;
 }
 
+/* carry[i] = {prn, phase} of channel i after the previous call (in) / after this one (out); may be NULL */
+struct ChainCarry {
+    int prn[GPSBB_MAX_CHAN];
+    double phase[GPSBB_MAX_CHAN];
+};
+static void chain_carrier_host(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp, double *seed,
+                               int nthreads, ChainCarry *carry);
+
 /* ---- batch planning -------------------------------------------------------------------------------- */
 
 static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int nch, double delt,
@@ -405,6 +413,16 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         HIPCHK(h, hipMemcpyAsync(b->d_kstep.p, b->h_kstep.data(), nbc * 4, hipMemcpyHostToDevice, upload_stream));
     }
     b->h_ch.assign(ch, ch + nbc);
+    if ((flags & GPSBB_CHAIN_CARRIER) && !fixed && nblocks > 1) {
+        /* blocks consecutive in time: resolve the carrier phase at the start of every block here, exactly
+         * (same jump-ahead as the device, one host thread per channel), so that the device's chains are all
+         * independent.  Walking the blocks in order on the device would serialise the whole pre-pass. */
+        std::vector<double> seeds(nbc);
+        chain_carrier_host(ch, nblocks, nch, delt, nsamp, seeds.data(), 0, nullptr);
+        for (size_t k = 0; k < nbc; k++)
+            if (b->h_ch[k].prn > 0)
+                b->h_ch[k].carr_phase = seeds[k];
+    }
     HIPCHK(h, hipMemcpyAsync(b->d_ch.p, b->h_ch.data(), nbc * sizeof(gpsbb_chan_t), hipMemcpyHostToDevice, upload_stream));
     HIPCHK(h, hipMemcpyAsync(b->d_row_off.p, b->row_off.data(), (2 * nbc + 1) * 8, hipMemcpyHostToDevice, upload_stream));
     b->ran = false;
@@ -515,8 +533,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         HIPCHK(h, hipEventCreateWithFlags(&b->synth_done[set], hipEventDisableTiming));
     const BatchDev p = batch_dev(b, set);
     const int cbase = ((int)nbc + 63) / 64 * 64;
-    const int ncarr = (b->flags & GPSBB_CHAIN_CARRIER) ? b->nch : (int)nbc;
-    const int lanes = cbase + ncarr;
+    const int lanes = cbase + (int)nbc;
     if (b->ev_used == b->evs.size()) {
         if (b->evs.size() >= 4096) {
             b->ev_used = 0; /* wrap: only the most recent runs are kept */
@@ -789,15 +806,6 @@ extern "C" int gpsbb_fill_block_ref(gpsbb_t *h, void *chan, const gpsbb_refchan_
 /* ================================================================================================== */
 /* time-sharded streaming with pinned host gather                                                     */
 /* ================================================================================================== */
-
-/* carry[i] = {prn, phase} of channel i after the previous call (in) / after this one (out); may be NULL */
-struct ChainCarry {
-    int prn[GPSBB_MAX_CHAN];
-    double phase[GPSBB_MAX_CHAN];
-};
-
-static void chain_carrier_host(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp, double *seed,
-                               int nthreads, ChainCarry *carry);
 
 struct gpsbb_stream {
     gpsbb *h = nullptr;

@@ -255,39 +255,19 @@ __global__ __launch_bounds__(GPSBB_SEED_WG) void k_seed(BatchDev p, int cbase)
         return;
     }
     const int g = gid - cbase;
-    if (g < 0)
+    if (g < 0 || g >= nbc)
         return;
-    if (p.flags & GPSBB_CHAIN_CARRIER) {
-        /* one lane per channel walks the blocks in time order: block b starts where b-1 ended, unless
-         * the channel was (re)allocated, in which case the descriptor's own carr_phase applies
-         * (allocateChannel, plutogpssim.c:1956-1964) */
-        if (g >= p.nch)
-            return;
-        int prev_prn = 0;
-        double prev_x = 0.0;
-        for (int b = 0; b < p.nblocks; b++) {
-            const gpsbb_chan_t &c = p.ch[(size_t)b * p.nch + g];
-            if (p.kph0) { /* fixed-point carrier: no rows; the host has already chained the start phases */
-                seed_carr_fixed(p, b, g);
-                continue;
-            }
-            const double x0 = (c.prn > 0 && c.prn == prev_prn) ? prev_x : c.carr_phase;
-            const ChainDone d = seed_carr_chain(p, b, g, x0, &prev_x);
-            p.row_cnt[chain_carr(p, b, g)] = d.cnt;
-            prev_prn = c.prn > 0 ? c.prn : 0;
-        }
-    } else {
-        if (g >= nbc)
-            return;
-        const int b = g / p.nch, i = g % p.nch;
-        if (p.kph0) {
-            seed_carr_fixed(p, b, i);
-            return;
-        }
-        double unused;
-        const ChainDone d = seed_carr_chain(p, b, i, p.ch[(size_t)b * p.nch + i].carr_phase, &unused);
-        p.row_cnt[chain_carr(p, b, i)] = d.cnt;
+    /* carrier chains: every block starts from its descriptor's carr_phase.  Blocks that continue each
+     * other (GPSBB_CHAIN_CARRIER) had their start phases resolved exactly on the host when the batch was
+     * set up, so all chains are independent here. */
+    const int b = g / p.nch, i = g % p.nch;
+    if (p.kph0) {
+        seed_carr_fixed(p, b, i);
+        return;
     }
+    double unused;
+    const ChainDone d = seed_carr_chain(p, b, i, p.ch[(size_t)b * p.nch + i].carr_phase, &unused);
+    p.row_cnt[chain_carr(p, b, i)] = d.cnt;
 }
 
 /*

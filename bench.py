@@ -87,10 +87,20 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # one rank per GPU; GPSBB_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a box with fewer GPUs
+    # than ranks (functional check only: ranks then share devices)
+    backend = os.environ.get("GPSBB_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit("%d ranks but %d GPUs" % (world, ndev))
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     delt = 1.0 / args.fs
     B = args.blocks
@@ -128,7 +138,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=("cuda:%d" % local) if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()

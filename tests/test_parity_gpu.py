@@ -420,3 +420,43 @@ def test_randomised_shapes_and_dopplers(pkg, synth, oracle):
         for k in range(nblocks):
             assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
     synth.hazards(reset=True)
+
+
+def test_handle_and_batch_lifecycle(pkg, oracle):
+    """Create/destroy churn, one handle reused across shapes, many small blocks in one batch, API misuse."""
+    import ctypes as C
+    for _ in range(3):
+        with pkg.Synth(0) as s:
+            for nch, nsamp, nblocks in [(3, 1000, 1), (16, 5000, 7), (1, 17, 2), (12, 300000, 1)]:
+                ch = pkg.synth_descriptors(nblocks, nch=nch, seed=nch * 7 + nblocks)
+                want, _, _ = oracle.fill_blocks(ch, 1 / 4.092e6, nsamp)
+                b = s.batch(ch, 1 / 4.092e6, nsamp)
+                b.run()
+                s.sync()
+                assert (b.read()[0] == want).all()
+                b.close()
+                iq, _ = s.fill_block(ch[0], 1 / 4.092e6, nsamp)   # the scratch batch grows and shrinks with the call
+                assert (iq == want[0]).all()
+    with pkg.Synth(0) as s:
+        ch = pkg.synth_descriptors(3000, nch=4, seed=5)           # many short blocks, chained on the host
+        want, want_st, _ = oracle.fill_blocks(ch, 1 / 2.6e6, 2000, chain=True)
+        b = s.batch(ch, 1 / 2.6e6, 2000, flags=pkg.CHAIN_CARRIER)
+        b.run()
+        s.sync()
+        iq, st = b.read()
+        assert (iq == want).all() and st["carr_phase"].tobytes() == want_st["carr_phase"].tobytes()
+        b.close()
+        L = pkg.lib()
+        h = s._h
+        one = pkg.synth_descriptors(1, nch=2, seed=1)
+        out = C.c_void_p()
+        assert L.gpsbb_batch_create(h, one.ctypes.data, 0, 2, 1e-6, 10, 0, C.byref(out)) == -1      # nblocks < 1
+        assert L.gpsbb_batch_create(h, one.ctypes.data, 1, 17, 1e-6, 10, 0, C.byref(out)) == -1     # nch > 16
+        assert L.gpsbb_batch_create(h, one.ctypes.data, 1, 2, 1e-6, 10, 8, C.byref(out)) == -1      # unknown flag
+        assert L.gpsbb_batch_create(h, one.ctypes.data, 1, 2, -1.0, 10, 0, C.byref(out)) == -1      # delt <= 0
+        assert L.gpsbb_batch_read(None, None, None) == -7
+        st = s.stream(2, 1e-6, 100, 1, depth=2)
+        with pytest.raises(pkg.GpsbbError) as e:
+            st.pop()                                              # nothing pushed
+        assert e.value.rc == -7
+        st.close()

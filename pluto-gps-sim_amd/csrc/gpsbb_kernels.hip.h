@@ -345,7 +345,8 @@ struct WaveRows {
     int32_t n0[WAVE_ROW_CAP];
     uint32_t nav[WAVE_ROW_CAP];
     int32_t cbase[2 * GPSBB_MAX_CHAN]; /* first staged row of chain c (rows that change inside the tile) */
-    int32_t cr0[2 * GPSBB_MAX_CHAN];   /* pool row holding the tile's first sample, for the HBM fallback */
+    int32_t cr0[2 * GPSBB_MAX_CHAN];   /* pool row holding the tile's first sample */
+    int32_t ccnt[2 * GPSBB_MAX_CHAN];  /* rows of the chain that overlap the tile (+ terminator) */
 };
 
 /* LDS image of one workgroup (dynamic shared memory, 16-byte aligned carve) */
@@ -674,6 +675,7 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         if (has_chain) {
             W.cbase[lane] = base;
             W.cr0[lane] = r0;
+            W.ccnt[lane] = scnt;
         }
         if (in_lds && !all_uniform) {
             /* some chain changes row inside the tile: stage the rows in this wavefront's LDS slice */
@@ -711,15 +713,43 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                 const int uc = __builtin_amdgcn_readlane(uni, 2 * a);
                 const int uk = __builtin_amdgcn_readlane(uni, 2 * a + 1);
                 int dbx;
+                /* The tile's rows did not fit the wavefront's LDS slice (dense rows: high Doppler at a low
+                 * sample rate): stage just this channel's two chains, one row per lane, and scan them there;
+                 * only if even that does not fit do the lanes scan the pool in HBM. */
+                bool chan_lds = false;
+                int cb0 = 0, kb0 = 0;
+                if (!in_lds && !((uc & 1) && (uk & 1))) {
+                    const int nc = (uc & 1) ? 0 : W.ccnt[2 * a], nk = (uk & 1) ? 0 : W.ccnt[2 * a + 1];
+                    if (nc + nk <= WAVE_ROW_CAP) {
+                        const NcoRow *__restrict__ sc_ = p.rows + L.roff[2 * i] + W.cr0[2 * a];
+                        const NcoRow *__restrict__ sk_ = p.rows + L.roff[2 * i + 1] + W.cr0[2 * a + 1];
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        for (int r = lane; r < nc + nk; r += 64) {
+                            const NcoRow rw = r < nc ? sc_[r] : sk_[r - nc];
+                            W.n0[r] = rw.n0;
+                            W.nav[r] = rw.nav;
+                            W.xb[r] = rw.xb;
+                            W.inc[r] = rw.inc;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        chan_lds = true;
+                        cb0 = 0;
+                        kb0 = nc;
+                    }
+                } else if (in_lds) {
+                    chan_lds = true;
+                    cb0 = W.cbase[2 * a];
+                    kb0 = W.cbase[2 * a + 1];
+                }
                 if (uc & 1) {
                     xcb = readlane_u64(ubase, 2 * a) + (uint64_t)lane * readlane_u64(ustep, 2 * a);
                     nav = (uint32_t)__builtin_amdgcn_readlane((int)unav, 2 * a);
                     dbx = (nav >> 31) ? 0xfffe : 0;
                     nav &= 0x7fffffffu;
                 } else {
-                    if (in_lds)
-                        xcb = row_state_lds(W, W.cbase[2 * a], n0, &nav);
-                    else /* more rows than the LDS slice holds (very high Doppler / low sample rate): scan in HBM */
+                    if (chan_lds)
+                        xcb = row_state_lds(W, cb0, n0, &nav);
+                    else
                         xcb = row_state_global(p.rows + L.roff[2 * i], W.cr0[2 * a], n0, &nav);
                     dbx = nav_bit(L.dwrd[i], nav) < 0 ? 0xfffe : 0;
                 }
@@ -740,8 +770,8 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                 if (uk & 1) {
                     yk = bits_f64(readlane_u64(ubase, 2 * a + 1) + (uint64_t)lane * readlane_u64(ustep, 2 * a + 1));
                 } else {
-                    if (in_lds)
-                        xkb = row_state_lds(W, W.cbase[2 * a + 1], n0, &nav_unused);
+                    if (chan_lds)
+                        xkb = row_state_lds(W, kb0, n0, &nav_unused);
                     else
                         xkb = row_state_global(p.rows + L.roff[2 * i + 1], W.cr0[2 * a + 1], n0, &nav_unused);
                     yk = mul_rn(bits_f64(xkb), 512.0); /* exact */

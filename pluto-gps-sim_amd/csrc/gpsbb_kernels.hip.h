@@ -724,7 +724,9 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                         const NcoRow *__restrict__ sc_ = p.rows + L.roff[2 * i] + W.cr0[2 * a];
                         const NcoRow *__restrict__ sk_ = p.rows + L.roff[2 * i + 1] + W.cr0[2 * a + 1];
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        for (int r = lane; r < nc + nk; r += 64) {
+                        /* only the lanes with samples in the block are here (last tile): stride = their count */
+                        const int nlanes = (p.nsamp - wn0 + SPT - 1) / SPT < 64 ? (p.nsamp - wn0 + SPT - 1) / SPT : 64;
+                        for (int r = lane; r < nc + nk; r += nlanes) {
                             const NcoRow rw = r < nc ? sc_[r] : sk_[r - nc];
                             W.n0[r] = rw.n0;
                             W.nav[r] = rw.nav;

@@ -2,14 +2,17 @@
  * gpsbb-sim — end-to-end generator: RINEX-2 navigation file + position/motion -> int16 I/Q file, with the
  * reference's own program structure (front end -> fill -> TX hand-off) and the fill done on an MI355X.
  *
- *   gpsbb-sim -e nav.14n [-l lat,lon,h | -c x,y,z | -u motion.csv] [-t Y/M/D,h:m:s] [-T] [-i]
- *             [-s fs_hz] [-d seconds] [-n samples_per_block] [-N channels] [-g gpu] -o out.bin
+ *   gpsbb-sim -e nav.14n [-l lat,lon,h | -c x,y,z | -u motion.csv] [-t Y/M/D,h:m:s] [-T] [-i] [-3]
+ *             [-s fs_hz] [-d seconds] [-n samples_per_block] [-N channels] [-g gpu] [-F] -o out.bin
  *
  * Options mirror the reference's (plutogpssim.c:1991-2012, 2296-2390) where they concern the signal; the
  * Pluto-specific ones (-A -B -U -N host) have no meaning here.  -n defaults to 300000, the reference's
  * fixed block (plutogpssim.c:43-44); "-n 0" means fs/10 (time-continuous blocks, gps-sdr-sim semantics).
  * The main loop below is the reference's (c:2655-2806) with the inline sample loop replaced by
  * gpsbb_fill_block(): same mutex/condvar hand-off, same per-block front-end update, carrier phase fed back.
+ * -F ("fast") produces the same bytes faster than real time's structure allows: the front end runs ahead,
+ * blocks go through the streaming ring (gpsbb_stream_*, carrier chained exactly on host threads, pinned
+ * device-to-host gather on a side stream) and are written as they pop.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -23,7 +26,7 @@
 static void usage(void)
 {
     fprintf(stderr, "usage: gpsbb-sim -e nav [-l lat,lon,h|-c x,y,z|-u motion.csv] [-t Y/M/D,h:m:s] [-T] [-i] [-3]\n"
-                    "                 [-s fs_hz] [-d seconds] [-n samples_per_block] [-N channels] [-g gpu] -o out.bin\n");
+                    "                 [-s fs_hz] [-d seconds] [-n samples_per_block] [-N channels] [-g gpu] [-F] -o out.bin\n");
 }
 
 int main(int argc, char **argv)
@@ -37,10 +40,10 @@ int main(int argc, char **argv)
     long fs_hz = 3000000; /* TX_SAMPLE_FREQ c:43 */
     long nsamp = 300000;  /* NUM_SAMPLES c:44 */
     double duration = 1.0;
-    int gpu = 0, opt;
+    int gpu = 0, opt, fast = 0;
     const char *out_path = NULL;
 
-    while ((opt = getopt(argc, argv, "e:u:c:l:s:Tt:in:N:d:o:g:3")) != -1) {
+    while ((opt = getopt(argc, argv, "e:u:c:l:s:Tt:in:N:d:o:g:3F")) != -1) {
         switch (opt) {
         case 'e': cfg.navfile = optarg; break;
         case 'u': cfg.motion_file = optarg; break;
@@ -65,6 +68,7 @@ int main(int argc, char **argv)
         case 'd': duration = atof(optarg); break;
         case 'o': out_path = optarg; break;
         case 'g': gpu = atoi(optarg); break;
+        case 'F': fast = 1; break;
         default: usage(); return 1;
         }
     }
@@ -94,6 +98,43 @@ int main(int argc, char **argv)
         fprintf(stderr, "ERROR: cannot open %s\n", out_path);
         return 1;
     }
+    if (fast) {
+        /* offline generation: slots of up to 16 blocks through the ring, three in flight */
+        const int bps = nblocks < 16 ? (int)(nblocks > 0 ? nblocks : 1) : 16, depth = 3;
+        gpsbb_stream_t *st = NULL;
+        gpsbb_chan_t *slot = malloc((size_t)bps * cfg.max_chan * sizeof *slot);
+        rc = gpsbb_stream_create(bb, cfg.max_chan, delt, (int)nsamp, bps, depth, GPSBB_CHAIN_CARRIER, &st);
+        long pushed = 0, written = 0;
+        while (rc == GPSBB_OK && slot && written < nblocks) {
+            while (rc == GPSBB_OK && pushed < nblocks && gpsbb_stream_pending(st) < depth) {
+                /* a short last slot is padded with blocks that are generated but not written */
+                gpsfe_generate(fe, bps, slot);
+                rc = gpsbb_stream_push(st, slot);
+                pushed += bps;
+            }
+            const int16_t *iq = NULL;
+            if (rc == GPSBB_OK)
+                rc = gpsbb_stream_pop(st, &iq, NULL);
+            if (rc == GPSBB_OK) {
+                const long n = nblocks - written < bps ? nblocks - written : bps;
+                if (fwrite(iq, 4, (size_t)n * (size_t)nsamp, fout) != (size_t)n * (size_t)nsamp)
+                    rc = GPSBB_E_STATE;
+                written += n;
+            }
+        }
+        if (rc != GPSBB_OK)
+            fprintf(stderr, "ERROR: streaming: %s\n", gpsbb_strerror(rc));
+        if (st)
+            gpsbb_stream_destroy(st);
+        free(slot);
+        if (fout != stdout)
+            fclose(fout);
+        gpsbb_destroy(bb);
+        gpsfe_close(fe);
+        fprintf(stderr, "%ld blocks of %ld samples written\n", written, nsamp);
+        return rc == GPSBB_OK ? 0 : 1;
+    }
+
     gpsbb_tx_t *tx = NULL;
     if (gpsbb_tx_create(&tx, (size_t)nsamp, gpsbb_tx_push_to_file, fout) != 0) {
         fprintf(stderr, "ERROR: cannot start the TX surface\n");

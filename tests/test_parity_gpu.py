@@ -320,6 +320,13 @@ def test_gpsbb_sim_end_to_end_file(pkg, tmp_path):
     iq = np.fromfile(out, np.int16).reshape(3, nsamp, 2)
     for blk in range(3):
         assert sha(iq[blk]) == str(z["iq_sha256"][blk]), blk
+    # -F: the same bytes through the streaming ring (front end running ahead, host-chained carrier)
+    fast = str(tmp_path / "iq_fast.bin")
+    subprocess.run([exe, "-e", os.path.join(GOLDEN, "synth3540.14n"), "-l", "30.286502,120.032669,100",
+                    "-s", "2600000", "-d", "30.1", "-F", "-o", fast], check=True, stderr=subprocess.DEVNULL)
+    iq = np.fromfile(fast, np.int16).reshape(301, nsamp, 2)
+    for k, blk in enumerate(int(b) for b in z["blocks"]):
+        assert sha(iq[blk]) == str(z["iq_sha256"][k]), blk
 
 
 # ---- GPSBB_FIXED_CARRIER: the reference's `#ifndef FLOAT_CARR_PHASE` carrier NCO -------------------------

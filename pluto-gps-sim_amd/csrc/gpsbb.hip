@@ -324,11 +324,11 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     if ((e = hipMalloc((void **)&h->d_tabs, sizeof tabs)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&h->d_ca, ca.size() * 4)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&h->d_status, 4)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void **)&h->d_hz, 16)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&h->d_hz, 16 + 128)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h->d_tabs, tabs, sizeof tabs, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h->d_ca, ca.data(), ca.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemset(h->d_status, 0, 4)) != hipSuccess) return fail(e);
-    if ((e = hipMemset(h->d_hz, 0, 16)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(h->d_hz, 0, 16 + 128)) != hipSuccess) return fail(e);
     /* k_synth carves ~76 KB of dynamic LDS per workgroup: above the 64 KB default limit */
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(SynthLds))) != hipSuccess) return fail(e);
@@ -491,6 +491,17 @@ extern "C" size_t gpsbb_batch_iq_bytes(const gpsbb_batch_t *b)
     return b ? (size_t)b->nblocks * (size_t)b->nsamp * 4 : 0;
 }
 
+/* measurement only (builds with -DGPSBB_PROF): k_synth's section timers, wall cycles summed over wavefronts */
+extern "C" int gpsbb_test_read_prof(gpsbb_t *h, unsigned long long out[16], int reset)
+{
+    if (!h || hipSetDevice(h->device) != hipSuccess ||
+        hipMemcpy(out, h->d_hz + 2, 128, hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    if (reset && hipMemset(h->d_hz + 2, 0, 128) != hipSuccess)
+        return -1;
+    return 0;
+}
+
 static int g_test_skip_seed = 0;
 extern "C" void gpsbb_test_skip_seed(int on) { g_test_skip_seed = on; }
 
@@ -506,7 +517,7 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.flags = b->flags;
     p.tabs = b->h->d_tabs;
     p.ca_bits = b->h->d_ca;
-    p.rows = b->d_rows[set].p;
+    p.rows = reinterpret_cast<SynRow *>(b->d_rows[set].p);
     p.row_off = b->d_row_off.p;
     p.tile_row = b->d_tile_row[set].p;
     p.row_cnt = b->d_row_cnt[set].p;
@@ -570,7 +581,8 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         const long wg_slots = (long)(h->sm_count > 0 ? h->sm_count : 256) * 2;
         const long chunks = ((long)b->ntiles + TILE_CHUNK - 1) / TILE_CHUNK;
         const long max_useful = (chunks + WAVES_PER_WG - 1) / WAVES_PER_WG;
-        long want = (wg_slots * 3 + b->nblocks - 1) / b->nblocks;
+        static const long oversub = getenv("GPSBB_OVERSUB") ? atol(getenv("GPSBB_OVERSUB")) : 12;
+        long want = (wg_slots * oversub + b->nblocks - 1) / b->nblocks;
         want = want < 1 ? 1 : (want > max_useful ? max_useful : want);
         const int gx = (int)want;
         hipLaunchKernelGGL(k_synth, dim3(gx, b->nblocks), dim3(TILE_THREADS), sizeof(SynthLds), h->s_compute, p, d_iq);

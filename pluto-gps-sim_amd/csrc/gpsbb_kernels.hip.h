@@ -62,6 +62,22 @@ constexpr int WAVE_ROW_CAP = GPSBB_ROW_CAP;           /* rows of all chains of o
 
 constexpr uint32_t ST_ROW_OVERFLOW = 1u;
 
+/*
+ * One row of a chain's table as the device pool holds it (24 bytes, the same slots as gpsbb_nco.h's NcoRow
+ * {n0, nav, bits, inc}).  Inside a row every step adds the same whole number of units in the last place
+ * and never leaves the binade, so the state at sample n is x + (n - n0)*S with S = inc * ulp: one FMA
+ * gives it exactly (the product is exact, the sum is a representable number, so the single rounding does
+ * nothing).  Code rows carry the data bit that is valid for the whole row in nav bit 31 (1 = dataBit -1);
+ * carrier rows are stored scaled by 512 (exact), which is how the walk indexes the 512-entry tables.
+ */
+struct SynRow {
+    int32_t n0;
+    uint32_t nav;
+    double x;
+    double S;
+};
+static_assert(sizeof(SynRow) == sizeof(NcoRow), "row pool is sized for NcoRow");
+
 /* Everything the kernels need about one batch; passed by value as the kernel argument. */
 struct BatchDev {
     const gpsbb_chan_t *ch;         /* [nblocks*nch] descriptors, block-major                        */
@@ -70,7 +86,7 @@ struct BatchDev {
     unsigned flags;
     const int32_t *tabs;            /* cos512[512] then sin512[512] (plutogpssim.c:93-161)           */
     const uint32_t *ca_bits;        /* [33][32] C/A chips per PRN, bit i of dword i>>5 = chip i      */
-    NcoRow *rows;                   /* row pool                                                      */
+    SynRow *rows;                   /* row pool                                                      */
     const uint64_t *row_off;        /* [2*nblocks*nch + 1] first row of each chain in the pool       */
     int32_t *tile_row;              /* [nblocks][ntiles+1][2*nch]: row (relative to its chain) holding each
                                        tile's first sample, column 2*channel + kind; the 2*nch entries of
@@ -112,20 +128,32 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src)
 /* ---- k_seed -------------------------------------------------------------------------------------- */
 
 struct RowSink {
-    NcoRow *rows;
+    SynRow *rows;
     uint32_t cap; /* rows available, not counting the sentinel slot */
     uint32_t cnt;
     bool overflow;
     unsigned long long *hz;
+    const uint32_t *dwrd; /* code chains: the channel's nav words; carrier chains: nullptr */
 
     __device__ __forceinline__ void row(int32_t n0, uint32_t nav, uint64_t xb, int64_t inc)
     {
         if (cnt < cap) {
-            NcoRow r;
+            /* one unit in the last place of xb's binade, as a double (subnormal below 2^-1022) */
+            uint32_t ex = (uint32_t)(xb >> 52) & 0x7ffu;
+            ex = ex ? ex : 1u;
+            const uint64_t ub = ex > 52u ? (uint64_t)(ex - 52u) << 52 : 1ull << (ex - 1u);
+            const double x = bits_f64(xb), S = mul_rn((double)inc, bits_f64(ub)); /* |inc| < 2^53: exact */
+            SynRow r;
             r.n0 = n0;
-            r.nav = nav;
-            r.xb = xb;
-            r.inc = inc;
+            if (dwrd) {
+                r.nav = nav | (nav_bit(dwrd, nav) < 0 ? 0x80000000u : 0u);
+                r.x = x;
+                r.S = S;
+            } else {
+                r.nav = 0;
+                r.x = mul_rn(x, 512.0);
+                r.S = mul_rn(S, 512.0);
+            }
             rows[cnt] = r;
         } else {
             overflow = true;
@@ -141,22 +169,22 @@ struct RowSink {
     {
         if (cnt > cap)
             cnt = cap;
-        NcoRow r;
+        SynRow r;
         r.n0 = INT32_MAX; /* sentinel: terminates every forward scan */
         r.nav = 0;
-        r.xb = 0;
-        r.inc = 0;
+        r.x = 0.0;
+        r.S = 0.0;
         rows[cnt] = r;
     }
 };
 
 /* what phase 2 of k_seed needs to know about the chain a lane has just built */
 struct ChainDone {
-    const NcoRow *rows;
+    const SynRow *rows;
     int cnt; /* 0 = this lane built nothing */
 };
 
-__device__ __forceinline__ RowSink make_sink(const BatchDev &p, int chain)
+__device__ __forceinline__ RowSink make_sink(const BatchDev &p, int chain, const uint32_t *dwrd)
 {
     RowSink s;
     const uint64_t o0 = p.row_off[chain], o1 = p.row_off[chain + 1];
@@ -165,6 +193,7 @@ __device__ __forceinline__ RowSink make_sink(const BatchDev &p, int chain)
     s.cnt = 0;
     s.overflow = false;
     s.hz = p.hazards;
+    s.dwrd = dwrd;
     return s;
 }
 
@@ -180,7 +209,7 @@ __device__ inline ChainDone seed_code_chain(const BatchDev &p, int b, int i)
         return d;
     }
     const int chain = chain_code(p, b, i);
-    RowSink sink = make_sink(p, chain);
+    RowSink sink = make_sink(p, chain, c.dwrd);
     uint32_t nav = nav_pack(c.icode, c.ibit, c.iword);
     const double s = mul_rn(c.f_code, p.delt); /* plutogpssim.c:2709: f_code * delt, rounded on its own */
     const double x = build_rows<NCO_CODE>(c.code_phase, s, nav, p.nsamp, sink);
@@ -211,7 +240,7 @@ __device__ inline ChainDone seed_carr_chain(const BatchDev &p, int b, int i, dou
         return d;
     }
     const int chain = chain_carr(p, b, i);
-    RowSink sink = make_sink(p, chain);
+    RowSink sink = make_sink(p, chain, nullptr);
     uint32_t nav = 0;
     const double s = mul_rn(c.f_carr, p.delt); /* plutogpssim.c:2741 */
     const double x = build_rows<NCO_CARR>(x0, s, nav, p.nsamp, sink);
@@ -285,7 +314,7 @@ __global__ __launch_bounds__(256) void k_tile_index(BatchDev p)
     const int cnt = p.row_cnt[chain];
     if (cnt == 0)
         return;
-    const NcoRow *__restrict__ rows = p.rows + p.row_off[chain];
+    const SynRow *__restrict__ rows = p.rows + p.row_off[chain];
     const int nbc = p.nblocks * p.nch;
     const int kind = chain >= nbc ? 1 : 0, bi = chain - kind * nbc;
     int32_t *__restrict__ tr = p.tile_row + tile_row_at(p, bi / p.nch, 0, bi % p.nch, kind);
@@ -338,15 +367,14 @@ __device__ __forceinline__ uint32_t v2s_u32(v2s v)
     return u;
 }
 
-/* a wavefront's private slice of LDS: the rows of every chain that overlap its current tile (SoA) */
-struct WaveRows {
-    uint64_t xb[WAVE_ROW_CAP];
-    int64_t inc[WAVE_ROW_CAP];
-    int32_t n0[WAVE_ROW_CAP];
-    uint32_t nav[WAVE_ROW_CAP];
-    int32_t cbase[2 * GPSBB_MAX_CHAN]; /* first staged row of chain c (rows that change inside the tile) */
-    int32_t cr0[2 * GPSBB_MAX_CHAN];   /* pool row holding the tile's first sample */
-    int32_t ccnt[2 * GPSBB_MAX_CHAN];  /* rows of the chain that overlap the tile (+ terminator) */
+/* a wavefront's private slice of LDS: the rows of every chain that overlap its current tile, one slot per
+ * row, chain after chain.  Filled by LDS-DMA (global_load_lds_dwordx4 / _dword): lane k of a load owns
+ * slot k, nothing passes through registers and the copy of the next tile's rows runs under the current
+ * tile's last channel. */
+struct __attribute__((aligned(16))) WaveRows {
+    uint4 a[WAVE_ROW_CAP];       /* {n0, nav, x.lo, x.hi} */
+    uint32_t s_lo[WAVE_ROW_CAP]; /* S */
+    uint32_t s_hi[WAVE_ROW_CAP];
 };
 
 /* LDS image of one workgroup (dynamic shared memory, 16-byte aligned carve) */
@@ -364,22 +392,15 @@ struct SynthLds {
     int32_t nact;
 };
 
-/* state of one NCO at sample n, scanning forward from row r (global-memory fallback) */
-__device__ __forceinline__ uint64_t row_state_global(const NcoRow *__restrict__ rows, int r, int n, uint32_t *nav)
+/* state of one NCO at sample n, scanning forward from the first of `rows` (global-memory fallback) */
+__device__ __forceinline__ double row_state_global(const SynRow *__restrict__ rows, int n, uint32_t *nav)
 {
+    int r = 0;
     while (rows[r + 1].n0 <= n)
         r++;
-    const NcoRow row = rows[r];
+    const SynRow row = rows[r];
     *nav = row.nav;
-    return row.xb + (uint64_t)((int64_t)(n - row.n0) * row.inc);
-}
-
-__device__ __forceinline__ uint64_t row_state_lds(const WaveRows &W, int r, int n, uint32_t *nav)
-{
-    while (W.n0[r + 1] <= n)
-        r++;
-    *nav = W.nav[r];
-    return W.xb[r] + (uint64_t)((int64_t)(n - W.n0[r]) * W.inc[r]);
+    return __fma_rn((double)(n - row.n0), row.S, row.x);
 }
 
 __device__ __forceinline__ double hi_lo_f64(int hi, int lo) { return __hiloint2double(hi, lo); }
@@ -390,6 +411,101 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
     return ((uint64_t)hi << 32) | lo;
+}
+
+/* ---- wavefront-level helpers -------------------------------------------------------------------- */
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or_zero(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+/* inclusive prefix sum over the 64 lanes, all in the VALU's data-parallel-primitive path: four shifts inside
+ * each row of 16 lanes, then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3 */
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += dpp_or_zero<0x111, 0xf>(v); /* row_shr:1 */
+    v += dpp_or_zero<0x112, 0xf>(v); /* row_shr:2 */
+    v += dpp_or_zero<0x114, 0xf>(v); /* row_shr:4 */
+    v += dpp_or_zero<0x118, 0xf>(v); /* row_shr:8 */
+    v += dpp_or_zero<0x142, 0xa>(v); /* row_bcast:15 into rows 1 and 3 */
+    v += dpp_or_zero<0x143, 0xc>(v); /* row_bcast:31 into rows 2 and 3 */
+    return v;
+}
+
+/* lane `src` (per-lane index) of a 64-bit value */
+__device__ __forceinline__ uint64_t bpermute_u64(uint64_t v, int src)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+/* one row per lane, HBM -> LDS without touching registers: the lane's row lands in slot (first + lane) */
+__device__ __forceinline__ void dma_row(uint64_t src, WaveRows &W, int first)
+{
+    __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)src, (lptr_t)&W.a[first], 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(src + 16), (lptr_t)&W.s_lo[first], 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(src + 20), (lptr_t)&W.s_hi[first], 4, 0, 0);
+}
+
+/*
+ * Start the copy of one tile's rows into the wavefront's slice.  Lane c is chain c of the block; its rows
+ * trA..trB overlap the tile.  The chains' slot ranges come from a prefix sum over the lanes; slot k's chain
+ * is the number of chains whose range ends at or before k.  Returns false (nothing issued) when the tile
+ * has more rows than the slice holds: such tiles stage channel by channel (see k_synth).
+ */
+__device__ __forceinline__ bool stage_tile(WaveRows &W, int lane, int nchains, bool has_chain, uint64_t row0_addr,
+                                           int trA, int trB, int &base, int &cnt)
+{
+    cnt = has_chain ? trB - trA + 1 : 0;
+    const int incl = wave_incl_scan(cnt);
+    base = incl - cnt;
+    const int R = __builtin_amdgcn_readlane(incl, 63);
+    if (R > WAVE_ROW_CAP)
+        return false;
+    /* slot k holds row trA + (k - base) of its chain, i.e. address [row 0 + (trA - base) rows] + k rows */
+    const uint64_t addr_c = row0_addr + (uint64_t)((int64_t)(trA - base) * (int64_t)sizeof(SynRow));
+    int ck = 0;
+    for (int c = 0; c < nchains; c++)
+        ck += __builtin_amdgcn_readlane(incl, c) <= lane;
+    const uint64_t a0 = bpermute_u64(addr_c, ck) + (uint64_t)lane * sizeof(SynRow);
+    if (lane < R)
+        dma_row(a0, W, 0);
+    if (R > 64) {
+        ck = 0;
+        for (int c = 0; c < nchains; c++)
+            ck += __builtin_amdgcn_readlane(incl, c) <= lane + 64;
+        const uint64_t a1 = bpermute_u64(addr_c, ck) + (uint64_t)(lane + 64) * sizeof(SynRow);
+        if (lane + 64 < R)
+            dma_row(a1, W, 64);
+    }
+    return true;
+}
+
+/*
+ * State of one chain at sample n (this lane's first sample).  The chain's rows sit in slots
+ * sbase .. sbase+scnt-1 and their first samples in slot_n0a / slot_n0b (lane k = slot k / 64+k): the
+ * lane's row is found by counting the rows that start at or before n, each compared through a scalar
+ * register, then fetched with one 16-byte and two 4-byte LDS reads.
+ */
+__device__ __forceinline__ double chain_state(const WaveRows &W, int sbase, int scnt, int slot_n0a, int slot_n0b, int n,
+                                              uint32_t *nav)
+{
+    int slot = sbase;
+    for (int j = 1; j < scnt; j++) {
+        const int k = sbase + j;
+        const int t = k < 64 ? __builtin_amdgcn_readlane(slot_n0a, k) : __builtin_amdgcn_readlane(slot_n0b, k - 64);
+        slot += t <= n;
+    }
+    const uint4 r = W.a[slot];
+    const double S = hi_lo_f64((int)W.s_hi[slot], (int)W.s_lo[slot]);
+    *nav = r.y;
+    return __fma_rn((double)(n - (int)r.x), S, hi_lo_f64((int)r.w, (int)r.z));
 }
 
 /*
@@ -505,8 +621,35 @@ __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc
     }
 }
 
+#ifdef GPSBB_PROF
+/* section timers (tools/prof_sections.py): wall cycles per wavefront between marks, summed into hazards[2+k] */
+#define PROF_DECL                                                                                                  \
+    unsigned long long prof_t0 = __builtin_readcyclecounter(), prof_tp = prof_t0,                                  \
+                       prof_s[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_MARK(k)                                                  \
+    do {                                                              \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        const unsigned long long t_ = __builtin_readcyclecounter();   \
+        prof_s[k] += t_ - prof_tp;                                    \
+        prof_tp = t_;                                                 \
+        __builtin_amdgcn_sched_barrier(0);                            \
+    } while (0)
+#define PROF_FLUSH                                                    \
+    do {                                                              \
+        prof_s[15] = __builtin_readcyclecounter() - prof_t0;          \
+        if ((threadIdx.x & 63) == 0)                                  \
+            for (int k_ = 0; k_ < 16; k_++)                           \
+                atomicAdd(p.hazards + 2 + k_, prof_s[k_]);            \
+    } while (0)
+#else
+#define PROF_DECL
+#define PROF_MARK(k)
+#define PROF_FLUSH
+#endif
+
 __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(BatchDev p, int16_t *__restrict__ iq)
 {
+    PROF_DECL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     SynthLds &L = *reinterpret_cast<SynthLds *>(smem_raw);
 
@@ -568,226 +711,169 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
     }
     __syncthreads();
     const int nact = L.nact;
+    PROF_MARK(0);
 
-    /* ---- from here on every wavefront works alone: a contiguous range of tiles, no workgroup barrier ---- */
+    /* ---- from here on every wavefront works alone: chunks of consecutive tiles, no workgroup barrier ---- */
     const int wave = tid >> 6, lane = tid & 63;
     WaveRows &W = L.wr[wave];
     const int ntw = p.ntiles;
     /* lane c serves chain c = (channel c>>1, kind c&1) of this block */
     const bool fixed_carr = p.kph0 != nullptr; /* fixed-point carrier variant: carrier chains have no rows */
     const bool has_chain = lane < 2 * nact && !(fixed_carr && (lane & 1));
-    const int32_t *__restrict__ lane_tr = p.tile_row + tile_row_at(p, b, 0, has_chain ? L.act[lane >> 1] : 0, lane & 1);
+    const int my_chan = has_chain ? L.act[lane >> 1] : 0;
+    const int32_t *__restrict__ lane_tr = p.tile_row + tile_row_at(p, b, 0, my_chan, lane & 1);
     const size_t tstride = 2 * (size_t)p.nch; /* the 2*nch entries of one tile are contiguous: one cache line */
-    const NcoRow *__restrict__ lane_rows = p.rows + L.roff[has_chain ? 2 * L.act[lane >> 1] + (lane & 1) : 0];
+    const uint64_t row0_addr = (uint64_t)(uintptr_t)(p.rows + L.roff[has_chain ? 2 * my_chan + (lane & 1) : 0]);
+    const int nchains = 2 * nact;
 
     /* Tiles are handed out dynamically in chunks of TILE_CHUNK consecutive tiles from a per-block counter:
      * a wavefront that shares its SIMD with another kernel (the next run's seeding pre-pass runs
      * concurrently) simply takes fewer chunks instead of stretching the whole launch. */
-  for (;;) {
-    int chunk = 0;
-    if (lane == 0)
-        chunk = atomicAdd(&p.tile_ctr[b], TILE_CHUNK);
-    const int wt_begin = __builtin_amdgcn_readfirstlane(chunk);
-    if (wt_begin >= ntw)
-        break;
-    const int wt_end = wt_begin + TILE_CHUNK < ntw ? wt_begin + TILE_CHUNK : ntw;
+    for (;;) {
+        int chunk = 0;
+        if (lane == 0)
+            chunk = atomicAdd(&p.tile_ctr[b], TILE_CHUNK);
+        const int wt_begin = __builtin_amdgcn_readfirstlane(chunk);
+        if (wt_begin >= ntw)
+            break;
+        const int wt_end = wt_begin + TILE_CHUNK < ntw ? wt_begin + TILE_CHUNK : ntw;
 
-    int r_first = 0, r_next = 0;
-    if (has_chain) { /* lanes without a chain keep re-reading row 0 of a valid region */
-        r_first = lane_tr[wt_begin * tstride];
-        r_next = lane_tr[(wt_begin + 1) * tstride];
-    } /* row holding the first sample of tile wt / wt+1 */
-    /* rows are fetched one tile ahead: row 0 of the chain for the tile and the start of row 1 */
-    NcoRow pre_row0 = lane_rows[r_first];
-    int pre_n1 = lane_rows[r_first + 1].n0;
-
-    for (int wt = wt_begin; wt < wt_end; wt++) {
-        const int wn0 = wt * TILE;      /* first run start of this tile (wave-uniform) */
-        const int wnl = wn0 + 63 * SPT; /* last run start */
-
-        /* -- the rows of chain `lane` that overlap this tile: r_first..r_next plus the scan terminator -- */
-        const int r0 = r_first;
-        const int cnt = has_chain ? r_next - r0 + 2 : 0;
-        const int ci_ = has_chain ? L.act[lane >> 1] : 0;
-        const NcoRow *__restrict__ src = p.rows + L.roff[2 * ci_ + (lane & 1)] + r0;
-        /* prefetch the row index of the tile after next: a contiguous range per wavefront makes this
-         * tile's r_next the next tile's r_first */
-        int r_after = r_next;
-        if (has_chain && wt + 2 <= ntw)
-            r_after = lane_tr[(wt + 2) * tstride];
-
-        /* this tile's first row (and where the second starts) were fetched during the previous tile; they
-         * decide whether the chain is uniform over this tile.  Issue the next tile's now (lanes without a
-         * chain re-read row 0 of a valid region). */
-        NcoRow row[2];
-        row[0] = pre_row0;
-        row[1].n0 = pre_n1;
-        if (r_next != r_first) { /* rows span many tiles: usually the next tile starts in the same row */
-            pre_row0 = lane_rows[r_next];
-            pre_n1 = lane_rows[r_next + 1].n0;
-        }
-
-        /* A chain whose first row covers all 64 run starts of the tile ("uniform", the usual case: rows
-         * are thousands of samples long) needs no table at all: its lanes' states are
-         * ubase + lane*ustep.  Computed here by the chain's lane, broadcast later with v_readlane. */
-        int uni = 0;      /* bit 0: uniform; bit 1: additionally no wrap anywhere in the tile */
-        uint64_t ubase = 0, ustep = 0;
-        uint32_t unav = 0; /* code chains: nav counters, bit 31 = data bit is -1 */
-        if (cnt > 0) {
-            uni = row[1].n0 > wnl;
-            /* a row is a regular run: no wrap and no binade change between its samples.  If it reaches
-             * past the tile, no lane can wrap inside its run and the wrap tests are not needed at all */
-            if (row[1].n0 >= wn0 + TILE)
-                uni |= 2;
-            ubase = row[0].xb + (uint64_t)((int64_t)(wn0 - row[0].n0) * row[0].inc);
-            ustep = (uint64_t)(row[0].inc * SPT);
-            if (lane & 1) {
-                /* carrier: the walk uses the phase scaled by 512 = the same mantissa, exponent + 9 */
-                const uint32_t ex = (uint32_t)(ubase >> 52) & 0x7ffu;
-                if (ex != 0)
-                    ubase += 9ull << 52;
-                else if (ubase != 0)
-                    uni = 0; /* subnormal phase: leave it to the generic path */
-            } else {
-                unav = row[0].nav | (nav_bit(L.dwrd[ci_], row[0].nav) < 0 ? 0x80000000u : 0u); /* bit 31: dataBit = -1 */
-            }
-        }
-
-        /* only when some chain changes row inside the tile are its rows staged in LDS: then (and only then)
-         * the chains' slots in the wavefront's slice are laid out with a prefix sum over the lanes */
-        const bool all_uniform = __all((uni & 1) || cnt == 0);
-        int base = 0;
-        bool in_lds = true;
-        const int scnt = (uni & 1) ? 0 : cnt; /* uniform chains need no slot */
-        if (!all_uniform) {
-            int incl = scnt;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_up(incl, o);
-                if (lane >= o)
-                    incl += t;
-            }
-            base = incl - scnt;
-            in_lds = __shfl(incl, 63) <= WAVE_ROW_CAP;
-        }
-
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* the previous tile's readers are done */
+        /* tile index entries of this chain: the row holding the first sample of tile wt, wt+1, wt+2 */
+        int trA = 0, trB = 0, trC = 0;
         if (has_chain) {
-            W.cbase[lane] = base;
-            W.cr0[lane] = r0;
-            W.ccnt[lane] = scnt;
+            trA = lane_tr[wt_begin * tstride];
+            trB = lane_tr[(wt_begin + 1) * tstride];
+            trC = lane_tr[(wt_begin + 2 <= ntw ? wt_begin + 2 : ntw) * tstride];
         }
-        if (in_lds && !all_uniform) {
-            /* some chain changes row inside the tile: stage the rows in this wavefront's LDS slice */
-            if (scnt > 0) {
-                W.n0[base] = row[0].n0;
-                W.nav[base] = row[0].nav;
-                W.xb[base] = row[0].xb;
-                W.inc[base] = row[0].inc;
-            }
-            for (int r = 1; r < scnt; r++) {
-                const NcoRow rw = src[r];
-                W.n0[base + r] = rw.n0;
-                W.nav[base + r] = rw.nav;
-                W.xb[base + r] = rw.xb;
-                W.inc[base + r] = rw.inc;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* LDS is in order within a wavefront */
-        r_first = r_next;
-        r_next = r_after;
+        /* slots of this chain's rows in the slice for the current tile; ovf: the tile's rows do not fit */
+        int cbase, ccnt;
+        bool ovf = !stage_tile(W, lane, nchains, has_chain, row0_addr, trA, trB, cbase, ccnt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int slot_n0a = (int)W.a[lane].x, slot_n0b = (int)W.a[64 + lane].x;
+        PROF_MARK(1);
 
-        const int n0 = wn0 + lane * SPT;
-        if (n0 < p.nsamp) {
+        for (int wt = wt_begin; wt < wt_end; wt++) {
+            const bool more = wt + 1 < wt_end;
+            const int wn0 = wt * TILE;       /* first sample of the tile (wave-uniform) */
+            const int n0 = wn0 + lane * SPT; /* this lane's run; lanes past the block end compute and store nothing */
+            const int nvalid = p.nsamp - n0 < SPT ? p.nsamp - n0 : SPT;
+            int nbase = 0, ncnt = 0;
+            bool novf = false, staged = false;
+            unsigned long long hz_itable = 0;
             v2s acc[SPT];
 #pragma unroll
             for (int j = 0; j < SPT; j++)
                 acc[j] = v2s{0, 0};
-            const int nvalid = p.nsamp - n0 < SPT ? p.nsamp - n0 : SPT;
-            unsigned long long hz_itable = 0;
+#ifdef GPSBB_PROF
+            prof_s[10]++;
+            prof_s[11] += ovf;
+#endif
 
             for (int a = 0; a < nact; a++) {
                 const int i = L.act[a];
-                uint32_t nav, nav_unused;
-                uint64_t xcb, xkb;
-                const int uc = __builtin_amdgcn_readlane(uni, 2 * a);
-                const int uk = __builtin_amdgcn_readlane(uni, 2 * a + 1);
-                int dbx;
-                /* The tile's rows did not fit the wavefront's LDS slice (dense rows: high Doppler at a low
-                 * sample rate): stage just this channel's two chains, one row per lane, and scan them there;
-                 * only if even that does not fit do the lanes scan the pool in HBM. */
-                bool chan_lds = false;
-                int cb0 = 0, kb0 = 0;
-                if (!in_lds && !((uc & 1) && (uk & 1))) {
-                    const int nc = (uc & 1) ? 0 : W.ccnt[2 * a], nk = (uk & 1) ? 0 : W.ccnt[2 * a + 1];
-                    if (nc + nk <= WAVE_ROW_CAP) {
-                        const NcoRow *__restrict__ sc_ = p.rows + L.roff[2 * i] + W.cr0[2 * a];
-                        const NcoRow *__restrict__ sk_ = p.rows + L.roff[2 * i + 1] + W.cr0[2 * a + 1];
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        /* only the lanes with samples in the block are here (last tile): stride = their count */
-                        const int nlanes = (p.nsamp - wn0 + SPT - 1) / SPT < 64 ? (p.nsamp - wn0 + SPT - 1) / SPT : 64;
-                        for (int r = lane; r < nc + nk; r += nlanes) {
-                            const NcoRow rw = r < nc ? sc_[r] : sk_[r - nc];
-                            W.n0[r] = rw.n0;
-                            W.nav[r] = rw.nav;
-                            W.xb[r] = rw.xb;
-                            W.inc[r] = rw.inc;
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        chan_lds = true;
-                        cb0 = 0;
-                        kb0 = nc;
+                /* -- where this lane's run starts in the two chains of channel i -- */
+                int sb_c = 0, sb_k = 0;
+                const int sc_c = __builtin_amdgcn_readlane(ccnt, 2 * a), sc_k = __builtin_amdgcn_readlane(ccnt, 2 * a + 1);
+                bool glob = false;
+                if (!ovf) {
+                    sb_c = __builtin_amdgcn_readlane(cbase, 2 * a);
+                    sb_k = __builtin_amdgcn_readlane(cbase, 2 * a + 1);
+                } else if (sc_c + sc_k <= WAVE_ROW_CAP) {
+                    /* The tile's rows did not fit the slice (dense rows: high Doppler at a low sample rate):
+                     * stage just this channel's two chains and look them up there. */
+                    const uint64_t tile_addr = row0_addr + (uint64_t)trA * sizeof(SynRow);
+                    const uint64_t ac = readlane_u64(tile_addr, 2 * a), ak = readlane_u64(tile_addr, 2 * a + 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the previous channel's lookups are done */
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int k = lane + 64 * h;
+                        if (k < sc_c + sc_k)
+                            dma_row(k < sc_c ? ac + (uint64_t)k * sizeof(SynRow) : ak + (uint64_t)(k - sc_c) * sizeof(SynRow),
+                                    W, 64 * h);
                     }
-                } else if (in_lds) {
-                    chan_lds = true;
-                    cb0 = W.cbase[2 * a];
-                    kb0 = W.cbase[2 * a + 1];
-                }
-                if (uc & 1) {
-                    xcb = readlane_u64(ubase, 2 * a) + (uint64_t)lane * readlane_u64(ustep, 2 * a);
-                    nav = (uint32_t)__builtin_amdgcn_readlane((int)unav, 2 * a);
-                    dbx = (nav >> 31) ? 0xfffe : 0;
-                    nav &= 0x7fffffffu;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    slot_n0a = (int)W.a[lane].x;
+                    slot_n0b = (int)W.a[64 + lane].x;
+                    sb_k = sc_c;
                 } else {
-                    if (chan_lds)
-                        xcb = row_state_lds(W, cb0, n0, &nav);
-                    else
-                        xcb = row_state_global(p.rows + L.roff[2 * i], W.cr0[2 * a], n0, &nav);
-                    dbx = nav_bit(L.dwrd[i], nav) < 0 ? 0xfffe : 0;
+                    glob = true; /* last resort: every lane scans the pool in HBM */
                 }
-                const double xc = bits_f64(xcb);
-                /* can any lane of this wavefront wrap inside its run?  Known to be impossible when the
-                 * chain's row reaches past the tile; otherwise compare with the per-channel limits */
-                const bool code_w = (uc & 2) ? false : (bool)__any(!(xc < L.xlim[i]));
+                uint32_t nav_raw, nav_unused;
+                double xc;
+                if (!glob) {
+                    xc = chain_state(W, sb_c, sc_c, slot_n0a, slot_n0b, n0, &nav_raw);
+                } else {
+                    const uint64_t tile_addr = row0_addr + (uint64_t)trA * sizeof(SynRow);
+                    xc = row_state_global((const SynRow *)(uintptr_t)readlane_u64(tile_addr, 2 * a), n0, &nav_raw);
+                }
+                const int dbx = (nav_raw >> 31) ? 0xfffe : 0; /* dataBit -1: flips the chip's +-1 in 16 bits */
+                const uint32_t nav = nav_raw & 0x7fffffffu;
+                /* Can any lane of this wavefront wrap inside its run?  Impossible when the whole tile lies in
+                 * one row of the chain (a wrap is a row boundary); otherwise compare with the channel's limits. */
+                const bool code_w = (sc_c == 1 && !glob) ? false : (bool)__any(!(xc < L.xlim[i]));
+                double yk = 0.0;
+                uint32_t ph = 0, kstep = 0;
+                bool carr_w = false;
                 if (fixed_carr) {
-                    const uint32_t kstep = (uint32_t)p.kstep[(size_t)b * p.nch + i];
-                    const uint32_t ph = p.kph0[(size_t)b * p.nch + i] + (uint32_t)n0 * kstep;
+                    kstep = (uint32_t)p.kstep[(size_t)b * p.nch + i];
+                    ph = p.kph0[(size_t)b * p.nch + i] + (uint32_t)n0 * kstep;
+                } else {
+                    if (!glob) {
+                        yk = chain_state(W, sb_k, sc_k, slot_n0a, slot_n0b, n0, &nav_unused);
+                    } else {
+                        const uint64_t tile_addr = row0_addr + (uint64_t)trA * sizeof(SynRow);
+                        yk = row_state_global((const SynRow *)(uintptr_t)readlane_u64(tile_addr, 2 * a + 1), n0, &nav_unused);
+                    }
+                    carr_w = (sc_k == 1 && !glob) ? false : (bool)__any(!(yk < L.yhi[i]) || !(yk > L.ylo[i]));
+                }
+                PROF_MARK(2);
+
+                /* -- before the last channel's walk: start the copy of the next tile's rows -- */
+                if (a == nact - 1 && more) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this tile's lookups have returned */
+                    novf = !stage_tile(W, lane, nchains, has_chain, row0_addr, trB, trC, nbase, ncnt);
+                    trA = trB;
+                    trB = trC;
+                    if (has_chain && wt + 3 <= ntw)
+                        trC = lane_tr[(wt + 3) * tstride];
+                    staged = true;
+                    PROF_MARK(3);
+                }
+
+                if (fixed_carr) {
                     if (!code_w)
                         walk_channel<false, 2>(L, i, xc, 0.0, ph, kstep, nav, dbx, acc, nvalid, hz_itable);
                     else
                         walk_channel<true, 2>(L, i, xc, 0.0, ph, kstep, nav, dbx, acc, nvalid, hz_itable);
-                    continue;
-                }
-                double yk;
-                if (uk & 1) {
-                    yk = bits_f64(readlane_u64(ubase, 2 * a + 1) + (uint64_t)lane * readlane_u64(ustep, 2 * a + 1));
-                } else {
-                    if (chan_lds)
-                        xkb = row_state_lds(W, kb0, n0, &nav_unused);
-                    else
-                        xkb = row_state_global(p.rows + L.roff[2 * i + 1], W.cr0[2 * a + 1], n0, &nav_unused);
-                    yk = mul_rn(bits_f64(xkb), 512.0); /* exact */
-                }
-                const bool carr_w = (uk & 2) ? false : (bool)__any(!(yk < L.yhi[i]) || !(yk > L.ylo[i]));
-                if (!code_w && !carr_w)
+                } else if (!code_w && !carr_w) {
                     walk_channel<false, 0>(L, i, xc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
-                else if (!code_w)
+                } else if (!code_w) {
                     walk_channel<false, 1>(L, i, xc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
-                else if (!carr_w)
+                } else if (!carr_w) {
                     walk_channel<true, 0>(L, i, xc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
-                else
+                } else {
                     walk_channel<true, 1>(L, i, xc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
+                }
+                PROF_MARK(4);
             }
+            if (more && !staged) { /* no active channel */
+                novf = !stage_tile(W, lane, nchains, has_chain, row0_addr, trB, trC, nbase, ncnt);
+                trA = trB;
+                trB = trC;
+                if (has_chain && wt + 3 <= ntw)
+                    trC = lane_tr[(wt + 3) * tstride];
+            }
+            if (more) {
+                /* the next tile's rows have had the last walk to arrive; waiting here, before this tile's
+                 * stores are issued, keeps the wait from covering the stores as well */
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                slot_n0a = (int)W.a[lane].x;
+                slot_n0b = (int)W.a[64 + lane].x;
+                cbase = nbase;
+                ccnt = ncnt;
+                ovf = novf;
+            }
+            PROF_MARK(5);
             if (hz_itable)
                 atomicAdd(p.hazards, hz_itable);
 
@@ -804,9 +890,10 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                     if (j < nvalid)
                         out[j] = v2s_u32(acc[j]);
             }
+            PROF_MARK(6);
         }
-    }
-  } /* chunk loop */
+    } /* chunk loop */
+    PROF_FLUSH;
 }
 
 /* pure write stream of the same shape as k_synth's output: the empirical int16x2 write ceiling */

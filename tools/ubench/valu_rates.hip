@@ -8,10 +8,17 @@
 template <int OP>
 __global__ __launch_bounds__(256) void k(double *out, double s, int n)
 {
+    __shared__ unsigned scratch[4 * 1088];
+    for (int i = threadIdx.x; i < 4 * 1088; i += 256) scratch[i] = 0;
+    __syncthreads();
     double a[8];
     int b[8];
     for (int i = 0; i < 8; i++) { a[i] = threadIdx.x * 0.001 + i; b[i] = threadIdx.x + i; }
+    const int laddr = ((threadIdx.x & 63) * 17 + (threadIdx.x >> 6) * 1088) * 4;
+    const int raddr = (((threadIdx.x * 2654435761u) >> 8) & 1023) * 4; // random table lookups
+    int x0 = threadIdx.x, x1 = blockIdx.x;
     for (int it = 0; it < n; it++) {
+        if (OP >= 19 && OP <= 23) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             if (OP == 0) a[i] = __dadd_rn(a[i], s);
@@ -22,10 +29,28 @@ __global__ __launch_bounds__(256) void k(double *out, double s, int n)
             if (OP == 5) a[i] = __dmul_rn(a[i], s);
             if (OP == 6) b[i] = __double2hiint(a[i]) >= 0x408FF800 ? b[i] + 1 : b[i];
             if (OP == 7) { asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(b[i]) : "v"(a[i])); }
+            if (OP == 8) { asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "s"(s)); }
+            if (OP == 9) { asm volatile("v_floor_f64 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7])); }
+            if (OP == 10) b[i] += a[(i + 1) & 7] >= s ? 1 : 0;
+            if (OP == 11) { asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(a[i]) : "v"(b[i])); }
+            if (OP == 12) { atomicAdd(&scratch[(threadIdx.x & 63) * 17 + ((b[i] + it) & 15) + (threadIdx.x >> 6) * 1088], (unsigned)i); }
+            if (OP == 13) { asm volatile("v_pk_add_u16 %0, %1, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 14) { unsigned long long t = (unsigned long long)(unsigned)b[i] * (unsigned)b[(i + 1) & 7] + (unsigned long long)b[(i + 2) & 7]; b[i] = (int)(t >> 20); }
+            if (OP == 15) { asm volatile("v_cmp_ge_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(b[i]) : "v"(a[(i + 1) & 7]), "s"(s) : "vcc"); }
+            if (OP == 16) { asm volatile("v_cmp_lt_u64 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(b[i]) : "v"(a[(i + 1) & 7]), "s"(s), "v"(b[(i + 1) & 7]) : "vcc"); }
+            if (OP == 19) { asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(b[i]) : "v"(laddr), "n"(i * 4)); }
+            if (OP == 20) { asm volatile("ds_read_i8 %0, %1 offset:%2" : "=v"(b[i]) : "v"(laddr), "n"(i * 4)); }
+            if (OP == 21) { asm volatile("ds_add_u32 %0, %1 offset:%2" : : "v"(laddr), "v"(b[i]), "n"(i * 4)); }
+            if (OP == 22) { asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(b[i]) : "v"(raddr), "n"(i * 4)); }
+            if (OP == 23) { asm volatile("ds_read_b32 %0, %3 offset:%4\n\tv_xor_b32 %1, %1, %2\n\tv_xor_b32 %2, %1, %2\n\tv_xor_b32 %1, %1, %2\n\tv_xor_b32 %2, %1, %2" : "=v"(b[i]), "+v"(x0), "+v"(x1) : "v"(laddr), "n"(i * 4)); }
+            if (OP == 24) { asm volatile("v_xor_b32 %0, %0, %1\n\tv_xor_b32 %1, %0, %1\n\tv_xor_b32 %0, %0, %1\n\tv_xor_b32 %1, %0, %1" : "+v"(x0), "+v"(x1)); }
+            if (OP == 17) { scratch[(threadIdx.x & 63) * 17 + ((b[i] + it) & 15) + (threadIdx.x >> 6) * 1088] = (unsigned)i; }
+            if (OP == 18) { b[i] += scratch[(threadIdx.x & 63) * 17 + ((b[(i+1)&7] + it) & 15) + (threadIdx.x >> 6) * 1088]; }
         }
     }
     double r = 0;
     for (int i = 0; i < 8; i++) r += a[i] + b[i];
+    r += scratch[threadIdx.x] + x0 + x1;
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
@@ -60,5 +85,22 @@ int main()
     run<3>("v_xor_b32", 1);
     run<4>("v_pk_mad_u16", 1);
     run<6>("cmp hi + cndmask/add", 2);
+    run<8>("v_fma_f64", 1);
+    run<9>("v_floor_f64", 1);
+    run<10>("cmp_ge_f64 + cndmask + add (C)", 1);
+    run<11>("v_cvt_f64_i32", 1);
+    run<12>("addr calc + ds_add_u32", 1);
+    run<13>("v_pk_add_u16", 1);
+    run<14>("mad_u64_u32 + shift (C)", 1);
+    run<15>("v_cmp_ge_f64 + v_addc", 2);
+    run<16>("v_cmp_lt_u64 + v_cndmask", 2);
+    run<17>("addr calc + ds_write_b32", 1);
+    run<19>("ds_read_b32 (stride 17)", 1);
+    run<20>("ds_read_i8 (stride 17)", 1);
+    run<21>("ds_add_u32 (stride 17)", 1);
+    run<22>("ds_read_b32 (random)", 1);
+    run<24>("4x v_xor", 4);
+    run<23>("ds_read_b32 + 4x v_xor (per group)", 1);
+    run<18>("addr calc + ds_read_b32 + add", 1);
     return 0;
 }

@@ -5,11 +5,12 @@
  *
  *   k_seed        NCO seeding pre-pass.  One lane per NCO chain (block x channel x {code, carrier}).
  *                 Walks the chain with the exact jump-ahead of gpsbb_nco.h — O(#binade crossings +
- *                 #wraps), not O(#samples) — and writes the chain's row table {n0, bits(x), inc, nav} and
- *                 the end-of-block state (the reference's live-out, plutogpssim.c:2741-2746).  This
- *                 replaces the sample-to-sample dependency of plutogpssim.c:2709/2741 with a table any
- *                 lane can index.  Sequential per chain, so it runs on its own stream into double-buffered
- *                 tables and overlaps the previous run's k_synth.
+ *                 #wraps), not O(#samples) — and writes the chain's row table and the end-of-block state
+ *                 (the reference's live-out, plutogpssim.c:2741-2746).  A row is {n0, nav, x, S}: inside it
+ *                 the state at sample n is exactly fma(n - n0, S, x).  This replaces the sample-to-sample
+ *                 dependency of plutogpssim.c:2709/2741 with a table any lane can index.  Sequential per
+ *                 chain, so it runs on its own stream into double-buffered tables and overlaps the previous
+ *                 run's k_synth.
  *
  *   k_tile_index  One thread per (chain, 1/64 of the tiles): which row holds the first sample of every
  *                 1024-sample tile.  Laid out [block][tile][chain] so one tile's 32 entries share a line.
@@ -20,9 +21,12 @@
  *                 packed as int16x2 — the product dataBit*codeCA*table*gain of c:2701-2702 factorises into
  *                 sign * that LUT because IEEE multiply and truncation are odd-symmetric — the 1023 C/A
  *                 chips as +-1 bytes and the 60 nav words.  After that every wavefront works alone: it
- *                 takes chunks of tiles from a per-block counter, fetches the rows one tile ahead, derives
- *                 each lane's start state (usually base + lane*step broadcast with v_readlane), steps both
- *                 NCOs with genuine IEEE double adds (__dadd_rn, never an FMA), accumulates all channels in
+ *                 takes chunks of tiles from a per-block counter; the rows of all 2*nch chains that overlap
+ *                 a tile (about 70 at 25 MS/s: binade crossings cluster after every wrap) are copied into
+ *                 the wavefront's LDS slice by LDS-DMA, one row per lane, while the previous tile's last
+ *                 channel is still being walked; each lane finds its row per chain by counting row starts
+ *                 through scalar registers and gets its start state with one FMA; then it steps both NCOs
+ *                 with genuine IEEE double adds (__dadd_rn, never an FMA), accumulates all channels in
  *                 packed int16x2 (wrap-around == the reference's (short) cast, c:2754-2755) and stores
  *                 16-byte vectors.
  *

@@ -387,6 +387,8 @@ struct SynthLds {
     int8_t chip[GPSBB_MAX_CHAN][1024];          /* codeCA as +1/-1 per chip (plutogpssim.c:2737)       */
     uint32_t dwrd[GPSBB_MAX_CHAN][GPSBB_N_DWRD]; /* nav words                                          */
     double sc[GPSBB_MAX_CHAN];                  /* f_code*delt                                         */
+    double rsc[GPSBB_MAX_CHAN];                 /* 1/sc where a run of SPT samples holds at most one chip boundary
+                                                   (sc*(SPT-1) < 1, i.e. sample rates above ~15.4 MS/s), else 0 */
     double sk512[GPSBB_MAX_CHAN];               /* f_carr*delt*512 (carrier phase is walked scaled by 512: exact) */
     double xlim[GPSBB_MAX_CHAN];                /* a run starting below this code phase cannot reach 1023     */
     double ylo[GPSBB_MAX_CHAN], yhi[GPSBB_MAX_CHAN]; /* ... strictly inside (ylo, yhi): no carrier wrap       */
@@ -498,7 +500,7 @@ __device__ __forceinline__ bool stage_tile(WaveRows &W, int lane, int nchains, b
  * register, then fetched with one 16-byte and two 4-byte LDS reads.
  */
 __device__ __forceinline__ double chain_state(const WaveRows &W, int sbase, int scnt, int slot_n0a, int slot_n0b, int n,
-                                              uint32_t *nav)
+                                              uint32_t *nav, double *S_out)
 {
     int slot = sbase;
     for (int j = 1; j < scnt; j++) {
@@ -509,6 +511,7 @@ __device__ __forceinline__ double chain_state(const WaveRows &W, int sbase, int 
     const uint4 r = W.a[slot];
     const double S = hi_lo_f64((int)W.s_hi[slot], (int)W.s_lo[slot]);
     *nav = r.y;
+    *S_out = S;
     return __fma_rn((double)(n - (int)r.x), S, hi_lo_f64((int)r.w, (int)r.z));
 }
 
@@ -532,8 +535,9 @@ struct RunNav {
     int dbx0, dbx1, jw;
 };
 
-/* phase 1 of a group: table indices of WALK_G samples, both NCOs advanced (two chains of IEEE adds) */
-template <bool CODEW, int CARR>
+/* phase 1 of a group: table indices of WALK_G samples, both NCOs advanced (two chains of IEEE adds).
+ * CODE: 0 straight line, 1 with the 1023 wrap, 2 no per-sample code work at all (see walk_channel). */
+template <int CODE, int CARR>
 __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc, double sk, double &xc, double &yk,
                                              uint32_t &ph, uint32_t kstep, RunNav &rn, int (&it)[WALK_G],
                                              int (&ci)[WALK_G], int jbase, int nvalid, unsigned long long &hz_itable)
@@ -552,11 +556,13 @@ __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc
             if (jbase + u < nvalid)
                 hz_itable++;
         }
-        ci[u] = (int)xc; /* c:2737 */
-        xc = add_rn(xc, sc); /* c:2709 */
+        if (CODE != 2) {
+            ci[u] = (int)xc;     /* c:2737 */
+            xc = add_rn(xc, sc); /* c:2709 */
+        }
         if (CARR != 2)
             yk = add_rn(yk, sk); /* c:2741, scaled by 512 */
-        if (CODEW) {
+        if (CODE == 1) {
             if (__double2hiint(xc) >= 0x408FF800) { /* xc >= 1023.0 (xc >= 0) */
                 xc = add_rn(xc, -1023.0);
                 rn.nav = nav_advance(rn.nav);
@@ -575,17 +581,24 @@ __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc
 }
 
 /*
- * SPT consecutive samples of one channel.  CODEW = false / CARR = 0 are the straight-line versions used when
+ * SPT consecutive samples of one channel.  CODE = 0 / CARR = 0 are the straight-line versions used when
  * no lane of the wavefront can reach a code / carrier wrap inside its run (decided by the caller): that
- * NCO's update is then a single IEEE add.  With CODEW / CARR = 1 it is the reference's full update
+ * NCO's update is then a single IEEE add.  With CODE / CARR = 1 it is the reference's full update
  * (plutogpssim.c:2709-2746) with the comparisons done on the high dword of the double.  CARR = 2 is the
  * reference's fixed-point carrier (32-bit accumulator, c:2699/2748).
+ *
+ * CODE = 2: the whole tile lies in one row of the code chain (state at step j of the run = fma(j, Sc, xc)
+ * exactly) and a run advances by less than one chip, so it sees at most one chip boundary.  The code NCO is
+ * then not stepped at all: the boundary's position jc (first j with floor(state) > floor(xc)) comes from
+ * one approximate division, biased upward and settled by one exact FMA + compare, and every sample selects
+ * one of two pre-signed chips with a compare against its (compile-time) position.
+ *
  * Software-pipelined by hand: the LDS reads of group k are issued, then the indices of group k+1 are
  * computed (pure VALU, covers the LDS latency), then group k is accumulated.
  */
-template <bool CODEW, int CARR>
-__device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc, double yk, uint32_t ph, uint32_t kstep,
-                                             uint32_t nav, int dbx0, v2s (&acc)[SPT], int nvalid,
+template <int CODE, int CARR>
+__device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc, double Sc, double yk, uint32_t ph,
+                                             uint32_t kstep, uint32_t nav, int dbx0, v2s (&acc)[SPT], int nvalid,
                                              unsigned long long &hz_itable)
 {
     constexpr int G = WALK_G;
@@ -597,8 +610,23 @@ __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc
     rn.nav = nav;
     rn.dbx0 = rn.dbx1 = dbx0;
     rn.jw = SPT;
+    int jc = 0;
+    int sg_a = 0, sg_b = 0;
+    if (CODE == 2) {
+        const int c0 = (int)xc;                 /* chip index of the run's first sample, c:2737 */
+        const double cn = (double)(c0 + 1);      /* the boundary the run may cross */
+        /* r = (cn - xc)/Sc steps to the boundary; q >= r by the bias (the quotient is good to ~2^-35:
+         * 1/sc instead of 1/Sc, three roundings), so k = floor(q) is floor(r) or, just below an integer,
+         * floor(r)+1 = ceil(r); the exact state at step k decides */
+        const double kf = floor(__fma_rn(add_rn(cn, -xc), L.rsc[i], 0x1p-30));
+        jc = (int)kf + (__fma_rn(kf, Sc, xc) >= cn ? 0 : 1);
+        sg_a = (int)chip[c0] ^ dbx0;
+        sg_b = (int)chip[c0 + 1] ^ dbx0;
+        /* keep the two signed chips as they are: the compiler would otherwise select first and XOR per sample */
+        asm volatile("" : "+v"(sg_a), "+v"(sg_b));
+    }
     int it[G], ci[G];
-    walk_indices<CODEW, CARR>(L, i, sc, sk, xc, yk, ph, kstep, rn, it, ci, 0, nvalid, hz_itable);
+    walk_indices<CODE, CARR>(L, i, sc, sk, xc, yk, ph, kstep, rn, it, ci, 0, nvalid, hz_itable);
 #pragma unroll
     for (int j0 = 0; j0 < SPT; j0 += G) {
         __builtin_amdgcn_sched_barrier(0);
@@ -608,18 +636,24 @@ __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc
 #pragma unroll
         for (int u = 0; u < G; u++) {
             av[u] = amp[it[u]];
-            cv[u] = (int)chip[ci[u]];
+            if (CODE != 2)
+                cv[u] = (int)chip[ci[u]];
         }
         __builtin_amdgcn_sched_barrier(0);
         /* phase 1 of the next group while the reads are in flight */
         if (j0 + G < SPT)
-            walk_indices<CODEW, CARR>(L, i, sc, sk, xc, yk, ph, kstep, rn, it, ci, j0 + G, nvalid, hz_itable);
+            walk_indices<CODE, CARR>(L, i, sc, sk, xc, yk, ph, kstep, rn, it, ci, j0 + G, nvalid, hz_itable);
         __builtin_amdgcn_sched_barrier(0);
         /* phase 3: acc += amp * (codeCA*dataBit), packed int16x2 (c:2701-2706) */
 #pragma unroll
         for (int u = 0; u < G; u++) {
-            const int dbx = CODEW ? (j0 + u < rn.jw ? rn.dbx0 : rn.dbx1) : rn.dbx0;
-            const short sg = (short)(cv[u] ^ dbx);
+            short sg;
+            if (CODE == 2) {
+                sg = (short)(j0 + u < jc ? sg_a : sg_b);
+            } else {
+                const int dbx = CODE == 1 ? (j0 + u < rn.jw ? rn.dbx0 : rn.dbx1) : rn.dbx0;
+                sg = (short)(cv[u] ^ dbx);
+            }
             acc[j0 + u] += u32_v2s(av[u]) * v2s{sg, sg};
         }
     }
@@ -672,6 +706,7 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         const double sc = mul_rn(cb[tid].f_code, p.delt);
         const double sk = mul_rn(mul_rn(cb[tid].f_carr, p.delt), 512.0);
         L.sc[tid] = sc;
+        L.rsc[tid] = (sc >= 0x1p-10 && sc * (double)(SPT - 1) < 1.0) ? 1.0 / sc : 0.0;
         L.sk512[tid] = sk;
         /* (SPT+2) steps of margin: the accumulated rounding of SPT adds is far below one step */
         const double span = (double)(SPT + 2);
@@ -803,9 +838,9 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                     glob = true; /* last resort: every lane scans the pool in HBM */
                 }
                 uint32_t nav_raw, nav_unused;
-                double xc;
+                double xc, Sc = 0.0, S_unused;
                 if (!glob) {
-                    xc = chain_state(W, sb_c, sc_c, slot_n0a, slot_n0b, n0, &nav_raw);
+                    xc = chain_state(W, sb_c, sc_c, slot_n0a, slot_n0b, n0, &nav_raw, &Sc);
                 } else {
                     const uint64_t tile_addr = row0_addr + (uint64_t)trA * sizeof(SynRow);
                     xc = row_state_global((const SynRow *)(uintptr_t)readlane_u64(tile_addr, 2 * a), n0, &nav_raw);
@@ -814,7 +849,9 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                 const uint32_t nav = nav_raw & 0x7fffffffu;
                 /* Can any lane of this wavefront wrap inside its run?  Impossible when the whole tile lies in
                  * one row of the chain (a wrap is a row boundary); otherwise compare with the channel's limits. */
-                const bool code_w = (sc_c == 1 && !glob) ? false : (bool)__any(!(xc < L.xlim[i]));
+                const bool code_row = sc_c == 1 && !glob; /* the tile lies in one row of the code chain */
+                const bool code_w = code_row ? false : (bool)__any(!(xc < L.xlim[i]));
+                const bool code_1 = code_row && L.rsc[i] != 0.0; /* ... and a run holds at most one chip boundary */
                 double yk = 0.0;
                 uint32_t ph = 0, kstep = 0;
                 bool carr_w = false;
@@ -823,7 +860,7 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                     ph = p.kph0[(size_t)b * p.nch + i] + (uint32_t)n0 * kstep;
                 } else {
                     if (!glob) {
-                        yk = chain_state(W, sb_k, sc_k, slot_n0a, slot_n0b, n0, &nav_unused);
+                        yk = chain_state(W, sb_k, sc_k, slot_n0a, slot_n0b, n0, &nav_unused, &S_unused);
                     } else {
                         const uint64_t tile_addr = row0_addr + (uint64_t)trA * sizeof(SynRow);
                         yk = row_state_global((const SynRow *)(uintptr_t)readlane_u64(tile_addr, 2 * a + 1), n0, &nav_unused);
@@ -845,18 +882,25 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                 }
 
                 if (fixed_carr) {
-                    if (!code_w)
-                        walk_channel<false, 2>(L, i, xc, 0.0, ph, kstep, nav, dbx, acc, nvalid, hz_itable);
+                    if (code_1)
+                        walk_channel<2, 2>(L, i, xc, Sc, 0.0, ph, kstep, nav, dbx, acc, nvalid, hz_itable);
+                    else if (!code_w)
+                        walk_channel<0, 2>(L, i, xc, Sc, 0.0, ph, kstep, nav, dbx, acc, nvalid, hz_itable);
                     else
-                        walk_channel<true, 2>(L, i, xc, 0.0, ph, kstep, nav, dbx, acc, nvalid, hz_itable);
+                        walk_channel<1, 2>(L, i, xc, Sc, 0.0, ph, kstep, nav, dbx, acc, nvalid, hz_itable);
+                } else if (code_1) {
+                    if (!carr_w)
+                        walk_channel<2, 0>(L, i, xc, Sc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
+                    else
+                        walk_channel<2, 1>(L, i, xc, Sc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
                 } else if (!code_w && !carr_w) {
-                    walk_channel<false, 0>(L, i, xc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
+                    walk_channel<0, 0>(L, i, xc, Sc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
                 } else if (!code_w) {
-                    walk_channel<false, 1>(L, i, xc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
+                    walk_channel<0, 1>(L, i, xc, Sc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
                 } else if (!carr_w) {
-                    walk_channel<true, 0>(L, i, xc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
+                    walk_channel<1, 0>(L, i, xc, Sc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
                 } else {
-                    walk_channel<true, 1>(L, i, xc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
+                    walk_channel<1, 1>(L, i, xc, Sc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
                 }
                 PROF_MARK(4);
             }

@@ -565,8 +565,6 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     if (!(g_test_skip_seed && b->run_count >= 2)) /* measurement hook: time k_synth alone on tables already built */
     {
         hipLaunchKernelGGL(k_seed, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, h->s_seed, p, cbase);
-        const long long nthr = 2ll * (long long)nbc * TIDX_PARTS;
-        hipLaunchKernelGGL(k_tile_index, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, h->s_seed, p);
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(ev[1], h->s_seed));

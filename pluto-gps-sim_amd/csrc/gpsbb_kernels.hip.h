@@ -1,19 +1,18 @@
 /*
  * gpsbb_kernels.hip.h — the device side of libgpsbb: hand-written HIP for gfx950 (CDNA4).
  *
- * Three kernels per batch of blocks:
+ * Two kernels per batch of blocks:
  *
  *   k_seed        NCO seeding pre-pass.  One lane per NCO chain (block x channel x {code, carrier}).
  *                 Walks the chain with the exact jump-ahead of gpsbb_nco.h — O(#binade crossings +
  *                 #wraps), not O(#samples) — and writes the chain's row table and the end-of-block state
  *                 (the reference's live-out, plutogpssim.c:2741-2746).  A row is {n0, nav, x, S}: inside it
  *                 the state at sample n is exactly fma(n - n0, S, x).  This replaces the sample-to-sample
- *                 dependency of plutogpssim.c:2709/2741 with a table any lane can index.  Sequential per
+ *                 dependency of plutogpssim.c:2709/2741 with a table any lane can index.  While emitting
+ *                 rows it also fills the tile index: which row holds the first sample of every 1024-sample
+ *                 tile, laid out [block][tile][chain] so one tile's 32 entries share a line.  Sequential per
  *                 chain, so it runs on its own stream into double-buffered tables and overlaps the previous
  *                 run's k_synth.
- *
- *   k_tile_index  One thread per (chain, 1/64 of the tiles): which row holds the first sample of every
- *                 1024-sample tile.  Laid out [block][tile][chain] so one tile's 32 entries share a line.
  *
  *   k_synth       The sample loop itself (plutogpssim.c:2690-2756), one lane per run of SPT consecutive
  *                 output samples, one wavefront per tile.  Per workgroup the per-channel tables are staged
@@ -138,19 +137,39 @@ struct RowSink {
     bool overflow;
     unsigned long long *hz;
     const uint32_t *dwrd; /* code chains: the channel's nav words; carrier chains: nullptr */
+    uint32_t dbit;        /* code chains: 0x80000000 while the current data bit is -1 (refreshed by nav_fetch) */
+    int32_t *tr;          /* this chain's column of the tile index: where the next tile's entry goes */
+    size_t tstride;       /* ... and the distance to the one after */
+    int64_t tile_n0;      /* first sample of that tile */
+    int64_t tile_end;     /* ntiles*TILE: first sample past the last tile */
 
     __device__ __forceinline__ void row(int32_t n0, uint32_t nav, uint64_t xb, int64_t inc)
     {
+        /* tiles that start before this row belong to the previous one */
+        {
+            /* lanes run in lockstep, rows do not: a long row leaves several tiles to fill in at once */
+            const int64_t lim = n0 < tile_end ? n0 : tile_end;
+            const int32_t prev = (int32_t)(cnt < cap ? cnt : cap) - 1;
+            while (tile_n0 < lim) {
+                *tr = prev;
+                tr += tstride;
+                tile_n0 += TILE;
+            }
+        }
         if (cnt < cap) {
             /* one unit in the last place of xb's binade, as a double (subnormal below 2^-1022) */
             uint32_t ex = (uint32_t)(xb >> 52) & 0x7ffu;
             ex = ex ? ex : 1u;
             const uint64_t ub = ex > 52u ? (uint64_t)(ex - 52u) << 52 : 1ull << (ex - 1u);
-            const double x = bits_f64(xb), S = mul_rn((double)inc, bits_f64(ub)); /* |inc| < 2^53: exact */
+            /* S = inc*ub, exact: |inc| < 2^53 goes to double in two exact 32-bit halves */
+            const uint64_t ia = (uint64_t)(inc < 0 ? -inc : inc);
+            const double u = bits_f64(ub);
+            const double sa = __fma_rn((double)(uint32_t)(ia >> 32), mul_rn(u, 4294967296.0), mul_rn((double)(uint32_t)ia, u));
+            const double x = bits_f64(xb), S = inc < 0 ? -sa : sa;
             SynRow r;
             r.n0 = n0;
             if (dwrd) {
-                r.nav = nav | (nav_bit(dwrd, nav) < 0 ? 0x80000000u : 0u);
+                r.nav = nav | dbit;
                 r.x = x;
                 r.S = S;
             } else {
@@ -164,15 +183,19 @@ struct RowSink {
         }
         cnt++;
     }
+    /* a data-bit boundary (c:2717-2733): the rows from here on carry the new bit */
     __device__ __forceinline__ void nav_fetch(uint32_t nav)
     {
         if (nav_iword(nav) >= GPSBB_N_DWRD)
             atomicAdd(hz + 1, 1ull);
+        dbit = nav_bit(dwrd, nav) < 0 ? 0x80000000u : 0u;
     }
     __device__ __forceinline__ void finish()
     {
         if (cnt > cap)
             cnt = cap;
+        for (; tile_n0 <= tile_end; tile_n0 += TILE, tr += tstride) /* the remaining tiles and entry [ntiles] */
+            *tr = (int32_t)cnt - 1;
         SynRow r;
         r.n0 = INT32_MAX; /* sentinel: terminates every forward scan */
         r.nav = 0;
@@ -188,7 +211,7 @@ struct ChainDone {
     int cnt; /* 0 = this lane built nothing */
 };
 
-__device__ __forceinline__ RowSink make_sink(const BatchDev &p, int chain, const uint32_t *dwrd)
+__device__ __forceinline__ RowSink make_sink(const BatchDev &p, int chain, const uint32_t *dwrd, uint32_t nav0)
 {
     RowSink s;
     const uint64_t o0 = p.row_off[chain], o1 = p.row_off[chain + 1];
@@ -198,6 +221,13 @@ __device__ __forceinline__ RowSink make_sink(const BatchDev &p, int chain, const
     s.overflow = false;
     s.hz = p.hazards;
     s.dwrd = dwrd;
+    s.dbit = dwrd && nav_bit(dwrd, nav0) < 0 ? 0x80000000u : 0u;
+    const int nbc = p.nblocks * p.nch;
+    const int kind = chain >= nbc ? 1 : 0, bi = chain - kind * nbc;
+    s.tr = p.tile_row + tile_row_at(p, bi / p.nch, 0, bi % p.nch, kind);
+    s.tstride = 2 * (size_t)p.nch;
+    s.tile_n0 = 0;
+    s.tile_end = (int64_t)p.ntiles * TILE;
     return s;
 }
 
@@ -213,8 +243,8 @@ __device__ inline ChainDone seed_code_chain(const BatchDev &p, int b, int i)
         return d;
     }
     const int chain = chain_code(p, b, i);
-    RowSink sink = make_sink(p, chain, c.dwrd);
     uint32_t nav = nav_pack(c.icode, c.ibit, c.iword);
+    RowSink sink = make_sink(p, chain, c.dwrd, nav);
     const double s = mul_rn(c.f_code, p.delt); /* plutogpssim.c:2709: f_code * delt, rounded on its own */
     const double x = build_rows<NCO_CODE>(c.code_phase, s, nav, p.nsamp, sink);
     sink.finish();
@@ -244,7 +274,7 @@ __device__ inline ChainDone seed_carr_chain(const BatchDev &p, int b, int i, dou
         return d;
     }
     const int chain = chain_carr(p, b, i);
-    RowSink sink = make_sink(p, chain, nullptr);
+    RowSink sink = make_sink(p, chain, nullptr, 0u);
     uint32_t nav = 0;
     const double s = mul_rn(c.f_carr, p.delt); /* plutogpssim.c:2741 */
     const double x = build_rows<NCO_CARR>(x0, s, nav, p.nsamp, sink);
@@ -268,9 +298,13 @@ __device__ inline void seed_carr_fixed(const BatchDev &p, int b, int i)
 
 /* grid: lanes [0, nbc) = code chains; lanes [cbase, ...) = carrier chains (cbase = nbc rounded up to a
  * wave so that the two kinds of chain never share a wavefront).  Writes each chain's rows, end state and
- * row count; the tile index is filled by k_tile_index, massively parallel, afterwards. */
+ * row count, and — as the rows are emitted — the tile index: tile_row[t] = the row holding sample t*TILE
+ * (t = 0..ntiles-1), [ntiles] = the last row. */
 #ifndef GPSBB_SEED_WG
 #define GPSBB_SEED_WG 256
+#endif
+#ifndef GPSBB_SEED_PRIO
+#define GPSBB_SEED_PRIO 3
 #endif
 /* Four wavefronts per workgroup (one per SIMD of a CU): measured best trade between the pre-pass's own
  * speed (chains sharing a SIMD slow each other by ~1/3) and how many CUs it takes away from the previous
@@ -279,7 +313,7 @@ __global__ __launch_bounds__(GPSBB_SEED_WG) void k_seed(BatchDev p, int cbase)
 {
     /* the chain walk is a long dependent instruction stream: let it issue whenever it is ready (it uses a
      * small fraction of the issue slots, so the co-resident synthesis wavefronts hardly notice) */
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(GPSBB_SEED_PRIO);
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nbc = p.nblocks * p.nch;
     if (gid < nbc) {
@@ -301,57 +335,6 @@ __global__ __launch_bounds__(GPSBB_SEED_WG) void k_seed(BatchDev p, int cbase)
     double unused;
     const ChainDone d = seed_carr_chain(p, b, i, p.ch[(size_t)b * p.nch + i].carr_phase, &unused);
     p.row_cnt[chain_carr(p, b, i)] = d.cnt;
-}
-
-/*
- * tile_row[chain][t] = index of the row holding sample t*TILE (t = 0..ntiles-1), [ntiles] = last row.
- * 64 lanes per chain, each a contiguous slice of the tiles: binary search for the first one, then a
- * forward walk.  One thread per (chain, slice): ~2 M independent threads for the headline batch.
- */
-constexpr int TIDX_PARTS = 64;
-__global__ __launch_bounds__(256) void k_tile_index(BatchDev p)
-{
-    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int chain = (int)(id / TIDX_PARTS), part = (int)(id % TIDX_PARTS);
-    if (chain >= 2 * p.nblocks * p.nch)
-        return;
-    const int cnt = p.row_cnt[chain];
-    if (cnt == 0)
-        return;
-    const SynRow *__restrict__ rows = p.rows + p.row_off[chain];
-    const int nbc = p.nblocks * p.nch;
-    const int kind = chain >= nbc ? 1 : 0, bi = chain - kind * nbc;
-    int32_t *__restrict__ tr = p.tile_row + tile_row_at(p, bi / p.nch, 0, bi % p.nch, kind);
-    const size_t tstride = 2 * (size_t)p.nch;
-    const int per = (p.ntiles + 1 + TIDX_PARTS - 1) / TIDX_PARTS;
-    const int t0 = part * per;
-    const int t1 = t0 + per < p.ntiles + 1 ? t0 + per : p.ntiles + 1;
-    if (t0 >= t1)
-        return;
-    /* largest r with rows[r].n0 <= t0*TILE (rows[0].n0 == 0) */
-    const long long s0 = (long long)t0 * TILE;
-    int lo = 0, hi = cnt - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if ((long long)rows[mid].n0 <= s0)
-            lo = mid;
-        else
-            hi = mid - 1;
-    }
-    int r = lo;
-    int nxt = rows[r + 1].n0; /* the sentinel row terminates the walk */
-    for (int t = t0; t < t1; t++) {
-        if (t == p.ntiles) {
-            tr[t * tstride] = cnt - 1;
-            break;
-        }
-        const int st = t * TILE;
-        while (nxt <= st) {
-            r++;
-            nxt = rows[r + 1].n0;
-        }
-        tr[t * tstride] = r;
-    }
 }
 
 /* ---- k_synth ------------------------------------------------------------------------------------- */

@@ -68,6 +68,29 @@ def test_high_doppler_and_slow_channels(pkg, synth, oracle):
     assert_state_equal(st, want_st[0], ch["prn"] > 0)
 
 
+def test_steps_that_hit_chip_and_table_boundaries_exactly(pkg, synth, oracle):
+    """Sample rates at which a run of 16 samples holds at most one chip boundary take the path that locates
+    the boundary instead of stepping the code NCO.  With f_code*delt and f_carr*delt binary fractions the
+    phases land exactly on integers / table-index boundaries, the case the locating division must settle
+    with its exact check; start phases on and next to boundaries, both Doppler signs, two block lengths."""
+    fs = 2.0 ** 25
+    for nsamp, seed in ((70001, 41), (1 << 17, 42)):
+        ch = pkg.synth_descriptors(1, nch=16, seed=seed)[0]
+        ch["f_code"] = [2.0 ** 20, 2.0 ** 20, 2.0 ** 20, 2.0 ** 20 + 2.0 ** 10, 2.0 ** 20 - 2.0 ** 9, 2.0 ** 19,
+                        2.0 ** 20, 1.023e6, 2.0 ** 20, 2.0 ** 20, 3.0 * 2.0 ** 18, 2.0 ** 20, 2.0 ** 20, 2.0 ** 20,
+                        2.0 ** 20 + 1.0, 2.0 ** 21 - 2.0 ** 12]
+        ch["code_phase"] = [0.0, 5.0, 1022.96875, 7.5, 100.0, 1022.5, 2.0 ** -5, 511.0, 1.0 - 2.0 ** -5, 512.0,
+                            3.0, 1022.0, 0.5, 64.0, 255.0, 1000.0]
+        ch["f_carr"] = [2.0 ** 12, -2.0 ** 12, 2.0 ** 11, -2.0 ** 11, 2.0 ** 14, -2.0 ** 14, 3.0 * 2.0 ** 10, 0.0,
+                        2.0 ** 16, -2.0 ** 16, 2.0 ** 12, 2.0 ** 12, -2.0 ** 12, 2.0 ** 8, -2.0 ** 8, 2.0 ** 12 + 1.0]
+        ch["carr_phase"] = [0.0, 0.0, 0.5, 1.0 / 512, 1.0 - 1.0 / 512, 2.0 ** -13, 0.25, 0.75, 0.0, 0.5,
+                            1.0 - 2.0 ** -13, 2.0 ** -9, 511.0 / 512, 0.125, 0.375, 0.0]
+        want_iq, want_st, _ = oracle.fill_blocks(ch, 1.0 / fs, nsamp)
+        iq, st = synth.fill_block(ch, 1.0 / fs, nsamp)
+        assert (iq == want_iq[0]).all(), nsamp
+        assert_state_equal(st, want_st[0], ch["prn"] > 0)
+
+
 def test_inactive_and_empty_channels(pkg, synth, oracle):
     ch = pkg.synth_descriptors(1, nch=8, seed=41)[0]
     ch["prn"][[1, 4, 7]] = 0

@@ -226,6 +226,144 @@ GPSBB_HD int64_t regular_run(uint64_t xb, uint64_t sb, int64_t kcap, int64_t &in
     return k < kcap ? k : kcap;
 }
 
+GPSBB_HD double fma_rn(double a, double b, double c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fma_rn(a, b, c);
+#else
+    return __builtin_fma(a, b, c);
+#endif
+}
+
+/* The step of a regular run as a double: S = inc * ulp(x), exact (|inc| < 2^53 goes to double in two exact
+ * 32-bit halves; ulp may be subnormal).  The state j steps into the run is then fma(j, S, x) exactly: the
+ * product is exact, the sum is a representable number, so the single rounding does nothing. */
+GPSBB_HD double step_of_inc(uint64_t xb, int64_t inc)
+{
+    uint32_t ex = (uint32_t)(xb >> 52) & 0x7ffu;
+    ex = ex ? ex : 1u;
+    const double u = bits_f64(ex > 52u ? (uint64_t)(ex - 52u) << 52 : 1ull << (ex - 1u));
+    const uint64_t ia = (uint64_t)(inc < 0 ? -inc : inc);
+    const double sa = fma_rn((double)(uint32_t)(ia >> 32), mul_rn(u, 4294967296.0), mul_rn((double)(uint32_t)ia, u));
+    return inc < 0 ? -sa : sa;
+}
+
+/*
+ * regular_run() in double arithmetic, for the common case: x and s normal and not tiny (>= 2^-900), x > 0
+ * at least two binades above s, below the wrap threshold's binade limit.  Same contract — k consecutive
+ * steps that add exactly S = RN(s/ulp)*ulp and stay strictly inside x's binade (below 1023 for the code
+ * NCO) — and the same k, but S directly and a fraction of the instructions (the device pre-pass is one
+ * lane per chain and bound by the length of this dependent chain).  Returns -1 when the case is not
+ * covered: the caller then uses regular_run().
+ *   S:   adding and subtracting C = 1.5*2^e rounds s to a multiple of ulp(x) with ties to even — exactly the
+ *        increment an IEEE add applies to an even mantissa; a tie with an odd mantissa is an explicit step;
+ *   k:   floor(room / |S|), room = exact distance to the last state inside the binade: reciprocal estimate
+ *        + Newton step (error far below 1 for quotients < 2^32; larger ones are capped anyway), settled by
+ *        the exact remainder fma(-k, |S|, room).
+ */
+template <int KIND>
+GPSBB_HD int64_t regular_run_f64(double x, double s, int64_t kcap, double &S)
+{
+    const uint64_t xb = f64_bits(x), sb = f64_bits(s);
+    const int ex = (int)((xb >> 52) & 0x7ff), es = (int)((sb >> 52) & 0x7ff);
+    const int d = ex - es;
+    if ((xb >> 63) || ex < 123 || es < 123 || d < 2 || d > 50)
+        return -1;
+    if (KIND == NCO_CARR ? ex >= 1023 : ex >= 1023 + 10)
+        return -1;
+    const double lo = bits_f64((uint64_t)ex << 52);               /* 2^e              */
+    const double u = bits_f64((uint64_t)(ex - 52) << 52);          /* ulp of the binade */
+    const double C = bits_f64(((uint64_t)ex << 52) | (1ull << 51)); /* 1.5 * 2^e, even mantissa */
+    S = add_rn(add_rn(s, C), -C);
+    const double r = add_rn(s, -S); /* exact: the bits of s below ulp(x) */
+    if ((f64_bits(r) & F64_ABS) == f64_bits(u) - F64_HID && (xb & 1))
+        return 0; /* half-way case on an odd mantissa: one explicit step makes it even */
+    if (S == 0.0)
+        return -1; /* |s| <= ulp/2: x does not move (or the power-of-two corner); left to regular_run() */
+    double room;
+    if (S > 0.0) {
+        const double top = (KIND == NCO_CODE && ex == 1023 + 9) ? 1023.0 : add_rn(lo, lo);
+        room = add_rn(add_rn(top, -u), -x); /* stay at or below top - ulp */
+    } else {
+        room = add_rn(x, -add_rn(lo, u)); /* stay at or above 2^e + ulp */
+    }
+    const double Sa = bits_f64(f64_bits(S) & F64_ABS);
+    if (!(room >= Sa))
+        return 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double rs = __builtin_amdgcn_rcp(Sa);
+    rs = fma_rn(fma_rn(-Sa, rs, 1.0), rs, rs);
+#else
+    const double rs = 1.0 / Sa;
+#endif
+    const double kq = room * rs;
+    if (kq >= 4294967296.0)
+        return kcap; /* sample counts are below 2^31 */
+    double kf = __builtin_floor(kq);
+    const double rem = fma_rn(-kf, Sa, room); /* exact: |rem| < 2|S| */
+    if (rem < 0.0)
+        kf -= 1.0;
+    else if (rem >= Sa)
+        kf += 1.0;
+    /* kcap is a sample count (< 2^31): single-instruction conversions on the device */
+    if (kf >= (double)(int32_t)kcap)
+        return kcap;
+    return (int64_t)(int32_t)kf;
+}
+
+/*
+ * build_rows() for the device pool: rows as {n0, nav, x, S} (see step_of_inc), the fast regular run first.
+ * `sink.row(n0, nav, x, S)` once per row in increasing n0; `sink.nav_fetch(nav)` as in build_rows().
+ */
+template <int KIND, class Sink>
+GPSBB_HD double build_rows_f64(double x, double s, uint32_t &nav, int nsamp, Sink &sink)
+{
+    const uint64_t sb = f64_bits(s);
+    int64_t n = 0;
+    while (n < nsamp) {
+        double S;
+        int64_t k = regular_run_f64<KIND>(x, s, (int64_t)nsamp - n, S);
+        if (k >= 0) {
+            sink.row((int32_t)n, nav, x, S);
+            if (k > 0)
+                x = fma_rn((double)(int32_t)k, S, x);
+        } else {
+            int64_t inc;
+            const uint64_t xb = f64_bits(x);
+            k = regular_run<KIND>(xb, sb, (int64_t)nsamp - n, inc);
+            sink.row((int32_t)n, nav, x, step_of_inc(xb, inc));
+            if (k > 0)
+                x = bits_f64(xb + (uint64_t)(k * inc));
+        }
+        if (k > 0) {
+            n += k;
+            if (n >= nsamp)
+                break;
+        }
+        /* one explicit step, sample n -> n+1 */
+        const uint64_t before = f64_bits(x);
+        bool wrapped = false;
+        if (KIND == NCO_CODE) {
+            wrapped = code_step(x, s);
+            if (wrapped) {
+                nav = nav_advance(nav);
+                if (nav_icode(nav) == 0)
+                    sink.nav_fetch(nav);
+            }
+        } else {
+            carr_step(x, s);
+        }
+        n += 1;
+        if (!wrapped && f64_bits(x) == before) {
+            /* x + s rounds back to x and nothing wrapped: constant from here on */
+            if (n < nsamp)
+                sink.row((int32_t)n, nav, x, 0.0);
+            break;
+        }
+    }
+    return x;
+}
+
 /*
  * Advance a carrier NCO by n steps exactly (no rows emitted): used by the host chaining helper and by
  * tests.  O(number of regular runs) instead of O(n).

@@ -1084,6 +1084,39 @@ extern "C" int gpsbb_test_build_rows(int kind, double x0, double s, unsigned nav
     return sink.cnt;
 }
 
+namespace {
+struct HostSinkF64 {
+    gpsbb_test_row_t *rows;
+    int cap, cnt;
+    void row(int32_t n0, uint32_t nav, double x, double S)
+    {
+        if (cnt < cap) {
+            rows[cnt].n0 = n0;
+            rows[cnt].nav = nav;
+            rows[cnt].xb = f64_bits(x);
+            rows[cnt].inc = (int64_t)f64_bits(S);
+        }
+        cnt++;
+    }
+    void nav_fetch(uint32_t) {}
+};
+} /* namespace */
+
+/* the row builder the device pre-pass runs (build_rows_f64): rows as {n0, nav, bits(x), bits(S)} */
+extern "C" int gpsbb_test_build_rows_f64(int kind, double x0, double s, unsigned nav0, int nsamp,
+                                         gpsbb_test_row_t *rows, int cap, double *x_end, unsigned *nav_end)
+{
+    HostSinkF64 sink{rows, cap, 0};
+    uint32_t nav = nav0;
+    double x = kind == NCO_CODE ? build_rows_f64<NCO_CODE>(x0, s, nav, nsamp, sink)
+                                : build_rows_f64<NCO_CARR>(x0, s, nav, nsamp, sink);
+    if (x_end)
+        *x_end = x;
+    if (nav_end)
+        *nav_end = nav;
+    return sink.cnt;
+}
+
 extern "C" unsigned long long gpsbb_test_row_bound(int kind, double s_abs, int nsamp)
 {
     return kind == NCO_CODE ? row_bound(s_abs, 1023.0, 9, nsamp) : row_bound(s_abs, 1.0, -1, nsamp);

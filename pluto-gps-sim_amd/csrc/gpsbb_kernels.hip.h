@@ -143,11 +143,11 @@ struct RowSink {
     int64_t tile_n0;      /* first sample of that tile */
     int64_t tile_end;     /* ntiles*TILE: first sample past the last tile */
 
-    __device__ __forceinline__ void row(int32_t n0, uint32_t nav, uint64_t xb, int64_t inc)
+    __device__ __forceinline__ void row(int32_t n0, uint32_t nav, double x, double S)
     {
-        /* tiles that start before this row belong to the previous one */
         {
-            /* lanes run in lockstep, rows do not: a long row leaves several tiles to fill in at once */
+            /* tiles that start before this row belong to the previous one.  Lanes run in lockstep, rows do
+             * not: a long row leaves several tiles to fill in at once */
             const int64_t lim = n0 < tile_end ? n0 : tile_end;
             const int32_t prev = (int32_t)(cnt < cap ? cnt : cap) - 1;
             while (tile_n0 < lim) {
@@ -157,15 +157,6 @@ struct RowSink {
             }
         }
         if (cnt < cap) {
-            /* one unit in the last place of xb's binade, as a double (subnormal below 2^-1022) */
-            uint32_t ex = (uint32_t)(xb >> 52) & 0x7ffu;
-            ex = ex ? ex : 1u;
-            const uint64_t ub = ex > 52u ? (uint64_t)(ex - 52u) << 52 : 1ull << (ex - 1u);
-            /* S = inc*ub, exact: |inc| < 2^53 goes to double in two exact 32-bit halves */
-            const uint64_t ia = (uint64_t)(inc < 0 ? -inc : inc);
-            const double u = bits_f64(ub);
-            const double sa = __fma_rn((double)(uint32_t)(ia >> 32), mul_rn(u, 4294967296.0), mul_rn((double)(uint32_t)ia, u));
-            const double x = bits_f64(xb), S = inc < 0 ? -sa : sa;
             SynRow r;
             r.n0 = n0;
             if (dwrd) {
@@ -246,7 +237,7 @@ __device__ inline ChainDone seed_code_chain(const BatchDev &p, int b, int i)
     uint32_t nav = nav_pack(c.icode, c.ibit, c.iword);
     RowSink sink = make_sink(p, chain, c.dwrd, nav);
     const double s = mul_rn(c.f_code, p.delt); /* plutogpssim.c:2709: f_code * delt, rounded on its own */
-    const double x = build_rows<NCO_CODE>(c.code_phase, s, nav, p.nsamp, sink);
+    const double x = build_rows_f64<NCO_CODE>(c.code_phase, s, nav, p.nsamp, sink);
     sink.finish();
     if (sink.overflow)
         atomicOr(p.status, ST_ROW_OVERFLOW);
@@ -277,7 +268,7 @@ __device__ inline ChainDone seed_carr_chain(const BatchDev &p, int b, int i, dou
     RowSink sink = make_sink(p, chain, nullptr, 0u);
     uint32_t nav = 0;
     const double s = mul_rn(c.f_carr, p.delt); /* plutogpssim.c:2741 */
-    const double x = build_rows<NCO_CARR>(x0, s, nav, p.nsamp, sink);
+    const double x = build_rows_f64<NCO_CARR>(x0, s, nav, p.nsamp, sink);
     sink.finish();
     if (sink.overflow)
         atomicOr(p.status, ST_ROW_OVERFLOW);

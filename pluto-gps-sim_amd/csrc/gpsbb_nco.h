@@ -249,12 +249,11 @@ GPSBB_HD double step_of_inc(uint64_t xb, int64_t inc)
 }
 
 /*
- * regular_run() in double arithmetic, for the common case: x and s normal and not tiny (>= 2^-900), x > 0
- * at least two binades above s, below the wrap threshold's binade limit.  Same contract — k consecutive
- * steps that add exactly S = RN(s/ulp)*ulp and stay strictly inside x's binade (below 1023 for the code
- * NCO) — and the same k, but S directly and a fraction of the instructions (the device pre-pass is one
- * lane per chain and bound by the length of this dependent chain).  Returns -1 when the case is not
- * covered: the caller then uses regular_run().
+ * regular_run() in double arithmetic, for x and s normal and not tiny (>= 2^-900).  Same contract — k
+ * consecutive steps that add exactly S = RN(s/ulp)*ulp and stay strictly inside x's binade (below 1023 for
+ * the code NCO) — but S directly and a fraction of the instructions (the device pre-pass is one lane per
+ * chain and bound by the length of this dependent chain).  Returns -1 when the case is not covered: the
+ * caller then uses regular_run().
  *   S:   adding and subtracting C = 1.5*2^e rounds s to a multiple of ulp(x) with ties to even — exactly the
  *        increment an IEEE add applies to an even mantissa; a tie with an odd mantissa is an explicit step;
  *   k:   floor(room / |S|), room = exact distance to the last state inside the binade: reciprocal estimate
@@ -267,9 +266,15 @@ GPSBB_HD int64_t regular_run_f64(double x, double s, int64_t kcap, double &S)
     const uint64_t xb = f64_bits(x), sb = f64_bits(s);
     const int ex = (int)((xb >> 52) & 0x7ff), es = (int)((sb >> 52) & 0x7ff);
     const int d = ex - es;
-    if ((xb >> 63) || ex < 123 || es < 123 || d < 2 || d > 50)
-        return -1;
-    if (KIND == NCO_CARR ? ex >= 1023 : ex >= 1023 + 10)
+    S = 0.0; /* a row that is a single explicit step still gets a finite S: its state is fma(0, S, x) */
+    /* explicit step, as in regular_run(): negative / zero / subnormal x, x at or above the wrap threshold's
+     * binade limit, x not above s's binade — and, here, also x only one binade above s (two or three steps,
+     * which regular_run() would take as a run): that keeps 1.5*2^e + s inside x's binade below */
+    if ((xb >> 63) || ex == 0 || (KIND == NCO_CARR ? ex >= 1023 : ex >= 1023 + 10) || (es >= 123 && d < 2))
+        return 0;
+    /* rare: tiny x or s, s == 0, steps far below ulp(x) — every lane of a wavefront that needs this costs
+     * all of its lanes the long way, so it must stay rare */
+    if (ex < 123 || es < 123 || d > 50)
         return -1;
     const double lo = bits_f64((uint64_t)ex << 52);               /* 2^e              */
     const double u = bits_f64((uint64_t)(ex - 52) << 52);          /* ulp of the binade */

@@ -21,6 +21,10 @@ double gpsbb_test_carr_jump(double x, double s, long long n);
 double gpsbb_test_code_jump(double x, double s, long long n, long long *wraps);
 int gpsbb_test_build_rows(int kind, double x0, double s, unsigned nav0, int nsamp, gpsbb_test_row_t *rows,
                           int cap, double *x_end, unsigned *nav_end);
+/* the builder the device pre-pass uses: xb = bits of x at n0, inc = bits of the double step S; the state at
+ * sample n of a row is fma(n - n0, S, x) */
+int gpsbb_test_build_rows_f64(int kind, double x0, double s, unsigned nav0, int nsamp, gpsbb_test_row_t *rows,
+                              int cap, double *x_end, unsigned *nav_end);
 /* measurement only: after the first two runs of a batch (both table sets built) skip k_seed, so that
  * k_synth can be timed alone on unchanged tables */
 void gpsbb_test_skip_seed(int on);

@@ -164,6 +164,78 @@ def test_rows_code_and_nav(pkg):
         assert nav_end == adv(w)
 
 
+def rows_f64_for(pkg, kind, x0, s, nav0, nsamp):
+    L = pkg.lib()
+    cap = int(L.gpsbb_test_row_bound(kind, abs(s), nsamp))
+    rows = np.zeros(cap, pkg.ROW_DTYPE)
+    xe, ne = C.c_double(), C.c_uint()
+    L.gpsbb_test_build_rows_f64.restype = C.c_int
+    L.gpsbb_test_build_rows_f64.argtypes = [C.c_int, C.c_double, C.c_double, C.c_uint, C.c_int, C.c_void_p, C.c_int,
+                                            C.POINTER(C.c_double), C.POINTER(C.c_uint)]
+    cnt = L.gpsbb_test_build_rows_f64(kind, x0, s, nav0, nsamp, rows.ctypes.data, cap, C.byref(xe), C.byref(ne))
+    assert cnt <= cap, "row bound violated: %d > %d (kind=%d s=%r)" % (cnt, cap, kind, s)
+    return rows[:cnt], xe.value, ne.value
+
+
+def check_f64_rows(pkg, kind, x0, s, nav0, nsamp, traj, nav_at=None):
+    """The device pre-pass's builder (double arithmetic, rows {n0, nav, x, S}): same end state as the integer
+    builder, row count within the bound, and, sample by sample against the brute-force trajectory,
+    x + (n - n0)*S in exact rational arithmetic is the state at n (that is what one FMA returns)."""
+    from fractions import Fraction
+    _, xe_i, nav_i = rows_for(pkg, kind, x0, s, nav0, nsamp)
+    rf, xe_f, nav_f = rows_f64_for(pkg, kind, x0, s, nav0, nsamp)
+    assert bits(xe_f) == bits(xe_i) and nav_f == nav_i
+    n0 = rf["n0"].astype(np.int64)
+    assert n0[0] == 0 and (np.diff(n0) > 0).all()
+    xs = rf["xb"].view(np.float64)
+    Ss = rf["inc"].view(np.float64)
+    assert (rf["xb"] == np.array([bits(traj[int(k)]) for k in n0], np.uint64)).all()
+    if nav_at is not None:
+        for r in rf:
+            assert r["nav"] == nav_at(int(r["n0"]))
+    rng = random.Random(len(rf) * 7919 + nsamp)
+    picks = set(int(v) - 1 for v in n0[1:]) | {nsamp - 1}
+    picks |= set(rng.randrange(nsamp) for _ in range(300))
+    for n in sorted(picks):
+        r = int(np.searchsorted(n0, n, side="right")) - 1
+        got = Fraction(float(xs[r])) + (n - int(n0[r])) * Fraction(float(Ss[r]))
+        assert got == Fraction(traj[n]), (kind, x0, s, n, r)
+
+
+def test_rows_f64_builder_carrier(pkg):
+    rng = random.Random(15)
+    cases = carr_cases(rng, 40) + [
+        (0.5, 2.0 ** -10), (0.0, -1e-4), (1.0, 3e-4), (0.5, 0.0), (0.3, -0.125), (0.3, 0.125), (0.5, 2.0 ** -60),
+        (0.5, 1e-300), (0.75, -1e-300), (2.0 ** -30, -(2.0 ** -31)), (0.5 + 2.0 ** -53, 2.0 ** -54 + 2.0 ** -80),
+        (0.3, 2.0 ** -10 + 2.0 ** -62), (0.3, -(2.0 ** -10 + 2.0 ** -62)), (0.7, 3 * 2.0 ** -12),
+        (0.25, 2.0 ** -13), (0.25, -(2.0 ** -13)), (1e-290, 1e-295), (0.6, 2.0 ** -3 - 2.0 ** -56)]
+    for x0, s in cases:
+        nsamp = rng.choice([1, 100, 4096, 50000])
+        rec = []
+        brute_carr(x0, s, nsamp, rec)
+        check_f64_rows(pkg, 1, x0, s, 0, nsamp, rec)
+
+
+def test_rows_f64_builder_code(pkg):
+    rng = random.Random(16)
+    cases = []
+    for _ in range(25):
+        fs = rng.choice(FS + [2.0 ** 25])
+        cases.append((rng.random() * 1023.0, (1.023e6 + rng.uniform(-6000, 6000) / 1540.0) * (1.0 / fs)))
+    cases += [(0.0, 1.023), (1022.999999, 1.5), (1022.5, 0.5), (512.0, 0.25), (0.0, 0.04092), (1023.0 - 2.0 ** -43, 0.3),
+              (5.0, 2.0 ** -5), (1022.96875, 2.0 ** -5), (0.0, 2.0 ** -4), (700.0, 1.0), (3.0, 1e-3)]
+    for x0, s in cases:
+        nsamp = rng.choice([1, 3000, 60000])
+        rec = []
+        brute_code(x0, s, nsamp, rec)
+
+        def nav_at(n, rec=rec):
+            t = 3 + rec[n][1]
+            c, t = t % 20, t // 20 + 7
+            return c | ((t % 30) << 5) | ((20 + t // 30) << 10)
+        check_f64_rows(pkg, 0, x0, s, 3 | (7 << 5) | (20 << 10), nsamp, [v[0] for v in rec], nav_at)
+
+
 def test_chain_carrier_host_matches_oracle(pkg, oracle):
     ch = pkg.synth_descriptors(6, nch=5, seed=77)
     ch["prn"][3:, 2] = 9          # channel re-allocated to another PRN at block 3: phase restarts

@@ -140,20 +140,21 @@ struct RowSink {
     uint32_t dbit;        /* code chains: 0x80000000 while the current data bit is -1 (refreshed by nav_fetch) */
     int32_t *tr;          /* this chain's column of the tile index: where the next tile's entry goes */
     size_t tstride;       /* ... and the distance to the one after */
-    int64_t tile_n0;      /* first sample of that tile */
-    int64_t tile_end;     /* ntiles*TILE: first sample past the last tile */
+    int32_t tile_t;       /* that tile's number */
+    int32_t ntiles;
 
     __device__ __forceinline__ void row(int32_t n0, uint32_t nav, double x, double S)
     {
         {
             /* tiles that start before this row belong to the previous one.  Lanes run in lockstep, rows do
              * not: a long row leaves several tiles to fill in at once */
-            const int64_t lim = n0 < tile_end ? n0 : tile_end;
+            const int32_t nt = (int32_t)(((int64_t)n0 + TILE - 1) / TILE); /* tiles that start before n0 */
+            const int32_t lim = nt < ntiles ? nt : ntiles;
             const int32_t prev = (int32_t)(cnt < cap ? cnt : cap) - 1;
-            while (tile_n0 < lim) {
+            while (tile_t < lim) {
                 *tr = prev;
                 tr += tstride;
-                tile_n0 += TILE;
+                tile_t++;
             }
         }
         if (cnt < cap) {
@@ -185,7 +186,7 @@ struct RowSink {
     {
         if (cnt > cap)
             cnt = cap;
-        for (; tile_n0 <= tile_end; tile_n0 += TILE, tr += tstride) /* the remaining tiles and entry [ntiles] */
+        for (; tile_t <= ntiles; tile_t++, tr += tstride) /* the remaining tiles and entry [ntiles] */
             *tr = (int32_t)cnt - 1;
         SynRow r;
         r.n0 = INT32_MAX; /* sentinel: terminates every forward scan */
@@ -217,8 +218,8 @@ __device__ __forceinline__ RowSink make_sink(const BatchDev &p, int chain, const
     const int kind = chain >= nbc ? 1 : 0, bi = chain - kind * nbc;
     s.tr = p.tile_row + tile_row_at(p, bi / p.nch, 0, bi % p.nch, kind);
     s.tstride = 2 * (size_t)p.nch;
-    s.tile_n0 = 0;
-    s.tile_end = (int64_t)p.ntiles * TILE;
+    s.tile_t = 0;
+    s.ntiles = p.ntiles;
     return s;
 }
 

@@ -156,8 +156,11 @@ struct DevBuf {
     {
         if (n <= cap)
             return hipSuccess;
-        if (p)
-            (void)hipFree(p);
+        if (p) {
+            (void)hipFree(p); /* synchronises the device: grow with head-room so that a ring whose slots see
+                                 slightly different row counts stops re-allocating after a few pushes */
+            n += n / 4;
+        }
         p = nullptr;
         cap = 0;
         hipError_t e = hipMalloc((void **)&p, n * sizeof(T));

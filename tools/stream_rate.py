@@ -15,6 +15,13 @@ from __graft_entry__ import load_package  # noqa: E402
 def main():
     pkg = load_package()
     nch, fs, nsamp, bps, depth, nslots = 16, 25e6, 2500000, 16, 3, 24
+    for a in sys.argv[1:]:  # --depth=N --bps=N --slots=N
+        if a.startswith("--depth="):
+            depth = int(a.split("=")[1])
+        if a.startswith("--bps="):
+            bps = int(a.split("=")[1])
+        if a.startswith("--slots="):
+            nslots = int(a.split("=")[1])
     ch = pkg.synth_descriptors(bps * nslots, nch=nch, seed=0x5EED)
     with pkg.Synth(0) as s:
         flags = pkg.CHAIN_CARRIER if "--chain" in sys.argv else 0

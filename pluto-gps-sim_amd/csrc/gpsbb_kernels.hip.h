@@ -57,7 +57,10 @@ constexpr int TILE_THREADS = GPSBB_WG;      /* wave64 x (GPSBB_WG/64) per workgr
 constexpr int SPT = GPSBB_SPT;              /* consecutive samples per lane (16 -> 64 bytes of output) */
 constexpr int TILE = 64 * SPT;              /* samples per tile = one pass of one wavefront (the row-index granule) */
 constexpr int WAVES_PER_WG = TILE_THREADS / 64;
-constexpr int TILE_CHUNK = 4;               /* consecutive tiles a wavefront takes at a time */
+#ifndef GPSBB_TILE_CHUNK
+#define GPSBB_TILE_CHUNK 4
+#endif
+constexpr int TILE_CHUNK = GPSBB_TILE_CHUNK;               /* consecutive tiles a wavefront takes at a time */
 #ifndef GPSBB_ROW_CAP
 #define GPSBB_ROW_CAP 128
 #endif

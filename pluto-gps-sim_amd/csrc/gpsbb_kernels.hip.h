@@ -58,7 +58,7 @@ constexpr int SPT = GPSBB_SPT;              /* consecutive samples per lane (16 
 constexpr int TILE = 64 * SPT;              /* samples per tile = one pass of one wavefront (the row-index granule) */
 constexpr int WAVES_PER_WG = TILE_THREADS / 64;
 #ifndef GPSBB_TILE_CHUNK
-#define GPSBB_TILE_CHUNK 4
+#define GPSBB_TILE_CHUNK 2
 #endif
 constexpr int TILE_CHUNK = GPSBB_TILE_CHUNK;               /* consecutive tiles a wavefront takes at a time */
 #ifndef GPSBB_ROW_CAP

@@ -14,6 +14,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -134,11 +137,80 @@ uint64_t row_bound(double s_abs, double range, int top_e, int nsamp)
 /* handle / batch                                                                                     */
 /* ================================================================================================== */
 
+/* A few host threads that stay around between calls (host-side seeding of small batches): starting two
+ * dozen threads costs more than the work they are given. */
+struct WorkPool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::function<void(size_t)> job;
+    size_t njobs = 0, next = 0, running = 0;
+    unsigned long gen = 0;
+    bool stop = false;
+
+    explicit WorkPool(size_t nworkers)
+    {
+        for (size_t t = 0; t < nworkers; t++)
+            th.emplace_back([this] { loop(); });
+    }
+    ~WorkPool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto &t : th)
+            t.join();
+    }
+    void loop()
+    {
+        unsigned long seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv_work.wait(lk, [&] { return stop || gen != seen; });
+            if (stop)
+                return;
+            seen = gen;
+            drain(lk);
+        }
+    }
+    /* take jobs until none is left; called with the lock held */
+    void drain(std::unique_lock<std::mutex> &lk)
+    {
+        running++;
+        while (next < njobs) {
+            const size_t j = next++;
+            lk.unlock();
+            job(j);
+            lk.lock();
+        }
+        if (--running == 0)
+            cv_done.notify_all();
+    }
+    /* run f(0..n-1) on the workers and the calling thread; returns when all are done */
+    void run(size_t n, std::function<void(size_t)> f)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        job = std::move(f);
+        njobs = n;
+        next = 0;
+        gen++;
+        cv_work.notify_all();
+        drain(lk);
+        cv_done.wait(lk, [&] { return running == 0 && next >= njobs; });
+        njobs = 0;
+    }
+};
+
 struct gpsbb {
     int device = 0;
     hipStream_t s_seed = nullptr;    /* NCO seeding pre-pass (k_seed) and descriptor uploads            */
     hipStream_t s_compute = nullptr; /* synthesis kernel (k_synth)                                      */
     hipStream_t s_copy = nullptr;    /* device-to-host gather                                            */
+    std::vector<uint32_t> h_ca;      /* host copy of the C/A chips (seeding of small batches on the host)  */
+    unsigned long long host_dwrd_oob = 0; /* hazards counted by host-side seeding                         */
+    WorkPool *pool = nullptr;        /* host threads for seeding small batches (created on first use)      */
     int32_t *d_tabs = nullptr;
     uint32_t *d_ca = nullptr;
     uint32_t *d_status = nullptr;
@@ -204,6 +276,11 @@ struct gpsbb_batch {
     unsigned run_count = 0;
     int last_set = 0;
     DevBuf<int16_t> d_iq;
+    /* seeding on the host (small batches): pinned images of the row pool, tile index and end states */
+    SynRow *hs_rows = nullptr;
+    int32_t *hs_tile_row = nullptr;
+    gpsbb_chan_state_t *hs_end = nullptr;
+    size_t hs_rows_cap = 0, hs_tr_cap = 0, hs_end_cap = 0;
     std::vector<uint64_t> row_off;
     std::vector<gpsbb_chan_t> h_ch; /* library-owned copy: the caller's array may go away after the call */
     struct Ev4 { hipEvent_t e[4]; }; /* seed start/end (seed stream), synth start/end (compute stream) */
@@ -277,6 +354,8 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
         (void)hipFree(h->d_status);
     if (h->d_hz)
         (void)hipFree(h->d_hz);
+    delete h->pool;
+    h->pool = nullptr;
     if (h->s_seed)
         (void)hipStreamDestroy(h->s_seed);
     if (h->s_compute)
@@ -330,6 +409,7 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     if ((e = hipMalloc((void **)&h->d_hz, 16 + 128)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h->d_tabs, tabs, sizeof tabs, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h->d_ca, ca.data(), ca.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    h->h_ca = ca;
     if ((e = hipMemset(h->d_status, 0, 4)) != hipSuccess) return fail(e);
     if ((e = hipMemset(h->d_hz, 0, 16 + 128)) != hipSuccess) return fail(e);
     /* k_synth carves ~76 KB of dynamic LDS per workgroup: above the 64 KB default limit */
@@ -461,6 +541,12 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         if (b->synth_done[k])
             (void)hipEventDestroy(b->synth_done[k]);
     }
+    if (b->hs_rows)
+        (void)hipHostFree(b->hs_rows);
+    if (b->hs_tile_row)
+        (void)hipHostFree(b->hs_tile_row);
+    if (b->hs_end)
+        (void)hipHostFree(b->hs_end);
     b->d_iq.release();
     for (auto &t : b->evs)
         for (auto &e : t.e)
@@ -503,6 +589,198 @@ extern "C" int gpsbb_test_read_prof(gpsbb_t *h, unsigned long long out[16], int 
     if (reset && hipMemset(h->d_hz + 2, 0, 128) != hipSuccess)
         return -1;
     return 0;
+}
+
+/* ---- seeding on the host --------------------------------------------------------------------------
+ * k_seed takes as long as its longest chain (one lane walks one chain, ~2 us per row), whatever the number
+ * of chains.  For a handful of blocks — the drop-in single-block call above all — a few host threads walk
+ * the same chains with the same code (gpsbb_nco.h) an order of magnitude faster per row, and the tables
+ * (a few MB) are uploaded instead.  Same rows, same tile index, same end states as the kernel writes. */
+namespace {
+
+constexpr size_t HOST_SEED_MAX_CHANNELS = 64; /* blocks x channels up to which the host seeds */
+
+struct HostRowSink {
+    SynRow *rows;
+    uint32_t cap, cnt;
+    bool overflow;
+    unsigned long long dwrd_oob;
+    const uint32_t *dwrd;
+    uint32_t dbit;
+    int32_t *tr;
+    size_t tstride;
+    int32_t tile_t, ntiles;
+
+    void row(int32_t n0, uint32_t nav, double x, double S)
+    {
+        const int32_t nt = (int32_t)(((int64_t)n0 + TILE - 1) / TILE);
+        const int32_t lim = nt < ntiles ? nt : ntiles;
+        const int32_t prev = (int32_t)(cnt < cap ? cnt : cap) - 1;
+        for (; tile_t < lim; tile_t++, tr += tstride)
+            *tr = prev;
+        if (cnt < cap) {
+            SynRow r;
+            r.n0 = n0;
+            if (dwrd) {
+                r.nav = nav | dbit;
+                r.x = x;
+                r.S = S;
+            } else {
+                r.nav = 0;
+                r.x = mul_rn(x, 512.0);
+                r.S = mul_rn(S, 512.0);
+            }
+            rows[cnt] = r;
+        } else {
+            overflow = true;
+        }
+        cnt++;
+    }
+    void nav_fetch(uint32_t nav)
+    {
+        if (nav_iword(nav) >= GPSBB_N_DWRD)
+            dwrd_oob++;
+        dbit = nav_bit(dwrd, nav) < 0 ? 0x80000000u : 0u;
+    }
+    void finish()
+    {
+        if (cnt > cap)
+            cnt = cap;
+        for (; tile_t <= ntiles; tile_t++, tr += tstride)
+            *tr = (int32_t)cnt - 1;
+        SynRow r;
+        r.n0 = INT32_MAX;
+        r.nav = 0;
+        r.x = 0.0;
+        r.S = 0.0;
+        rows[cnt] = r;
+    }
+};
+
+/* one chain (kind 0 = code, 1 = carrier) of channel k = block*nch + i: what seed_code_chain /
+ * seed_carr_chain / seed_carr_fixed do on the device.  Returns false on a row-pool overflow. */
+bool host_seed_chain(const gpsbb_batch *b, int kind, size_t k, unsigned long long *dwrd_oob)
+{
+    const gpsbb_chan_t &c = b->h_ch[k];
+    gpsbb_chan_state_t &e = b->hs_end[k];
+    const size_t nbc = (size_t)b->nblocks * b->nch;
+    const bool fixed = (b->flags & GPSBB_FIXED_CARRIER) != 0;
+    if (c.prn <= 0) {
+        if (kind == 0) {
+            e.code_phase = 0.0;
+            e.iword = e.ibit = e.icode = e.dataBit = e.codeCA = 0;
+            e._pad = 0;
+        } else {
+            e.carr_phase = 0.0;
+        }
+        return true;
+    }
+    if (kind == 1 && fixed) {
+        e.carr_phase = (double)(uint32_t)(b->h_kph0[k] + (uint32_t)b->nsamp * (uint32_t)b->h_kstep[k]);
+        return true;
+    }
+    const size_t chain = (size_t)kind * nbc + k;
+    HostRowSink sink;
+    sink.rows = b->hs_rows + b->row_off[chain];
+    sink.cap = (uint32_t)(b->row_off[chain + 1] - b->row_off[chain] - 1);
+    sink.cnt = 0;
+    sink.overflow = false;
+    sink.dwrd_oob = 0;
+    sink.dwrd = kind == 0 ? c.dwrd : nullptr;
+    uint32_t nav = kind == 0 ? nav_pack(c.icode, c.ibit, c.iword) : 0u;
+    sink.dbit = kind == 0 && nav_bit(c.dwrd, nav) < 0 ? 0x80000000u : 0u;
+    const size_t blk = k / (size_t)b->nch, i = k % (size_t)b->nch;
+    sink.tr = b->hs_tile_row + (blk * ((size_t)b->ntiles + 1)) * (2 * (size_t)b->nch) + 2 * i + (size_t)kind;
+    sink.tstride = 2 * (size_t)b->nch;
+    sink.tile_t = 0;
+    sink.ntiles = b->ntiles;
+    if (kind == 0) {
+        const double s = mul_rn(c.f_code, b->delt);
+        const double x = build_rows_f64<NCO_CODE>(c.code_phase, s, nav, b->nsamp, sink);
+        sink.finish();
+        e.code_phase = x;
+        e.iword = nav_iword(nav);
+        e.ibit = nav_ibit(nav);
+        e.icode = nav_icode(nav);
+        e.dataBit = nav_bit(c.dwrd, nav);
+        const int ci = (int)x;
+        e.codeCA = (int)((b->h->h_ca[(size_t)c.prn * 32 + (ci >> 5)] >> (ci & 31)) & 1u) * 2 - 1;
+        e._pad = 0;
+    } else {
+        const double s = mul_rn(c.f_carr, b->delt);
+        e.carr_phase = build_rows_f64<NCO_CARR>(c.carr_phase, s, nav, b->nsamp, sink);
+        sink.finish();
+    }
+    *dwrd_oob += sink.dwrd_oob;
+    return !sink.overflow;
+}
+
+int host_pinned_reserve(void **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap)
+        return hipSuccess;
+    if (*p)
+        (void)hipHostFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    bytes += bytes / 4;
+    hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+    if (e == hipSuccess)
+        *cap = bytes;
+    return e;
+}
+
+} /* namespace */
+
+/* 0 = by size (default), 1 = always on the device, 2 = always on the host; tests run both ways */
+static int g_seed_mode = 0;
+extern "C" void gpsbb_test_seed_mode(int mode) { g_seed_mode = mode; }
+
+static bool host_seeding_wanted(const gpsbb_batch *b)
+{
+    static const bool off = getenv("GPSBB_DEVICE_SEED_ONLY") != nullptr;
+    static const size_t lim = getenv("GPSBB_HOST_SEED_MAX") ? (size_t)atol(getenv("GPSBB_HOST_SEED_MAX")) : HOST_SEED_MAX_CHANNELS;
+    if (g_seed_mode)
+        return g_seed_mode == 2;
+    return !off && (size_t)b->nblocks * b->nch <= lim;
+}
+
+/* Build the tables of one run on host threads and queue their upload on the seeding stream. */
+static int host_seed_run(gpsbb_batch *b, int set, hipStream_t stream)
+{
+    gpsbb *h = b->h;
+    const size_t nbc = (size_t)b->nblocks * b->nch;
+    const size_t tr_n = 2 * nbc * ((size_t)b->ntiles + 1);
+    HIPCHK(h, (hipError_t)host_pinned_reserve((void **)&b->hs_rows, &b->hs_rows_cap, (b->total_rows + 4) * sizeof(SynRow)));
+    HIPCHK(h, (hipError_t)host_pinned_reserve((void **)&b->hs_tile_row, &b->hs_tr_cap, tr_n * sizeof(int32_t)));
+    HIPCHK(h, (hipError_t)host_pinned_reserve((void **)&b->hs_end, &b->hs_end_cap, nbc * sizeof(gpsbb_chan_state_t)));
+    const size_t nchains = 2 * nbc;
+    if (!h->pool) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        size_t n = hw ? hw : 4;
+        n = n > 32 ? 32 : n;
+        h->pool = new (std::nothrow) WorkPool(n - 1);
+        if (!h->pool)
+            return GPSBB_E_NOMEM;
+    }
+    const size_t nthr = nchains; /* one slot of results per job */
+    std::vector<unsigned long long> oob(nthr, 0ull);
+    std::vector<char> ok(nthr, 1);
+    /* carrier chains first: they are the long ones */
+    h->pool->run(nchains, [&](size_t j) {
+        const int kind = j < nbc ? 1 : 0;
+        if (!host_seed_chain(b, kind, j < nbc ? j : j - nbc, &oob[j]))
+            ok[j] = 0;
+    });
+    for (size_t t = 0; t < nthr; t++) {
+        h->host_dwrd_oob += oob[t];
+        if (!ok[t])
+            return GPSBB_E_INTERNAL;
+    }
+    HIPCHK(h, hipMemcpyAsync(b->d_rows[set].p, b->hs_rows, b->total_rows * sizeof(SynRow), hipMemcpyHostToDevice, stream));
+    HIPCHK(h, hipMemcpyAsync(b->d_tile_row[set].p, b->hs_tile_row, tr_n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    HIPCHK(h, hipMemcpyAsync(b->d_end[set].p, b->hs_end, nbc * sizeof(gpsbb_chan_state_t), hipMemcpyHostToDevice, stream));
+    return GPSBB_OK;
 }
 
 static int g_test_skip_seed = 0;
@@ -565,8 +843,17 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     if (b->synth_pending[set])
         HIPCHK(h, hipStreamWaitEvent(h->s_seed, b->synth_done[set], 0));
     HIPCHK(h, hipEventRecord(ev[0], h->s_seed));
-    if (!(g_test_skip_seed && b->run_count >= 2)) /* measurement hook: time k_synth alone on tables already built */
-    {
+    if (g_test_skip_seed && b->run_count >= 2) {
+        /* measurement hook: time k_synth alone on tables already built */
+    } else if (host_seeding_wanted(b)) {
+        /* the previous user of the pinned images (this batch's last run) has been copied out: its upload was
+         * followed by k_synth, which synth_done[] of that set covers; a lone batch runs are far apart */
+        if (b->synth_pending[set ^ 1])
+            HIPCHK(h, hipEventSynchronize(b->synth_done[set ^ 1]));
+        const int rc = host_seed_run(b, set, h->s_seed);
+        if (rc != GPSBB_OK)
+            return rc;
+    } else {
         hipLaunchKernelGGL(k_seed, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, h->s_seed, p, cbase);
     }
     HIPCHK(h, hipGetLastError());
@@ -658,9 +945,11 @@ extern "C" int gpsbb_get_hazards(gpsbb_t *h, gpsbb_hazards_t *out, int reset)
     unsigned long long v[2];
     HIPCHK(h, hipMemcpy(v, h->d_hz, 16, hipMemcpyDeviceToHost));
     out->itable_512 = v[0];
-    out->dwrd_oob = v[1];
-    if (reset)
+    out->dwrd_oob = v[1] + h->host_dwrd_oob;
+    if (reset) {
         HIPCHK(h, hipMemset(h->d_hz, 0, 16));
+        h->host_dwrd_oob = 0;
+    }
     return GPSBB_OK;
 }
 

@@ -116,7 +116,7 @@ __device__ __forceinline__ int chain_carr(const BatchDev &p, int b, int i) { ret
 
 /* nav data bit (+1/-1) for packed counters, from 60 words at `dwrd` (plutogpssim.c:1781, 2732) */
 template <class P>
-__device__ __forceinline__ int nav_bit(const P dwrd, uint32_t nav)
+__host__ __device__ __forceinline__ int nav_bit(const P dwrd, uint32_t nav)
 {
     int w = nav_iword(nav);
     w = w < GPSBB_N_DWRD ? w : GPSBB_N_DWRD - 1; /* latent OOB of the reference: defined as dwrd[59] */

@@ -25,6 +25,9 @@ int gpsbb_test_build_rows(int kind, double x0, double s, unsigned nav0, int nsam
  * sample n of a row is fma(n - n0, S, x) */
 int gpsbb_test_build_rows_f64(int kind, double x0, double s, unsigned nav0, int nsamp, gpsbb_test_row_t *rows,
                               int cap, double *x_end, unsigned *nav_end);
+/* where the NCO tables of a run are built: 0 = by batch size (default: small batches on host threads), 1 = always
+ * by k_seed on the device, 2 = always on the host */
+void gpsbb_test_seed_mode(int mode);
 /* measurement only: after the first two runs of a batch (both table sets built) skip k_seed, so that
  * k_synth can be timed alone on unchanged tables */
 void gpsbb_test_skip_seed(int on);

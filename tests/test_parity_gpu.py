@@ -22,6 +22,15 @@ def assert_state_equal(got, want, active):
         assert g.tobytes() == w.tobytes(), f
 
 
+@pytest.fixture(autouse=True, params=["seeded-by-k_seed", "seeded-on-host"])
+def seed_mode(pkg, request):
+    """The NCO tables of a run are built by k_seed on the device or, for small batches, by host threads running
+    the same code: every test below runs both ways (by default the batch size decides)."""
+    pkg.lib().gpsbb_test_seed_mode(1 if request.param == "seeded-by-k_seed" else 2)
+    yield
+    pkg.lib().gpsbb_test_seed_mode(0)
+
+
 def test_native_library_is_what_runs(pkg, synth):
     """The loaded shared object is the in-tree HIP build and it owns a device handle."""
     maps = open("/proc/self/maps").read()

@@ -461,6 +461,33 @@ def test_randomised_shapes_and_dopplers(pkg, synth, oracle):
     synth.hazards(reset=True)
 
 
+def test_time_shards_through_the_ring_give_one_digest(pkg, synth, oracle):
+    """BASELINE configs[4] in small: a stream continuous in time (drifting Dopplers, carrier carried from block
+    to block) cut into 1, 2 and 3 contiguous time shards; each shard is rendered on its own through the
+    streaming ring from the exact carrier seed of its first block.  The per-block digests must equal the
+    oracle's render of the whole stream, whatever the number of shards and the slot size."""
+    import hashlib
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("shard_stream", os.path.join(os.path.dirname(GOLDEN), "..", "tools",
+                                                                               "shard_stream.py"))
+    ss = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ss)
+    fs, nsamp, nblocks, nch = 25e6, 50000, 13, 16
+    delt = 1.0 / fs
+    ch = ss.stream_descriptors(pkg, nblocks, nch, seed=0xABCD)
+    ch["prn"][7:, 3] = 21                       # a channel re-allocated to another satellite: its phase restarts
+    want_iq, _, _ = oracle.fill_blocks(ch, delt, nsamp, chain=True)
+    want = [hashlib.sha256(want_iq[k].tobytes()).digest() for k in range(nblocks)]
+    seeds = pkg.chain_carrier_host(ch, delt, nsamp)
+    for world, bps in ((1, 4), (2, 3), (3, 2)):
+        got = []
+        for rank in range(world):
+            b0, b1 = pkg.shard_blocks(nblocks, rank, world)
+            d, _ = ss.shard_digests(pkg, synth, ch, seeds, b0, b1, delt, nsamp, bps)
+            got += d
+        assert got == want, (world, bps)
+
+
 def test_handle_and_batch_lifecycle(pkg, oracle):
     """Create/destroy churn, one handle reused across shapes, many small blocks in one batch, API misuse."""
     import ctypes as C

@@ -487,7 +487,11 @@ __device__ __forceinline__ double chain_state(const WaveRows &W, int sbase, int 
         slot += t <= n;
     }
     const uint4 r = W.a[slot];
-    const double S = hi_lo_f64((int)W.s_hi[slot], (int)W.s_lo[slot]);
+    /* &s_lo[slot], written so that the compiler does not derive it from &a[slot] with a 64-bit multiply-add */
+    uint32_t sa;
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(sa) : "v"(slot), "v"((uint32_t)(uintptr_t)(lptr_t)&W.s_lo[0]));
+    typedef __attribute__((address_space(3))) const uint32_t *lds_u32_t;
+    const double S = hi_lo_f64((int)((lds_u32_t)(uintptr_t)sa)[WAVE_ROW_CAP], (int)((lds_u32_t)(uintptr_t)sa)[0]);
     *nav = r.y;
     *S_out = S;
     return __fma_rn((double)(n - (int)r.x), S, hi_lo_f64((int)r.w, (int)r.z));

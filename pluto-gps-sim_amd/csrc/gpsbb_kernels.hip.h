@@ -145,20 +145,29 @@ struct RowSink {
     size_t tstride;       /* ... and the distance to the one after */
     int32_t tile_t;       /* that tile's number */
     int32_t ntiles;
+    int32_t wrap_tile;    /* last tile in which a row that follows a wrap started (-2: none yet) */
 
-    __device__ __forceinline__ void row(int32_t n0, uint32_t nav, double x, double S)
+    __device__ __forceinline__ void row(int32_t n0, uint32_t nav, double x, double S, bool after_wrap)
     {
         {
-            /* tiles that start before this row belong to the previous one.  Lanes run in lockstep, rows do
-             * not: a long row leaves several tiles to fill in at once */
+            /* tiles that start before this row belong to the previous one, a tile that starts with it to this
+             * one.  Lanes run in lockstep, rows do not: a long row leaves several tiles to fill in at once.
+             * Entry e also carries, in bit 31, whether a row that follows a wrap started in tile e-1. */
             const int32_t nt = (int32_t)(((int64_t)n0 + TILE - 1) / TILE); /* tiles that start before n0 */
             const int32_t lim = nt < ntiles ? nt : ntiles;
-            const int32_t prev = (int32_t)(cnt < cap ? cnt : cap) - 1;
+            const int32_t here = (int32_t)(cnt < cap ? cnt : cap);
             while (tile_t < lim) {
-                *tr = prev;
+                *tr = (here - 1) | (tile_t - 1 == wrap_tile ? (int32_t)0x80000000 : 0);
                 tr += tstride;
                 tile_t++;
             }
+            if (tile_t < ntiles && tile_t * TILE == n0) {
+                *tr = here | (tile_t - 1 == wrap_tile ? (int32_t)0x80000000 : 0);
+                tr += tstride;
+                tile_t++;
+            }
+            if (after_wrap)
+                wrap_tile = n0 / TILE;
         }
         if (cnt < cap) {
             SynRow r;
@@ -190,7 +199,7 @@ struct RowSink {
         if (cnt > cap)
             cnt = cap;
         for (; tile_t <= ntiles; tile_t++, tr += tstride) /* the remaining tiles and entry [ntiles] */
-            *tr = (int32_t)cnt - 1;
+            *tr = ((int32_t)cnt - 1) | (tile_t - 1 == wrap_tile ? (int32_t)0x80000000 : 0);
         SynRow r;
         r.n0 = INT32_MAX; /* sentinel: terminates every forward scan */
         r.nav = 0;
@@ -223,6 +232,7 @@ __device__ __forceinline__ RowSink make_sink(const BatchDev &p, int chain, const
     s.tstride = 2 * (size_t)p.nch;
     s.tile_t = 0;
     s.ntiles = p.ntiles;
+    s.wrap_tile = -2;
     return s;
 }
 
@@ -368,8 +378,6 @@ struct SynthLds {
     double rsc[GPSBB_MAX_CHAN];                 /* 1/sc where a run of SPT samples holds at most one chip boundary
                                                    (sc*(SPT-1) < 1, i.e. sample rates above ~15.4 MS/s), else 0 */
     double sk512[GPSBB_MAX_CHAN];               /* f_carr*delt*512 (carrier phase is walked scaled by 512: exact) */
-    double xlim[GPSBB_MAX_CHAN];                /* a run starting below this code phase cannot reach 1023     */
-    double ylo[GPSBB_MAX_CHAN], yhi[GPSBB_MAX_CHAN]; /* ... strictly inside (ylo, yhi): no carrier wrap       */
     WaveRows wr[WAVES_PER_WG];
     uint64_t roff[2 * GPSBB_MAX_CHAN];          /* first pool row of chain (a, kind) of this block     */
     int32_t act[GPSBB_MAX_CHAN];
@@ -437,23 +445,31 @@ __device__ __forceinline__ void dma_row(uint64_t src, WaveRows &W, int first)
     __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(src + 20), (lptr_t)&W.s_hi[first], 4, 0, 0);
 }
 
+/* what stage_tile() tells chain lane c about the tile: its slot range in the slice; ok = 0: nothing was
+ * copied because the tile has more rows than the slice holds */
+struct Staged {
+    int base, cnt, ok;
+};
+
 /*
  * Start the copy of one tile's rows into the wavefront's slice.  Lane c is chain c of the block; its rows
  * trA..trB overlap the tile.  The chains' slot ranges come from a prefix sum over the lanes; slot k's chain
- * is the number of chains whose range ends at or before k.  Returns false (nothing issued) when the tile
- * has more rows than the slice holds: such tiles stage channel by channel (see k_synth).
+ * is the number of chains whose range ends at or before k.  Not inlined: it is called from every variant of
+ * the channel loop (once per tile).
  */
-__device__ __forceinline__ bool stage_tile(WaveRows &W, int lane, int nchains, bool has_chain, uint64_t row0_addr,
-                                           int trA, int trB, int &base, int &cnt)
+__device__ __noinline__ Staged stage_tile(WaveRows &W, int lane, int nchains, bool has_chain, uint64_t row0_addr, int trA,
+                                          int trB)
 {
-    cnt = has_chain ? trB - trA + 1 : 0;
-    const int incl = wave_incl_scan(cnt);
-    base = incl - cnt;
+    Staged st;
+    st.cnt = has_chain ? trB - trA + 1 : 0;
+    const int incl = wave_incl_scan(st.cnt);
+    st.base = incl - st.cnt;
     const int R = __builtin_amdgcn_readlane(incl, 63);
-    if (R > WAVE_ROW_CAP)
-        return false;
+    st.ok = R <= WAVE_ROW_CAP;
+    if (!st.ok)
+        return st;
     /* slot k holds row trA + (k - base) of its chain, i.e. address [row 0 + (trA - base) rows] + k rows */
-    const uint64_t addr_c = row0_addr + (uint64_t)((int64_t)(trA - base) * (int64_t)sizeof(SynRow));
+    const uint64_t addr_c = row0_addr + (uint64_t)((int64_t)(trA - st.base) * (int64_t)sizeof(SynRow));
     int ck = 0;
     for (int c = 0; c < nchains; c++)
         ck += __builtin_amdgcn_readlane(incl, c) <= lane;
@@ -468,7 +484,29 @@ __device__ __forceinline__ bool stage_tile(WaveRows &W, int lane, int nchains, b
         if (lane + 64 < R)
             dma_row(a1, W, 64);
     }
-    return true;
+    return st;
+}
+
+/* A tile whose rows do not fit the slice (dense rows: high Doppler at a low sample rate): copy just one
+ * channel's two chains (nc + nk <= WAVE_ROW_CAP rows from ac / ak) and wait for them.  Returns the first
+ * samples of slots lane and 64+lane. */
+struct SlotN0 {
+    int a, b;
+};
+__device__ __noinline__ SlotN0 stage_channel(WaveRows &W, int lane, uint64_t ac, uint64_t ak, int nc, int nk)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the previous channel's lookups are done */
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int k = lane + 64 * h;
+        if (k < nc + nk)
+            dma_row(k < nc ? ac + (uint64_t)k * sizeof(SynRow) : ak + (uint64_t)(k - nc) * sizeof(SynRow), W, 64 * h);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SlotN0 r;
+    r.a = (int)W.a[lane].x;
+    r.b = (int)W.a[64 + lane].x;
+    return r;
 }
 
 /*
@@ -690,11 +728,6 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         L.sc[tid] = sc;
         L.rsc[tid] = (sc >= 0x1p-10 && sc * (double)(SPT - 1) < 1.0) ? 1.0 / sc : 0.0;
         L.sk512[tid] = sk;
-        /* (SPT+2) steps of margin: the accumulated rounding of SPT adds is far below one step */
-        const double span = (double)(SPT + 2);
-        L.xlim[tid] = 1023.0 - span * sc;
-        L.yhi[tid] = sk > 0.0 ? 512.0 - span * sk : 512.0;
-        L.ylo[tid] = sk < 0.0 ? -span * sk : -1.0;
     }
     for (int e = tid; e < p.nch * 512; e += TILE_THREADS) {
         const int i = e >> 9, k = e & 511;
@@ -746,6 +779,9 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
     const size_t tstride = 2 * (size_t)p.nch; /* the 2*nch entries of one tile are contiguous: one cache line */
     const uint64_t row0_addr = (uint64_t)(uintptr_t)(p.rows + L.roff[has_chain ? 2 * my_chan + (lane & 1) : 0]);
     const int nchains = 2 * nact;
+    /* code chain lanes: a run of this channel holds at most one chip boundary (see walk_channel, CODE = 2) */
+    const bool one_chip = has_chain && !(lane & 1) && L.rsc[my_chan] != 0.0;
+    constexpr int TR_ROW = 0x7fffffff; /* tile index entry: row number; bit 31: a wrap in the previous tile */
 
     /* Tiles are handed out dynamically in chunks of TILE_CHUNK consecutive tiles from a per-block counter:
      * a wavefront that shares its SIMD with another kernel (the next run's seeding pre-pass runs
@@ -766,9 +802,10 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
             trB = lane_tr[(wt_begin + 1) * tstride];
             trC = lane_tr[(wt_begin + 2 <= ntw ? wt_begin + 2 : ntw) * tstride];
         }
-        /* slots of this chain's rows in the slice for the current tile; ovf: the tile's rows do not fit */
-        int cbase, ccnt;
-        bool ovf = !stage_tile(W, lane, nchains, has_chain, row0_addr, trA, trB, cbase, ccnt);
+        /* slots of this chain's rows in the slice for the current tile; ovf: the tile's rows do not fit;
+         * cwrap: one of the chain's rows that start in the tile follows a wrap */
+        Staged cur = stage_tile(W, lane, nchains, has_chain, row0_addr, trA & TR_ROW, trB & TR_ROW);
+        bool cwrap = trB < 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int slot_n0a = (int)W.a[lane].x, slot_n0b = (int)W.a[64 + lane].x;
         PROF_MARK(1);
@@ -778,8 +815,10 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
             const int wn0 = wt * TILE;       /* first sample of the tile (wave-uniform) */
             const int n0 = wn0 + lane * SPT; /* this lane's run; lanes past the block end compute and store nothing */
             const int nvalid = p.nsamp - n0 < SPT ? p.nsamp - n0 : SPT;
-            int nbase = 0, ncnt = 0;
-            bool novf = false, staged = false;
+            const int cbase = cur.base, ccnt = cur.cnt;
+            const bool ovf = !cur.ok;
+            Staged nxt = {0, 0, 1};
+            bool nwrap = false;
             unsigned long long hz_itable = 0;
             v2s acc[SPT];
 #pragma unroll
@@ -790,104 +829,93 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
             prof_s[11] += ovf;
 #endif
 
-            for (int a = 0; a < nact; a++) {
-                const int i = L.act[a];
-                /* -- where this lane's run starts in the two chains of channel i -- */
-                int sb_c = 0, sb_k = 0;
-                const int sc_c = __builtin_amdgcn_readlane(ccnt, 2 * a), sc_k = __builtin_amdgcn_readlane(ccnt, 2 * a + 1);
-                bool glob = false;
-                if (!ovf) {
-                    sb_c = __builtin_amdgcn_readlane(cbase, 2 * a);
-                    sb_k = __builtin_amdgcn_readlane(cbase, 2 * a + 1);
-                } else if (sc_c + sc_k <= WAVE_ROW_CAP) {
-                    /* The tile's rows did not fit the slice (dense rows: high Doppler at a low sample rate):
-                     * stage just this channel's two chains and look them up there. */
-                    const uint64_t tile_addr = row0_addr + (uint64_t)trA * sizeof(SynRow);
-                    const uint64_t ac = readlane_u64(tile_addr, 2 * a), ak = readlane_u64(tile_addr, 2 * a + 1);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the previous channel's lookups are done */
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const int k = lane + 64 * h;
-                        if (k < sc_c + sc_k)
-                            dma_row(k < sc_c ? ac + (uint64_t)k * sizeof(SynRow) : ak + (uint64_t)(k - sc_c) * sizeof(SynRow),
-                                    W, 64 * h);
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    slot_n0a = (int)W.a[lane].x;
-                    slot_n0b = (int)W.a[64 + lane].x;
-                    sb_k = sc_c;
-                } else {
-                    glob = true; /* last resort: every lane scans the pool in HBM */
-                }
-                uint32_t nav_raw, nav_unused;
-                double xc, Sc = 0.0, S_unused;
-                if (!glob) {
-                    xc = chain_state(W, sb_c, sc_c, slot_n0a, slot_n0b, n0, &nav_raw, &Sc);
-                } else {
-                    const uint64_t tile_addr = row0_addr + (uint64_t)trA * sizeof(SynRow);
-                    xc = row_state_global((const SynRow *)(uintptr_t)readlane_u64(tile_addr, 2 * a), n0, &nav_raw);
-                }
-                const int dbx = (nav_raw >> 31) ? 0xfffe : 0; /* dataBit -1: flips the chip's +-1 in 16 bits */
-                const uint32_t nav = nav_raw & 0x7fffffffu;
-                /* Can any lane of this wavefront wrap inside its run?  Impossible when the whole tile lies in
-                 * one row of the chain (a wrap is a row boundary); otherwise compare with the channel's limits. */
-                const bool code_row = sc_c == 1 && !glob; /* the tile lies in one row of the code chain */
-                const bool code_w = code_row ? false : (bool)__any(!(xc < L.xlim[i]));
-                const bool code_1 = code_row && L.rsc[i] != 0.0; /* ... and a run holds at most one chip boundary */
-                double yk = 0.0;
-                uint32_t ph = 0, kstep = 0;
-                bool carr_w = false;
-                if (fixed_carr) {
-                    kstep = (uint32_t)p.kstep[(size_t)b * p.nch + i];
-                    ph = p.kph0[(size_t)b * p.nch + i] + (uint32_t)n0 * kstep;
-                } else {
-                    if (!glob) {
-                        yk = chain_state(W, sb_k, sc_k, slot_n0a, slot_n0b, n0, &nav_unused, &S_unused);
-                    } else {
-                        const uint64_t tile_addr = row0_addr + (uint64_t)trA * sizeof(SynRow);
-                        yk = row_state_global((const SynRow *)(uintptr_t)readlane_u64(tile_addr, 2 * a + 1), n0, &nav_unused);
-                    }
-                    carr_w = (sc_k == 1 && !glob) ? false : (bool)__any(!(yk < L.yhi[i]) || !(yk > L.ylo[i]));
-                }
-                PROF_MARK(2);
+            /* Which walk each channel needs follows from its two chains' rows alone: no row starts inside the
+             * tile -> no wrap (and, for the code, the one-boundary walk where it applies); a row that follows a
+             * wrap starts inside it (the tile index says so) -> the wrap-capable update; else straight line.
+             * Channels are taken variant by variant, so that inside each loop the accumulators stay where they
+             * are (sums modulo 2^16 do not care about the order). */
+            const int kcode = ccnt == 1 ? (one_chip ? 2 : 0) : (cwrap ? 1 : 0);
+            const bool code_lane = has_chain && !(lane & 1);
+            const uint64_t m_c0 = __ballot(code_lane && kcode == 0), m_c1 = __ballot(code_lane && kcode == 1),
+                           m_c2 = __ballot(code_lane && kcode == 2);
+            const uint64_t m_k1 = __ballot(has_chain && (lane & 1) && cwrap) >> 1; /* on the channel's even bit */
+            int remaining = nact;
 
-                /* -- before the last channel's walk: start the copy of the next tile's rows -- */
-                if (a == nact - 1 && more) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this tile's lookups have returned */
-                    novf = !stage_tile(W, lane, nchains, has_chain, row0_addr, trB, trC, nbase, ncnt);
-                    trA = trB;
-                    trB = trC;
-                    if (has_chain && wt + 3 <= ntw)
-                        trC = lane_tr[(wt + 3) * tstride];
-                    staged = true;
-                    PROF_MARK(3);
-                }
+            /* one channel with walk variant <CODE, CARR>; `a` = its index among the active channels */
+#define GPSBB_CHANNEL(CODE, CARR, MASK)                                                                                \
+    for (uint64_t m_ = (MASK); m_; m_ &= m_ - 1) {                                                                     \
+        const int a = (int)(__builtin_ctzll(m_) >> 1);                                                                 \
+        const int i = L.act[a];                                                                                        \
+        /* -- where this lane's run starts in the two chains of channel i -- */                                       \
+        int sb_c = 0, sb_k = 0;                                                                                        \
+        const int sc_c = __builtin_amdgcn_readlane(ccnt, 2 * a), sc_k = __builtin_amdgcn_readlane(ccnt, 2 * a + 1);    \
+        bool glob = false;                                                                                             \
+        if (!ovf) {                                                                                                    \
+            sb_c = __builtin_amdgcn_readlane(cbase, 2 * a);                                                            \
+            sb_k = __builtin_amdgcn_readlane(cbase, 2 * a + 1);                                                        \
+        } else if (sc_c + sc_k <= WAVE_ROW_CAP) {                                                                      \
+            const uint64_t tile_addr = row0_addr + (uint64_t)(trA & TR_ROW) * sizeof(SynRow);                          \
+            const SlotN0 sn = stage_channel(W, lane, readlane_u64(tile_addr, 2 * a), readlane_u64(tile_addr, 2 * a + 1), \
+                                            sc_c, sc_k);                                                               \
+            slot_n0a = sn.a;                                                                                           \
+            slot_n0b = sn.b;                                                                                           \
+            sb_k = sc_c;                                                                                               \
+        } else {                                                                                                       \
+            glob = true; /* last resort: every lane scans the pool in HBM */                                           \
+        }                                                                                                              \
+        uint32_t nav_raw, nav_unused;                                                                                  \
+        double xc, Sc = 0.0, S_unused, yk = 0.0;                                                                       \
+        uint32_t ph = 0, kstep = 0;                                                                                    \
+        if (!glob) {                                                                                                   \
+            xc = chain_state(W, sb_c, sc_c, slot_n0a, slot_n0b, n0, &nav_raw, &Sc);                                    \
+        } else {                                                                                                       \
+            const uint64_t tile_addr = row0_addr + (uint64_t)(trA & TR_ROW) * sizeof(SynRow);                          \
+            xc = row_state_global((const SynRow *)(uintptr_t)readlane_u64(tile_addr, 2 * a), n0, &nav_raw);            \
+        }                                                                                                              \
+        const int dbx = (nav_raw >> 31) ? 0xfffe : 0; /* dataBit -1: flips the chip's +-1 in 16 bits */               \
+        const uint32_t nav = nav_raw & 0x3fffffffu;                                                                    \
+        if (CARR == 2) {                                                                                               \
+            kstep = (uint32_t)p.kstep[(size_t)b * p.nch + i];                                                          \
+            ph = p.kph0[(size_t)b * p.nch + i] + (uint32_t)n0 * kstep;                                                 \
+        } else if (!glob) {                                                                                            \
+            yk = chain_state(W, sb_k, sc_k, slot_n0a, slot_n0b, n0, &nav_unused, &S_unused);                           \
+        } else {                                                                                                       \
+            const uint64_t tile_addr = row0_addr + (uint64_t)(trA & TR_ROW) * sizeof(SynRow);                          \
+            yk = row_state_global((const SynRow *)(uintptr_t)readlane_u64(tile_addr, 2 * a + 1), n0, &nav_unused);     \
+        }                                                                                                              \
+        PROF_MARK(2);                                                                                                  \
+        /* -- before the tile's last walk: start the copy of the next tile's rows -- */                               \
+        if (--remaining == 0 && more) {                                                                                \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this tile's lookups have returned */                 \
+            nxt = stage_tile(W, lane, nchains, has_chain, row0_addr, trB & TR_ROW, trC & TR_ROW);                      \
+            nwrap = trC < 0;                                                                                           \
+            trA = trB;                                                                                                 \
+            trB = trC;                                                                                                 \
+            if (has_chain && wt + 3 <= ntw)                                                                            \
+                trC = lane_tr[(wt + 3) * tstride];                                                                     \
+            PROF_MARK(3);                                                                                              \
+        }                                                                                                              \
+        walk_channel<CODE, CARR>(L, i, xc, Sc, yk, ph, kstep, nav, dbx, acc, nvalid, hz_itable);                       \
+        PROF_MARK(4);                                                                                                  \
+    }
 
-                if (fixed_carr) {
-                    if (code_1)
-                        walk_channel<2, 2>(L, i, xc, Sc, 0.0, ph, kstep, nav, dbx, acc, nvalid, hz_itable);
-                    else if (!code_w)
-                        walk_channel<0, 2>(L, i, xc, Sc, 0.0, ph, kstep, nav, dbx, acc, nvalid, hz_itable);
-                    else
-                        walk_channel<1, 2>(L, i, xc, Sc, 0.0, ph, kstep, nav, dbx, acc, nvalid, hz_itable);
-                } else if (code_1) {
-                    if (!carr_w)
-                        walk_channel<2, 0>(L, i, xc, Sc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
-                    else
-                        walk_channel<2, 1>(L, i, xc, Sc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
-                } else if (!code_w && !carr_w) {
-                    walk_channel<0, 0>(L, i, xc, Sc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
-                } else if (!code_w) {
-                    walk_channel<0, 1>(L, i, xc, Sc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
-                } else if (!carr_w) {
-                    walk_channel<1, 0>(L, i, xc, Sc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
-                } else {
-                    walk_channel<1, 1>(L, i, xc, Sc, yk, 0u, 0u, nav, dbx, acc, nvalid, hz_itable);
-                }
-                PROF_MARK(4);
+            if (fixed_carr) {
+                GPSBB_CHANNEL(2, 2, m_c2)
+                GPSBB_CHANNEL(0, 2, m_c0)
+                GPSBB_CHANNEL(1, 2, m_c1)
+            } else {
+                GPSBB_CHANNEL(2, 0, m_c2 & ~m_k1)
+                GPSBB_CHANNEL(0, 0, m_c0 & ~m_k1)
+                GPSBB_CHANNEL(2, 1, m_c2 & m_k1)
+                GPSBB_CHANNEL(0, 1, m_c0 & m_k1)
+                GPSBB_CHANNEL(1, 0, m_c1 & ~m_k1)
+                GPSBB_CHANNEL(1, 1, m_c1 & m_k1)
             }
-            if (more && !staged) { /* no active channel */
-                novf = !stage_tile(W, lane, nchains, has_chain, row0_addr, trB, trC, nbase, ncnt);
+#undef GPSBB_CHANNEL
+
+            if (more && remaining == nact) { /* no active channel: nothing above ran */
+                nxt = stage_tile(W, lane, nchains, has_chain, row0_addr, trB & TR_ROW, trC & TR_ROW);
+                nwrap = trC < 0;
                 trA = trB;
                 trB = trC;
                 if (has_chain && wt + 3 <= ntw)
@@ -899,9 +927,8 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 slot_n0a = (int)W.a[lane].x;
                 slot_n0b = (int)W.a[64 + lane].x;
-                cbase = nbase;
-                ccnt = ncnt;
-                ovf = novf;
+                cur = nxt;
+                cwrap = nwrap;
             }
             PROF_MARK(5);
             if (hz_itable)

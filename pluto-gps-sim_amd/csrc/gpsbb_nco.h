@@ -92,14 +92,19 @@ GPSBB_HD bool code_step(double &x, double s)
     return false;
 }
 
-/* One genuine step of the carrier NCO (plutogpssim.c:2741-2746). */
-GPSBB_HD void carr_step(double &x, double s)
+/* One genuine step of the carrier NCO (plutogpssim.c:2741-2746).  Returns true when a wrap fired. */
+GPSBB_HD bool carr_step(double &x, double s)
 {
     x = add_rn(x, s);
-    if (x >= 1.0)
+    if (x >= 1.0) {
         x = add_rn(x, -1.0);
-    else if (x < 0.0)
+        return true;
+    }
+    if (x < 0.0) {
         x = add_rn(x, 1.0);
+        return true;
+    }
+    return false;
 }
 
 /* Nav-message counters of one channel (plutogpssim.h:166-169) packed for the rows:
@@ -318,25 +323,31 @@ GPSBB_HD int64_t regular_run_f64(double x, double s, int64_t kcap, double &S)
 
 /*
  * build_rows() for the device pool: rows as {n0, nav, x, S} (see step_of_inc), the fast regular run first.
- * `sink.row(n0, nav, x, S)` once per row in increasing n0; `sink.nav_fetch(nav)` as in build_rows().
+ * `sink.row(n0, nav, x, S, after_wrap)` once per row in increasing n0 — after_wrap: the step that led to
+ * the row's first sample wrapped (code: the 1023 roll-over; carrier: either wrap), or the row starts at the
+ * carrier's latent 1.0 (table index 512, defined as 0): that is what decides whether a wavefront walking
+ * these samples needs the wrap-capable update; `sink.nav_fetch(nav)` as in build_rows().
  */
 template <int KIND, class Sink>
 GPSBB_HD double build_rows_f64(double x, double s, uint32_t &nav, int nsamp, Sink &sink)
 {
     const uint64_t sb = f64_bits(s);
     int64_t n = 0;
+    bool after_wrap = false;
     while (n < nsamp) {
         double S;
         int64_t k = regular_run_f64<KIND>(x, s, (int64_t)nsamp - n, S);
+        if (KIND == NCO_CARR && !(x < 1.0))
+            after_wrap = true;
         if (k >= 0) {
-            sink.row((int32_t)n, nav, x, S);
+            sink.row((int32_t)n, nav, x, S, after_wrap);
             if (k > 0)
                 x = fma_rn((double)(int32_t)k, S, x);
         } else {
             int64_t inc;
             const uint64_t xb = f64_bits(x);
             k = regular_run<KIND>(xb, sb, (int64_t)nsamp - n, inc);
-            sink.row((int32_t)n, nav, x, step_of_inc(xb, inc));
+            sink.row((int32_t)n, nav, x, step_of_inc(xb, inc), after_wrap);
             if (k > 0)
                 x = bits_f64(xb + (uint64_t)(k * inc));
         }
@@ -356,13 +367,14 @@ GPSBB_HD double build_rows_f64(double x, double s, uint32_t &nav, int nsamp, Sin
                     sink.nav_fetch(nav);
             }
         } else {
-            carr_step(x, s);
+            wrapped = carr_step(x, s);
         }
+        after_wrap = wrapped;
         n += 1;
         if (!wrapped && f64_bits(x) == before) {
             /* x + s rounds back to x and nothing wrapped: constant from here on */
             if (n < nsamp)
-                sink.row((int32_t)n, nav, x, 0.0);
+                sink.row((int32_t)n, nav, x, 0.0, false);
             break;
         }
     }

@@ -16,15 +16,20 @@ def bits(x):
     return struct.unpack("<Q", struct.pack("<d", x))[0]
 
 
-def brute_carr(x, s, n, record=None):
+def brute_carr(x, s, n, record=None, wraps=None):
+    w = 0
     for _ in range(n):
         if record is not None:
             record.append(x)
+        if wraps is not None:
+            wraps.append(w)
         x = x + s
         if x >= 1.0:
             x -= 1.0
+            w += 1
         elif x < 0.0:
             x += 1.0
+            w += 1
     return x
 
 
@@ -177,7 +182,7 @@ def rows_f64_for(pkg, kind, x0, s, nav0, nsamp):
     return rows[:cnt], xe.value, ne.value
 
 
-def check_f64_rows(pkg, kind, x0, s, nav0, nsamp, traj, nav_at=None):
+def check_f64_rows(pkg, kind, x0, s, nav0, nsamp, traj, nav_at=None, wraps_at=None):
     """The device pre-pass's builder (double arithmetic, rows {n0, nav, x, S}): same end state as the integer
     builder, row count within the bound, and, sample by sample against the brute-force trajectory,
     x + (n - n0)*S in exact rational arithmetic is the state at n (that is what one FMA returns)."""
@@ -192,7 +197,17 @@ def check_f64_rows(pkg, kind, x0, s, nav0, nsamp, traj, nav_at=None):
     assert (rf["xb"] == np.array([bits(traj[int(k)]) for k in n0], np.uint64)).all()
     if nav_at is not None:
         for r in rf:
-            assert r["nav"] == nav_at(int(r["n0"]))
+            assert (r["nav"] & 0x3fffffff) == nav_at(int(r["n0"]))
+    if wraps_at is not None:
+        # bit 30: the step that led to the row's first sample wrapped; every wrap starts a row
+        for r in rf:
+            k = int(r["n0"])
+            want = (k > 0 and wraps_at[k] != wraps_at[k - 1]) or (kind == 1 and traj[k] >= 1.0)
+            assert bool(r["nav"] & 0x40000000) == want, (kind, x0, s, k)
+        starts = set(int(k) for k in n0)
+        for k in range(1, nsamp):
+            if wraps_at[k] != wraps_at[k - 1]:
+                assert k in starts, (kind, x0, s, k)
     rng = random.Random(len(rf) * 7919 + nsamp)
     picks = set(int(v) - 1 for v in n0[1:]) | {nsamp - 1}
     picks |= set(rng.randrange(nsamp) for _ in range(300))
@@ -211,9 +226,9 @@ def test_rows_f64_builder_carrier(pkg):
         (0.25, 2.0 ** -13), (0.25, -(2.0 ** -13)), (1e-290, 1e-295), (0.6, 2.0 ** -3 - 2.0 ** -56)]
     for x0, s in cases:
         nsamp = rng.choice([1, 100, 4096, 50000])
-        rec = []
-        brute_carr(x0, s, nsamp, rec)
-        check_f64_rows(pkg, 1, x0, s, 0, nsamp, rec)
+        rec, wr = [], []
+        brute_carr(x0, s, nsamp, rec, wr)
+        check_f64_rows(pkg, 1, x0, s, 0, nsamp, rec, None, wr)
 
 
 def test_rows_f64_builder_code(pkg):
@@ -233,7 +248,7 @@ def test_rows_f64_builder_code(pkg):
             t = 3 + rec[n][1]
             c, t = t % 20, t // 20 + 7
             return c | ((t % 30) << 5) | ((20 + t // 30) << 10)
-        check_f64_rows(pkg, 0, x0, s, 3 | (7 << 5) | (20 << 10), nsamp, [v[0] for v in rec], nav_at)
+        check_f64_rows(pkg, 0, x0, s, 3 | (7 << 5) | (20 << 10), nsamp, [v[0] for v in rec], nav_at, [v[1] for v in rec])
 
 
 def test_chain_carrier_host_matches_oracle(pkg, oracle):

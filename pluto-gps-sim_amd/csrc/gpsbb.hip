@@ -609,22 +609,25 @@ struct HostRowSink {
     uint32_t dbit;
     int32_t *tr;
     size_t tstride;
-    int32_t tile_t, ntiles, wrap_tile;
+    int32_t tile_t, ntiles, wrap_pend;
 
     void row(int32_t n0, uint32_t nav, double x, double S, bool after_wrap)
     {
         const int32_t nt = (int32_t)(((int64_t)n0 + TILE - 1) / TILE);
         const int32_t lim = nt < ntiles ? nt : ntiles;
         const int32_t here = (int32_t)(cnt < cap ? cnt : cap);
-        for (; tile_t < lim; tile_t++, tr += tstride)
-            *tr = (here - 1) | (tile_t - 1 == wrap_tile ? (int32_t)0x80000000 : 0);
-        if (tile_t < ntiles && tile_t * TILE == n0) {
-            *tr = here | (tile_t - 1 == wrap_tile ? (int32_t)0x80000000 : 0);
-            tr += tstride;
-            tile_t++;
+        for (; tile_t < lim; tile_t++, tr += tstride) {
+            *tr = (here - 1) | wrap_pend;
+            wrap_pend = 0;
         }
-        if (after_wrap)
-            wrap_tile = n0 / TILE;
+        if (after_wrap) {
+            if ((n0 & (TILE - 1)) == 0 && tile_t < ntiles) {
+                *tr = here | wrap_pend;
+                tr += tstride;
+                tile_t++;
+            }
+            wrap_pend = (int32_t)0x80000000;
+        }
         if (cnt < cap) {
             SynRow r;
             r.n0 = n0;
@@ -653,8 +656,10 @@ struct HostRowSink {
     {
         if (cnt > cap)
             cnt = cap;
-        for (; tile_t <= ntiles; tile_t++, tr += tstride)
-            *tr = ((int32_t)cnt - 1) | (tile_t - 1 == wrap_tile ? (int32_t)0x80000000 : 0);
+        for (; tile_t <= ntiles; tile_t++, tr += tstride) {
+            *tr = ((int32_t)cnt - 1) | wrap_pend;
+            wrap_pend = 0;
+        }
         SynRow r;
         r.n0 = INT32_MAX;
         r.nav = 0;
@@ -701,7 +706,7 @@ bool host_seed_chain(const gpsbb_batch *b, int kind, size_t k, unsigned long lon
     sink.tstride = 2 * (size_t)b->nch;
     sink.tile_t = 0;
     sink.ntiles = b->ntiles;
-    sink.wrap_tile = -2;
+    sink.wrap_pend = 0;
     if (kind == 0) {
         const double s = mul_rn(c.f_code, b->delt);
         const double x = build_rows_f64<NCO_CODE>(c.code_phase, s, nav, b->nsamp, sink);

@@ -145,29 +145,33 @@ struct RowSink {
     size_t tstride;       /* ... and the distance to the one after */
     int32_t tile_t;       /* that tile's number */
     int32_t ntiles;
-    int32_t wrap_tile;    /* last tile in which a row that follows a wrap started (-2: none yet) */
+    int32_t wrap_pend;    /* 0x80000000 while a row that follows a wrap has started in the tile before tile_t */
 
     __device__ __forceinline__ void row(int32_t n0, uint32_t nav, double x, double S, bool after_wrap)
     {
         {
-            /* tiles that start before this row belong to the previous one, a tile that starts with it to this
-             * one.  Lanes run in lockstep, rows do not: a long row leaves several tiles to fill in at once.
-             * Entry e also carries, in bit 31, whether a row that follows a wrap started in tile e-1. */
+            /* tiles that start before this row belong to the previous one (a tile that starts with it gets its
+             * entry when the next row arrives).  Lanes run in lockstep, rows do not: a long row leaves several
+             * tiles to fill in at once.  Entry e also carries, in bit 31, whether a row that follows a wrap
+             * started in tile e-1. */
             const int32_t nt = (int32_t)(((int64_t)n0 + TILE - 1) / TILE); /* tiles that start before n0 */
             const int32_t lim = nt < ntiles ? nt : ntiles;
             const int32_t here = (int32_t)(cnt < cap ? cnt : cap);
             while (tile_t < lim) {
-                *tr = (here - 1) | (tile_t - 1 == wrap_tile ? (int32_t)0x80000000 : 0);
+                *tr = (here - 1) | wrap_pend; /* the first entry written after a wrap row is its tile's successor */
+                wrap_pend = 0;
                 tr += tstride;
                 tile_t++;
             }
-            if (tile_t < ntiles && tile_t * TILE == n0) {
-                *tr = here | (tile_t - 1 == wrap_tile ? (int32_t)0x80000000 : 0);
-                tr += tstride;
-                tile_t++;
+            if (after_wrap) {
+                if ((n0 & (TILE - 1)) == 0 && tile_t < ntiles) { /* the row opens a tile: its entry now, so
+                                                                    that the flag below goes to the next one */
+                    *tr = here | wrap_pend;
+                    tr += tstride;
+                    tile_t++;
+                }
+                wrap_pend = (int32_t)0x80000000;
             }
-            if (after_wrap)
-                wrap_tile = n0 / TILE;
         }
         if (cnt < cap) {
             SynRow r;
@@ -199,7 +203,10 @@ struct RowSink {
         if (cnt > cap)
             cnt = cap;
         for (; tile_t <= ntiles; tile_t++, tr += tstride) /* the remaining tiles and entry [ntiles] */
-            *tr = ((int32_t)cnt - 1) | (tile_t - 1 == wrap_tile ? (int32_t)0x80000000 : 0);
+        {
+            *tr = ((int32_t)cnt - 1) | wrap_pend;
+            wrap_pend = 0;
+        }
         SynRow r;
         r.n0 = INT32_MAX; /* sentinel: terminates every forward scan */
         r.nav = 0;
@@ -232,7 +239,7 @@ __device__ __forceinline__ RowSink make_sink(const BatchDev &p, int chain, const
     s.tstride = 2 * (size_t)p.nch;
     s.tile_t = 0;
     s.ntiles = p.ntiles;
-    s.wrap_tile = -2;
+    s.wrap_pend = 0;
     return s;
 }
 

@@ -452,6 +452,20 @@ __device__ __forceinline__ void dma_row(uint64_t src, WaveRows &W, int first)
     __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)(src + 20), (lptr_t)&W.s_hi[first], 4, 0, 0);
 }
 
+/* The chain that owns slot k: the number of chains whose slot range ends at or before k, i.e. the number of
+ * lanes c with incl[c] <= k.  incl is non-decreasing over the lanes, so a branch-free binary search does it
+ * in six steps, each fetching another lane's value with ds_bpermute. */
+__device__ __forceinline__ int chain_of_slot(int incl, int k)
+{
+    int lo = 0;
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1) {
+        const int t = __builtin_amdgcn_ds_bpermute((lo + step - 1) << 2, incl);
+        lo += t <= k ? step : 0;
+    }
+    return lo;
+}
+
 /* what stage_tile() tells chain lane c about the tile: its slot range in the slice; ok = 0: nothing was
  * copied because the tile has more rows than the slice holds */
 struct Staged {
@@ -460,12 +474,10 @@ struct Staged {
 
 /*
  * Start the copy of one tile's rows into the wavefront's slice.  Lane c is chain c of the block; its rows
- * trA..trB overlap the tile.  The chains' slot ranges come from a prefix sum over the lanes; slot k's chain
- * is the number of chains whose range ends at or before k.  Not inlined: it is called from every variant of
- * the channel loop (once per tile).
+ * trA..trB overlap the tile.  The chains' slot ranges come from a prefix sum over the lanes, slot k's chain
+ * from chain_of_slot().  Not inlined: it is called from every variant of the channel loop (once per tile).
  */
-__device__ __noinline__ Staged stage_tile(WaveRows &W, int lane, int nchains, bool has_chain, uint64_t row0_addr, int trA,
-                                          int trB)
+__device__ __noinline__ Staged stage_tile(WaveRows &W, int lane, bool has_chain, uint64_t row0_addr, int trA, int trB)
 {
     Staged st;
     st.cnt = has_chain ? trB - trA + 1 : 0;
@@ -477,17 +489,11 @@ __device__ __noinline__ Staged stage_tile(WaveRows &W, int lane, int nchains, bo
         return st;
     /* slot k holds row trA + (k - base) of its chain, i.e. address [row 0 + (trA - base) rows] + k rows */
     const uint64_t addr_c = row0_addr + (uint64_t)((int64_t)(trA - st.base) * (int64_t)sizeof(SynRow));
-    int ck = 0;
-    for (int c = 0; c < nchains; c++)
-        ck += __builtin_amdgcn_readlane(incl, c) <= lane;
-    const uint64_t a0 = bpermute_u64(addr_c, ck) + (uint64_t)lane * sizeof(SynRow);
+    const uint64_t a0 = bpermute_u64(addr_c, chain_of_slot(incl, lane)) + (uint64_t)lane * sizeof(SynRow);
     if (lane < R)
         dma_row(a0, W, 0);
     if (R > 64) {
-        ck = 0;
-        for (int c = 0; c < nchains; c++)
-            ck += __builtin_amdgcn_readlane(incl, c) <= lane + 64;
-        const uint64_t a1 = bpermute_u64(addr_c, ck) + (uint64_t)(lane + 64) * sizeof(SynRow);
+        const uint64_t a1 = bpermute_u64(addr_c, chain_of_slot(incl, lane + 64)) + (uint64_t)(lane + 64) * sizeof(SynRow);
         if (lane + 64 < R)
             dma_row(a1, W, 64);
     }
@@ -785,7 +791,6 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
     const int32_t *__restrict__ lane_tr = p.tile_row + tile_row_at(p, b, 0, my_chan, lane & 1);
     const size_t tstride = 2 * (size_t)p.nch; /* the 2*nch entries of one tile are contiguous: one cache line */
     const uint64_t row0_addr = (uint64_t)(uintptr_t)(p.rows + L.roff[has_chain ? 2 * my_chan + (lane & 1) : 0]);
-    const int nchains = 2 * nact;
     /* code chain lanes: a run of this channel holds at most one chip boundary (see walk_channel, CODE = 2) */
     const bool one_chip = has_chain && !(lane & 1) && L.rsc[my_chan] != 0.0;
     constexpr int TR_ROW = 0x7fffffff; /* tile index entry: row number; bit 31: a wrap in the previous tile */
@@ -811,7 +816,7 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         }
         /* slots of this chain's rows in the slice for the current tile; ovf: the tile's rows do not fit;
          * cwrap: one of the chain's rows that start in the tile follows a wrap */
-        Staged cur = stage_tile(W, lane, nchains, has_chain, row0_addr, trA & TR_ROW, trB & TR_ROW);
+        Staged cur = stage_tile(W, lane, has_chain, row0_addr, trA & TR_ROW, trB & TR_ROW);
         bool cwrap = trB < 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int slot_n0a = (int)W.a[lane].x, slot_n0b = (int)W.a[64 + lane].x;
@@ -894,7 +899,7 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         /* -- before the tile's last walk: start the copy of the next tile's rows -- */                               \
         if (--remaining == 0 && more) {                                                                                \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this tile's lookups have returned */                 \
-            nxt = stage_tile(W, lane, nchains, has_chain, row0_addr, trB & TR_ROW, trC & TR_ROW);                      \
+            nxt = stage_tile(W, lane, has_chain, row0_addr, trB & TR_ROW, trC & TR_ROW);                      \
             nwrap = trC < 0;                                                                                           \
             trA = trB;                                                                                                 \
             trB = trC;                                                                                                 \
@@ -921,7 +926,7 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
 #undef GPSBB_CHANNEL
 
             if (more && remaining == nact) { /* no active channel: nothing above ran */
-                nxt = stage_tile(W, lane, nchains, has_chain, row0_addr, trB & TR_ROW, trC & TR_ROW);
+                nxt = stage_tile(W, lane, has_chain, row0_addr, trB & TR_ROW, trC & TR_ROW);
                 nwrap = trC < 0;
                 trA = trB;
                 trB = trC;

@@ -264,8 +264,10 @@ struct gpsbb_batch {
     DevBuf<int32_t> d_tile_row[2];
     DevBuf<int32_t> d_row_cnt[2];
     DevBuf<int32_t> d_tile_ctr;
+    DevBuf<int32_t> d_seed_order; /* lane -> chain plan of k_seed (see BatchDev) */
     DevBuf<uint32_t> d_kph0; /* fixed-point carrier variant: start phase and step per (block, channel) */
     DevBuf<int32_t> d_kstep;
+    std::vector<int32_t> h_seed_order;
     std::vector<uint32_t> h_kph0;
     std::vector<int32_t> h_kstep;
     const int *fixed_prev_prn = nullptr;      /* stream chaining of the fixed-point carrier (host side) */
@@ -508,6 +510,39 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     }
     HIPCHK(h, hipMemcpyAsync(b->d_ch.p, b->h_ch.data(), nbc * sizeof(gpsbb_chan_t), hipMemcpyHostToDevice, upload_stream));
     HIPCHK(h, hipMemcpyAsync(b->d_row_off.p, b->row_off.data(), (2 * nbc + 1) * 8, hipMemcpyHostToDevice, upload_stream));
+    {
+        /* which chain each lane of k_seed walks (BatchDev::seed_order).  k_seed takes as long as its slowest
+         * wavefront: rows of its longest chain x the time of one turn of the loop, which grows with the
+         * number of lanes that are out of step.  Measured (400 x 16 chains, |f_carr| uniform up to 5 kHz):
+         * 6.3 ms in block order, 6.1 ms with the carrier chains by descending |f_carr|, 5.3 ms with the
+         * longest 16 % of them in wavefronts of 16 and the next 32 % in wavefronts of 32.  (16 chains per
+         * wavefront throughout does not help small batches: 16-block ring slots 6.0e9 vs 6.6e9 samples/s.) */
+        std::vector<int32_t> carr(nbc);
+        for (size_t k = 0; k < nbc; k++)
+            carr[k] = (int32_t)k;
+        const gpsbb_chan_t *hc = b->h_ch.data();
+        std::sort(carr.begin(), carr.end(), [hc](int32_t x, int32_t y) {
+            const double fx = hc[x].prn > 0 ? std::fabs(hc[x].f_carr) : -1.0, fy = hc[y].prn > 0 ? std::fabs(hc[y].f_carr) : -1.0;
+            return fx > fy || (fx == fy && x < y);
+        });
+        std::vector<int32_t> &order = b->h_seed_order;
+        order.clear();
+        auto waves_of = [&](const int32_t *chains, size_t n, size_t per_wave, int32_t add) {
+            for (size_t c = 0; c < n; c += per_wave)
+                for (size_t l = 0; l < 64; l++)
+                    order.push_back(l < per_wave && c + l < n ? chains[c + l] + add : -1);
+        };
+        std::vector<int32_t> code(nbc);
+        for (size_t k = 0; k < nbc; k++)
+            code[k] = (int32_t)k;
+        waves_of(code.data(), nbc, 64, 0);
+        const size_t sparse = nbc / 100, n16 = sparse * 16, n32 = sparse * 32;
+        waves_of(carr.data(), n16, 16, (int32_t)nbc);
+        waves_of(carr.data() + n16, n32, 32, (int32_t)nbc);
+        waves_of(carr.data() + n16 + n32, nbc - n16 - n32, 64, (int32_t)nbc);
+        HIPCHK(h, (hipError_t)b->d_seed_order.reserve(order.size()));
+        HIPCHK(h, hipMemcpyAsync(b->d_seed_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, upload_stream));
+    }
     b->ran = false;
     return GPSBB_OK;
 }
@@ -535,6 +570,7 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         b->d_tile_row[k].release();
         b->d_row_cnt[k].release();
         b->d_tile_ctr.release();
+        b->d_seed_order.release();
         b->d_kph0.release();
         b->d_kstep.release();
         b->d_end[k].release();
@@ -821,6 +857,8 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.end = b->d_end[set].p;
     p.status = b->h->d_status;
     p.hazards = b->h->d_hz;
+    p.seed_order = b->d_seed_order.p;
+    p.seed_lanes = (int)b->h_seed_order.size();
     return p;
 }
 
@@ -837,8 +875,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     if (!b->synth_done[set])
         HIPCHK(h, hipEventCreateWithFlags(&b->synth_done[set], hipEventDisableTiming));
     const BatchDev p = batch_dev(b, set);
-    const int cbase = ((int)nbc + 63) / 64 * 64;
-    const int lanes = cbase + (int)nbc;
+    const int lanes = (int)b->h_seed_order.size();
     if (b->ev_used == b->evs.size()) {
         if (b->evs.size() >= 4096) {
             b->ev_used = 0; /* wrap: only the most recent runs are kept */
@@ -867,7 +904,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         if (rc != GPSBB_OK)
             return rc;
     } else {
-        hipLaunchKernelGGL(k_seed, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, h->s_seed, p, cbase);
+        hipLaunchKernelGGL(k_seed, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, h->s_seed, p);
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(ev[1], h->s_seed));

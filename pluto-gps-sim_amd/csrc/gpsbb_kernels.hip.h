@@ -103,6 +103,12 @@ struct BatchDev {
     const uint32_t *kph0;           /* fixed-point carrier variant (GPSBB_FIXED_CARRIER): [nblocks*nch] 32-bit
                                        phase accumulator at the start of each block, else NULL          */
     const int32_t *kstep;           /* ... and its per-sample step (int)round(2^25*f_carr*delt), c:2675 */
+    int seed_lanes;                 /* entries of seed_order */
+    const int32_t *seed_order;      /* the chain each lane of k_seed walks: kind*nblocks*nch + block*nch + channel,
+                                       -1 = idle lane.  Planned by the host: code and carrier chains never share
+                                       a wavefront, carrier chains go by descending |f_carr| and the longest get
+                                       wavefronts with few lanes (a wavefront runs as long as its longest chain
+                                       and every extra lane adds turns of the loops its lanes do not share)   */
     uint32_t *status;               /* self-check word                                               */
     unsigned long long *hazards;    /* [0] itable_512, [1] dwrd_oob                                  */
 };
@@ -308,10 +314,9 @@ __device__ inline void seed_carr_fixed(const BatchDev &p, int b, int i)
     p.end[k].carr_phase = p.ch[k].prn > 0 ? (double)(uint32_t)(p.kph0[k] + (uint32_t)p.nsamp * (uint32_t)p.kstep[k]) : 0.0;
 }
 
-/* grid: lanes [0, nbc) = code chains; lanes [cbase, ...) = carrier chains (cbase = nbc rounded up to a
- * wave so that the two kinds of chain never share a wavefront).  Writes each chain's rows, end state and
- * row count, and — as the rows are emitted — the tile index: tile_row[t] = the row holding sample t*TILE
- * (t = 0..ntiles-1), [ntiles] = the last row. */
+/* One lane per chain as planned in seed_order.  Writes each chain's rows, end state and row count, and — as
+ * the rows are emitted — the tile index: tile_row[t] = the row holding sample t*TILE (t = 0..ntiles-1),
+ * [ntiles] = the last row. */
 #ifndef GPSBB_SEED_WG
 #define GPSBB_SEED_WG 256
 #endif
@@ -319,27 +324,29 @@ __device__ inline void seed_carr_fixed(const BatchDev &p, int b, int i)
 #define GPSBB_SEED_PRIO 3
 #endif
 /* Four wavefronts per workgroup (one per SIMD of a CU): measured best trade between the pre-pass's own
- * speed (chains sharing a SIMD slow each other by ~1/3) and how many CUs it takes away from the previous
- * run's k_synth, which it overlaps (64: step 9.39 ms, 256: 9.18 ms, 1024: 10.6 ms per 1e9 samples). */
-__global__ __launch_bounds__(GPSBB_SEED_WG) void k_seed(BatchDev p, int cbase)
+ * speed (chains sharing a SIMD slow each other by ~1/3) and how much it disturbs the previous run's k_synth,
+ * which it overlaps. */
+__global__ __launch_bounds__(GPSBB_SEED_WG) void k_seed(BatchDev p)
 {
     /* the chain walk is a long dependent instruction stream: let it issue whenever it is ready (it uses a
      * small fraction of the issue slots, so the co-resident synthesis wavefronts hardly notice) */
     __builtin_amdgcn_s_setprio(GPSBB_SEED_PRIO);
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= p.seed_lanes)
+        return;
+    const int c = p.seed_order[gid];
+    if (c < 0)
+        return;
     const int nbc = p.nblocks * p.nch;
-    if (gid < nbc) {
-        const ChainDone d = seed_code_chain(p, gid / p.nch, gid % p.nch);
-        p.row_cnt[chain_code(p, gid / p.nch, gid % p.nch)] = d.cnt;
+    if (c < nbc) {
+        const ChainDone d = seed_code_chain(p, c / p.nch, c % p.nch);
+        p.row_cnt[chain_code(p, c / p.nch, c % p.nch)] = d.cnt;
         return;
     }
-    const int g = gid - cbase;
-    if (g < 0 || g >= nbc)
-        return;
     /* carrier chains: every block starts from its descriptor's carr_phase.  Blocks that continue each
      * other (GPSBB_CHAIN_CARRIER) had their start phases resolved exactly on the host when the batch was
      * set up, so all chains are independent here. */
-    const int b = g / p.nch, i = g % p.nch;
+    const int g = c - nbc, b = g / p.nch, i = g % p.nch;
     if (p.kph0) {
         seed_carr_fixed(p, b, i);
         return;

@@ -864,7 +864,7 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
 #define GPSBB_CHANNEL(CODE, CARR, MASK)                                                                                \
     for (uint64_t m_ = (MASK); m_; m_ &= m_ - 1) {                                                                     \
         const int a = (int)(__builtin_ctzll(m_) >> 1);                                                                 \
-        const int i = L.act[a];                                                                                        \
+        const int i = __builtin_amdgcn_readfirstlane(L.act[a]); /* scalar: the table addresses become SALU work */    \
         /* -- where this lane's run starts in the two chains of channel i -- */                                       \
         int sb_c = 0, sb_k = 0;                                                                                        \
         const int sc_c = __builtin_amdgcn_readlane(ccnt, 2 * a), sc_k = __builtin_amdgcn_readlane(ccnt, 2 * a + 1);    \

@@ -408,12 +408,12 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     if ((e = hipMalloc((void **)&h->d_tabs, sizeof tabs)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&h->d_ca, ca.size() * 4)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&h->d_status, 4)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void **)&h->d_hz, 16 + 128)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&h->d_hz, 16)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h->d_tabs, tabs, sizeof tabs, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h->d_ca, ca.data(), ca.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     h->h_ca = ca;
     if ((e = hipMemset(h->d_status, 0, 4)) != hipSuccess) return fail(e);
-    if ((e = hipMemset(h->d_hz, 0, 16 + 128)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(h->d_hz, 0, 16)) != hipSuccess) return fail(e);
     /* k_synth carves ~76 KB of dynamic LDS per workgroup: above the 64 KB default limit */
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(SynthLds))) != hipSuccess) return fail(e);
@@ -614,17 +614,6 @@ extern "C" int gpsbb_batch_create(gpsbb_t *h, const gpsbb_chan_t *ch, int nblock
 extern "C" size_t gpsbb_batch_iq_bytes(const gpsbb_batch_t *b)
 {
     return b ? (size_t)b->nblocks * (size_t)b->nsamp * 4 : 0;
-}
-
-/* measurement only (builds with -DGPSBB_PROF): k_synth's section timers, wall cycles summed over wavefronts */
-extern "C" int gpsbb_test_read_prof(gpsbb_t *h, unsigned long long out[16], int reset)
-{
-    if (!h || hipSetDevice(h->device) != hipSuccess ||
-        hipMemcpy(out, h->d_hz + 2, 128, hipMemcpyDeviceToHost) != hipSuccess)
-        return -1;
-    if (reset && hipMemset(h->d_hz + 2, 0, 128) != hipSuccess)
-        return -1;
-    return 0;
 }
 
 /* ---- seeding on the host --------------------------------------------------------------------------

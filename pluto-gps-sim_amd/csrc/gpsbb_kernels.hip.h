@@ -699,35 +699,8 @@ __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc
     }
 }
 
-#ifdef GPSBB_PROF
-/* section timers (tools/prof_sections.py): wall cycles per wavefront between marks, summed into hazards[2+k] */
-#define PROF_DECL                                                                                                  \
-    unsigned long long prof_t0 = __builtin_readcyclecounter(), prof_tp = prof_t0,                                  \
-                       prof_s[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define PROF_MARK(k)                                                  \
-    do {                                                              \
-        __builtin_amdgcn_sched_barrier(0);                            \
-        const unsigned long long t_ = __builtin_readcyclecounter();   \
-        prof_s[k] += t_ - prof_tp;                                    \
-        prof_tp = t_;                                                 \
-        __builtin_amdgcn_sched_barrier(0);                            \
-    } while (0)
-#define PROF_FLUSH                                                    \
-    do {                                                              \
-        prof_s[15] = __builtin_readcyclecounter() - prof_t0;          \
-        if ((threadIdx.x & 63) == 0)                                  \
-            for (int k_ = 0; k_ < 16; k_++)                           \
-                atomicAdd(p.hazards + 2 + k_, prof_s[k_]);            \
-    } while (0)
-#else
-#define PROF_DECL
-#define PROF_MARK(k)
-#define PROF_FLUSH
-#endif
-
 __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(BatchDev p, int16_t *__restrict__ iq)
 {
-    PROF_DECL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     SynthLds &L = *reinterpret_cast<SynthLds *>(smem_raw);
 
@@ -785,7 +758,6 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
     }
     __syncthreads();
     const int nact = L.nact;
-    PROF_MARK(0);
 
     /* ---- from here on every wavefront works alone: chunks of consecutive tiles, no workgroup barrier ---- */
     const int wave = tid >> 6, lane = tid & 63;
@@ -827,7 +799,6 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         bool cwrap = trB < 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int slot_n0a = (int)W.a[lane].x, slot_n0b = (int)W.a[64 + lane].x;
-        PROF_MARK(1);
 
         for (int wt = wt_begin; wt < wt_end; wt++) {
             const bool more = wt + 1 < wt_end;
@@ -843,10 +814,6 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
 #pragma unroll
             for (int j = 0; j < SPT; j++)
                 acc[j] = v2s{0, 0};
-#ifdef GPSBB_PROF
-            prof_s[10]++;
-            prof_s[11] += ovf;
-#endif
 
             /* Which walk each channel needs follows from its two chains' rows alone: no row starts inside the
              * tile -> no wrap (and, for the code, the one-boundary walk where it applies); a row that follows a
@@ -902,7 +869,6 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
             const uint64_t tile_addr = row0_addr + (uint64_t)(trA & TR_ROW) * sizeof(SynRow);                          \
             yk = row_state_global((const SynRow *)(uintptr_t)readlane_u64(tile_addr, 2 * a + 1), n0, &nav_unused);     \
         }                                                                                                              \
-        PROF_MARK(2);                                                                                                  \
         /* -- before the tile's last walk: start the copy of the next tile's rows -- */                               \
         if (--remaining == 0 && more) {                                                                                \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this tile's lookups have returned */                 \
@@ -912,10 +878,8 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
             trB = trC;                                                                                                 \
             if (has_chain && wt + 3 <= ntw)                                                                            \
                 trC = lane_tr[(wt + 3) * tstride];                                                                     \
-            PROF_MARK(3);                                                                                              \
         }                                                                                                              \
         walk_channel<CODE, CARR>(L, i, xc, Sc, yk, ph, kstep, nav, dbx, acc, nvalid, hz_itable);                       \
-        PROF_MARK(4);                                                                                                  \
     }
 
             if (fixed_carr) {
@@ -949,7 +913,6 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                 cur = nxt;
                 cwrap = nwrap;
             }
-            PROF_MARK(5);
             if (hz_itable)
                 atomicAdd(p.hazards, hz_itable);
 
@@ -966,10 +929,8 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                     if (j < nvalid)
                         out[j] = v2s_u32(acc[j]);
             }
-            PROF_MARK(6);
         }
     } /* chunk loop */
-    PROF_FLUSH;
 }
 
 /* pure write stream of the same shape as k_synth's output: the empirical int16x2 write ceiling */

@@ -31,8 +31,6 @@ void gpsbb_test_seed_mode(int mode);
 /* measurement only: after the first two runs of a batch (both table sets built) skip k_seed, so that
  * k_synth can be timed alone on unchanged tables */
 void gpsbb_test_skip_seed(int on);
-struct gpsbb;
-int gpsbb_test_read_prof(struct gpsbb *h, unsigned long long out[16], int reset);
 unsigned long long gpsbb_test_row_bound(int kind, double s_abs, int nsamp);
 
 #ifdef __cplusplus

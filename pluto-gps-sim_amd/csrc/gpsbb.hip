@@ -209,7 +209,7 @@ struct gpsbb {
     hipStream_t s_compute = nullptr; /* synthesis kernel (k_synth)                                      */
     hipStream_t s_copy = nullptr;    /* device-to-host gather                                            */
     std::vector<uint32_t> h_ca;      /* host copy of the C/A chips (seeding of small batches on the host)  */
-    unsigned long long host_dwrd_oob = 0; /* hazards counted by host-side seeding                         */
+    unsigned long long host_dwrd_oob = 0, host_itable_512 = 0; /* hazards counted by host-side seeding      */
     WorkPool *pool = nullptr;        /* host threads for seeding small batches (created on first use)      */
     int32_t *d_tabs = nullptr;
     uint32_t *d_ca = nullptr;
@@ -629,7 +629,7 @@ struct HostRowSink {
     SynRow *rows;
     uint32_t cap, cnt;
     bool overflow;
-    unsigned long long dwrd_oob;
+    unsigned long long dwrd_oob, itable_512;
     const uint32_t *dwrd;
     uint32_t dbit;
     int32_t *tr;
@@ -671,6 +671,7 @@ struct HostRowSink {
         }
         cnt++;
     }
+    void table_index_512() { itable_512++; }
     void nav_fetch(uint32_t nav)
     {
         if (nav_iword(nav) >= GPSBB_N_DWRD)
@@ -696,7 +697,7 @@ struct HostRowSink {
 
 /* one chain (kind 0 = code, 1 = carrier) of channel k = block*nch + i: what seed_code_chain /
  * seed_carr_chain / seed_carr_fixed do on the device.  Returns false on a row-pool overflow. */
-bool host_seed_chain(const gpsbb_batch *b, int kind, size_t k, unsigned long long *dwrd_oob)
+bool host_seed_chain(const gpsbb_batch *b, int kind, size_t k, unsigned long long *dwrd_oob, unsigned long long *itable_512)
 {
     const gpsbb_chan_t &c = b->h_ch[k];
     gpsbb_chan_state_t &e = b->hs_end[k];
@@ -723,6 +724,7 @@ bool host_seed_chain(const gpsbb_batch *b, int kind, size_t k, unsigned long lon
     sink.cnt = 0;
     sink.overflow = false;
     sink.dwrd_oob = 0;
+    sink.itable_512 = 0;
     sink.dwrd = kind == 0 ? c.dwrd : nullptr;
     uint32_t nav = kind == 0 ? nav_pack(c.icode, c.ibit, c.iword) : 0u;
     sink.dbit = kind == 0 && nav_bit(c.dwrd, nav) < 0 ? 0x80000000u : 0u;
@@ -750,6 +752,7 @@ bool host_seed_chain(const gpsbb_batch *b, int kind, size_t k, unsigned long lon
         sink.finish();
     }
     *dwrd_oob += sink.dwrd_oob;
+    *itable_512 += sink.itable_512;
     return !sink.overflow;
 }
 
@@ -802,16 +805,17 @@ static int host_seed_run(gpsbb_batch *b, int set, hipStream_t stream)
             return GPSBB_E_NOMEM;
     }
     const size_t nthr = nchains; /* one slot of results per job */
-    std::vector<unsigned long long> oob(nthr, 0ull);
+    std::vector<unsigned long long> oob(nthr, 0ull), i512(nthr, 0ull);
     std::vector<char> ok(nthr, 1);
     /* carrier chains first: they are the long ones */
     h->pool->run(nchains, [&](size_t j) {
         const int kind = j < nbc ? 1 : 0;
-        if (!host_seed_chain(b, kind, j < nbc ? j : j - nbc, &oob[j]))
+        if (!host_seed_chain(b, kind, j < nbc ? j : j - nbc, &oob[j], &i512[j]))
             ok[j] = 0;
     });
     for (size_t t = 0; t < nthr; t++) {
         h->host_dwrd_oob += oob[t];
+        h->host_itable_512 += i512[t];
         if (!ok[t])
             return GPSBB_E_INTERNAL;
     }
@@ -984,10 +988,12 @@ extern "C" int gpsbb_get_hazards(gpsbb_t *h, gpsbb_hazards_t *out, int reset)
     unsigned long long v[2];
     HIPCHK(h, hipMemcpy(v, h->d_hz, 16, hipMemcpyDeviceToHost));
     out->itable_512 = v[0];
+    out->itable_512 += h->host_itable_512;
     out->dwrd_oob = v[1] + h->host_dwrd_oob;
     if (reset) {
         HIPCHK(h, hipMemset(h->d_hz, 0, 16));
         h->host_dwrd_oob = 0;
+        h->host_itable_512 = 0;
     }
     return GPSBB_OK;
 }
@@ -1430,6 +1436,7 @@ struct HostSinkF64 {
         cnt++;
     }
     void nav_fetch(uint32_t) {}
+    void table_index_512() {}
 };
 } /* namespace */
 

@@ -197,6 +197,8 @@ struct RowSink {
         }
         cnt++;
     }
+    /* a sample whose carrier phase is exactly 1.0: table index 512, one past the reference's tables */
+    __device__ __forceinline__ void table_index_512() { atomicAdd(hz, 1ull); }
     /* a data-bit boundary (c:2717-2733): the rows from here on carry the new bit */
     __device__ __forceinline__ void nav_fetch(uint32_t nav)
     {
@@ -580,7 +582,7 @@ struct RunNav {
 template <int CODE, int CARR>
 __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc, double sk, double &xc, double &yk,
                                              uint32_t &ph, uint32_t kstep, RunNav &rn, int (&it)[WALK_G],
-                                             int (&ci)[WALK_G], int jbase, int nvalid, unsigned long long &hz_itable)
+                                             int (&ci)[WALK_G], int jbase, uint32_t wlim, int wadj)
 {
     constexpr bool CARRW = CARR == 1;
 #pragma unroll
@@ -591,11 +593,9 @@ __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc
         } else {
             it[u] = (int)yk; /* floor(carr_phase*512), c:2697 (yk = carr_phase*512 >= 0) */
         }
-        if (CARRW && it[u] > 511) { /* carr_phase == 1.0: latent OOB of the reference, defined as &511 */
-            it[u] &= 511;
-            if (jbase + u < nvalid)
-                hz_itable++;
-        }
+        if (CARRW)
+            it[u] &= 511; /* carr_phase == 1.0: latent OOB of the reference, defined as &511 (counted where the
+                             rows are built: such a state is always the first sample of a row) */
         if (CODE != 2) {
             ci[u] = (int)xc;     /* c:2737 */
             xc = add_rn(xc, sc); /* c:2709 */
@@ -613,9 +613,11 @@ __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc
             }
         }
         if (CARRW) {
-            const int h = __double2hiint(yk);
-            const int adj = h >= 0x40800000 ? (int)0xC0800000 : (h < 0 ? 0x40800000 : 0); /* -512 / +512 / 0 */
-            yk = add_rn(yk, hi_lo_f64(adj, 0)); /* c:2743-2746; adding +0.0 is exact */
+            /* c:2743-2746.  Only one of the two wraps can fire for a given sign of the step, so one unsigned
+             * compare of the high dword does it: step >= 0: yk >= 512.0 (wlim 0x40800000, then -512);
+             * step < 0: yk < 0 (sign bit set, wlim 0x80000000, then +512).  Adding +0.0 is exact. */
+            const uint32_t h = (uint32_t)__double2hiint(yk);
+            yk = add_rn(yk, hi_lo_f64(h >= wlim ? wadj : 0, 0));
         }
     }
 }
@@ -638,11 +640,14 @@ __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc
  */
 template <int CODE, int CARR>
 __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc, double Sc, double yk, uint32_t ph,
-                                             uint32_t kstep, uint32_t nav, int dbx0, v2s (&acc)[SPT], int nvalid,
-                                             unsigned long long &hz_itable)
+                                             uint32_t kstep, uint32_t nav, int dbx0, v2s (&acc)[SPT])
 {
     constexpr int G = WALK_G;
     const double sc = L.sc[i], sk = L.sk512[i];
+    /* wrap-capable carrier update: which wrap the sign of the step allows (wave-uniform) */
+    const bool down = __builtin_amdgcn_readfirstlane(__double2hiint(sk)) < 0;
+    const uint32_t wlim = down ? 0x80000000u : 0x40800000u;
+    const int wadj = down ? 0x40800000 : (int)0xC0800000;
     const uint32_t *__restrict__ amp = L.amp[i];
     const int8_t *__restrict__ chip = L.chip[i];
     /* codeCA*dataBit: chip sign (+1/-1) XOR-ed with 0xfffe when dataBit = -1 flips +-1 in 16 bits */
@@ -666,7 +671,7 @@ __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc
         asm volatile("" : "+v"(sg_a), "+v"(sg_b));
     }
     int it[G], ci[G];
-    walk_indices<CODE, CARR>(L, i, sc, sk, xc, yk, ph, kstep, rn, it, ci, 0, nvalid, hz_itable);
+    walk_indices<CODE, CARR>(L, i, sc, sk, xc, yk, ph, kstep, rn, it, ci, 0, wlim, wadj);
 #pragma unroll
     for (int j0 = 0; j0 < SPT; j0 += G) {
         __builtin_amdgcn_sched_barrier(0);
@@ -682,7 +687,7 @@ __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc
         __builtin_amdgcn_sched_barrier(0);
         /* phase 1 of the next group while the reads are in flight */
         if (j0 + G < SPT)
-            walk_indices<CODE, CARR>(L, i, sc, sk, xc, yk, ph, kstep, rn, it, ci, j0 + G, nvalid, hz_itable);
+            walk_indices<CODE, CARR>(L, i, sc, sk, xc, yk, ph, kstep, rn, it, ci, j0 + G, wlim, wadj);
         __builtin_amdgcn_sched_barrier(0);
         /* phase 3: acc += amp * (codeCA*dataBit), packed int16x2 (c:2701-2706) */
 #pragma unroll
@@ -809,7 +814,6 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
             const bool ovf = !cur.ok;
             Staged nxt = {0, 0, 1};
             bool nwrap = false;
-            unsigned long long hz_itable = 0;
             v2s acc[SPT];
 #pragma unroll
             for (int j = 0; j < SPT; j++)
@@ -879,7 +883,7 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
             if (has_chain && wt + 3 <= ntw)                                                                            \
                 trC = lane_tr[(wt + 3) * tstride];                                                                     \
         }                                                                                                              \
-        walk_channel<CODE, CARR>(L, i, xc, Sc, yk, ph, kstep, nav, dbx, acc, nvalid, hz_itable);                       \
+        walk_channel<CODE, CARR>(L, i, xc, Sc, yk, ph, kstep, nav, dbx, acc);                                          \
     }
 
             if (fixed_carr) {
@@ -913,8 +917,6 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                 cur = nxt;
                 cwrap = nwrap;
             }
-            if (hz_itable)
-                atomicAdd(p.hazards, hz_itable);
 
             /* ---- store: int16 I,Q interleaved (c:2754-2755) ---- */
             uint32_t *out = reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + n0;

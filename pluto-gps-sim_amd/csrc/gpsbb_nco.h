@@ -326,7 +326,8 @@ GPSBB_HD int64_t regular_run_f64(double x, double s, int64_t kcap, double &S)
  * `sink.row(n0, nav, x, S, after_wrap)` once per row in increasing n0 — after_wrap: the step that led to
  * the row's first sample wrapped (code: the 1023 roll-over; carrier: either wrap), or the row starts at the
  * carrier's latent 1.0 (table index 512, defined as 0): that is what decides whether a wavefront walking
- * these samples needs the wrap-capable update; `sink.nav_fetch(nav)` as in build_rows().
+ * these samples needs the wrap-capable update; `sink.table_index_512()` for every sample whose carrier phase
+ * is exactly 1.0 (always the first sample of a row); `sink.nav_fetch(nav)` as in build_rows().
  */
 template <int KIND, class Sink>
 GPSBB_HD double build_rows_f64(double x, double s, uint32_t &nav, int nsamp, Sink &sink)
@@ -337,8 +338,10 @@ GPSBB_HD double build_rows_f64(double x, double s, uint32_t &nav, int nsamp, Sin
     while (n < nsamp) {
         double S;
         int64_t k = regular_run_f64<KIND>(x, s, (int64_t)nsamp - n, S);
-        if (KIND == NCO_CARR && !(x < 1.0))
+        if (KIND == NCO_CARR && !(x < 1.0)) {
             after_wrap = true;
+            sink.table_index_512(); /* the reference's latent out-of-bounds table read, c:2697-2702 */
+        }
         if (k >= 0) {
             sink.row((int32_t)n, nav, x, S, after_wrap);
             if (k > 0)

@@ -603,14 +603,11 @@ __device__ __forceinline__ void walk_indices(const SynthLds &L, int i, double sc
         if (CARR != 2)
             yk = add_rn(yk, sk); /* c:2741, scaled by 512 */
         if (CODE == 1) {
-            if (__double2hiint(xc) >= 0x408FF800) { /* xc >= 1023.0 (xc >= 0) */
-                xc = add_rn(xc, -1023.0);
-                rn.nav = nav_advance(rn.nav);
-                if (nav_icode(rn.nav) == 0) { /* c:2717-2733: new data bit from the next sample on */
-                    rn.dbx1 = nav_bit(L.dwrd[i], rn.nav) < 0 ? 0xfffe : 0;
-                    rn.jw = jbase + u + 1;
-                }
-            }
+            /* c:2711-2734 without a branch: a run holds at most one roll-over (a period is >= 666 samples), the
+             * data bit that follows it (rn.dbx1) was looked up before the walk; here only where it happens */
+            const bool w = __double2hiint(xc) >= 0x408FF800; /* xc >= 1023.0 (xc >= 0) */
+            xc = add_rn(xc, hi_lo_f64(w ? (int)0xC08FF800 : 0, 0)); /* -1023.0 or +0.0 */
+            rn.jw = w ? jbase + u + 1 : rn.jw;
         }
         if (CARRW) {
             /* c:2743-2746.  Only one of the two wraps can fire for a given sign of the step, so one unsigned
@@ -655,6 +652,11 @@ __device__ __forceinline__ void walk_channel(const SynthLds &L, int i, double xc
     rn.nav = nav;
     rn.dbx0 = rn.dbx1 = dbx0;
     rn.jw = SPT;
+    if (CODE == 1) {
+        const uint32_t nav1 = nav_advance(nav); /* counters after the run's one possible roll-over */
+        if (nav_icode(nav1) == 0)               /* c:2717-2733: a new data bit from the next sample on */
+            rn.dbx1 = nav_bit(L.dwrd[i], nav1) < 0 ? 0xfffe : 0;
+    }
     int jc = 0;
     int sg_a = 0, sg_b = 0;
     if (CODE == 2) {

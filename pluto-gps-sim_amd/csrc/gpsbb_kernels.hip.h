@@ -531,6 +531,15 @@ __device__ __noinline__ SlotN0 stage_channel(WaveRows &W, int lane, uint64_t ac,
     return r;
 }
 
+/* ... and the same copy into one half of the slice (slots first .. first+63, nc + nk <= 64) without waiting:
+ * in such tiles the next channel's rows are fetched while the current channel is walked */
+__device__ __noinline__ void prefetch_channel(WaveRows &W, int lane, uint64_t ac, uint64_t ak, int nc, int nk, int first)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* lookups in this half are done */
+    if (lane < nc + nk)
+        dma_row(lane < nc ? ac + (uint64_t)lane * sizeof(SynRow) : ak + (uint64_t)(lane - nc) * sizeof(SynRow), W, first);
+}
+
 /*
  * State of one chain at sample n (this lane's first sample).  The chain's rows sit in slots
  * sbase .. sbase+scnt-1 and their first samples in slot_n0a / slot_n0b (lane k = slot k / 64+k): the
@@ -833,36 +842,29 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
             const uint64_t m_k1 = __ballot(has_chain && (lane & 1) && cwrap) >> 1; /* on the channel's even bit */
             int remaining = nact;
 
-            /* one channel with walk variant <CODE, CARR>; `a` = its index among the active channels */
-#define GPSBB_CHANNEL(CODE, CARR, MASK)                                                                                \
-    for (uint64_t m_ = (MASK); m_; m_ &= m_ - 1) {                                                                     \
-        const int a = (int)(__builtin_ctzll(m_) >> 1);                                                                 \
-        const int i = __builtin_amdgcn_readfirstlane(L.act[a]); /* scalar: the table addresses become SALU work */    \
-        /* -- where this lane's run starts in the two chains of channel i -- */                                       \
-        int sb_c = 0, sb_k = 0;                                                                                        \
-        const int sc_c = __builtin_amdgcn_readlane(ccnt, 2 * a), sc_k = __builtin_amdgcn_readlane(ccnt, 2 * a + 1);    \
-        bool glob = false;                                                                                             \
-        if (!ovf) {                                                                                                    \
-            sb_c = __builtin_amdgcn_readlane(cbase, 2 * a);                                                            \
-            sb_k = __builtin_amdgcn_readlane(cbase, 2 * a + 1);                                                        \
-        } else if (sc_c + sc_k <= WAVE_ROW_CAP) {                                                                      \
-            const uint64_t tile_addr = row0_addr + (uint64_t)(trA & TR_ROW) * sizeof(SynRow);                          \
-            const SlotN0 sn = stage_channel(W, lane, readlane_u64(tile_addr, 2 * a), readlane_u64(tile_addr, 2 * a + 1), \
-                                            sc_c, sc_k);                                                               \
-            slot_n0a = sn.a;                                                                                           \
-            slot_n0b = sn.b;                                                                                           \
-            sb_k = sc_c;                                                                                               \
-        } else {                                                                                                       \
-            glob = true; /* last resort: every lane scans the pool in HBM */                                           \
-        }                                                                                                              \
+            /* one channel: its start states from the rows in the slice (sb_* / sc_*: first slot and number of
+             * rows of its code / carrier chain), then the walk */
+#define GPSBB_STAGE_NEXT_TILE                                                                                          \
+    {                                                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this tile's lookups have returned */                     \
+        nxt = stage_tile(W, lane, has_chain, row0_addr, trB & TR_ROW, trC & TR_ROW);                                   \
+        nwrap = trC < 0;                                                                                               \
+        trA = trB;                                                                                                     \
+        trB = trC;                                                                                                     \
+        if (has_chain && wt + 3 <= ntw)                                                                                \
+            trC = lane_tr[(wt + 3) * tstride];                                                                         \
+    }
+            /* BEFORE_WALK: what to start between the lookups and the walk (the next copy into the slice) */
+#define GPSBB_LOOKUP_AND_WALK(CODE, CARR, BEFORE_WALK)                                                                 \
+    {                                                                                                                  \
         uint32_t nav_raw, nav_unused;                                                                                  \
         double xc, Sc = 0.0, S_unused, yk = 0.0;                                                                       \
         uint32_t ph = 0, kstep = 0;                                                                                    \
         if (!glob) {                                                                                                   \
             xc = chain_state(W, sb_c, sc_c, slot_n0a, slot_n0b, n0, &nav_raw, &Sc);                                    \
         } else {                                                                                                       \
-            const uint64_t tile_addr = row0_addr + (uint64_t)(trA & TR_ROW) * sizeof(SynRow);                          \
-            xc = row_state_global((const SynRow *)(uintptr_t)readlane_u64(tile_addr, 2 * a), n0, &nav_raw);            \
+            const uint64_t ta_ = row0_addr + (uint64_t)(trA & TR_ROW) * sizeof(SynRow);                                \
+            xc = row_state_global((const SynRow *)(uintptr_t)readlane_u64(ta_, 2 * a), n0, &nav_raw);                  \
         }                                                                                                              \
         const int dbx = (nav_raw >> 31) ? 0xfffe : 0; /* dataBit -1: flips the chip's +-1 in 16 bits */               \
         const uint32_t nav = nav_raw & 0x3fffffffu;                                                                    \
@@ -872,23 +874,81 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         } else if (!glob) {                                                                                            \
             yk = chain_state(W, sb_k, sc_k, slot_n0a, slot_n0b, n0, &nav_unused, &S_unused);                           \
         } else {                                                                                                       \
-            const uint64_t tile_addr = row0_addr + (uint64_t)(trA & TR_ROW) * sizeof(SynRow);                          \
-            yk = row_state_global((const SynRow *)(uintptr_t)readlane_u64(tile_addr, 2 * a + 1), n0, &nav_unused);     \
+            const uint64_t ta_ = row0_addr + (uint64_t)(trA & TR_ROW) * sizeof(SynRow);                                \
+            yk = row_state_global((const SynRow *)(uintptr_t)readlane_u64(ta_, 2 * a + 1), n0, &nav_unused);           \
         }                                                                                                              \
-        /* -- before the tile's last walk: start the copy of the next tile's rows -- */                               \
-        if (--remaining == 0 && more) {                                                                                \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this tile's lookups have returned */                 \
-            nxt = stage_tile(W, lane, has_chain, row0_addr, trB & TR_ROW, trC & TR_ROW);                      \
-            nwrap = trC < 0;                                                                                           \
-            trA = trB;                                                                                                 \
-            trB = trC;                                                                                                 \
-            if (has_chain && wt + 3 <= ntw)                                                                            \
-                trC = lane_tr[(wt + 3) * tstride];                                                                     \
-        }                                                                                                              \
+        BEFORE_WALK                                                                                                    \
         walk_channel<CODE, CARR>(L, i, xc, Sc, yk, ph, kstep, nav, dbx, acc);                                          \
     }
 
-            if (fixed_carr) {
+            /* the channels of one walk variant (bit 2a of MASK = active channel a), rows of the whole tile staged */
+#define GPSBB_CHANNEL(CODE, CARR, MASK)                                                                                \
+    for (uint64_t m_ = (MASK); m_; m_ &= m_ - 1) {                                                                     \
+        const int a = (int)(__builtin_ctzll(m_) >> 1);                                                                 \
+        const int i = __builtin_amdgcn_readfirstlane(L.act[a]); /* scalar: the table addresses become SALU work */    \
+        const int sc_c = __builtin_amdgcn_readlane(ccnt, 2 * a), sc_k = __builtin_amdgcn_readlane(ccnt, 2 * a + 1);    \
+        const int sb_c = __builtin_amdgcn_readlane(cbase, 2 * a), sb_k = __builtin_amdgcn_readlane(cbase, 2 * a + 1);  \
+        constexpr bool glob = false;                                                                                   \
+        --remaining;                                                                                                   \
+        /* before the tile's last walk: start the copy of the next tile's rows */                                     \
+        GPSBB_LOOKUP_AND_WALK(CODE, CARR, if (remaining == 0 && more) GPSBB_STAGE_NEXT_TILE)                           \
+    }
+
+            /* A tile whose rows do not fit the slice (dense rows: high Doppler at a low sample rate, wraps in
+             * nearly every tile): channel by channel, wrap-capable walks throughout; the rows of channel a+1 are
+             * copied into the other half of the slice while channel a is walked.  A channel with more than 64
+             * rows takes the whole slice and waits; with more than the slice holds, lanes scan the pool in HBM. */
+#define GPSBB_DENSE_TILE(CARR)                                                                                         \
+    {                                                                                                                  \
+        const uint64_t tile_addr = row0_addr + (uint64_t)(trA & TR_ROW) * sizeof(SynRow);                              \
+        int nc = __builtin_amdgcn_readlane(ccnt, 0), nk = __builtin_amdgcn_readlane(ccnt, 1);                          \
+        bool half_ok = nact > 0 && nc + nk <= 64;                                                                      \
+        if (half_ok)                                                                                                   \
+            prefetch_channel(W, lane, readlane_u64(tile_addr, 0), readlane_u64(tile_addr, 1), nc, nk, 0);              \
+        for (int a = 0; a < nact; a++) {                                                                               \
+            const int i = __builtin_amdgcn_readfirstlane(L.act[a]);                                                    \
+            const int sc_c = nc, sc_k = nk;                                                                            \
+            int sb_c = 0, sb_k = sc_c;                                                                                 \
+            bool glob = false;                                                                                         \
+            if (half_ok) {                                                                                             \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+                if (a & 1)                                                                                             \
+                    slot_n0b = (int)W.a[64 + lane].x;                                                                  \
+                else                                                                                                   \
+                    slot_n0a = (int)W.a[lane].x;                                                                       \
+                sb_c = 64 * (a & 1);                                                                                   \
+                sb_k = sb_c + sc_c;                                                                                    \
+            } else if (sc_c + sc_k <= WAVE_ROW_CAP) {                                                                  \
+                const SlotN0 sn = stage_channel(W, lane, readlane_u64(tile_addr, 2 * a), readlane_u64(tile_addr, 2 * a + 1), \
+                                                sc_c, sc_k);                                                           \
+                slot_n0a = sn.a;                                                                                       \
+                slot_n0b = sn.b;                                                                                       \
+            } else {                                                                                                   \
+                glob = true;                                                                                           \
+            }                                                                                                          \
+            const bool last = a + 1 == nact;                                                                           \
+            if (!last) {                                                                                               \
+                nc = __builtin_amdgcn_readlane(ccnt, 2 * a + 2);                                                       \
+                nk = __builtin_amdgcn_readlane(ccnt, 2 * a + 3);                                                       \
+            }                                                                                                          \
+            /* between this channel's lookups and its walk: the next channel's rows, or the next tile's */           \
+            GPSBB_LOOKUP_AND_WALK(                                                                                     \
+                1, CARR, if (!last) {                                                                                  \
+                    half_ok = nc + nk <= 64;                                                                           \
+                    if (half_ok)                                                                                       \
+                        prefetch_channel(W, lane, readlane_u64(tile_addr, 2 * a + 2), readlane_u64(tile_addr, 2 * a + 3), \
+                                         nc, nk, 64 * ((a + 1) & 1));                                                  \
+                } else if (more) GPSBB_STAGE_NEXT_TILE)                                                                \
+        }                                                                                                              \
+        remaining = 0;                                                                                                 \
+    }
+
+            if (ovf) {
+                if (fixed_carr)
+                    GPSBB_DENSE_TILE(2)
+                else
+                    GPSBB_DENSE_TILE(1)
+            } else if (fixed_carr) {
                 GPSBB_CHANNEL(2, 2, m_c2)
                 GPSBB_CHANNEL(0, 2, m_c0)
                 GPSBB_CHANNEL(1, 2, m_c1)
@@ -900,16 +960,12 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
                 GPSBB_CHANNEL(1, 0, m_c1 & ~m_k1)
                 GPSBB_CHANNEL(1, 1, m_c1 & m_k1)
             }
+            if (more && nact == 0) /* no active channel: nothing above ran */
+                GPSBB_STAGE_NEXT_TILE
 #undef GPSBB_CHANNEL
-
-            if (more && remaining == nact) { /* no active channel: nothing above ran */
-                nxt = stage_tile(W, lane, has_chain, row0_addr, trB & TR_ROW, trC & TR_ROW);
-                nwrap = trC < 0;
-                trA = trB;
-                trB = trC;
-                if (has_chain && wt + 3 <= ntw)
-                    trC = lane_tr[(wt + 3) * tstride];
-            }
+#undef GPSBB_DENSE_TILE
+#undef GPSBB_LOOKUP_AND_WALK
+#undef GPSBB_STAGE_NEXT_TILE
             if (more) {
                 /* the next tile's rows have had the last walk to arrive; waiting here, before this tile's
                  * stores are issued, keeps the wait from covering the stores as well */

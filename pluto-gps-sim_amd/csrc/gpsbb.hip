@@ -515,8 +515,8 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
          * wavefront: rows of its longest chain x the time of one turn of the loop, which grows with the
          * number of lanes that are out of step.  Measured (400 x 16 chains, |f_carr| uniform up to 5 kHz):
          * 6.3 ms in block order, 6.1 ms with the carrier chains by descending |f_carr|, 5.3 ms with the
-         * longest 16 % of them in wavefronts of 16 and the next 32 % in wavefronts of 32.  (16 chains per
-         * wavefront throughout does not help small batches: 16-block ring slots 6.0e9 vs 6.6e9 samples/s.) */
+         * longest of them in wavefronts of few lanes.  (16 chains per wavefront throughout does not help
+         * small batches: 16-block ring slots 6.0e9 vs 6.6e9 samples/s.) */
         std::vector<int32_t> carr(nbc);
         for (size_t k = 0; k < nbc; k++)
             carr[k] = (int32_t)k;
@@ -536,10 +536,12 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         for (size_t k = 0; k < nbc; k++)
             code[k] = (int32_t)k;
         waves_of(code.data(), nbc, 64, 0);
-        const size_t sparse = nbc / 100, n16 = sparse * 16, n32 = sparse * 32;
-        waves_of(carr.data(), n16, 16, (int32_t)nbc);
-        waves_of(carr.data() + n16, n32, 32, (int32_t)nbc);
-        waves_of(carr.data() + n16 + n32, nbc - n16 - n32, 64, (int32_t)nbc);
+        /* the longest 8 % in wavefronts of 8, the next 16 % in wavefronts of 16, the next 32 % in wavefronts of 32 */
+        const size_t n8 = nbc * 8 / 100 / 8 * 8, n16 = nbc * 16 / 100 / 16 * 16, n32 = nbc * 32 / 100 / 32 * 32;
+        waves_of(carr.data(), n8, 8, (int32_t)nbc);
+        waves_of(carr.data() + n8, n16, 16, (int32_t)nbc);
+        waves_of(carr.data() + n8 + n16, n32, 32, (int32_t)nbc);
+        waves_of(carr.data() + n8 + n16 + n32, nbc - n8 - n16 - n32, 64, (int32_t)nbc);
         HIPCHK(h, (hipError_t)b->d_seed_order.reserve(order.size()));
         HIPCHK(h, hipMemcpyAsync(b->d_seed_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, upload_stream));
     }

@@ -475,38 +475,49 @@ __device__ __forceinline__ int chain_of_slot(int incl, int k)
     return lo;
 }
 
-/* what stage_tile() tells chain lane c about the tile: its slot range in the slice; ok = 0: nothing was
- * copied because the tile has more rows than the slice holds */
+/* what plan_tile() tells about a tile: to chain lane c its slot range in the slice (base, cnt), to slot lane k
+ * the address of its row (a0 for slot k, a1 for slot 64+k), to all the number of rows R; ok = 0: the tile
+ * has more rows than the slice holds */
 struct Staged {
-    int base, cnt, ok;
+    int base, cnt, ok, R;
+    uint64_t a0, a1;
 };
 
 /*
- * Start the copy of one tile's rows into the wavefront's slice.  Lane c is chain c of the block; its rows
+ * Plan the copy of one tile's rows into the wavefront's slice.  Lane c is chain c of the block; its rows
  * trA..trB overlap the tile.  The chains' slot ranges come from a prefix sum over the lanes, slot k's chain
- * from chain_of_slot().  Not inlined: it is called from every variant of the channel loop (once per tile).
+ * from chain_of_slot().  Not inlined (it is needed in every variant of the channel loop, once per tile) —
+ * and for that reason it only plans: a function waits for its outstanding memory operations before it
+ * returns, so the copy itself (issue_tile) is issued by the caller and stays asynchronous.
  */
-__device__ __noinline__ Staged stage_tile(WaveRows &W, int lane, bool has_chain, uint64_t row0_addr, int trA, int trB)
+__device__ __noinline__ Staged plan_tile(int lane, bool has_chain, uint64_t row0_addr, int trA, int trB)
 {
     Staged st;
     st.cnt = has_chain ? trB - trA + 1 : 0;
     const int incl = wave_incl_scan(st.cnt);
     st.base = incl - st.cnt;
-    const int R = __builtin_amdgcn_readlane(incl, 63);
-    st.ok = R <= WAVE_ROW_CAP;
+    st.R = __builtin_amdgcn_readlane(incl, 63);
+    st.ok = st.R <= WAVE_ROW_CAP;
+    st.a0 = st.a1 = 0;
     if (!st.ok)
         return st;
     /* slot k holds row trA + (k - base) of its chain, i.e. address [row 0 + (trA - base) rows] + k rows */
     const uint64_t addr_c = row0_addr + (uint64_t)((int64_t)(trA - st.base) * (int64_t)sizeof(SynRow));
-    const uint64_t a0 = bpermute_u64(addr_c, chain_of_slot(incl, lane)) + (uint64_t)lane * sizeof(SynRow);
-    if (lane < R)
-        dma_row(a0, W, 0);
-    if (R > 64) {
-        const uint64_t a1 = bpermute_u64(addr_c, chain_of_slot(incl, lane + 64)) + (uint64_t)(lane + 64) * sizeof(SynRow);
-        if (lane + 64 < R)
-            dma_row(a1, W, 64);
-    }
+    st.a0 = bpermute_u64(addr_c, chain_of_slot(incl, lane)) + (uint64_t)lane * sizeof(SynRow);
+    if (st.R > 64)
+        st.a1 = bpermute_u64(addr_c, chain_of_slot(incl, lane + 64)) + (uint64_t)(lane + 64) * sizeof(SynRow);
     return st;
+}
+
+/* start the planned copy: one row per lane, HBM -> LDS, nothing waits */
+__device__ __forceinline__ void issue_tile(WaveRows &W, int lane, const Staged &st)
+{
+    if (st.ok) {
+        if (lane < st.R)
+            dma_row(st.a0, W, 0);
+        if (st.R > 64 && lane + 64 < st.R)
+            dma_row(st.a1, W, 64);
+    }
 }
 
 /* A tile whose rows do not fit the slice (dense rows: high Doppler at a low sample rate): copy just one
@@ -532,8 +543,9 @@ __device__ __noinline__ SlotN0 stage_channel(WaveRows &W, int lane, uint64_t ac,
 }
 
 /* ... and the same copy into one half of the slice (slots first .. first+63, nc + nk <= 64) without waiting:
- * in such tiles the next channel's rows are fetched while the current channel is walked */
-__device__ __noinline__ void prefetch_channel(WaveRows &W, int lane, uint64_t ac, uint64_t ak, int nc, int nk, int first)
+ * in such tiles the next channel's rows are fetched while the current channel is walked.  Inlined: see
+ * plan_tile() */
+__device__ __forceinline__ void prefetch_channel(WaveRows &W, int lane, uint64_t ac, uint64_t ak, int nc, int nk, int first)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* lookups in this half are done */
     if (lane < nc + nk)
@@ -811,7 +823,8 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
         }
         /* slots of this chain's rows in the slice for the current tile; ovf: the tile's rows do not fit;
          * cwrap: one of the chain's rows that start in the tile follows a wrap */
-        Staged cur = stage_tile(W, lane, has_chain, row0_addr, trA & TR_ROW, trB & TR_ROW);
+        Staged cur = plan_tile(lane, has_chain, row0_addr, trA & TR_ROW, trB & TR_ROW);
+        issue_tile(W, lane, cur);
         bool cwrap = trB < 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int slot_n0a = (int)W.a[lane].x, slot_n0b = (int)W.a[64 + lane].x;
@@ -823,7 +836,7 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
             const int nvalid = p.nsamp - n0 < SPT ? p.nsamp - n0 : SPT;
             const int cbase = cur.base, ccnt = cur.cnt;
             const bool ovf = !cur.ok;
-            Staged nxt = {0, 0, 1};
+            Staged nxt = {0, 0, 1, 0, 0, 0};
             bool nwrap = false;
             v2s acc[SPT];
 #pragma unroll
@@ -847,7 +860,8 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
 #define GPSBB_STAGE_NEXT_TILE                                                                                          \
     {                                                                                                                  \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this tile's lookups have returned */                     \
-        nxt = stage_tile(W, lane, has_chain, row0_addr, trB & TR_ROW, trC & TR_ROW);                                   \
+        nxt = plan_tile(lane, has_chain, row0_addr, trB & TR_ROW, trC & TR_ROW);                                       \
+        issue_tile(W, lane, nxt);                                                                                      \
         nwrap = trC < 0;                                                                                               \
         trA = trB;                                                                                                     \
         trB = trC;                                                                                                     \

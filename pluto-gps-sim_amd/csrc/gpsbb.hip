@@ -450,6 +450,8 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     b->delt = delt;
     b->flags = flags;
     b->ntiles = (nsamp + TILE - 1) / TILE;
+    if (2ull * nbc * ((unsigned long long)b->ntiles + 1) >= (1ull << 32))
+        return GPSBB_E_NOMEM; /* the tile index is addressed with 32-bit element offsets (16 GiB of it) */
 
     /* row pool plan: chain id = kind*nbc + block*nch + channel */
     b->row_off.assign(2 * nbc + 1, 0);

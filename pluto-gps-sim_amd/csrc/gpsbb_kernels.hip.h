@@ -147,8 +147,9 @@ struct RowSink {
     unsigned long long *hz;
     const uint32_t *dwrd; /* code chains: the channel's nav words; carrier chains: nullptr */
     uint32_t dbit;        /* code chains: 0x80000000 while the current data bit is -1 (refreshed by nav_fetch) */
-    int32_t *tr;          /* this chain's column of the tile index: where the next tile's entry goes */
-    size_t tstride;       /* ... and the distance to the one after */
+    int32_t *tile_row;    /* the batch's tile index */
+    uint32_t tr;          /* this chain's column in it: element of the next tile's entry (32-bit: the index is */
+    uint32_t tstride;     /* sized well below 2^32 entries) ... and the distance to the one after             */
     int32_t tile_t;       /* that tile's number */
     int32_t ntiles;
     int32_t wrap_pend;    /* 0x80000000 while a row that follows a wrap has started in the tile before tile_t */
@@ -160,11 +161,11 @@ struct RowSink {
              * entry when the next row arrives).  Lanes run in lockstep, rows do not: a long row leaves several
              * tiles to fill in at once.  Entry e also carries, in bit 31, whether a row that follows a wrap
              * started in tile e-1. */
-            const int32_t nt = (int32_t)(((int64_t)n0 + TILE - 1) / TILE); /* tiles that start before n0 */
+            const int32_t nt = (int32_t)(((uint32_t)n0 + (uint32_t)(TILE - 1)) / (uint32_t)TILE); /* tiles that start before n0 */
             const int32_t lim = nt < ntiles ? nt : ntiles;
             const int32_t here = (int32_t)(cnt < cap ? cnt : cap);
             while (tile_t < lim) {
-                *tr = (here - 1) | wrap_pend; /* the first entry written after a wrap row is its tile's successor */
+                tile_row[tr] = (here - 1) | wrap_pend; /* the first entry written after a wrap row is its tile's successor */
                 wrap_pend = 0;
                 tr += tstride;
                 tile_t++;
@@ -172,7 +173,7 @@ struct RowSink {
             if (after_wrap) {
                 if ((n0 & (TILE - 1)) == 0 && tile_t < ntiles) { /* the row opens a tile: its entry now, so
                                                                     that the flag below goes to the next one */
-                    *tr = here | wrap_pend;
+                    tile_row[tr] = here | wrap_pend;
                     tr += tstride;
                     tile_t++;
                 }
@@ -212,7 +213,7 @@ struct RowSink {
             cnt = cap;
         for (; tile_t <= ntiles; tile_t++, tr += tstride) /* the remaining tiles and entry [ntiles] */
         {
-            *tr = ((int32_t)cnt - 1) | wrap_pend;
+            tile_row[tr] = ((int32_t)cnt - 1) | wrap_pend;
             wrap_pend = 0;
         }
         SynRow r;
@@ -243,8 +244,9 @@ __device__ __forceinline__ RowSink make_sink(const BatchDev &p, int chain, const
     s.dbit = dwrd && nav_bit(dwrd, nav0) < 0 ? 0x80000000u : 0u;
     const int nbc = p.nblocks * p.nch;
     const int kind = chain >= nbc ? 1 : 0, bi = chain - kind * nbc;
-    s.tr = p.tile_row + tile_row_at(p, bi / p.nch, 0, bi % p.nch, kind);
-    s.tstride = 2 * (size_t)p.nch;
+    s.tile_row = p.tile_row;
+    s.tr = (uint32_t)tile_row_at(p, bi / p.nch, 0, bi % p.nch, kind);
+    s.tstride = 2u * (uint32_t)p.nch;
     s.tile_t = 0;
     s.ntiles = p.ntiles;
     s.wrap_pend = 0;

@@ -266,7 +266,7 @@ GPSBB_HD double step_of_inc(uint64_t xb, int64_t inc)
  *        the exact remainder fma(-k, |S|, room).
  */
 template <int KIND>
-GPSBB_HD int64_t regular_run_f64(double x, double s, int64_t kcap, double &S)
+GPSBB_HD int32_t regular_run_f64(double x, double s, int32_t kcap, double &S)
 {
     const uint64_t xb = f64_bits(x), sb = f64_bits(s);
     const int ex = (int)((xb >> 52) & 0x7ff), es = (int)((sb >> 52) & 0x7ff);
@@ -315,10 +315,9 @@ GPSBB_HD int64_t regular_run_f64(double x, double s, int64_t kcap, double &S)
         kf -= 1.0;
     else if (rem >= Sa)
         kf += 1.0;
-    /* kcap is a sample count (< 2^31): single-instruction conversions on the device */
-    if (kf >= (double)(int32_t)kcap)
+    if (kf >= (double)kcap)
         return kcap;
-    return (int64_t)(int32_t)kf;
+    return (int32_t)kf;
 }
 
 /*
@@ -333,26 +332,26 @@ template <int KIND, class Sink>
 GPSBB_HD double build_rows_f64(double x, double s, uint32_t &nav, int nsamp, Sink &sink)
 {
     const uint64_t sb = f64_bits(s);
-    int64_t n = 0;
+    int32_t n = 0; /* sample counts fit 32 bits: no 64-bit integer arithmetic on the chain's critical path */
     bool after_wrap = false;
     while (n < nsamp) {
         double S;
-        int64_t k = regular_run_f64<KIND>(x, s, (int64_t)nsamp - n, S);
+        int32_t k = regular_run_f64<KIND>(x, s, nsamp - n, S);
         if (KIND == NCO_CARR && !(x < 1.0)) {
             after_wrap = true;
             sink.table_index_512(); /* the reference's latent out-of-bounds table read, c:2697-2702 */
         }
         if (k >= 0) {
-            sink.row((int32_t)n, nav, x, S, after_wrap);
+            sink.row(n, nav, x, S, after_wrap);
             if (k > 0)
-                x = fma_rn((double)(int32_t)k, S, x);
+                x = fma_rn((double)k, S, x);
         } else {
             int64_t inc;
             const uint64_t xb = f64_bits(x);
-            k = regular_run<KIND>(xb, sb, (int64_t)nsamp - n, inc);
-            sink.row((int32_t)n, nav, x, step_of_inc(xb, inc), after_wrap);
+            k = (int32_t)regular_run<KIND>(xb, sb, (int64_t)(nsamp - n), inc);
+            sink.row(n, nav, x, step_of_inc(xb, inc), after_wrap);
             if (k > 0)
-                x = bits_f64(xb + (uint64_t)(k * inc));
+                x = bits_f64(xb + (uint64_t)((int64_t)k * inc));
         }
         if (k > 0) {
             n += k;
@@ -377,7 +376,7 @@ GPSBB_HD double build_rows_f64(double x, double s, uint32_t &nav, int nsamp, Sin
         if (!wrapped && f64_bits(x) == before) {
             /* x + s rounds back to x and nothing wrapped: constant from here on */
             if (n < nsamp)
-                sink.row((int32_t)n, nav, x, 0.0, false);
+                sink.row(n, nav, x, 0.0, false);
             break;
         }
     }

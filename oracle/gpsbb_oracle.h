@@ -8,7 +8,7 @@
  * Pinning status: the restatement is checked bit-for-bit against the reference's own statements —
  * the loop body plutogpssim.c:2690-2756 and the front-end functions plutogpssim.c:93-1989 compiled
  * verbatim from /root/reference by oracle/ref/build_ref.sh into oracle/_ref/ (see oracle/ref/README.md
- * for exactly which lines are the reference's and which are harness glue) — by tests/test_oracle_vs_ref.py
+ * for exactly which lines are the reference's and which are harness glue) — by tests/test_oracle.py and tests/test_frontend.py
  * in the build container, and against the golden vectors generated from that build and committed under
  * tests/golden/ everywhere else.  The reference ships no tests or golden vectors of its own, and its
  * whole-program build needs libiio/libad9361/libcurl headers this image lacks, so no whole-program

@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--shapes", action="store_true", help="a few extreme shapes instead of random small ones")
     a = ap.parse_args()
     import torch  # noqa: F401  (first: the HIP runtime)
     from __graft_entry__ import load_package
@@ -28,8 +29,12 @@ def main():
     oracle = ob.Oracle()
     rng = np.random.default_rng(a.seed)
     lib = pkg.lib()
+    # (fs, nsamp, nch, nblocks): one very long block, many tiny blocks, many one-sample blocks, a block one
+    # sample longer than a multiple of the tile, a wide batch at the headline geometry
+    shapes = [(25e6, 1 << 24, 2, 1), (2.6e6, 777, 12, 3000), (10e6, 1, 16, 5000), (25e6, 1024 * 300 + 1, 16, 3),
+              (25e6, 2500000, 16, 6), (1e6, 5000000, 3, 2)]
     with pkg.Synth(0) as synth:
-        for case in range(a.cases):
+        for case in range(len(shapes) * 2 if a.shapes else a.cases):
             fs = float(rng.choice([1e6, 2.6e6, 3e6, 4.092e6, 10e6, 16e6, 25e6, 30e6, 2.0 ** 25, 50e6]))
             nsamp = int(rng.choice([rng.integers(1, 3000), rng.integers(3000, 120000), 1024 * int(rng.integers(1, 60))]))
             nch = int(rng.integers(1, 17))
@@ -37,6 +42,9 @@ def main():
             fixed = bool(rng.integers(0, 4) == 0)
             chain = bool(rng.integers(0, 2))
             mode = int(rng.integers(1, 3))            # 1: k_seed, 2: host threads
+            if a.shapes:
+                fs, nsamp, nch, nblocks = shapes[case // 2]
+                fixed, mode = False, 1 + case % 2
             ch = pkg.synth_descriptors(nblocks, nch=nch, seed=int(rng.integers(1, 2 ** 31)))
             scale = 10.0 ** rng.uniform(-3, np.log10(0.124 * fs), size=(nblocks, nch))
             ch["f_carr"] = np.where(rng.random((nblocks, nch)) < 0.5, -1.0, 1.0) * scale
@@ -67,7 +75,7 @@ def main():
                 if st[f][act].tobytes() != want_st[f][act].tobytes():
                     raise SystemExit("END STATE MISMATCH %r field %s" % (what, f))
         lib.gpsbb_test_seed_mode(0)
-    print("fuzz_parity: %d cases bit-exact (seed %d)" % (a.cases, a.seed))
+    print("fuzz_parity: %d cases bit-exact (seed %d)" % (len(shapes) * 2 if a.shapes else a.cases, a.seed))
 
 
 if __name__ == "__main__":

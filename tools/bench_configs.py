@@ -29,7 +29,8 @@ def run(pkg, synth, name, nav, motion, max_chan, fs, nsamp, nblocks, batch_block
     ch["carr_phase"][ch["prn"] <= 0] = 0.0
     t_chain = time.perf_counter() - t0
     batches = [synth.batch(ch[k:k + batch_blocks], 1.0 / fs, nsamp) for k in range(0, nblocks, batch_blocks)]
-    for b in batches[:2]:
+    for b in batches:  # every batch once before the clock starts: its device buffers are allocated on first use
+        b.run()
         b.run()
     synth.sync()
     t0 = time.perf_counter()

@@ -206,7 +206,8 @@ struct WorkPool {
 struct gpsbb {
     int device = 0;
     hipStream_t s_seed = nullptr;    /* NCO seeding pre-pass (k_seed) and descriptor uploads            */
-    hipStream_t s_seed2 = nullptr;   /* ... of every other slot of a streaming ring (created with the ring) */
+    hipStream_t s_seed2 = nullptr;   /* ... of every other batch / slot of a streaming ring (created on first use) */
+    unsigned batches_created = 0;
     hipStream_t s_compute = nullptr; /* synthesis kernel (k_synth)                                      */
     hipStream_t s_copy = nullptr;    /* device-to-host gather                                            */
     std::vector<uint32_t> h_ca;      /* host copy of the C/A chips (seeding of small batches on the host)  */
@@ -571,6 +572,19 @@ static gpsbb_batch *batch_new(gpsbb *h)
     return b;
 }
 
+/* every other batch (and every other slot of a ring) seeds on the handle's second stream, created on first use */
+static hipError_t use_second_seed_stream(gpsbb_batch *b)
+{
+    gpsbb *h = b->h;
+    if (!h->s_seed2) {
+        hipError_t e = hipStreamCreateWithFlags(&h->s_seed2, hipStreamNonBlocking);
+        if (e != hipSuccess)
+            return e;
+    }
+    b->seed_stream = h->s_seed2;
+    return hipSuccess;
+}
+
 extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
 {
     if (!b)
@@ -618,12 +632,14 @@ extern "C" int gpsbb_batch_create(gpsbb_t *h, const gpsbb_chan_t *ch, int nblock
     gpsbb_batch *b = batch_new(h);
     if (!b)
         return GPSBB_E_NOMEM;
-    int rc = batch_setup(b, ch, nblocks, nch, delt, nsamp, flags, h->s_seed);
+    if (h->batches_created++ & 1) /* batches created one after the other seed side by side */
+        HIPCHK(h, use_second_seed_stream(b));
+    int rc = batch_setup(b, ch, nblocks, nch, delt, nsamp, flags, b->seed_stream);
     if (rc != GPSBB_OK) {
         gpsbb_batch_destroy(b);
         return rc;
     }
-    HIPCHK(h, hipStreamSynchronize(h->s_seed));
+    HIPCHK(h, hipStreamSynchronize(b->seed_stream));
     *out = b;
     return GPSBB_OK;
 }
@@ -1238,12 +1254,8 @@ extern "C" int gpsbb_stream_create(gpsbb_t *h, int nch, double delt, int nsamp, 
     for (auto &sl : s->slots) {
         sl.batch = batch_new(h);
         hipError_t e = sl.batch ? hipSuccess : hipErrorOutOfMemory;
-        if (e == hipSuccess && ((&sl - &s->slots[0]) & 1)) {
-            if (!h->s_seed2)
-                e = hipStreamCreateWithFlags(&h->s_seed2, hipStreamNonBlocking);
-            if (e == hipSuccess)
-                sl.batch->seed_stream = h->s_seed2;
-        }
+        if (e == hipSuccess && ((&sl - &s->slots[0]) & 1))
+            e = use_second_seed_stream(sl.batch);
         if (e == hipSuccess) e = (hipError_t)sl.batch->d_iq.reserve(iq_bytes / 2);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_iq, iq_bytes, hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_end, end_bytes, hipHostMallocDefault);

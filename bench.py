@@ -63,8 +63,8 @@ def cpu_baseline(pkg, ch, delt, nsamp, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=400, help="0.1 s blocks per step and GPU")
     ap.add_argument("--nch", type=int, default=16)
     ap.add_argument("--fs", type=float, default=25e6)

@@ -124,7 +124,7 @@ def main():
             dist.barrier()
 
     if args.synth_only:
-        pkg.lib().gpsbb_test_skip_seed(1)
+        synth.set_option(pkg.OPT_SKIP_SEED, 1)
         args.warmup = max(args.warmup, 2)
     for _ in range(args.warmup):
         batch.run(out.data_ptr())

@@ -35,6 +35,8 @@ assert CHAN_DTYPE.itemsize == 296 and STATE_DTYPE.itemsize == 40 and ROW_DTYPE.i
 
 CHAIN_CARRIER = 1
 FIXED_CARRIER = 2
+OPT_SEED_WHERE, OPT_SYNTH_KERNEL, OPT_SKIP_SEED = 1, 2, 3
+INFO_LAST_KERNEL, INFO_EXACT_RUNS = 1, 2
 
 ERRORS = {0: "GPSBB_OK", -1: "GPSBB_E_BADARG", -2: "GPSBB_E_BADCHAN", -3: "GPSBB_E_HIP", -4: "GPSBB_E_NOMEM",
           -5: "GPSBB_E_INTERNAL", -6: "GPSBB_E_NODEVICE", -7: "GPSBB_E_STATE"}
@@ -46,7 +48,7 @@ API_SYMBOLS = [
     "gpsbb_batch_iq_bytes", "gpsbb_batch_run", "gpsbb_sync", "gpsbb_batch_read", "gpsbb_batch_device_iq",
     "gpsbb_get_hazards", "gpsbb_batch_last_timing", "gpsbb_batch_timing_stats", "gpsbb_fill_ceiling", "gpsbb_stream_create",
     "gpsbb_stream_destroy", "gpsbb_stream_push", "gpsbb_stream_pop", "gpsbb_stream_pending",
-    "gpsbb_codegen", "gpsbb_sincos_tables", "gpsbb_chain_carrier_host",
+    "gpsbb_codegen", "gpsbb_sincos_tables", "gpsbb_chain_carrier_host", "gpsbb_set_option", "gpsbb_get_info",
 ]
 
 
@@ -82,6 +84,8 @@ def lib():
         L.gpsbb_strerror.argtypes = [i]
         L.gpsbb_strerror.restype = C.c_char_p
         L.gpsbb_last_hip_error.argtypes = [vp]
+        L.gpsbb_set_option.argtypes = [vp, i, C.c_long]
+        L.gpsbb_get_info.argtypes = [vp, i, C.POINTER(C.c_uint64)]
         L.gpsbb_fill_block.argtypes = [vp, vp, i, d, i, vp, vp]
         L.gpsbb_fill_block_ex.argtypes = [vp, vp, i, d, i, u, vp, vp]
         L.gpsbb_fill_block_ref.argtypes = [vp, vp, vp, i, vp, d, i, vp]
@@ -207,6 +211,16 @@ class Synth:
         v = np.zeros(2, np.uint64)
         _chk(lib().gpsbb_get_hazards(self._h, v.ctypes.data, int(reset)), "gpsbb_get_hazards")
         return {"itable_512": int(v[0]), "dwrd_oob": int(v[1])}
+
+    def set_option(self, option, value):
+        """gpsbb_set_option: OPT_SEED_WHERE / OPT_SYNTH_KERNEL / OPT_SKIP_SEED (per handle)"""
+        _chk(lib().gpsbb_set_option(self._h, option, value), "gpsbb_set_option")
+
+    def info(self, what):
+        """gpsbb_get_info: INFO_LAST_KERNEL / INFO_EXACT_RUNS"""
+        v = C.c_uint64()
+        _chk(lib().gpsbb_get_info(self._h, what, C.byref(v)), "gpsbb_get_info")
+        return int(v.value)
 
     def fill_ceiling(self, d_ptr, nbytes, iters=10):
         ms = C.c_float()

@@ -22,6 +22,7 @@
 
 #include "gpsbb.h"
 #include "gpsbb_kernels.hip.h"
+#include "gpsbb_events.hip.h"
 #include "gpsbb_nco.h"
 #include "gpsbb_testhooks.h"
 
@@ -131,6 +132,60 @@ uint64_t row_bound(double s_abs, double range, int top_e, int nsamp)
     return (uint64_t)(laps * per_lap) + 16;
 }
 
+/*
+ * Can the breakpoint kernel render these blocks, and with which per-channel constants (EvConst)?  Eligible
+ * when, for every active channel, a run of SPT samples holds at most one chip change (sc*15.5 < 1) and at
+ * most EV_KC_MAX table-index changes, and, per block, the I sums cannot reach 2^15 (sum of 512*|gain|+1: the
+ * packed I/Q arithmetic of that kernel needs it; the reference's (short) wrap-around is then unreachable
+ * too).  Steps are the individually rounded products the kernels and the reference use (c:2709, 2741).
+ */
+bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vector<EvConst> &out)
+{
+    const size_t nbc = (size_t)nblocks * nch;
+    out.resize(nbc);
+    const double reach = (double)SPT - 0.5;
+    for (int blk = 0; blk < nblocks; blk++) {
+        double amp_sum = 0.0;
+        for (int i = 0; i < nch; i++) {
+            const gpsbb_chan_t &c = ch[(size_t)blk * nch + i];
+            EvConst &K = out[(size_t)blk * nch + i];
+            memset(&K, 0, sizeof K);
+            if (c.prn <= 0)
+                continue;
+            amp_sum += 512.0 * std::fabs(c.gain) + 1.0;
+            const volatile double sc = c.f_code * delt, sk = c.f_carr * delt;
+            const double S = sk * 512.0, aS = std::fabs(S);
+            if (!(sc * reach < 1.0) || !(sc >= 0x1p-20))
+                return false;
+            K.S = S;
+            K.sc = sc;
+            K.rsc = 1.0 / sc;
+            K.thrC = 0.5 - (EV_MODEL_ERR * K.rsc + EV_T_EPS);
+            K.down = S < 0.0;
+            if (aS == 0.0) {
+                K.rS = 0x1p+1000; /* the index never changes */
+                K.thrK = 0.25;
+                K.kc = 1;
+            } else if (aS < 0x1p-28) {
+                K.rS = 0x1p+1000; /* the model error exceeds a quarter of a step: every run is recomputed exactly */
+                K.thrK = 0.25;
+                K.kc = -1;
+            } else {
+                K.rS = 1.0 / aS;
+                const double w = EV_MODEL_ERR * K.rS + EV_T_EPS;
+                K.thrK = 0.5 - w;
+                const double kc = std::floor((reach + w) * aS) + 1.0;
+                if (kc > (double)EV_KC_MAX)
+                    return false;
+                K.kc = (int)kc;
+            }
+        }
+        if (!(amp_sum < 32768.0))
+            return false;
+    }
+    return true;
+}
+
 } /* namespace */
 
 /* ================================================================================================== */
@@ -220,6 +275,11 @@ struct gpsbb {
     int last_hip = 0;
     gpsbb_batch *scratch = nullptr;
     int sm_count = 0;
+    /* per-handle options (gpsbb_set_option) */
+    int opt_seed_where = 0;   /* 0 by size, 1 always k_seed, 2 always host threads */
+    int opt_synth_kernel = 0; /* 0 automatic, 1 always the per-sample kernel */
+    int opt_skip_seed = 0;    /* measurement: re-use the tables of the first two runs of a batch */
+    int last_kernel = 0;      /* synthesis kernel of the last launch: 1 per-sample, 2 breakpoint */
 };
 
 template <class T>
@@ -280,6 +340,15 @@ struct gpsbb_batch {
     const int *fixed_prev_prn = nullptr;      /* stream chaining of the fixed-point carrier (host side) */
     const uint32_t *fixed_prev_phase = nullptr;
     DevBuf<gpsbb_chan_state_t> d_end[2];
+    /* breakpoint kernel (ev): exact tile-start states instead of rows + tile index, and per-channel constants */
+    bool ev = false;
+    DevBuf<double> d_tile_x[2];
+    DevBuf<uint32_t> d_tile_nav[2];
+    DevBuf<EvConst> d_evc;
+    std::vector<EvConst> h_evc;
+    double *hs_tile_x = nullptr;
+    uint32_t *hs_tile_nav = nullptr;
+    size_t hs_tx_cap = 0, hs_tn_cap = 0;
     hipEvent_t synth_done[2] = {nullptr, nullptr};
     bool synth_pending[2] = {false, false};
     unsigned run_count = 0;
@@ -326,6 +395,49 @@ extern "C" const char *gpsbb_strerror(int err)
 }
 
 extern "C" int gpsbb_last_hip_error(const gpsbb_t *h) { return h ? h->last_hip : 0; }
+
+extern "C" int gpsbb_set_option(gpsbb_t *h, int option, long value)
+{
+    if (!h)
+        return GPSBB_E_BADARG;
+    switch (option) {
+    case GPSBB_OPT_SEED_WHERE:
+        if (value < 0 || value > 2)
+            return GPSBB_E_BADARG;
+        h->opt_seed_where = (int)value;
+        return GPSBB_OK;
+    case GPSBB_OPT_SYNTH_KERNEL:
+        if (value < 0 || value > 1)
+            return GPSBB_E_BADARG;
+        h->opt_synth_kernel = (int)value;
+        return GPSBB_OK;
+    case GPSBB_OPT_SKIP_SEED:
+        h->opt_skip_seed = value != 0;
+        return GPSBB_OK;
+    default:
+        return GPSBB_E_BADARG;
+    }
+}
+
+extern "C" int gpsbb_get_info(gpsbb_t *h, int what, uint64_t *out)
+{
+    if (!h || !out)
+        return GPSBB_E_BADARG;
+    switch (what) {
+    case GPSBB_INFO_LAST_KERNEL:
+        *out = (uint64_t)h->last_kernel;
+        return GPSBB_OK;
+    case GPSBB_INFO_EXACT_RUNS: {
+        HIPCHK(h, hipSetDevice(h->device));
+        unsigned long long v = 0;
+        HIPCHK(h, hipMemcpy(&v, h->d_hz + 2, 8, hipMemcpyDeviceToHost));
+        *out = v;
+        return GPSBB_OK;
+    }
+    default:
+        return GPSBB_E_BADARG;
+    }
+}
 
 extern "C" int gpsbb_codegen(int prn, uint8_t ca[GPSBB_CA_LEN])
 {
@@ -419,15 +531,17 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     if ((e = hipMalloc((void **)&h->d_tabs, sizeof tabs)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&h->d_ca, ca.size() * 4)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&h->d_status, 4)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void **)&h->d_hz, 16)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&h->d_hz, 32)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h->d_tabs, tabs, sizeof tabs, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h->d_ca, ca.data(), ca.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     h->h_ca = ca;
     if ((e = hipMemset(h->d_status, 0, 4)) != hipSuccess) return fail(e);
-    if ((e = hipMemset(h->d_hz, 0, 16)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(h->d_hz, 0, 32)) != hipSuccess) return fail(e);
     /* k_synth carves ~76 KB of dynamic LDS per workgroup: above the 64 KB default limit */
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(SynthLds))) != hipSuccess) return fail(e);
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(EvLds))) != hipSuccess) return fail(e);
     *out = h;
     return GPSBB_OK;
 }
@@ -464,13 +578,17 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     if (2ull * nbc * ((unsigned long long)b->ntiles + 1) >= (1ull << 32))
         return GPSBB_E_NOMEM; /* the tile index is addressed with 32-bit element offsets (16 GiB of it) */
 
-    /* row pool plan: chain id = kind*nbc + block*nch + channel */
+    /* Which synthesis kernel: the breakpoint kernel (gpsbb_events.hip.h) where every run of SPT samples holds
+     * at most one chip change and at most EV_KC_MAX table-index changes and the I sums stay below 2^15. */
+    b->ev = !fixed && h->opt_synth_kernel != 1 && ev_plan(ch, nblocks, nch, delt, b->h_evc);
+
+    /* row pool plan (per-sample kernel): chain id = kind*nbc + block*nch + channel */
     b->row_off.assign(2 * nbc + 1, 0);
     uint64_t off = 0;
     for (int kind = 0; kind < 2; kind++)
         for (size_t k = 0; k < nbc; k++) {
             b->row_off[kind * nbc + k] = off;
-            if (ch[k].prn > 0 && !(kind == 1 && fixed)) {
+            if (ch[k].prn > 0 && !(kind == 1 && fixed) && !b->ev) {
                 const double s = kind == 0 ? ch[k].f_code * delt : std::fabs(ch[k].f_carr * delt);
                 off += (kind == 0 ? row_bound(s, 1023.0, 9, nsamp) : row_bound(s, 1.0, -1, nsamp)) + 1;
             } else {
@@ -480,8 +598,28 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     b->row_off[2 * nbc] = off;
     b->total_rows = off;
 
+    /* device scratch of both table sets, sized here so that a launch never allocates (growing frees, and
+     * a free synchronises the device) */
     HIPCHK(h, (hipError_t)b->d_ch.reserve(nbc));
     HIPCHK(h, (hipError_t)b->d_row_off.reserve(2 * nbc + 1));
+    HIPCHK(h, (hipError_t)b->d_tile_ctr.reserve((size_t)nblocks));
+    for (int set = 0; set < 2; set++) {
+        HIPCHK(h, (hipError_t)b->d_end[set].reserve(nbc));
+        if (b->ev) {
+            HIPCHK(h, (hipError_t)b->d_tile_x[set].reserve(2 * nbc * (size_t)b->ntiles));
+            HIPCHK(h, (hipError_t)b->d_tile_nav[set].reserve(nbc * (size_t)b->ntiles));
+        } else {
+            HIPCHK(h, (hipError_t)b->d_rows[set].reserve(b->total_rows + 4)); /* + slack: k_synth prefetches one row past a chain */
+            HIPCHK(h, (hipError_t)b->d_tile_row[set].reserve(2 * nbc * ((size_t)b->ntiles + 1)));
+            HIPCHK(h, (hipError_t)b->d_row_cnt[set].reserve(2 * nbc));
+        }
+        if (!b->synth_done[set])
+            HIPCHK(h, hipEventCreateWithFlags(&b->synth_done[set], hipEventDisableTiming));
+    }
+    if (b->ev) {
+        HIPCHK(h, (hipError_t)b->d_evc.reserve(nbc));
+        HIPCHK(h, hipMemcpyAsync(b->d_evc.p, b->h_evc.data(), nbc * sizeof(EvConst), hipMemcpyHostToDevice, upload_stream));
+    }
     if (fixed) {
         /* start phase and step of the 32-bit accumulator per (block, channel); the chain across blocks is
          * plain modular arithmetic, resolved here (c:2675, 2748) */
@@ -605,6 +743,9 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         b->d_kph0.release();
         b->d_kstep.release();
         b->d_end[k].release();
+        b->d_tile_x[k].release();
+        b->d_tile_nav[k].release();
+        b->d_evc.release();
         if (b->synth_done[k])
             (void)hipEventDestroy(b->synth_done[k]);
     }
@@ -614,6 +755,10 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         (void)hipHostFree(b->hs_tile_row);
     if (b->hs_end)
         (void)hipHostFree(b->hs_end);
+    if (b->hs_tile_x)
+        (void)hipHostFree(b->hs_tile_x);
+    if (b->hs_tile_nav)
+        (void)hipHostFree(b->hs_tile_nav);
     b->d_iq.release();
     for (auto &t : b->evs)
         for (auto &e : t.e)
@@ -750,6 +895,33 @@ bool host_seed_chain(const gpsbb_batch *b, int kind, size_t k, unsigned long lon
         e.carr_phase = (double)(uint32_t)(b->h_kph0[k] + (uint32_t)b->nsamp * (uint32_t)b->h_kstep[k]);
         return true;
     }
+    const size_t blk = k / (size_t)b->nch, i = k % (size_t)b->nch;
+    if (b->ev) {
+        /* breakpoint kernel: tile-start states instead of rows (what k_seed<true> writes) */
+        uint32_t nav = kind == 0 ? nav_pack(c.icode, c.ibit, c.iword) : 0u;
+        TileSink sink = make_tile_sink(b->hs_tile_x, b->hs_tile_nav, b->nch, b->ntiles, (int)blk, (int)i, kind,
+                                       kind == 0 ? c.dwrd : nullptr, nav, nullptr);
+        if (kind == 0) {
+            const double s = mul_rn(c.f_code, b->delt);
+            const double x = build_rows_f64<NCO_CODE>(c.code_phase, s, nav, b->nsamp, sink);
+            sink.finish();
+            e.code_phase = x;
+            e.iword = nav_iword(nav);
+            e.ibit = nav_ibit(nav);
+            e.icode = nav_icode(nav);
+            e.dataBit = nav_bit(c.dwrd, nav);
+            const int ci = (int)x;
+            e.codeCA = (int)((b->h->h_ca[(size_t)c.prn * 32 + (ci >> 5)] >> (ci & 31)) & 1u) * 2 - 1;
+            e._pad = 0;
+        } else {
+            const double s = mul_rn(c.f_carr, b->delt);
+            e.carr_phase = build_rows_f64<NCO_CARR>(c.carr_phase, s, nav, b->nsamp, sink);
+            sink.finish();
+        }
+        *itable_512 += sink.hz_local[0];
+        *dwrd_oob += sink.hz_local[1];
+        return true;
+    }
     const size_t chain = (size_t)kind * nbc + k;
     HostRowSink sink;
     sink.rows = b->hs_rows + b->row_off[chain];
@@ -761,7 +933,6 @@ bool host_seed_chain(const gpsbb_batch *b, int kind, size_t k, unsigned long lon
     sink.dwrd = kind == 0 ? c.dwrd : nullptr;
     uint32_t nav = kind == 0 ? nav_pack(c.icode, c.ibit, c.iword) : 0u;
     sink.dbit = kind == 0 && nav_bit(c.dwrd, nav) < 0 ? 0x80000000u : 0u;
-    const size_t blk = k / (size_t)b->nch, i = k % (size_t)b->nch;
     sink.tr = b->hs_tile_row + (blk * ((size_t)b->ntiles + 1)) * (2 * (size_t)b->nch) + 2 * i + (size_t)kind;
     sink.tstride = 2 * (size_t)b->nch;
     sink.tile_t = 0;
@@ -806,16 +977,13 @@ int host_pinned_reserve(void **p, size_t *cap, size_t bytes)
 
 } /* namespace */
 
-/* 0 = by size (default), 1 = always on the device, 2 = always on the host; tests run both ways */
-static int g_seed_mode = 0;
-extern "C" void gpsbb_test_seed_mode(int mode) { g_seed_mode = mode; }
-
+/* where the NCO tables of a run are built: by size (default), or as GPSBB_OPT_SEED_WHERE says (tests run both ways) */
 static bool host_seeding_wanted(const gpsbb_batch *b)
 {
     static const bool off = getenv("GPSBB_DEVICE_SEED_ONLY") != nullptr;
     static const size_t lim = getenv("GPSBB_HOST_SEED_MAX") ? (size_t)atol(getenv("GPSBB_HOST_SEED_MAX")) : HOST_SEED_MAX_CHANNELS;
-    if (g_seed_mode)
-        return g_seed_mode == 2;
+    if (b->h->opt_seed_where)
+        return b->h->opt_seed_where == 2;
     return !off && (size_t)b->nblocks * b->nch <= lim;
 }
 
@@ -825,8 +993,14 @@ static int host_seed_run(gpsbb_batch *b, int set, hipStream_t stream)
     gpsbb *h = b->h;
     const size_t nbc = (size_t)b->nblocks * b->nch;
     const size_t tr_n = 2 * nbc * ((size_t)b->ntiles + 1);
-    HIPCHK(h, (hipError_t)host_pinned_reserve((void **)&b->hs_rows, &b->hs_rows_cap, (b->total_rows + 4) * sizeof(SynRow)));
-    HIPCHK(h, (hipError_t)host_pinned_reserve((void **)&b->hs_tile_row, &b->hs_tr_cap, tr_n * sizeof(int32_t)));
+    const size_t tx_n = 2 * nbc * (size_t)b->ntiles, tn_n = nbc * (size_t)b->ntiles;
+    if (b->ev) {
+        HIPCHK(h, (hipError_t)host_pinned_reserve((void **)&b->hs_tile_x, &b->hs_tx_cap, tx_n * sizeof(double)));
+        HIPCHK(h, (hipError_t)host_pinned_reserve((void **)&b->hs_tile_nav, &b->hs_tn_cap, tn_n * sizeof(uint32_t)));
+    } else {
+        HIPCHK(h, (hipError_t)host_pinned_reserve((void **)&b->hs_rows, &b->hs_rows_cap, (b->total_rows + 4) * sizeof(SynRow)));
+        HIPCHK(h, (hipError_t)host_pinned_reserve((void **)&b->hs_tile_row, &b->hs_tr_cap, tr_n * sizeof(int32_t)));
+    }
     HIPCHK(h, (hipError_t)host_pinned_reserve((void **)&b->hs_end, &b->hs_end_cap, nbc * sizeof(gpsbb_chan_state_t)));
     const size_t nchains = 2 * nbc;
     if (!h->pool) {
@@ -852,14 +1026,16 @@ static int host_seed_run(gpsbb_batch *b, int set, hipStream_t stream)
         if (!ok[t])
             return GPSBB_E_INTERNAL;
     }
-    HIPCHK(h, hipMemcpyAsync(b->d_rows[set].p, b->hs_rows, b->total_rows * sizeof(SynRow), hipMemcpyHostToDevice, stream));
-    HIPCHK(h, hipMemcpyAsync(b->d_tile_row[set].p, b->hs_tile_row, tr_n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    if (b->ev) {
+        HIPCHK(h, hipMemcpyAsync(b->d_tile_x[set].p, b->hs_tile_x, tx_n * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIPCHK(h, hipMemcpyAsync(b->d_tile_nav[set].p, b->hs_tile_nav, tn_n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    } else {
+        HIPCHK(h, hipMemcpyAsync(b->d_rows[set].p, b->hs_rows, b->total_rows * sizeof(SynRow), hipMemcpyHostToDevice, stream));
+        HIPCHK(h, hipMemcpyAsync(b->d_tile_row[set].p, b->hs_tile_row, tr_n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    }
     HIPCHK(h, hipMemcpyAsync(b->d_end[set].p, b->hs_end, nbc * sizeof(gpsbb_chan_state_t), hipMemcpyHostToDevice, stream));
     return GPSBB_OK;
 }
-
-static int g_test_skip_seed = 0;
-extern "C" void gpsbb_test_skip_seed(int on) { g_test_skip_seed = on; }
 
 static BatchDev batch_dev(const gpsbb_batch *b, int set)
 {
@@ -885,6 +1061,10 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.hazards = b->h->d_hz;
     p.seed_order = b->d_seed_order.p;
     p.seed_lanes = (int)b->h_seed_order.size();
+    p.ev = b->ev ? 1 : 0;
+    p.tile_x = b->d_tile_x[set].p;
+    p.tile_nav = b->d_tile_nav[set].p;
+    p.evc = b->d_evc.p;
     return p;
 }
 
@@ -892,14 +1072,6 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
 {
     gpsbb *h = b->h;
     const int set = (int)(b->run_count & 1u);
-    const size_t nbc = (size_t)b->nblocks * b->nch;
-    HIPCHK(h, (hipError_t)b->d_rows[set].reserve(b->total_rows + 4)); /* + slack: k_synth prefetches one row past a chain */
-    HIPCHK(h, (hipError_t)b->d_tile_row[set].reserve(2 * nbc * ((size_t)b->ntiles + 1)));
-    HIPCHK(h, (hipError_t)b->d_end[set].reserve(nbc));
-    HIPCHK(h, (hipError_t)b->d_row_cnt[set].reserve(2 * nbc));
-    HIPCHK(h, (hipError_t)b->d_tile_ctr.reserve((size_t)b->nblocks));
-    if (!b->synth_done[set])
-        HIPCHK(h, hipEventCreateWithFlags(&b->synth_done[set], hipEventDisableTiming));
     const BatchDev p = batch_dev(b, set);
     const int lanes = (int)b->h_seed_order.size();
     if (b->ev_used == b->evs.size()) {
@@ -919,7 +1091,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     if (b->synth_pending[set])
         HIPCHK(h, hipStreamWaitEvent(b->seed_stream, b->synth_done[set], 0));
     HIPCHK(h, hipEventRecord(ev[0], b->seed_stream));
-    if (g_test_skip_seed && b->run_count >= 2) {
+    if (h->opt_skip_seed && b->run_count >= 2) {
         /* measurement hook: time k_synth alone on tables already built */
     } else if (host_seeding_wanted(b)) {
         /* the previous user of the pinned images (this batch's last run) has been copied out: its upload was
@@ -929,8 +1101,10 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         const int rc = host_seed_run(b, set, b->seed_stream);
         if (rc != GPSBB_OK)
             return rc;
+    } else if (b->ev) {
+        hipLaunchKernelGGL(k_seed<true>, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, b->seed_stream, p);
     } else {
-        hipLaunchKernelGGL(k_seed, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, b->seed_stream, p);
+        hipLaunchKernelGGL(k_seed<false>, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, b->seed_stream, p);
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(ev[1], b->seed_stream));
@@ -938,7 +1112,19 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     HIPCHK(h, hipStreamWaitEvent(h->s_compute, ev[1], 0));
     HIPCHK(h, hipMemsetAsync(b->d_tile_ctr.p, 0, (size_t)b->nblocks * sizeof(int32_t), h->s_compute));
     HIPCHK(h, hipEventRecord(ev[2], h->s_compute));
-    {
+    if (b->ev) {
+        /* one workgroup of EV_WG lanes per CU (its LDS tables take ~113 KB); several per block so that the chip
+         * stays full until the end of the launch, never more than there are chunks of tiles */
+        const long wg_slots = (long)(h->sm_count > 0 ? h->sm_count : 256);
+        const long chunks = ((long)b->ntiles + EV_CHUNK - 1) / EV_CHUNK;
+        const long max_useful = (chunks + EV_WAVES - 1) / EV_WAVES;
+        static const long oversub = getenv("GPSBB_EV_OVERSUB") ? atol(getenv("GPSBB_EV_OVERSUB")) : 8;
+        long want = (wg_slots * oversub + b->nblocks - 1) / b->nblocks;
+        want = want < 1 ? 1 : (want > max_useful ? max_useful : want);
+        hipLaunchKernelGGL(k_synth_ev, dim3((int)want, b->nblocks), dim3(EV_WG), sizeof(EvLds), h->s_compute, p, d_iq);
+        h->last_kernel = 2;
+    } else {
+        h->last_kernel = 1;
         /* Workgroups per block: enough of them to oversubscribe the chip ~3x (tiles are handed out
          * dynamically in chunks, so the tail is short), never more than there are chunks; the per-block
          * LDS tables (amplitude LUT, chips, nav words) are then built few times per block. */

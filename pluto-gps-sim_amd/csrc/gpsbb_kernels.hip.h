@@ -84,6 +84,20 @@ struct SynRow {
 };
 static_assert(sizeof(SynRow) == sizeof(NcoRow), "row pool is sized for NcoRow");
 
+/* Per (block, channel) constants of the breakpoint kernel (gpsbb_events.hip.h), built on the host at batch
+ * set-up from the descriptors with the same individually rounded products the kernels use. */
+struct EvConst {
+    double S;     /* carrier step per sample in table-index units: 512 * fl(f_carr*delt), exact             */
+    double rS;    /* 1/|S| (2^1000 where S == 0: no index change is ever in reach)                        */
+    double thrK;  /* a carrier breakpoint estimate t is trusted when |fract(t) - 0.5| <= thrK             */
+    double sc;    /* code step per sample in chips: fl(f_code*delt)                                       */
+    double rsc;   /* 1/sc                                                                                  */
+    double thrC;  /* as thrK, for the chip change                                                          */
+    int32_t kc;   /* carrier breakpoints a run of SPT samples can hold (1..4); -1: always recompute exactly */
+    int32_t down; /* S < 0                                                                                 */
+};
+static_assert(sizeof(EvConst) == 56, "EvConst layout");
+
 /* Everything the kernels need about one batch; passed by value as the kernel argument. */
 struct BatchDev {
     const gpsbb_chan_t *ch;         /* [nblocks*nch] descriptors, block-major                        */
@@ -110,7 +124,15 @@ struct BatchDev {
                                        wavefronts with few lanes (a wavefront runs as long as its longest chain
                                        and every extra lane adds turns of the loops its lanes do not share)   */
     uint32_t *status;               /* self-check word                                               */
-    unsigned long long *hazards;    /* [0] itable_512, [1] dwrd_oob                                  */
+    unsigned long long *hazards;    /* [0] itable_512, [1] dwrd_oob, [2] lane-runs k_synth_ev recomputed exactly */
+    /* breakpoint kernel (k_synth_ev): instead of rows and a tile index, k_seed leaves the exact state of every
+     * chain at the first sample of every tile */
+    int ev;                         /* 1: this batch runs on k_synth_ev                               */
+    double *tile_x;                 /* [nblocks][ntiles][2*nch]: column 2*channel = code phase (chips), 2*channel+1 =
+                                       carrier phase * 512, at sample tile*TILE                        */
+    uint32_t *tile_nav;             /* [nblocks][ntiles][nch]: bit 0 = the data bit in force is -1, bit 1 = the data
+                                       bit after the next code roll-over is -1                         */
+    const EvConst *evc;             /* [nblocks*nch]                                                  */
 };
 
 __device__ __forceinline__ size_t tile_row_at(const BatchDev &p, int b, int t, int i, int kind)
@@ -225,6 +247,106 @@ struct RowSink {
     }
 };
 
+/*
+ * What k_seed leaves for the breakpoint kernel: no rows, only the exact state of the chain at the first
+ * sample of every tile — fma(tile start - n0, S, x) of the row that holds it (exact, see SynRow) — and, for
+ * code chains, the data bit in force there and the one the next roll-over brings.  Same call sequence as
+ * RowSink (build_rows_f64 drives either).
+ */
+struct TileSink {
+    double *tx;         /* this chain's column of tile_x, at the next tile to write */
+    uint32_t *tn;       /* code chains: this channel's column of tile_nav; carrier chains: nullptr */
+    uint32_t xstride, nstride;
+    int32_t tile_t, ntiles;
+    /* the row being walked */
+    int32_t pn0;
+    double px, pS;
+    uint32_t pbits;
+    uint32_t cnt;
+    bool overflow; /* never: kept so that the chain drivers treat both sinks alike */
+    unsigned long long *hz;
+    unsigned long long hz_local[2];
+    const uint32_t *dwrd;
+    uint32_t dbit;
+
+    GPSBB_HD void flush(int32_t upto) /* tiles that start before sample `upto` lie in the current row */
+    {
+        const int32_t nt = (int32_t)(((uint32_t)upto + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
+        const int32_t lim = nt < ntiles ? nt : ntiles;
+        while (tile_t < lim) {
+            *tx = fma_rn((double)(tile_t * TILE - pn0), pS, px);
+            tx += xstride;
+            if (tn) {
+                *tn = pbits;
+                tn += nstride;
+            }
+            tile_t++;
+        }
+    }
+    GPSBB_HD void row(int32_t n0, uint32_t nav, double x, double S, bool)
+    {
+        if (cnt)
+            flush(n0);
+        pn0 = n0;
+        if (dwrd) {
+            px = x;
+            pS = S;
+            /* the data bit after the next roll-over (c:2717-2733): a new one only when icode rolls over too */
+            const uint32_t nav1 = nav_advance(nav);
+            const uint32_t nxt = nav_icode(nav1) == 0 ? (nav_bit(dwrd, nav1) < 0 ? 2u : 0u) : (dbit ? 2u : 0u);
+            pbits = (dbit ? 1u : 0u) | nxt;
+        } else {
+            px = mul_rn(x, 512.0);
+            pS = mul_rn(S, 512.0);
+            pbits = 0;
+        }
+        cnt++;
+    }
+    GPSBB_HD void table_index_512()
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicAdd(hz, 1ull);
+#else
+        hz_local[0]++;
+#endif
+    }
+    GPSBB_HD void nav_fetch(uint32_t nav)
+    {
+        if (nav_iword(nav) >= GPSBB_N_DWRD) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            atomicAdd(hz + 1, 1ull);
+#else
+            hz_local[1]++;
+#endif
+        }
+        dbit = nav_bit(dwrd, nav) < 0 ? 0x80000000u : 0u;
+    }
+    GPSBB_HD void finish() { flush(INT32_MAX - TILE); }
+};
+
+/* a TileSink for chain (b, i, kind) of a batch whose tile arrays start at tile_x / tile_nav */
+GPSBB_HD TileSink make_tile_sink(double *tile_x, uint32_t *tile_nav, int nch, int ntiles, int b, int i, int kind,
+                                 const uint32_t *dwrd, uint32_t nav0, unsigned long long *hz)
+{
+    TileSink s;
+    s.tx = tile_x + ((size_t)b * ntiles) * (2 * (size_t)nch) + 2 * i + kind;
+    s.tn = kind == 0 ? tile_nav + ((size_t)b * ntiles) * (size_t)nch + i : nullptr;
+    s.xstride = 2u * (uint32_t)nch;
+    s.nstride = (uint32_t)nch;
+    s.tile_t = 0;
+    s.ntiles = ntiles;
+    s.pn0 = 0;
+    s.px = s.pS = 0.0;
+    s.pbits = 0;
+    s.cnt = 0;
+    s.overflow = false;
+    s.hz = hz;
+    s.hz_local[0] = s.hz_local[1] = 0;
+    s.dwrd = dwrd;
+    s.dbit = dwrd && nav_bit(dwrd, nav0) < 0 ? 0x80000000u : 0u;
+    return s;
+}
+
 /* what phase 2 of k_seed needs to know about the chain a lane has just built */
 struct ChainDone {
     const SynRow *rows;
@@ -253,6 +375,8 @@ __device__ __forceinline__ RowSink make_sink(const BatchDev &p, int chain, const
     return s;
 }
 
+/* EV: the batch runs on the breakpoint kernel — tile states (TileSink) instead of rows + tile index (RowSink) */
+template <bool EV>
 __device__ inline ChainDone seed_code_chain(const BatchDev &p, int b, int i)
 {
     const gpsbb_chan_t &c = p.ch[(size_t)b * p.nch + i];
@@ -266,12 +390,22 @@ __device__ inline ChainDone seed_code_chain(const BatchDev &p, int b, int i)
     }
     const int chain = chain_code(p, b, i);
     uint32_t nav = nav_pack(c.icode, c.ibit, c.iword);
-    RowSink sink = make_sink(p, chain, c.dwrd, nav);
     const double s = mul_rn(c.f_code, p.delt); /* plutogpssim.c:2709: f_code * delt, rounded on its own */
-    const double x = build_rows_f64<NCO_CODE>(c.code_phase, s, nav, p.nsamp, sink);
-    sink.finish();
-    if (sink.overflow)
-        atomicOr(p.status, ST_ROW_OVERFLOW);
+    double x;
+    if (EV) {
+        TileSink sink = make_tile_sink(p.tile_x, p.tile_nav, p.nch, p.ntiles, b, i, 0, c.dwrd, nav, p.hazards);
+        x = build_rows_f64<NCO_CODE>(c.code_phase, s, nav, p.nsamp, sink);
+        sink.finish();
+        d.cnt = (int)sink.cnt;
+    } else {
+        RowSink sink = make_sink(p, chain, c.dwrd, nav);
+        x = build_rows_f64<NCO_CODE>(c.code_phase, s, nav, p.nsamp, sink);
+        sink.finish();
+        if (sink.overflow)
+            atomicOr(p.status, ST_ROW_OVERFLOW);
+        d.rows = sink.rows;
+        d.cnt = (int)sink.cnt;
+    }
     e.code_phase = x;
     e.iword = nav_iword(nav);
     e.ibit = nav_ibit(nav);
@@ -280,11 +414,10 @@ __device__ inline ChainDone seed_code_chain(const BatchDev &p, int b, int i)
     const int ci = (int)x;
     e.codeCA = (int)((p.ca_bits[c.prn * 32 + (ci >> 5)] >> (ci & 31)) & 1u) * 2 - 1; /* c:2737 */
     e._pad = 0;
-    d.rows = sink.rows;
-    d.cnt = (int)sink.cnt;
     return d;
 }
 
+template <bool EV>
 __device__ inline ChainDone seed_carr_chain(const BatchDev &p, int b, int i, double x0, double *x_end)
 {
     const gpsbb_chan_t &c = p.ch[(size_t)b * p.nch + i];
@@ -296,17 +429,25 @@ __device__ inline ChainDone seed_carr_chain(const BatchDev &p, int b, int i, dou
         return d;
     }
     const int chain = chain_carr(p, b, i);
-    RowSink sink = make_sink(p, chain, nullptr, 0u);
     uint32_t nav = 0;
     const double s = mul_rn(c.f_carr, p.delt); /* plutogpssim.c:2741 */
-    const double x = build_rows_f64<NCO_CARR>(x0, s, nav, p.nsamp, sink);
-    sink.finish();
-    if (sink.overflow)
-        atomicOr(p.status, ST_ROW_OVERFLOW);
+    double x;
+    if (EV) {
+        TileSink sink = make_tile_sink(p.tile_x, p.tile_nav, p.nch, p.ntiles, b, i, 1, nullptr, 0u, p.hazards);
+        x = build_rows_f64<NCO_CARR>(x0, s, nav, p.nsamp, sink);
+        sink.finish();
+        d.cnt = (int)sink.cnt;
+    } else {
+        RowSink sink = make_sink(p, chain, nullptr, 0u);
+        x = build_rows_f64<NCO_CARR>(x0, s, nav, p.nsamp, sink);
+        sink.finish();
+        if (sink.overflow)
+            atomicOr(p.status, ST_ROW_OVERFLOW);
+        d.rows = sink.rows;
+        d.cnt = (int)sink.cnt;
+    }
     e.carr_phase = x;
     *x_end = x;
-    d.rows = sink.rows;
-    d.cnt = (int)sink.cnt;
     return d;
 }
 
@@ -330,6 +471,7 @@ __device__ inline void seed_carr_fixed(const BatchDev &p, int b, int i)
 /* Four wavefronts per workgroup (one per SIMD of a CU): measured best trade between the pre-pass's own
  * speed (chains sharing a SIMD slow each other by ~1/3) and how much it disturbs the previous run's k_synth,
  * which it overlaps. */
+template <bool EV>
 __global__ __launch_bounds__(GPSBB_SEED_WG) void k_seed(BatchDev p)
 {
     /* the chain walk is a long dependent instruction stream: let it issue whenever it is ready (it uses a
@@ -343,8 +485,9 @@ __global__ __launch_bounds__(GPSBB_SEED_WG) void k_seed(BatchDev p)
         return;
     const int nbc = p.nblocks * p.nch;
     if (c < nbc) {
-        const ChainDone d = seed_code_chain(p, c / p.nch, c % p.nch);
-        p.row_cnt[chain_code(p, c / p.nch, c % p.nch)] = d.cnt;
+        const ChainDone d = seed_code_chain<EV>(p, c / p.nch, c % p.nch);
+        if (!EV)
+            p.row_cnt[chain_code(p, c / p.nch, c % p.nch)] = d.cnt;
         return;
     }
     /* carrier chains: every block starts from its descriptor's carr_phase.  Blocks that continue each
@@ -356,8 +499,9 @@ __global__ __launch_bounds__(GPSBB_SEED_WG) void k_seed(BatchDev p)
         return;
     }
     double unused;
-    const ChainDone d = seed_carr_chain(p, b, i, p.ch[(size_t)b * p.nch + i].carr_phase, &unused);
-    p.row_cnt[chain_carr(p, b, i)] = d.cnt;
+    const ChainDone d = seed_carr_chain<EV>(p, b, i, p.ch[(size_t)b * p.nch + i].carr_phase, &unused);
+    if (!EV)
+        p.row_cnt[chain_carr(p, b, i)] = d.cnt;
 }
 
 /* ---- k_synth ------------------------------------------------------------------------------------- */

@@ -1,6 +1,7 @@
 /*
  * gpsbb_testhooks.h — exported only so that tests can exercise, on the host and without a GPU, the very
- * same exact-jump-ahead code (gpsbb_nco.h) the device pre-pass runs.  Not part of the drop-in ABI.
+ * same exact-jump-ahead code (gpsbb_nco.h) the device pre-pass runs.  Pure functions: no state, no handle.
+ * Not part of the drop-in ABI.
  */
 #ifndef GPSBB_TESTHOOKS_H
 #define GPSBB_TESTHOOKS_H
@@ -25,12 +26,6 @@ int gpsbb_test_build_rows(int kind, double x0, double s, unsigned nav0, int nsam
  * sample n of a row is fma(n - n0, S, x) */
 int gpsbb_test_build_rows_f64(int kind, double x0, double s, unsigned nav0, int nsamp, gpsbb_test_row_t *rows,
                               int cap, double *x_end, unsigned *nav_end);
-/* where the NCO tables of a run are built: 0 = by batch size (default: small batches on host threads), 1 = always
- * by k_seed on the device, 2 = always on the host */
-void gpsbb_test_seed_mode(int mode);
-/* measurement only: after the first two runs of a batch (both table sets built) skip k_seed, so that
- * k_synth can be timed alone on unchanged tables */
-void gpsbb_test_skip_seed(int on);
 unsigned long long gpsbb_test_row_bound(int kind, double s_abs, int nsamp);
 
 #ifdef __cplusplus

@@ -22,13 +22,18 @@ def assert_state_equal(got, want, active):
         assert g.tobytes() == w.tobytes(), f
 
 
-@pytest.fixture(autouse=True, params=["seeded-by-k_seed", "seeded-on-host"])
-def seed_mode(pkg, request):
-    """The NCO tables of a run are built by k_seed on the device or, for small batches, by host threads running
-    the same code: every test below runs both ways (by default the batch size decides)."""
-    pkg.lib().gpsbb_test_seed_mode(1 if request.param == "seeded-by-k_seed" else 2)
+@pytest.fixture(autouse=True, params=["k_seed+auto", "host+auto", "k_seed+per-sample", "host+per-sample"])
+def seed_mode(pkg, synth, request):
+    """Every test below runs four ways.  The exact NCO pre-pass of a run is computed by k_seed on the device or,
+    for small batches, by host threads running the same code (by default the batch size decides); and the
+    synthesis kernel is chosen automatically (the breakpoint kernel k_synth_ev wherever it is eligible: sample
+    rates above ~16 MS/s) or forced to the per-sample kernel k_synth."""
+    where, kernel = request.param.split("+")
+    synth.set_option(pkg.OPT_SEED_WHERE, 1 if where == "k_seed" else 2)
+    synth.set_option(pkg.OPT_SYNTH_KERNEL, 1 if kernel == "per-sample" else 0)
     yield
-    pkg.lib().gpsbb_test_seed_mode(0)
+    synth.set_option(pkg.OPT_SEED_WHERE, 0)
+    synth.set_option(pkg.OPT_SYNTH_KERNEL, 0)
 
 
 def test_native_library_is_what_runs(pkg, synth):

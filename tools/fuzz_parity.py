@@ -33,6 +33,7 @@ def main():
     # sample longer than a multiple of the tile, a wide batch at the headline geometry
     shapes = [(25e6, 1 << 24, 2, 1), (2.6e6, 777, 12, 3000), (10e6, 1, 16, 5000), (25e6, 1024 * 300 + 1, 16, 3),
               (25e6, 2500000, 16, 6), (1e6, 5000000, 3, 2)]
+    used = {}
     with pkg.Synth(0) as synth:
         for case in range(len(shapes) * 2 if a.shapes else a.cases):
             fs = float(rng.choice([1e6, 2.6e6, 3e6, 4.092e6, 10e6, 16e6, 25e6, 30e6, 2.0 ** 25, 50e6]))
@@ -42,6 +43,7 @@ def main():
             fixed = bool(rng.integers(0, 4) == 0)
             chain = bool(rng.integers(0, 2))
             mode = int(rng.integers(1, 3))            # 1: k_seed, 2: host threads
+            kern = int(rng.integers(0, 2))            # 0: automatic (breakpoint kernel where eligible), 1: per-sample
             if a.shapes:
                 fs, nsamp, nch, nblocks = shapes[case // 2]
                 fixed, mode = False, 1 + case % 2
@@ -60,13 +62,15 @@ def main():
                 ch["carr_phase"] = np.floor(ch["carr_phase"] * 2.0 ** 32)
             flags = (pkg.FIXED_CARRIER if fixed else 0) | (pkg.CHAIN_CARRIER if chain else 0)
             want_iq, want_st, _ = oracle.fill_blocks(ch, 1.0 / fs, nsamp, chain=chain, fixed=fixed)
-            lib.gpsbb_test_seed_mode(mode)
+            synth.set_option(pkg.OPT_SEED_WHERE, mode)
+            synth.set_option(pkg.OPT_SYNTH_KERNEL, kern)
             b = synth.batch(ch, 1.0 / fs, nsamp, flags=flags)
             b.run()
             synth.sync()
             iq, st = b.read()
             b.close()
-            what = dict(case=case, fs=fs, nsamp=nsamp, nch=nch, nblocks=nblocks, fixed=fixed, chain=chain, mode=mode)
+            used[synth.info(pkg.INFO_LAST_KERNEL)] = used.get(synth.info(pkg.INFO_LAST_KERNEL), 0) + 1
+            what = dict(case=case, fs=fs, nsamp=nsamp, nch=nch, nblocks=nblocks, fixed=fixed, chain=chain, mode=mode, kern=kern)
             if not (iq == want_iq).all():
                 bad = np.argwhere(iq != want_iq)[0]
                 raise SystemExit("MISMATCH %r first at block %d sample %d" % (what, bad[0], bad[1]))
@@ -74,8 +78,10 @@ def main():
             for f in ("carr_phase", "code_phase", "iword", "ibit", "icode", "dataBit", "codeCA"):
                 if st[f][act].tobytes() != want_st[f][act].tobytes():
                     raise SystemExit("END STATE MISMATCH %r field %s" % (what, f))
-        lib.gpsbb_test_seed_mode(0)
-    print("fuzz_parity: %d cases bit-exact (seed %d)" % (len(shapes) * 2 if a.shapes else a.cases, a.seed))
+        exact_runs = synth.info(pkg.INFO_EXACT_RUNS)
+    print("fuzz_parity: %d cases bit-exact (seed %d); synthesis kernel used {1: per-sample, 2: breakpoint}: %r; "
+          "lane-runs recomputed exactly by the breakpoint kernel: %d" %
+          (len(shapes) * 2 if a.shapes else a.cases, a.seed, used, exact_runs))
 
 
 if __name__ == "__main__":

@@ -157,7 +157,7 @@ bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vec
             const double S = sk * 512.0, aS = std::fabs(S);
             if (!(sc * reach < 1.0) || !(sc >= 0x1p-20))
                 return false;
-            K.S = S;
+            K.S = aS; /* a falling carrier is walked mirrored: phase -y, step |S| */
             K.sc = sc;
             K.rsc = 1.0 / sc;
             K.thrC = 0.5 - (EV_MODEL_ERR * K.rsc + EV_T_EPS);

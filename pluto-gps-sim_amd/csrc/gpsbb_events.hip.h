@@ -45,12 +45,14 @@ namespace gpsbb_impl {
 constexpr int EV_WG = GPSBB_EV_WG;
 constexpr int EV_WAVES = EV_WG / 64;
 constexpr int EV_KC_MAX = 4;                       /* carrier breakpoints a run may hold */
-constexpr int EV_AMP_PAD = EV_KC_MAX;              /* table entries repeated before [0] and after [511] */
-constexpr int EV_AMP_STRIDE = 512 + 2 * EV_AMP_PAD;
+constexpr int EV_AMP_PAD = EV_KC_MAX;              /* table entries repeated after [511] */
+constexpr int EV_AMP_STRIDE = 512 + EV_AMP_PAD + 4;
+constexpr int EV_CHIP_LEN = 1024 + 80;             /* chips 0 .. 1023+79: a tile's model phase never passes 1023 + 1039*sc < 1023 + 68 */
 #ifndef GPSBB_EV_CHUNK
-#define GPSBB_EV_CHUNK 2
+#define GPSBB_EV_CHUNK 4
 #endif
-constexpr int EV_CHUNK = GPSBB_EV_CHUNK;
+constexpr int EV_CHUNK = GPSBB_EV_CHUNK;           /* consecutive tiles a wavefront takes at a time */
+constexpr int EV_ROW_DISCARD = 15;                 /* D row of changes that fall behind the run's last sample */
 
 /* bound used for |model - truth| (table-index units / chips); the derivation above gives < 2^-33.9 */
 #define EV_MODEL_ERR 0x1p-32
@@ -59,134 +61,233 @@ constexpr int EV_CHUNK = GPSBB_EV_CHUNK;
 
 /* LDS image of one workgroup */
 struct EvLds {
-    uint32_t amp[GPSBB_MAX_CHAN][EV_AMP_STRIDE]; /* P = Q*65536 + I of table index k at [EV_AMP_PAD + k], k = -PAD .. 511+PAD (mod 512) */
-    int8_t chipm[GPSBB_MAX_CHAN][1024];          /* 0 where codeCA = +1, -1 where codeCA = -1; [1023] = [0] */
-    uint32_t D[EV_WAVES][16][64];                /* difference arrays: row j & 15 (row 0 = discard), lane */
-    int32_t act[GPSBB_MAX_CHAN];
-    int32_t nact;
+    uint32_t amp[GPSBB_MAX_CHAN][EV_AMP_STRIDE]; /* P = Q*65536 + I of table index k mod 512 at [k], k = 0 .. 511+PAD;
+                                                    channels with a falling carrier: of index 511 - k */
+    uint16_t chip2[GPSBB_MAX_CHAN][EV_CHIP_LEN]; /* low byte: 0 where codeCA of chip c mod 1023 is +1, 0xff where -1;
+                                                    high byte: the same for chip c+1 */
+    uint32_t D[EV_WAVES][16][64];                /* difference arrays: row j-1 holds the change at sample j of the lane's
+                                                    run (row 15 = discard), one column per lane */
+    double tstate[EV_WAVES][2][2 * GPSBB_MAX_CHAN]; /* per wavefront, two tiles deep: the tile's exact states, column
+                                                    2*channel = code phase, 2*channel+1 = carrier phase*512 (512 - that
+                                                    for a falling carrier) */
 };
 
 /* (x ^ m) - m: x where m = 0, -x where m = -1 */
 __device__ __forceinline__ uint32_t signed_by(uint32_t x, uint32_t m) { return (x ^ m) - m; }
 
+/* wave-uniform loads through the scalar cache: the tables the host wrote before this kernel started are
+ * read-only here, so they may be read as constant-address-space data (s_load: the values arrive in scalar
+ * registers and cost no vector-memory or LDS slot) */
+template <class T>
+__device__ __forceinline__ T scalar_load(const T *p)
+{
+    typedef const __attribute__((address_space(4))) T *cptr_t;
+    return *(cptr_t)(uintptr_t)p;
+}
+
 /*
  * The exact recomputation of one lane's run of one channel (rare): advance both NCOs from the tile's exact
  * state by n_off genuine steps with the jump-ahead of gpsbb_nco.h, then walk the run sample by sample as the
- * reference does (c:2697-2746) and add the differences of its contributions.
+ * reference does (c:2697-2746) and add the differences of its contributions.  Returns the contribution at
+ * the run's first sample.
  */
-__device__ __noinline__ void ev_exact_run(EvLds &L, int wave, int lane, int i, const EvConst K, double xt, double yt,
-                                          uint32_t nb, int n_off, uint32_t *acc0)
+__device__ __noinline__ uint32_t ev_exact_run(EvLds &L, int wave, int lane, int i, const EvConst *kbi, const double *tile_x,
+                                              uint32_t nb, int n_off)
 {
+    const bool down = kbi->down != 0;
+    const double S = down ? -kbi->S : kbi->S, sc = kbi->sc;
+    const double xt = tile_x[2 * i], yt = tile_x[2 * i + 1];
     /* code NCO: at most one roll-over between the tile start and the end of the run (checked by the host) */
     int64_t wraps = 0;
-    double x = code_jump(xt, K.sc, (int64_t)n_off, &wraps);
+    double x = code_jump(xt, sc, (int64_t)n_off, &wraps);
     uint32_t dbm = (wraps > 0 ? (nb >> 1) & 1u : nb & 1u) ? 0xffffffffu : 0u;
     const uint32_t dbm_next = ((nb >> 1) & 1u) ? 0xffffffffu : 0u;
     /* carrier NCO in cycles (the tile state is stored scaled by 512, exactly) */
-    const double s = K.S * (1.0 / 512.0);
+    const double s = S * (1.0 / 512.0);
     double cp = carr_jump(yt * (1.0 / 512.0), s, (int64_t)n_off);
-    uint32_t prev = 0;
+    uint32_t prev = 0, first = 0;
 #pragma unroll 1
     for (int j = 0; j < SPT; j++) {
         const int it = (int)(cp * 512.0) & 511; /* c:2697; carr_phase == 1.0: index 512 defined as 0 */
         const int ci = (int)x;                  /* c:2737 */
-        const uint32_t m = (uint32_t)(int32_t)L.chipm[i][ci] ^ dbm;
-        const uint32_t v = signed_by(L.amp[i][EV_AMP_PAD + it], m);
+        const uint32_t m = (uint32_t)(int32_t)(int8_t)(L.chip2[i][ci] & 0xffu) ^ dbm;
+        const uint32_t v = signed_by(L.amp[i][down ? 511 - it : it], m);
         if (j == 0)
-            *acc0 += v;
+            first = v;
         else
-            __hip_atomic_fetch_add(&L.D[wave][j][lane], v - prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&L.D[wave][j - 1][lane], v - prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         prev = v;
-        if (code_step(x, K.sc)) /* c:2709-2734: the data bit of the next period */
+        if (code_step(x, sc)) /* c:2709-2734: the data bit of the next period */
             dbm = dbm_next;
         carr_step(cp, s); /* c:2741-2746 */
     }
+    return first;
+}
+
+/* per-channel constants of the fast path (scalar registers) */
+struct EvK {
+    double S, rS, thrK, sc, rsc, thrC;
+};
+__device__ __forceinline__ EvK ev_load_k(const EvConst *kb, int i)
+{
+    EvK k;
+    k.S = scalar_load(&kb[i].S);
+    k.rS = scalar_load(&kb[i].rS);
+    k.thrK = scalar_load(&kb[i].thrK);
+    k.sc = scalar_load(&kb[i].sc);
+    k.rsc = scalar_load(&kb[i].rsc);
+    k.thrC = scalar_load(&kb[i].thrC);
+    return k;
 }
 
 /*
- * One channel's contribution to this lane's run.  DOWN: the carrier step is negative; KC: carrier
- * breakpoints a run can hold (wave-uniform, from the host).  Returns nothing: D / acc0 are updated.
+ * First half of one channel's work on this lane's run: where the table index and the chip change, and the
+ * LDS reads of the values involved (issued, not waited for).  KC: carrier breakpoints a run can hold
+ * (wave-uniform, from the host).  A channel whose carrier falls is walked mirrored (phase 512 - y, step |S|,
+ * amplitude table stored back to front: floor(y) = 511 - floor(512 - y) wherever y is not an integer, and a
+ * lane that comes within the model error of one recomputes exactly anyway), so this code only knows rising
+ * phases.  The code phase is not reduced modulo 1023: the chip table simply continues past 1023.
  */
-template <bool DOWN, int KC>
-__device__ __forceinline__ void ev_channel(EvLds &L, int wave, int lane, int i, const EvConst K, double xt, double yt,
-                                           uint32_t nb, double off, bool lane_live, uint32_t &acc0,
-                                           unsigned long long *n_exact)
-{
-    const double one_minus_b = 1.0 - EV_MODEL_ERR;
-    /* ---- carrier: table index of the first sample and the samples at which it changes ---- */
-    const double y0 = __fma_rn(off, K.S, yt);
-    const double yf = floor(y0);
-    const double fr = y0 - yf; /* exact */
-    const int it0 = (int)yf & 511;
-    const double g = DOWN ? fr : 1.0 - fr; /* distance to the next index change */
-    bool unsafe = g > one_minus_b;         /* the previous change lies within the model error of sample 0 */
-    int jk[KC];
-    {
-        double t = g * K.rS;
-#pragma unroll
-        for (int k = 0; k < KC; k++) {
-            const double tq = fmin(t, 15.5);
-            const double fq = __builtin_amdgcn_fract(tq);
-            unsafe |= fabs(fq - 0.5) > K.thrK;
-            jk[k] = (int)tq + 1; /* 1..16 */
-            t += K.rS;
-        }
-    }
-    const uint32_t *ampi = &L.amp[i][EV_AMP_PAD + it0];
+template <int KC>
+struct EvHalf {
+    int jk[KC]; /* row of D (= sample - 1) of the k-th index change, 15 = not in this run */
+    int jc;     /* ... of the chip change */
+    int c0;     /* chip of the first sample, not reduced modulo 1023 */
+    bool unsafe;
     uint32_t A[KC + 1];
+    uint32_t ch2;
+};
+
+template <int KC>
+__device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK &K, double xt, double yt, double off)
+{
+    EvHalf<KC> h;
+    const double b = EV_MODEL_ERR;
+    /* ---- carrier: table index of the first sample and the samples at which it changes ---- */
+    const double y0 = __fma_rn(off, K.S, yt); /* >= 0 */
+    const double fr = __builtin_amdgcn_fract(y0);
+    const int it0 = (int)y0 & 511;
+    h.unsafe = fr < b; /* the previous change lies within the model error of sample 0 */
+    double t = (1.0 - fr) * K.rS; /* samples until the next index change */
+#pragma unroll
+    for (int k = 0; k < KC; k++) {
+        const double tq = fmin(t, 15.5);
+        h.unsafe |= fabs(__builtin_amdgcn_fract(tq) - 0.5) > K.thrK;
+        h.jk[k] = (int)tq; /* the change shows at sample (int)tq + 1: rows 0..14, or 15 */
+        t += K.rS;
+    }
+    const uint32_t *ampi = &L.amp[i][it0];
 #pragma unroll
     for (int k = 0; k <= KC; k++)
-        A[k] = DOWN ? ampi[-k] : ampi[k];
-
+        h.A[k] = ampi[k];
     /* ---- code: chip of the first sample and the sample at which it changes ---- */
-    double x0 = __fma_rn(off, K.sc, xt);
-    const bool wb = x0 >= 1023.0; /* rolled over since the tile start */
-    x0 = wb ? x0 - 1023.0 : x0;
-    const double xf = floor(x0);
-    const int c0 = (int)xf;
-    const double gc = 1.0 - (x0 - xf);
-    unsafe |= gc > one_minus_b;
-    const double tc = fmin(gc * K.rsc, 15.5);
-    unsafe |= fabs(__builtin_amdgcn_fract(tc) - 0.5) > K.thrC;
-    int jc = (int)tc + 1;
-    const int8_t *chp = &L.chipm[i][c0];
-    const uint32_t ma = (uint32_t)(int32_t)chp[0], mb = (uint32_t)(int32_t)chp[1];
-    const uint32_t db_cur = (nb & 1u) ? 0xffffffffu : 0u, db_next = (nb & 2u) ? 0xffffffffu : 0u;
-    const uint32_t dbA = wb ? db_next : db_cur;
-    const uint32_t dbB = c0 == 1022 ? db_next : dbA;
-    const uint32_t m0 = ma ^ dbA, m1 = mb ^ dbB;
-    jc = m0 == m1 ? 16 : jc; /* equal neighbours: nothing changes at the chip boundary */
+    const double x0 = __fma_rn(off, K.sc, xt);
+    const double frc = __builtin_amdgcn_fract(x0);
+    h.c0 = (int)x0;
+    h.unsafe |= frc < b;
+    const double tc = fmin((1.0 - frc) * K.rsc, 15.5);
+    h.unsafe |= fabs(__builtin_amdgcn_fract(tc) - 0.5) > K.thrC;
+    h.jc = (int)tc;
+    h.ch2 = L.chip2[i][h.c0];
+    return h;
+}
+
+/*
+ * Second half: signs, the contribution at sample 0 (into acc0) and its changes (into D).  db / db_next: the
+ * data bit in force at the tile start / after the next code roll-over as masks (0 = +1, -1 = -1; wave-uniform);
+ * DF: they differ, so lanes past the roll-over (chip index >= 1023) take the other one.
+ */
+template <int KC, bool DF>
+__device__ __forceinline__ void ev_second(EvLds &L, int wave, int lane, int i, EvHalf<KC> &h, uint32_t db, uint32_t db_next,
+                                          bool always_exact, bool lane_live, const EvConst *kb, const double *tile_x,
+                                          uint32_t nb, double off, uint32_t &acc0, unsigned long long *n_exact)
+{
+    const uint32_t ma = (uint32_t)(int32_t)(int8_t)(h.ch2 & 0xffu), mb = (uint32_t)(int32_t)(int8_t)(h.ch2 >> 8);
+    uint32_t m0, m1;
+    if (DF) {
+        m0 = ma ^ (h.c0 >= 1023 ? db_next : db);
+        m1 = mb ^ (h.c0 >= 1022 ? db_next : db);
+    } else {
+        m0 = ma ^ db;
+        m1 = mb ^ db;
+    }
+    int jc = m0 == m1 ? EV_ROW_DISCARD : h.jc; /* equal neighbours: nothing changes at the chip boundary */
 
     /* ---- rare: this lane cannot rule out that the model and the reference disagree ---- */
-    unsafe = (unsafe || K.kc < 0) && lane_live;
+    const bool unsafe = (h.unsafe || always_exact) && lane_live;
     if (__builtin_expect(__ballot(unsafe) != 0ull, 0)) {
         if (unsafe) {
-            /* its fast-path contribution becomes nothing (row 0 is the discard row) ... */
+            /* its fast-path contribution becomes nothing ... */
 #pragma unroll
             for (int k = 0; k < KC; k++)
-                jk[k] = 16;
-            jc = 16;
-            A[0] = 0;
+                h.jk[k] = EV_ROW_DISCARD;
+            jc = EV_ROW_DISCARD;
+            h.A[0] = 0;
             /* ... and the exact one takes its place */
-            ev_exact_run(L, wave, lane, i, K, xt, yt, nb, (int)off, &acc0);
+            acc0 += ev_exact_run(L, wave, lane, i, kb + i, tile_x, nb, (int)off);
             atomicAdd(n_exact, 1ull);
         }
     }
 
     /* ---- the contribution at sample 0 and its changes ---- */
-    acc0 += signed_by(A[0], m0);
-    uint32_t Ax = A[KC];
+    acc0 += signed_by(h.A[0], m0);
+    uint32_t Ax = h.A[KC];
 #pragma unroll
     for (int k = KC - 1; k >= 0; k--) {
-        const bool before = jk[k] < jc; /* the index change comes before the chip change */
+        const bool before = h.jk[k] < jc; /* the index change comes before the chip change */
         const uint32_t mk = before ? m0 : m1;
-        const uint32_t dk = signed_by(A[k + 1] - A[k], mk);
-        __hip_atomic_fetch_add(&L.D[wave][jk[k] & 15][lane], dk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        Ax = before ? Ax : A[k]; /* amplitude in force just before the chip change */
+        const uint32_t dk = signed_by(h.A[k + 1] - h.A[k], mk);
+        __hip_atomic_fetch_add(&L.D[wave][h.jk[k]][lane], dk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        Ax = before ? Ax : h.A[k]; /* amplitude in force just before the chip change */
     }
     /* the chip change flips the sign: -s0*A -> s1*A = 2*s1*A more */
-    __hip_atomic_fetch_add(&L.D[wave][jc & 15][lane], signed_by(Ax << 1, m1), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(&L.D[wave][jc][lane], signed_by(Ax << 1, m1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+/* what a wavefront knows about the tile it is working on */
+struct EvTile {
+    const double *ts;     /* LDS: the tile's states (mirrored where the carrier falls) */
+    const double *tile_x; /* global: the same, exact and not mirrored (for the exact recomputation) */
+    uint32_t dbits, dnext; /* bit i: channel i's data bit in force / after the next roll-over is -1 */
+    uint32_t exact_mask;   /* bit i: channel i is always recomputed exactly */
+};
+
+/* the channels of `mask` (bit i = channel i), all with KC breakpoints; two at a time, so that one channel's
+ * arithmetic covers the other's LDS latency */
+template <int KC, bool DF>
+__device__ __forceinline__ void ev_channels(EvLds &L, int wave, int lane, uint32_t mask, const EvConst *kb, const EvTile &T,
+                                            double off, bool lane_live, uint32_t &acc0, unsigned long long *n_exact)
+{
+#define GPSBB_EV_IN(i)                                                                                                 \
+    const EvK K##i = ev_load_k(kb, i);                                                                                 \
+    const double xt##i = T.ts[2 * i], yt##i = T.ts[2 * i + 1];
+#define GPSBB_EV_OUT(i, h)                                                                                             \
+    {                                                                                                                  \
+        const uint32_t db_ = 0u - ((T.dbits >> i) & 1u), dn_ = 0u - ((T.dnext >> i) & 1u);                             \
+        const uint32_t nb_ = ((T.dbits >> i) & 1u) | (((T.dnext >> i) & 1u) << 1);                                     \
+        ev_second<KC, DF>(L, wave, lane, i, h, db_, dn_, ((T.exact_mask >> i) & 1u) != 0, lane_live, kb, T.tile_x, nb_, \
+                          off, acc0, n_exact);                                                                         \
+    }
+    while (mask & (mask - 1)) { /* at least two channels left */
+        const int i0 = __builtin_ctz(mask);
+        mask &= mask - 1;
+        const int i1 = __builtin_ctz(mask);
+        mask &= mask - 1;
+        GPSBB_EV_IN(i0)
+        GPSBB_EV_IN(i1)
+        EvHalf<KC> h0 = ev_first<KC>(L, i0, Ki0, xti0, yti0, off);
+        EvHalf<KC> h1 = ev_first<KC>(L, i1, Ki1, xti1, yti1, off);
+        GPSBB_EV_OUT(i0, h0)
+        GPSBB_EV_OUT(i1, h1)
+    }
+    if (mask) {
+        const int i0 = __builtin_ctz(mask);
+        GPSBB_EV_IN(i0)
+        EvHalf<KC> h0 = ev_first<KC>(L, i0, Ki0, xti0, yti0, off);
+        GPSBB_EV_OUT(i0, h0)
+    }
+#undef GPSBB_EV_IN
+#undef GPSBB_EV_OUT
 }
 
 __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restrict__ iq)
@@ -197,18 +298,15 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const gpsbb_chan_t *__restrict__ cb = p.ch + (size_t)b * p.nch;
+    const EvConst *__restrict__ kb = p.evc + (size_t)b * p.nch;
     /* ---- stage the block's per-channel tables in LDS (once per workgroup) ---- */
-    if (tid == 0) {
-        int na = 0;
-        for (int i = 0; i < p.nch; i++)
-            if (cb[i].prn > 0)
-                L.act[na++] = i;
-        L.nact = na;
-    }
     for (int e = tid; e < p.nch * EV_AMP_STRIDE; e += EV_WG) {
-        const int i = e / EV_AMP_STRIDE, k = (e % EV_AMP_STRIDE - EV_AMP_PAD) & 511;
+        const int i = e / EV_AMP_STRIDE;
+        int k = (e % EV_AMP_STRIDE) & 511;
         uint32_t v = 0;
         if (cb[i].prn > 0) {
+            if (kb[i].down)
+                k = 511 - k; /* falling carrier: the table back to front (see ev_first) */
             const double g = cb[i].gain;
             /* (int)(table * gain): one IEEE multiply, truncation toward zero (plutogpssim.c:2701-2702) */
             const int ip = (int)mul_rn((double)p.tabs[k], g);
@@ -217,105 +315,125 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
         }
         L.amp[i][e % EV_AMP_STRIDE] = v;
     }
-    for (int e = tid; e < p.nch * 256; e += EV_WG) { /* four chips per lane */
-        const int i = e >> 8, q = e & 255;
+    for (int e = tid; e < p.nch * EV_CHIP_LEN; e += EV_WG) {
+        const int i = e / EV_CHIP_LEN, c = e % EV_CHIP_LEN;
         const int prn = cb[i].prn;
+        const int ca = c % GPSBB_CA_LEN, cb1 = (c + 1) % GPSBB_CA_LEN;
         uint32_t v = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int c = (4 * q + k) % GPSBB_CA_LEN; /* [1023] = [0] */
-            const uint32_t bit = prn > 0 ? (p.ca_bits[prn * 32 + (c >> 5)] >> (c & 31)) & 1u : 1u;
-            v |= (bit ? 0x00u : 0xffu) << (8 * k);
+        if (prn > 0) {
+            const uint32_t b0 = (p.ca_bits[prn * 32 + (ca >> 5)] >> (ca & 31)) & 1u;
+            const uint32_t b1 = (p.ca_bits[prn * 32 + (cb1 >> 5)] >> (cb1 & 31)) & 1u;
+            v = (b0 ? 0x00u : 0xffu) | (b1 ? 0x0000u : 0xff00u);
         }
-        reinterpret_cast<uint32_t *>(&L.chipm[i][0])[q] = v;
+        L.chip2[i][c] = (uint16_t)v;
     }
     for (int e = tid; e < EV_WAVES * 16 * 64; e += EV_WG)
         (&L.D[0][0][0])[e] = 0u;
     __syncthreads();
-    const int nact = L.nact;
 
     /* ---- from here on every wavefront works alone ---- */
     const int wave = tid >> 6, lane = tid & 63;
     const int ntw = p.ntiles;
     const int nch2 = 2 * p.nch;
-    const EvConst *__restrict__ kb = p.evc + (size_t)b * p.nch;
+    /* channels by the number of carrier breakpoints a run can hold (bit i = channel i) */
+    uint32_t mk[EV_KC_MAX];
+    uint32_t exact_mask;
+    {
+        const bool act = lane < p.nch && cb[lane < p.nch ? lane : 0].prn > 0;
+        const int kc = act ? kb[lane].kc : 0;
+#pragma unroll
+        for (int k = 0; k < EV_KC_MAX; k++)
+            mk[k] = (uint32_t)__ballot(act && (kc == k + 1 || (k == 0 && kc < 1)));
+        exact_mask = (uint32_t)__ballot(act && kc < 0);
+    }
+    /* lane c < 2*nch holds chain c = (channel c >> 1, kind c & 1) of the tile being staged */
+    const bool chain_lane = lane < nch2;
+    const bool mirror = chain_lane && (lane & 1) && kb[lane >> 1].down != 0;
     const double *__restrict__ tx = p.tile_x + (size_t)b * ntw * nch2;
     const uint32_t *__restrict__ tn = p.tile_nav + (size_t)b * ntw * p.nch;
     const double off = (double)(lane * SPT);
+    unsigned long long *n_exact = p.hazards + 2;
 
-    for (;;) {
-        int chunk = 0;
-        if (lane == 0)
-            chunk = atomicAdd(&p.tile_ctr[b], EV_CHUNK);
-        const int wt_begin = __builtin_amdgcn_readfirstlane(chunk);
-        if (wt_begin >= ntw)
-            break;
-        const int wt_end = wt_begin + EV_CHUNK < ntw ? wt_begin + EV_CHUNK : ntw;
-        /* exact states of all chains at the start of the tile: lane c holds chain c (2*channel + kind) */
-        double ts = lane < nch2 ? tx[(size_t)wt_begin * nch2 + lane] : 0.0;
-        uint32_t tnav = lane < p.nch ? tn[(size_t)wt_begin * p.nch + lane] : 0u;
-        for (int wt = wt_begin; wt < wt_end; wt++) {
-            double ts_next = 0.0;
-            uint32_t tnav_next = 0u;
-            if (wt + 1 < wt_end) {
-                ts_next = lane < nch2 ? tx[(size_t)(wt + 1) * nch2 + lane] : 0.0;
-                tnav_next = lane < p.nch ? tn[(size_t)(wt + 1) * p.nch + lane] : 0u;
-            }
-            const int n0 = wt * TILE + lane * SPT;
-            const int nvalid = p.nsamp - n0 < SPT ? p.nsamp - n0 : SPT;
-            const bool lane_live = nvalid > 0;
-            uint32_t acc0 = 0;
-            for (int a = 0; a < nact; a++) {
-                const int i = __builtin_amdgcn_readfirstlane(L.act[a]);
-                const EvConst K = kb[i];
-                const double xt = hi_lo_f64(__builtin_amdgcn_readlane(__double2hiint(ts), 2 * i),
-                                            __builtin_amdgcn_readlane(__double2loint(ts), 2 * i));
-                const double yt = hi_lo_f64(__builtin_amdgcn_readlane(__double2hiint(ts), 2 * i + 1),
-                                            __builtin_amdgcn_readlane(__double2loint(ts), 2 * i + 1));
-                const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane((int)tnav, i);
-                const int kc = K.kc < 1 ? 1 : K.kc;
-#define GPSBB_EV_CASE(DOWN, KC) ev_channel<DOWN, KC>(L, wave, lane, i, K, xt, yt, nb, off, lane_live, acc0, p.hazards + 2)
-                if (K.down) {
-                    switch (kc) {
-                    case 1: GPSBB_EV_CASE(true, 1); break;
-                    case 2: GPSBB_EV_CASE(true, 2); break;
-                    case 3: GPSBB_EV_CASE(true, 3); break;
-                    default: GPSBB_EV_CASE(true, 4); break;
-                    }
-                } else {
-                    switch (kc) {
-                    case 1: GPSBB_EV_CASE(false, 1); break;
-                    case 2: GPSBB_EV_CASE(false, 2); break;
-                    case 3: GPSBB_EV_CASE(false, 3); break;
-                    default: GPSBB_EV_CASE(false, 4); break;
-                    }
-                }
-#undef GPSBB_EV_CASE
-            }
-            /* ---- prefix sum over the run, back to int16 pairs, store (c:2754-2755) ---- */
-            uint32_t o[SPT];
-            uint32_t P = acc0;
-            o[0] = ((P + 0x8000u) & 0xffff0000u) | (P & 0xffffu);
-#pragma unroll
-            for (int j = 1; j < SPT; j++) {
-                P += __hip_atomic_exchange(&L.D[wave][j][lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                o[j] = ((P + 0x8000u) & 0xffff0000u) | (P & 0xffffu);
-            }
-            uint32_t *out = reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + n0;
-            if (nvalid == SPT && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) {
-                uint4 *o4 = reinterpret_cast<uint4 *>(out);
-#pragma unroll
-                for (int j = 0; j < SPT; j += 4)
-                    o4[j >> 2] = make_uint4(o[j], o[j + 1], o[j + 2], o[j + 3]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < SPT; j++)
-                    if (j < nvalid)
-                        out[j] = o[j];
-            }
-            ts = ts_next;
-            tnav = tnav_next;
+    /* chunks of EV_CHUNK consecutive tiles from a per-block counter; the next chunk is asked for while the
+     * current one is worked on, and a tile's states are fetched while the previous tile is worked on */
+    int base = 0;
+    if (lane == 0)
+        base = atomicAdd(&p.tile_ctr[b], EV_CHUNK);
+    base = __builtin_amdgcn_readfirstlane(base);
+    int pos = 0, buf = 0;
+    int pending = 0; /* lane 0: the next chunk, asked for at the first tile of the current one */
+    double ts_v = 0.0;
+    uint32_t nav_v = 0;
+    if (base < ntw) {
+        ts_v = chain_lane ? tx[(size_t)base * nch2 + lane] : 0.0;
+        nav_v = lane < p.nch ? tn[(size_t)base * p.nch + lane] : 0u;
+    }
+    while (base < ntw) {
+        const int wt = base + pos;
+        /* the tile's states -> this wavefront's LDS slot, its data bits -> scalar masks */
+        if (chain_lane)
+            L.tstate[wave][buf][lane] = mirror ? 512.0 - ts_v : ts_v;
+        EvTile T;
+        T.ts = L.tstate[wave][buf];
+        T.tile_x = tx + (size_t)wt * nch2;
+        T.dbits = (uint32_t)__ballot(nav_v & 1u);
+        T.dnext = (uint32_t)__ballot(nav_v & 2u);
+        T.exact_mask = exact_mask;
+        const uint32_t dflip = T.dbits ^ T.dnext;
+        /* which tile comes next, and its states on their way */
+        if (pos == 0 && lane == 0)
+            pending = atomicAdd(&p.tile_ctr[b], EV_CHUNK);
+        const bool last_of_chunk = pos + 1 >= EV_CHUNK || wt + 1 >= ntw;
+        int next_base = base, next_pos = pos + 1;
+        if (last_of_chunk) {
+            next_base = __builtin_amdgcn_readfirstlane(pending);
+            next_pos = 0;
         }
+        const int wt_next = next_base + next_pos;
+        if (wt_next < ntw) {
+            ts_v = chain_lane ? tx[(size_t)wt_next * nch2 + lane] : 0.0;
+            nav_v = lane < p.nch ? tn[(size_t)wt_next * p.nch + lane] : 0u;
+        }
+
+        const int n0 = wt * TILE + lane * SPT;
+        const int nvalid = p.nsamp - n0 < SPT ? p.nsamp - n0 : SPT;
+        const bool lane_live = nvalid > 0;
+        uint32_t acc0 = 0;
+        ev_channels<1, false>(L, wave, lane, mk[0] & ~dflip, kb, T, off, lane_live, acc0, n_exact);
+        ev_channels<2, false>(L, wave, lane, mk[1] & ~dflip, kb, T, off, lane_live, acc0, n_exact);
+        if (__builtin_expect((mk[2] | mk[3] | dflip) != 0u, 0)) {
+            ev_channels<3, false>(L, wave, lane, mk[2] & ~dflip, kb, T, off, lane_live, acc0, n_exact);
+            ev_channels<4, false>(L, wave, lane, mk[3] & ~dflip, kb, T, off, lane_live, acc0, n_exact);
+            ev_channels<1, true>(L, wave, lane, mk[0] & dflip, kb, T, off, lane_live, acc0, n_exact);
+            ev_channels<2, true>(L, wave, lane, mk[1] & dflip, kb, T, off, lane_live, acc0, n_exact);
+            ev_channels<3, true>(L, wave, lane, mk[2] & dflip, kb, T, off, lane_live, acc0, n_exact);
+            ev_channels<4, true>(L, wave, lane, mk[3] & dflip, kb, T, off, lane_live, acc0, n_exact);
+        }
+        /* ---- prefix sum over the run, back to int16 pairs, store (c:2754-2755) ---- */
+        uint32_t o[SPT];
+        uint32_t P = acc0;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            if (j)
+                P += __hip_atomic_exchange(&L.D[wave][j - 1][lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t t = P + 0x8000u; /* undoes the borrow of a negative I in the high half */
+            o[j] = ((P ^ t) & 0xffffu) ^ t; /* low half of P, high half of t */
+        }
+        uint32_t *out = reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + n0;
+        if (nvalid == SPT && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) {
+            uint4 *o4 = reinterpret_cast<uint4 *>(out);
+#pragma unroll
+            for (int j = 0; j < SPT; j += 4)
+                o4[j >> 2] = make_uint4(o[j], o[j + 1], o[j + 2], o[j + 3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < SPT; j++)
+                if (j < nvalid)
+                    out[j] = o[j];
+        }
+        base = next_base;
+        pos = next_pos;
+        buf ^= 1;
     }
 }
 

@@ -87,14 +87,14 @@ static_assert(sizeof(SynRow) == sizeof(NcoRow), "row pool is sized for NcoRow");
 /* Per (block, channel) constants of the breakpoint kernel (gpsbb_events.hip.h), built on the host at batch
  * set-up from the descriptors with the same individually rounded products the kernels use. */
 struct EvConst {
-    double S;     /* carrier step per sample in table-index units: 512 * fl(f_carr*delt), exact             */
+    double S;     /* |carrier step| per sample in table-index units: 512 * |fl(f_carr*delt)|, exact        */
     double rS;    /* 1/|S| (2^1000 where S == 0: no index change is ever in reach)                        */
     double thrK;  /* a carrier breakpoint estimate t is trusted when |fract(t) - 0.5| <= thrK             */
     double sc;    /* code step per sample in chips: fl(f_code*delt)                                       */
     double rsc;   /* 1/sc                                                                                  */
     double thrC;  /* as thrK, for the chip change                                                          */
     int32_t kc;   /* carrier breakpoints a run of SPT samples can hold (1..4); -1: always recompute exactly */
-    int32_t down; /* S < 0                                                                                 */
+    int32_t down; /* the carrier step is negative                                                         */
 };
 static_assert(sizeof(EvConst) == 56, "EvConst layout");
 

@@ -1062,6 +1062,8 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.seed_order = b->d_seed_order.p;
     p.seed_lanes = (int)b->h_seed_order.size();
     p.ev = b->ev ? 1 : 0;
+    static const int ev_chunk = getenv("GPSBB_EV_CHUNK") ? atoi(getenv("GPSBB_EV_CHUNK")) : EV_CHUNK;
+    p.ev_chunk = ev_chunk < 1 ? 1 : ev_chunk;
     p.tile_x = b->d_tile_x[set].p;
     p.tile_nav = b->d_tile_nav[set].p;
     p.evc = b->d_evc.p;
@@ -1113,15 +1115,19 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     HIPCHK(h, hipMemsetAsync(b->d_tile_ctr.p, 0, (size_t)b->nblocks * sizeof(int32_t), h->s_compute));
     HIPCHK(h, hipEventRecord(ev[2], h->s_compute));
     if (b->ev) {
-        /* one workgroup of EV_WG lanes per CU (its LDS tables take ~113 KB); several per block so that the chip
-         * stays full until the end of the launch, never more than there are chunks of tiles */
+        /* One workgroup of EV_WG lanes fits a CU (its LDS image takes ~140 KB).  Grid = (blocks, workgroups per
+         * block) with the block as the fast dimension, see k_synth_ev: enough workgroups per block that the
+         * chip is full when there are few blocks and that the last blocks in flight get helpers when there
+         * are many, never more than there are chunks of tiles. */
         const long wg_slots = (long)(h->sm_count > 0 ? h->sm_count : 256);
-        const long chunks = ((long)b->ntiles + EV_CHUNK - 1) / EV_CHUNK;
+        const long chunks = ((long)b->ntiles + p.ev_chunk - 1) / p.ev_chunk;
         const long max_useful = (chunks + EV_WAVES - 1) / EV_WAVES;
-        static const long oversub = getenv("GPSBB_EV_OVERSUB") ? atol(getenv("GPSBB_EV_OVERSUB")) : 8;
+        static const long oversub = getenv("GPSBB_EV_OVERSUB") ? atol(getenv("GPSBB_EV_OVERSUB")) : 3;
+        static const long min_wg = getenv("GPSBB_EV_MIN_WG") ? atol(getenv("GPSBB_EV_MIN_WG")) : 3;
         long want = (wg_slots * oversub + b->nblocks - 1) / b->nblocks;
-        want = want < 1 ? 1 : (want > max_useful ? max_useful : want);
-        hipLaunchKernelGGL(k_synth_ev, dim3((int)want, b->nblocks), dim3(EV_WG), sizeof(EvLds), h->s_compute, p, d_iq);
+        want = want < min_wg ? min_wg : want;
+        want = want > max_useful ? max_useful : want;
+        hipLaunchKernelGGL(k_synth_ev, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), h->s_compute, p, d_iq);
         h->last_kernel = 2;
     } else {
         h->last_kernel = 1;

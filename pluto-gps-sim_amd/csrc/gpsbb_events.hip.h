@@ -49,9 +49,9 @@ constexpr int EV_AMP_PAD = EV_KC_MAX;              /* table entries repeated aft
 constexpr int EV_AMP_STRIDE = 512 + EV_AMP_PAD + 4;
 constexpr int EV_CHIP_LEN = 1024 + 80;             /* chips 0 .. 1023+79: a tile's model phase never passes 1023 + 1039*sc < 1023 + 68 */
 #ifndef GPSBB_EV_CHUNK
-#define GPSBB_EV_CHUNK 4
+#define GPSBB_EV_CHUNK 2
 #endif
-constexpr int EV_CHUNK = GPSBB_EV_CHUNK;           /* consecutive tiles a wavefront takes at a time */
+constexpr int EV_CHUNK = GPSBB_EV_CHUNK;           /* consecutive tiles a wavefront takes at a time (default of BatchDev::ev_chunk) */
 constexpr int EV_ROW_DISCARD = 15;                 /* D row of changes that fall behind the run's last sample */
 
 /* bound used for |model - truth| (table-index units / chips); the derivation above gives < 2^-33.9 */
@@ -296,7 +296,14 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
     EvLds &L = *reinterpret_cast<EvLds *>(smem_raw);
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.y;
+    /* The block is the FAST grid dimension: the first workgroups dispatched are one per block, on as many
+     * CUs as there are; the workgroups with blockIdx.y > 0 come after them and join blocks that are still
+     * being worked on (tiles are handed out from a per-block counter), or leave at once if theirs is done.
+     * With the block as the slow dimension the launch proceeds in rounds of (CUs / workgroups per block)
+     * blocks and the last round leaves part of the chip idle: 2.4 instead of 2.1 ms. */
+    const int b = blockIdx.x;
+    if (blockIdx.y > 0 && __hip_atomic_load(&p.tile_ctr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.ntiles)
+        return;
     const gpsbb_chan_t *__restrict__ cb = p.ch + (size_t)b * p.nch;
     const EvConst *__restrict__ kb = p.evc + (size_t)b * p.nch;
     /* ---- stage the block's per-channel tables in LDS (once per workgroup) ---- */
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
      * current one is worked on, and a tile's states are fetched while the previous tile is worked on */
     int base = 0;
     if (lane == 0)
-        base = atomicAdd(&p.tile_ctr[b], EV_CHUNK);
+        base = atomicAdd(&p.tile_ctr[b], p.ev_chunk);
     base = __builtin_amdgcn_readfirstlane(base);
     int pos = 0, buf = 0;
     int pending = 0; /* lane 0: the next chunk, asked for at the first tile of the current one */
@@ -381,11 +388,15 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
         T.exact_mask = exact_mask;
         const uint32_t dflip = T.dbits ^ T.dnext;
         /* which tile comes next, and its states on their way */
-        if (pos == 0 && lane == 0)
-            pending = atomicAdd(&p.tile_ctr[b], EV_CHUNK);
-        const bool last_of_chunk = pos + 1 >= EV_CHUNK || wt + 1 >= ntw;
+        if (pos == 0 && lane == 0) {
+            /* a returning atomic whose result is not waited for here (written in assembly: the compiler would
+             * wait for it on the spot) */
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(pending) : "v"(p.tile_ctr + b), "v"(p.ev_chunk) : "memory");
+        }
+        const bool last_of_chunk = pos + 1 >= p.ev_chunk || wt + 1 >= ntw;
         int next_base = base, next_pos = pos + 1;
         if (last_of_chunk) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pending)::"memory");
             next_base = __builtin_amdgcn_readfirstlane(pending);
             next_pos = 0;
         }

@@ -128,6 +128,7 @@ struct BatchDev {
     /* breakpoint kernel (k_synth_ev): instead of rows and a tile index, k_seed leaves the exact state of every
      * chain at the first sample of every tile */
     int ev;                         /* 1: this batch runs on k_synth_ev                               */
+    int ev_chunk;                   /* consecutive tiles a wavefront of k_synth_ev takes at a time     */
     double *tile_x;                 /* [nblocks][ntiles][2*nch]: column 2*channel = code phase (chips), 2*channel+1 =
                                        carrier phase * 512, at sample tile*TILE                        */
     uint32_t *tile_nav;             /* [nblocks][ntiles][nch]: bit 0 = the data bit in force is -1, bit 1 = the data

@@ -23,6 +23,7 @@
 #include "gpsbb.h"
 #include "gpsbb_kernels.hip.h"
 #include "gpsbb_events.hip.h"
+#include "gpsbb_walk.hip.h"
 #include "gpsbb_nco.h"
 #include "gpsbb_testhooks.h"
 
@@ -312,6 +313,13 @@ struct DevBuf {
     }
 };
 
+/* Table sets of a batch.  Run k uses set k % nsets and its pre-pass may start as soon as the synthesis kernel
+ * that last read that set has finished.  Per-sample kernel: two sets (the pre-pass of run k+1 overlaps the
+ * synthesis of run k).  Breakpoint kernel: three, and consecutive runs seed on alternating streams: its
+ * pre-pass (k_walk) is as long as its longest chain whatever the batch size — longer than the synthesis it
+ * feeds — so two of them have to be in flight for the synthesis kernel to set the pace. */
+constexpr int NSETS = 3;
+
 struct gpsbb_batch {
     gpsbb *h = nullptr;
     /* the handle's seeding stream, or (odd slots of a ring) its second one: the pre-passes of two consecutive
@@ -327,9 +335,9 @@ struct gpsbb_batch {
     DevBuf<uint64_t> d_row_off;
     /* row tables / tile index / end states exist twice: run k uses set k&1, so that the seeding
      * pre-pass of run k+1 overlaps the synthesis kernel of run k (different streams) */
-    DevBuf<NcoRow> d_rows[2];
-    DevBuf<int32_t> d_tile_row[2];
-    DevBuf<int32_t> d_row_cnt[2];
+    DevBuf<NcoRow> d_rows[NSETS];
+    DevBuf<int32_t> d_tile_row[NSETS];
+    DevBuf<int32_t> d_row_cnt[NSETS];
     DevBuf<int32_t> d_tile_ctr;
     DevBuf<int32_t> d_seed_order; /* lane -> chain plan of k_seed (see BatchDev) */
     DevBuf<uint32_t> d_kph0; /* fixed-point carrier variant: start phase and step per (block, channel) */
@@ -339,18 +347,20 @@ struct gpsbb_batch {
     std::vector<int32_t> h_kstep;
     const int *fixed_prev_prn = nullptr;      /* stream chaining of the fixed-point carrier (host side) */
     const uint32_t *fixed_prev_phase = nullptr;
-    DevBuf<gpsbb_chan_state_t> d_end[2];
+    DevBuf<gpsbb_chan_state_t> d_end[NSETS];
     /* breakpoint kernel (ev): exact tile-start states instead of rows + tile index, and per-channel constants */
     bool ev = false;
-    DevBuf<double> d_tile_x[2];
-    DevBuf<uint32_t> d_tile_nav[2];
+    DevBuf<double> d_tile_x[NSETS];
+    DevBuf<uint32_t> d_tile_nav[NSETS];
     DevBuf<EvConst> d_evc;
     std::vector<EvConst> h_evc;
     double *hs_tile_x = nullptr;
     uint32_t *hs_tile_nav = nullptr;
     size_t hs_tx_cap = 0, hs_tn_cap = 0;
-    hipEvent_t synth_done[2] = {nullptr, nullptr};
-    bool synth_pending[2] = {false, false};
+    hipEvent_t synth_done[NSETS] = {nullptr, nullptr, nullptr};
+    bool synth_pending[NSETS] = {false, false, false};
+    hipEvent_t upload_done = nullptr; /* descriptors and plans of the last set-up are on the device */
+    int nsets = 2;                    /* table sets in use: run k works on set k % nsets */
     unsigned run_count = 0;
     int last_set = 0;
     DevBuf<int16_t> d_iq;
@@ -582,15 +592,17 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
      * at most one chip change and at most EV_KC_MAX table-index changes and the I sums stay below 2^15. */
     b->ev = !fixed && h->opt_synth_kernel != 1 && ev_plan(ch, nblocks, nch, delt, b->h_evc);
 
-    /* row pool plan (per-sample kernel): chain id = kind*nbc + block*nch + channel */
+    /* row pool plan: chain id = kind*nbc + block*nch + channel */
     b->row_off.assign(2 * nbc + 1, 0);
     uint64_t off = 0;
     for (int kind = 0; kind < 2; kind++)
         for (size_t k = 0; k < nbc; k++) {
             b->row_off[kind * nbc + k] = off;
-            if (ch[k].prn > 0 && !(kind == 1 && fixed) && !b->ev) {
+            if (ch[k].prn > 0 && !(kind == 1 && fixed)) {
                 const double s = kind == 0 ? ch[k].f_code * delt : std::fabs(ch[k].f_carr * delt);
                 off += (kind == 0 ? row_bound(s, 1023.0, 9, nsamp) : row_bound(s, 1.0, -1, nsamp)) + 1;
+                if (b->ev)
+                    off += (uint64_t)nsamp / (uint64_t)WALK_ROW_MAX + 1; /* k_walk cuts long rows */
             } else {
                 off += 1;
             }
@@ -603,11 +615,14 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     HIPCHK(h, (hipError_t)b->d_ch.reserve(nbc));
     HIPCHK(h, (hipError_t)b->d_row_off.reserve(2 * nbc + 1));
     HIPCHK(h, (hipError_t)b->d_tile_ctr.reserve((size_t)nblocks));
-    for (int set = 0; set < 2; set++) {
+    b->nsets = b->ev ? NSETS : 2;
+    for (int set = 0; set < b->nsets; set++) {
         HIPCHK(h, (hipError_t)b->d_end[set].reserve(nbc));
         if (b->ev) {
             HIPCHK(h, (hipError_t)b->d_tile_x[set].reserve(2 * nbc * (size_t)b->ntiles));
             HIPCHK(h, (hipError_t)b->d_tile_nav[set].reserve(nbc * (size_t)b->ntiles));
+            HIPCHK(h, (hipError_t)b->d_rows[set].reserve(b->total_rows + 4));
+            HIPCHK(h, (hipError_t)b->d_row_cnt[set].reserve(2 * nbc));
         } else {
             HIPCHK(h, (hipError_t)b->d_rows[set].reserve(b->total_rows + 4)); /* + slack: k_synth prefetches one row past a chain */
             HIPCHK(h, (hipError_t)b->d_tile_row[set].reserve(2 * nbc * ((size_t)b->ntiles + 1)));
@@ -672,8 +687,12 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         for (size_t k = 0; k < nbc; k++)
             carr[k] = (int32_t)k;
         const gpsbb_chan_t *hc = b->h_ch.data();
-        std::sort(carr.begin(), carr.end(), [hc](int32_t x, int32_t y) {
+        const bool by_sign = b->ev; /* k_walk runs the two directions in separate loops: keep them in separate wavefronts */
+        std::sort(carr.begin(), carr.end(), [hc, by_sign](int32_t x, int32_t y) {
             const double fx = hc[x].prn > 0 ? std::fabs(hc[x].f_carr) : -1.0, fy = hc[y].prn > 0 ? std::fabs(hc[y].f_carr) : -1.0;
+            const bool nx = by_sign && hc[x].prn > 0 && std::signbit(hc[x].f_carr), ny = by_sign && hc[y].prn > 0 && std::signbit(hc[y].f_carr);
+            if (nx != ny)
+                return ny;
             return fx > fy || (fx == fy && x < y);
         });
         std::vector<int32_t> &order = b->h_seed_order;
@@ -686,16 +705,28 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         std::vector<int32_t> code(nbc);
         for (size_t k = 0; k < nbc; k++)
             code[k] = (int32_t)k;
-        waves_of(code.data(), nbc, 64, 0);
-        /* the longest 8 % in wavefronts of 8, the next 16 % in wavefronts of 16, the next 32 % in wavefronts of 32 */
-        const size_t n8 = nbc * 8 / 100 / 8 * 8, n16 = nbc * 16 / 100 / 16 * 16, n32 = nbc * 32 / 100 / 32 * 32;
-        waves_of(carr.data(), n8, 8, (int32_t)nbc);
-        waves_of(carr.data() + n8, n16, 16, (int32_t)nbc);
-        waves_of(carr.data() + n8 + n16, n32, 32, (int32_t)nbc);
-        waves_of(carr.data() + n8 + n16 + n32, nbc - n8 - n16 - n32, 64, (int32_t)nbc);
+        if (b->ev) {
+            /* k_walk keeps the lanes of a wavefront in lockstep: a turn of its loop costs the same however many
+             * lanes take part, so wavefronts are full, the carrier chains by descending |f_carr| (a wavefront runs
+             * as long as its longest chain) and the longest ones first */
+            static const size_t lanes_per_wave = getenv("GPSBB_WALK_LANES") ? (size_t)atol(getenv("GPSBB_WALK_LANES")) : 64;
+            waves_of(carr.data(), nbc, lanes_per_wave, (int32_t)nbc);
+            waves_of(code.data(), nbc, 64, 0);
+        } else {
+            waves_of(code.data(), nbc, 64, 0);
+            /* the longest 8 % in wavefronts of 8, the next 16 % in wavefronts of 16, the next 32 % in wavefronts of 32 */
+            const size_t n8 = nbc * 8 / 100 / 8 * 8, n16 = nbc * 16 / 100 / 16 * 16, n32 = nbc * 32 / 100 / 32 * 32;
+            waves_of(carr.data(), n8, 8, (int32_t)nbc);
+            waves_of(carr.data() + n8, n16, 16, (int32_t)nbc);
+            waves_of(carr.data() + n8 + n16, n32, 32, (int32_t)nbc);
+            waves_of(carr.data() + n8 + n16 + n32, nbc - n8 - n16 - n32, 64, (int32_t)nbc);
+        }
         HIPCHK(h, (hipError_t)b->d_seed_order.reserve(order.size()));
         HIPCHK(h, hipMemcpyAsync(b->d_seed_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, upload_stream));
     }
+    if (!b->upload_done)
+        HIPCHK(h, hipEventCreateWithFlags(&b->upload_done, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(b->upload_done, upload_stream));
     b->ran = false;
     return GPSBB_OK;
 }
@@ -734,7 +765,9 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
     (void)hipStreamSynchronize(b->h->s_compute);
     b->d_ch.release();
     b->d_row_off.release();
-    for (int k = 0; k < 2; k++) {
+    if (b->upload_done)
+        (void)hipEventDestroy(b->upload_done);
+    for (int k = 0; k < NSETS; k++) {
         b->d_rows[k].release();
         b->d_tile_row[k].release();
         b->d_row_cnt[k].release();
@@ -1073,7 +1106,7 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
 static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
 {
     gpsbb *h = b->h;
-    const int set = (int)(b->run_count & 1u);
+    const int set = (int)(b->run_count % (unsigned)b->nsets);
     const BatchDev p = batch_dev(b, set);
     const int lanes = (int)b->h_seed_order.size();
     if (b->ev_used == b->evs.size()) {
@@ -1088,28 +1121,44 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     }
     hipEvent_t *ev = b->evs[b->ev_used++].e;
 
-    /* seeding pre-pass on its own stream: it may start as soon as the synthesis kernel that last read
-     * this buffer set (two runs ago) has finished, i.e. it overlaps the previous run's synthesis */
+    /* The pre-pass runs on a seeding stream of its own: it may start as soon as the synthesis kernel that last
+     * read this table set has finished, i.e. it overlaps the synthesis of the runs before it.  With three sets
+     * consecutive runs take the handle's two seeding streams in turn, so that two pre-passes are in flight. */
+    hipStream_t ss = b->seed_stream;
+    if (b->nsets > 2 && (b->run_count & 1u)) {
+        if (!h->s_seed2)
+            HIPCHK(h, hipStreamCreateWithFlags(&h->s_seed2, hipStreamNonBlocking));
+        ss = b->seed_stream == h->s_seed ? h->s_seed2 : h->s_seed;
+    }
+    if (b->upload_done)
+        HIPCHK(h, hipStreamWaitEvent(ss, b->upload_done, 0));
     if (b->synth_pending[set])
-        HIPCHK(h, hipStreamWaitEvent(b->seed_stream, b->synth_done[set], 0));
-    HIPCHK(h, hipEventRecord(ev[0], b->seed_stream));
-    if (h->opt_skip_seed && b->run_count >= 2) {
-        /* measurement hook: time k_synth alone on tables already built */
+        HIPCHK(h, hipStreamWaitEvent(ss, b->synth_done[set], 0));
+    HIPCHK(h, hipEventRecord(ev[0], ss));
+    if (h->opt_skip_seed && b->run_count >= (unsigned)b->nsets) {
+        /* measurement hook: time the synthesis kernel alone on tables already built */
     } else if (host_seeding_wanted(b)) {
         /* the previous user of the pinned images (this batch's last run) has been copied out: its upload was
-         * followed by k_synth, which synth_done[] of that set covers; a lone batch runs are far apart */
-        if (b->synth_pending[set ^ 1])
-            HIPCHK(h, hipEventSynchronize(b->synth_done[set ^ 1]));
-        const int rc = host_seed_run(b, set, b->seed_stream);
+         * followed by the synthesis kernel, which synth_done[] of that set covers */
+        const int prev = (set + b->nsets - 1) % b->nsets;
+        if (b->synth_pending[prev])
+            HIPCHK(h, hipEventSynchronize(b->synth_done[prev]));
+        const int rc = host_seed_run(b, set, ss);
         if (rc != GPSBB_OK)
             return rc;
     } else if (b->ev) {
-        hipLaunchKernelGGL(k_seed<true>, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, b->seed_stream, p);
+        static const bool old_seed = getenv("GPSBB_EV_KSEED") != nullptr; /* experiment: the one-kernel pre-pass */
+        if (old_seed) {
+            hipLaunchKernelGGL(k_seed<true>, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, ss, p);
+        } else {
+            hipLaunchKernelGGL(k_walk, dim3((lanes + GPSBB_WALK_WG - 1) / GPSBB_WALK_WG), dim3(GPSBB_WALK_WG), 0, ss, p);
+            hipLaunchKernelGGL(k_tiles, dim3(2 * b->nblocks * b->nch), dim3(GPSBB_TILES_WG), 0, ss, p);
+        }
     } else {
-        hipLaunchKernelGGL(k_seed<false>, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, b->seed_stream, p);
+        hipLaunchKernelGGL(k_seed<false>, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, ss, p);
     }
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(ev[1], b->seed_stream));
+    HIPCHK(h, hipEventRecord(ev[1], ss));
 
     HIPCHK(h, hipStreamWaitEvent(h->s_compute, ev[1], 0));
     HIPCHK(h, hipMemsetAsync(b->d_tile_ctr.p, 0, (size_t)b->nblocks * sizeof(int32_t), h->s_compute));

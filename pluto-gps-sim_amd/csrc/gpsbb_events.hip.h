@@ -92,11 +92,11 @@ __device__ __forceinline__ T scalar_load(const T *p)
  * the run's first sample.
  */
 __device__ __noinline__ uint32_t ev_exact_run(EvLds &L, int wave, int lane, int i, const EvConst *kbi, const double *tile_x,
-                                              uint32_t nb, int n_off)
+                                              int ntiles, uint32_t nb, int n_off)
 {
     const bool down = kbi->down != 0;
     const double S = down ? -kbi->S : kbi->S, sc = kbi->sc;
-    const double xt = tile_x[2 * i], yt = tile_x[2 * i + 1];
+    const double xt = tile_x[(size_t)(2 * i) * ntiles], yt = tile_x[(size_t)(2 * i + 1) * ntiles];
     /* code NCO: at most one roll-over between the tile start and the end of the run (checked by the host) */
     int64_t wraps = 0;
     double x = code_jump(xt, sc, (int64_t)n_off, &wraps);
@@ -200,7 +200,7 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK 
 template <int KC, bool DF>
 __device__ __forceinline__ void ev_second(EvLds &L, int wave, int lane, int i, EvHalf<KC> &h, uint32_t db, uint32_t db_next,
                                           bool always_exact, bool lane_live, const EvConst *kb, const double *tile_x,
-                                          uint32_t nb, double off, uint32_t &acc0, unsigned long long *n_exact)
+                                          int ntiles, uint32_t nb, double off, uint32_t &acc0, unsigned long long *n_exact)
 {
     const uint32_t ma = (uint32_t)(int32_t)(int8_t)(h.ch2 & 0xffu), mb = (uint32_t)(int32_t)(int8_t)(h.ch2 >> 8);
     uint32_t m0, m1;
@@ -224,7 +224,7 @@ __device__ __forceinline__ void ev_second(EvLds &L, int wave, int lane, int i, E
             jc = EV_ROW_DISCARD;
             h.A[0] = 0;
             /* ... and the exact one takes its place */
-            acc0 += ev_exact_run(L, wave, lane, i, kb + i, tile_x, nb, (int)off);
+            acc0 += ev_exact_run(L, wave, lane, i, kb + i, tile_x, ntiles, nb, (int)off);
             atomicAdd(n_exact, 1ull);
         }
     }
@@ -247,7 +247,9 @@ __device__ __forceinline__ void ev_second(EvLds &L, int wave, int lane, int i, E
 /* what a wavefront knows about the tile it is working on */
 struct EvTile {
     const double *ts;     /* LDS: the tile's states (mirrored where the carrier falls) */
-    const double *tile_x; /* global: the same, exact and not mirrored (for the exact recomputation) */
+    const double *tile_x; /* global: the same, exact and not mirrored (for the exact recomputation): chain c's is
+                             tile_x[c * ntiles] */
+    int ntiles;
     uint32_t dbits, dnext; /* bit i: channel i's data bit in force / after the next roll-over is -1 */
     uint32_t exact_mask;   /* bit i: channel i is always recomputed exactly */
 };
@@ -265,7 +267,8 @@ __device__ __forceinline__ void ev_channels(EvLds &L, int wave, int lane, uint32
     {                                                                                                                  \
         const uint32_t db_ = 0u - ((T.dbits >> i) & 1u), dn_ = 0u - ((T.dnext >> i) & 1u);                             \
         const uint32_t nb_ = ((T.dbits >> i) & 1u) | (((T.dnext >> i) & 1u) << 1);                                     \
-        ev_second<KC, DF>(L, wave, lane, i, h, db_, dn_, ((T.exact_mask >> i) & 1u) != 0, lane_live, kb, T.tile_x, nb_, \
+        ev_second<KC, DF>(L, wave, lane, i, h, db_, dn_, ((T.exact_mask >> i) & 1u) != 0, lane_live, kb, T.tile_x,      \
+                          T.ntiles, nb_,                                                                               \
                           off, acc0, n_exact);                                                                         \
     }
     while (mask & (mask - 1)) { /* at least two channels left */
@@ -356,8 +359,10 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
     /* lane c < 2*nch holds chain c = (channel c >> 1, kind c & 1) of the tile being staged */
     const bool chain_lane = lane < nch2;
     const bool mirror = chain_lane && (lane & 1) && kb[lane >> 1].down != 0;
-    const double *__restrict__ tx = p.tile_x + (size_t)b * ntw * nch2;
-    const uint32_t *__restrict__ tn = p.tile_nav + (size_t)b * ntw * p.nch;
+    /* this lane's chain (tile-contiguous) in the tile arrays */
+    const double *__restrict__ txb = p.tile_x + (size_t)b * ntw * nch2;
+    const double *__restrict__ tx = txb + (size_t)(chain_lane ? lane : 0) * ntw;
+    const uint32_t *__restrict__ tn = p.tile_nav + ((size_t)b * p.nch + (lane < p.nch ? lane : 0)) * ntw;
     const double off = (double)(lane * SPT);
     unsigned long long *n_exact = p.hazards + 2;
 
@@ -372,8 +377,8 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
     double ts_v = 0.0;
     uint32_t nav_v = 0;
     if (base < ntw) {
-        ts_v = chain_lane ? tx[(size_t)base * nch2 + lane] : 0.0;
-        nav_v = lane < p.nch ? tn[(size_t)base * p.nch + lane] : 0u;
+        ts_v = chain_lane ? tx[base] : 0.0;
+        nav_v = lane < p.nch ? tn[base] : 0u;
     }
     while (base < ntw) {
         const int wt = base + pos;
@@ -382,7 +387,8 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
             L.tstate[wave][buf][lane] = mirror ? 512.0 - ts_v : ts_v;
         EvTile T;
         T.ts = L.tstate[wave][buf];
-        T.tile_x = tx + (size_t)wt * nch2;
+        T.tile_x = txb + wt;
+        T.ntiles = ntw;
         T.dbits = (uint32_t)__ballot(nav_v & 1u);
         T.dnext = (uint32_t)__ballot(nav_v & 2u);
         T.exact_mask = exact_mask;
@@ -402,8 +408,8 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
         }
         const int wt_next = next_base + next_pos;
         if (wt_next < ntw) {
-            ts_v = chain_lane ? tx[(size_t)wt_next * nch2 + lane] : 0.0;
-            nav_v = lane < p.nch ? tn[(size_t)wt_next * p.nch + lane] : 0u;
+            ts_v = chain_lane ? tx[wt_next] : 0.0;
+            nav_v = lane < p.nch ? tn[wt_next] : 0u;
         }
 
         const int n0 = wt * TILE + lane * SPT;

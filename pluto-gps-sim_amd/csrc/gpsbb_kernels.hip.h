@@ -129,9 +129,10 @@ struct BatchDev {
      * chain at the first sample of every tile */
     int ev;                         /* 1: this batch runs on k_synth_ev                               */
     int ev_chunk;                   /* consecutive tiles a wavefront of k_synth_ev takes at a time     */
-    double *tile_x;                 /* [nblocks][ntiles][2*nch]: column 2*channel = code phase (chips), 2*channel+1 =
-                                       carrier phase * 512, at sample tile*TILE                        */
-    uint32_t *tile_nav;             /* [nblocks][ntiles][nch]: bit 0 = the data bit in force is -1, bit 1 = the data
+    double *tile_x;                 /* [nblocks][2*nch][ntiles]: row 2*channel = code phase (chips), 2*channel+1 =
+                                       carrier phase * 512, at sample tile*TILE (tile-contiguous per chain: the
+                                       pre-pass writes it coalesced, k_synth_ev reads it through the L2)  */
+    uint32_t *tile_nav;             /* [nblocks][nch][ntiles]: bit 0 = the data bit in force is -1, bit 1 = the data
                                        bit after the next code roll-over is -1                         */
     const EvConst *evc;             /* [nblocks*nch]                                                  */
 };
@@ -257,7 +258,6 @@ struct RowSink {
 struct TileSink {
     double *tx;         /* this chain's column of tile_x, at the next tile to write */
     uint32_t *tn;       /* code chains: this channel's column of tile_nav; carrier chains: nullptr */
-    uint32_t xstride, nstride;
     int32_t tile_t, ntiles;
     /* the row being walked */
     int32_t pn0;
@@ -274,13 +274,13 @@ struct TileSink {
     {
         const int32_t nt = (int32_t)(((uint32_t)upto + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
         const int32_t lim = nt < ntiles ? nt : ntiles;
+#ifdef GPSBB_EXP_NOFLUSH
+        tile_t = lim;
+#endif
         while (tile_t < lim) {
-            *tx = fma_rn((double)(tile_t * TILE - pn0), pS, px);
-            tx += xstride;
-            if (tn) {
-                *tn = pbits;
-                tn += nstride;
-            }
+            *tx++ = fma_rn((double)(tile_t * TILE - pn0), pS, px);
+            if (tn)
+                *tn++ = pbits;
             tile_t++;
         }
     }
@@ -330,10 +330,8 @@ GPSBB_HD TileSink make_tile_sink(double *tile_x, uint32_t *tile_nav, int nch, in
                                  const uint32_t *dwrd, uint32_t nav0, unsigned long long *hz)
 {
     TileSink s;
-    s.tx = tile_x + ((size_t)b * ntiles) * (2 * (size_t)nch) + 2 * i + kind;
-    s.tn = kind == 0 ? tile_nav + ((size_t)b * ntiles) * (size_t)nch + i : nullptr;
-    s.xstride = 2u * (uint32_t)nch;
-    s.nstride = (uint32_t)nch;
+    s.tx = tile_x + ((size_t)b * (2 * (size_t)nch) + 2 * i + kind) * (size_t)ntiles;
+    s.tn = kind == 0 ? tile_nav + ((size_t)b * (size_t)nch + i) * (size_t)ntiles : nullptr;
     s.tile_t = 0;
     s.ntiles = ntiles;
     s.pn0 = 0;

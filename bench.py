@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--fixed-carrier", action="store_true",
                     help="the reference's fixed-point carrier variant (GPSBB_FIXED_CARRIER); not the headline config")
+    ap.add_argument("--chain", action="store_true",
+                    help="the blocks of a step are consecutive in time (GPSBB_CHAIN_CARRIER): carrier chained exactly")
     ap.add_argument("--synth-only", action="store_true",
                     help="measurement aid: after warm-up re-run only k_synth on the tables already built")
     args = ap.parse_args()
@@ -113,6 +115,8 @@ def main():
         ch = ch.copy()
         ch["carr_phase"] = np.floor(ch["carr_phase"] * 2.0 ** 32)
         flags = pkg.FIXED_CARRIER
+    if args.chain:
+        flags |= pkg.CHAIN_CARRIER
     synth = pkg.Synth(local)
     batch = synth.batch(ch, delt, args.nsamp, flags=flags)
     out = torch.empty(B * args.nsamp * 2, dtype=torch.int16, device="cuda:%d" % local)

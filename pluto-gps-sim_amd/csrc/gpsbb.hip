@@ -280,7 +280,9 @@ struct gpsbb {
     int opt_seed_where = 0;   /* 0 by size, 1 always k_seed, 2 always host threads */
     int opt_synth_kernel = 0; /* 0 automatic, 1 always the per-sample kernel */
     int opt_skip_seed = 0;    /* measurement: re-use the tables of the first two runs of a batch */
+    int opt_chain_where = 0;  /* GPSBB_CHAIN_CARRIER: 0 automatic (on the device where k_synth_ev runs), 1 host threads */
     int last_kernel = 0;      /* synthesis kernel of the last launch: 1 per-sample, 2 breakpoint */
+    int last_chain_dev = 0;   /* the last launch resolved GPSBB_CHAIN_CARRIER on the device */
 };
 
 template <class T>
@@ -357,6 +359,11 @@ struct gpsbb_batch {
     double *hs_tile_x = nullptr;
     uint32_t *hs_tile_nav = nullptr;
     size_t hs_tx_cap = 0, hs_tn_cap = 0;
+    /* GPSBB_CHAIN_CARRIER resolved on the device (gpsbb_walk.hip.h: k_chain_prefix / k_chain_fix) */
+    bool chain_dev = false;
+    DevBuf<ChainAux> d_aux[NSETS];
+    std::vector<ChainAux> h_aux;
+    int carr_lanes = 0; /* lanes of the seed plan that walk carrier chains (they come first) */
     hipEvent_t synth_done[NSETS] = {nullptr, nullptr, nullptr};
     bool synth_pending[NSETS] = {false, false, false};
     hipEvent_t upload_done = nullptr; /* descriptors and plans of the last set-up are on the device */
@@ -424,6 +431,11 @@ extern "C" int gpsbb_set_option(gpsbb_t *h, int option, long value)
     case GPSBB_OPT_SKIP_SEED:
         h->opt_skip_seed = value != 0;
         return GPSBB_OK;
+    case GPSBB_OPT_CHAIN_WHERE:
+        if (value < 0 || value > 1)
+            return GPSBB_E_BADARG;
+        h->opt_chain_where = (int)value;
+        return GPSBB_OK;
     default:
         return GPSBB_E_BADARG;
     }
@@ -437,13 +449,17 @@ extern "C" int gpsbb_get_info(gpsbb_t *h, int what, uint64_t *out)
     case GPSBB_INFO_LAST_KERNEL:
         *out = (uint64_t)h->last_kernel;
         return GPSBB_OK;
-    case GPSBB_INFO_EXACT_RUNS: {
+    case GPSBB_INFO_EXACT_RUNS:
+    case GPSBB_INFO_CHAIN_FALLBACKS: {
         HIPCHK(h, hipSetDevice(h->device));
         unsigned long long v = 0;
-        HIPCHK(h, hipMemcpy(&v, h->d_hz + 2, 8, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(&v, h->d_hz + (what == GPSBB_INFO_EXACT_RUNS ? 2 : 4), 8, hipMemcpyDeviceToHost));
         *out = v;
         return GPSBB_OK;
     }
+    case GPSBB_INFO_CHAIN_ON_DEVICE:
+        *out = (uint64_t)h->last_chain_dev;
+        return GPSBB_OK;
     default:
         return GPSBB_E_BADARG;
     }
@@ -541,12 +557,12 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     if ((e = hipMalloc((void **)&h->d_tabs, sizeof tabs)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&h->d_ca, ca.size() * 4)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&h->d_status, 4)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void **)&h->d_hz, 32)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&h->d_hz, 64)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h->d_tabs, tabs, sizeof tabs, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h->d_ca, ca.data(), ca.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     h->h_ca = ca;
     if ((e = hipMemset(h->d_status, 0, 4)) != hipSuccess) return fail(e);
-    if ((e = hipMemset(h->d_hz, 0, 32)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(h->d_hz, 0, 64)) != hipSuccess) return fail(e);
     /* k_synth carves ~76 KB of dynamic LDS per workgroup: above the 64 KB default limit */
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(SynthLds))) != hipSuccess) return fail(e);
@@ -563,6 +579,8 @@ struct ChainCarry {
 };
 static void chain_carrier_host(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp, double *seed,
                                int nthreads, ChainCarry *carry);
+
+static bool host_seeding_wanted(const gpsbb_batch *b);
 
 /* ---- batch planning -------------------------------------------------------------------------------- */
 
@@ -664,7 +682,37 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         HIPCHK(h, hipMemcpyAsync(b->d_kstep.p, b->h_kstep.data(), nbc * 4, hipMemcpyHostToDevice, upload_stream));
     }
     b->h_ch.assign(ch, ch + nbc);
-    if ((flags & GPSBB_CHAIN_CARRIER) && !fixed && nblocks > 1) {
+    b->chain_dev = b->ev && (flags & GPSBB_CHAIN_CARRIER) && nblocks > 1 && h->opt_chain_where == 0 && !host_seeding_wanted(b);
+    if (b->chain_dev) {
+        /* The carrier chain is resolved exactly on the device, in parallel over the blocks (k_walk pass A,
+         * k_chain_prefix, k_walk pass B, k_chain_fix).  All the host contributes is a rough start phase per block:
+         * the descriptor's phase carried forward by nsamp*step in plain double arithmetic (good to ~1e-7 cycles
+         * after a few hundred blocks; pass A takes it from there). */
+        b->h_aux.assign(nbc, ChainAux());
+        for (int i = 0; i < nch; i++) {
+            double x = 0.0;
+            int prev_prn = 0;
+            for (int blk = 0; blk < nblocks; blk++) {
+                const gpsbb_chan_t &c = ch[(size_t)blk * nch + i];
+                ChainAux &a = b->h_aux[(size_t)blk * nch + i];
+                memset(&a, 0, sizeof a);
+                if (c.prn > 0) {
+                    if (c.prn != prev_prn)
+                        x = c.carr_phase;
+                    a.start0 = x;
+                    const volatile double sk = c.f_carr * delt;
+                    x = x + (double)nsamp * sk;
+                    x -= std::floor(x);
+                }
+                prev_prn = c.prn > 0 ? c.prn : 0;
+            }
+        }
+        for (int set = 0; set < b->nsets; set++) {
+            HIPCHK(h, (hipError_t)b->d_aux[set].reserve(nbc));
+            HIPCHK(h, hipMemcpyAsync(b->d_aux[set].p, b->h_aux.data(), nbc * sizeof(ChainAux), hipMemcpyHostToDevice, upload_stream));
+        }
+    }
+    if ((flags & GPSBB_CHAIN_CARRIER) && !fixed && nblocks > 1 && !b->chain_dev) {
         /* blocks consecutive in time: resolve the carrier phase at the start of every block here, exactly
          * (same jump-ahead as the device, one host thread per channel), so that the device's chains are all
          * independent.  Walking the blocks in order on the device would serialise the whole pre-pass. */
@@ -711,6 +759,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
              * as long as its longest chain) and the longest ones first */
             static const size_t lanes_per_wave = getenv("GPSBB_WALK_LANES") ? (size_t)atol(getenv("GPSBB_WALK_LANES")) : 64;
             waves_of(carr.data(), nbc, lanes_per_wave, (int32_t)nbc);
+            b->carr_lanes = (int)order.size();
             waves_of(code.data(), nbc, 64, 0);
         } else {
             waves_of(code.data(), nbc, 64, 0);
@@ -778,6 +827,7 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         b->d_end[k].release();
         b->d_tile_x[k].release();
         b->d_tile_nav[k].release();
+        b->d_aux[k].release();
         b->d_evc.release();
         if (b->synth_done[k])
             (void)hipEventDestroy(b->synth_done[k]);
@@ -1100,6 +1150,8 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.tile_x = b->d_tile_x[set].p;
     p.tile_nav = b->d_tile_nav[set].p;
     p.evc = b->d_evc.p;
+    p.chain_dev = b->chain_dev ? 1 : 0;
+    p.aux = b->chain_dev ? b->d_aux[set].p : nullptr;
     return p;
 }
 
@@ -1151,7 +1203,17 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         if (old_seed) {
             hipLaunchKernelGGL(k_seed<true>, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, ss, p);
         } else {
-            hipLaunchKernelGGL(k_walk, dim3((lanes + GPSBB_WALK_WG - 1) / GPSBB_WALK_WG), dim3(GPSBB_WALK_WG), 0, ss, p);
+            const dim3 wg_all((lanes + GPSBB_WALK_WG - 1) / GPSBB_WALK_WG);
+            if (b->chain_dev) {
+                BatchDev pa = p; /* pass A: the carrier chains only (they come first in the plan) */
+                pa.seed_lanes = b->carr_lanes;
+                hipLaunchKernelGGL(k_walk<1>, dim3((b->carr_lanes + GPSBB_WALK_WG - 1) / GPSBB_WALK_WG), dim3(GPSBB_WALK_WG), 0, ss, pa);
+                hipLaunchKernelGGL(k_chain_prefix, dim3(1), dim3(64), 0, ss, p);
+                hipLaunchKernelGGL(k_walk<2>, wg_all, dim3(GPSBB_WALK_WG), 0, ss, p);
+                hipLaunchKernelGGL(k_chain_fix, dim3(1), dim3(64), 0, ss, p);
+            } else {
+                hipLaunchKernelGGL(k_walk<0>, wg_all, dim3(GPSBB_WALK_WG), 0, ss, p);
+            }
             hipLaunchKernelGGL(k_tiles, dim3(2 * b->nblocks * b->nch), dim3(GPSBB_TILES_WG), 0, ss, p);
         }
     } else {
@@ -1178,8 +1240,10 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         want = want > max_useful ? max_useful : want;
         hipLaunchKernelGGL(k_synth_ev, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), h->s_compute, p, d_iq);
         h->last_kernel = 2;
+        h->last_chain_dev = b->chain_dev ? 1 : 0;
     } else {
         h->last_kernel = 1;
+        h->last_chain_dev = 0;
         /* Workgroups per block: enough of them to oversubscribe the chip ~3x (tiles are handed out
          * dynamically in chunks, so the tail is short), never more than there are chunks; the per-block
          * LDS tables (amplitude LUT, chips, nav words) are then built few times per block. */

@@ -98,6 +98,19 @@ struct EvConst {
 };
 static_assert(sizeof(EvConst) == 56, "EvConst layout");
 
+/* Per (block, channel) scratch of the device-side carrier chain (gpsbb_walk.hip.h, k_chain_fix). */
+struct ChainAux {
+    double start0; /* rough start phase (host: descriptor phase + sum of nsamp*step, in plain double arithmetic) */
+    double start1; /* start phase pass B walks from: good to a few units in the last place                  */
+    double endA;   /* end phase of pass A's walk from start0                                               */
+    double margin; /* pass B: smallest distance of a row's first or last state to an edge of its binade    */
+    double delta;  /* true state minus pass B's state, from row rstar on                                   */
+    int32_t rstar; /* pass B: rows emitted when the first wrap had happened (-1: none)                     */
+    int32_t nstar; /* ... and samples done                                                                */
+    uint32_t hz512; /* pass B: samples whose phase was exactly 1.0                                         */
+    uint32_t _pad;
+};
+
 /* Everything the kernels need about one batch; passed by value as the kernel argument. */
 struct BatchDev {
     const gpsbb_chan_t *ch;         /* [nblocks*nch] descriptors, block-major                        */
@@ -124,7 +137,9 @@ struct BatchDev {
                                        wavefronts with few lanes (a wavefront runs as long as its longest chain
                                        and every extra lane adds turns of the loops its lanes do not share)   */
     uint32_t *status;               /* self-check word                                               */
-    unsigned long long *hazards;    /* [0] itable_512, [1] dwrd_oob, [2] lane-runs k_synth_ev recomputed exactly */
+    unsigned long long *hazards;    /* [0] itable_512, [1] dwrd_oob, [2] lane-runs k_synth_ev recomputed exactly,
+                                       [3] scratch (hazards seen by walks whose rows are not the final ones),
+                                       [4] blocks k_chain_fix walked on its own                          */
     /* breakpoint kernel (k_synth_ev): instead of rows and a tile index, k_seed leaves the exact state of every
      * chain at the first sample of every tile */
     int ev;                         /* 1: this batch runs on k_synth_ev                               */
@@ -135,6 +150,8 @@ struct BatchDev {
     uint32_t *tile_nav;             /* [nblocks][nch][ntiles]: bit 0 = the data bit in force is -1, bit 1 = the data
                                        bit after the next code roll-over is -1                         */
     const EvConst *evc;             /* [nblocks*nch]                                                  */
+    int chain_dev;                  /* 1: GPSBB_CHAIN_CARRIER is resolved on the device (k_chain_prefix / k_chain_fix) */
+    ChainAux *aux;                  /* [nblocks*nch]                                                  */
 };
 
 __device__ __forceinline__ size_t tile_row_at(const BatchDev &p, int b, int t, int i, int kind)

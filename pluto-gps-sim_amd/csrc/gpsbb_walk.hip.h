@@ -38,6 +38,13 @@ struct WalkLane {
     uint32_t cap, cnt;
     bool active;
     bool stuck; /* x + s rounded back to x and nothing wrapped: the state is constant from here on */
+    /* carrier chains of a batch whose carrier is chained on the device (see k_chain_fix) */
+    bool store;        /* write rows (pass A of the chain only wants the end state) */
+    bool stop_at_wrap; /* end the walk right after the first wrap, or once past sample nstop */
+    int32_t nstop;
+    int32_t rstar, nstar; /* rows emitted / samples done when the first wrap had happened; -1: no wrap */
+    double margin;     /* smallest distance of a row's first or last state to an edge of its binade */
+    uint32_t hz512;    /* carrier: samples whose phase is exactly 1.0 (gpsbb_hazards_t.itable_512) */
 };
 
 /* code chains: the data bits of a row from the nav counters (c:2717-2733) */
@@ -78,7 +85,7 @@ __device__ __forceinline__ uint64_t walk_tiemask(uint64_t sb)
  * The rare cases — tiny or zero steps (es < 123), states more than 50 binades above the step, a state that
  * no longer moves — go through the integer version of the regular run (gpsbb_nco.h) behind a wave-uniform test.
  */
-template <int KIND, bool SNEG>
+template <int KIND, bool SNEG, bool TRACK>
 __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsigned long long *hz, uint32_t *status)
 {
     constexpr int TOPEX = KIND == NCO_CARR ? 1023 : 1023 + 10;
@@ -122,9 +129,16 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
         const int kcap = kleft < WALK_ROW_MAX ? kleft : WALK_ROW_MAX;
         int k = (expl || !(room >= Sa)) ? 0 : (ki < kcap ? ki : kcap);
         double x1 = __fma_rn((double)k, S, x);
+        if (TRACK) {
+            /* how close the row's first and last state come to the edges of their binade: the trajectory of a
+             * start phase that differs by less than that takes every rounding on the same grid (k_chain_fix) */
+            const double lo = __hiloint2double((int)(hi & 0xfff00000u), 0);
+            const double dl = add_rn(SNEG ? x1 : x, -lo), dh = add_rn(add_rn(lo, lo), -(SNEG ? x : x1));
+            w.margin = w.active ? fmin(w.margin, (weird || rare) ? 0.0 : fmin(dl, dh)) : w.margin;
+        }
         if (__builtin_expect(__ballot(rare || (w.active && weird)) != 0ull, 0)) {
             if (KIND == NCO_CARR && w.active && ex >= TOPEX && !(hi >> 31))
-                atomicAdd(hz, 1ull); /* carr_phase == 1.0: table index 512, one past the reference's tables */
+                w.hz512++; /* carr_phase == 1.0: table index 512, one past the reference's tables */
             if (rare && w.stuck) {
                 /* constant from here on: one row to the end of the block (cut like any other) */
                 k = kcap;
@@ -183,28 +197,70 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
             w.stuck = rare && step && !wrapped && f64_bits(x2) == f64_bits(x1);
         w.x = step ? x2 : (w.active ? x1 : w.x);
         w.n = step ? n1 + 1 : (w.active ? n1 : w.n); /* lanes waiting for the other direction's loop keep theirs */
-        w.active = step && w.n < nsamp;
+        bool go_on = step && w.n < nsamp;
+        if (KIND == NCO_CARR && TRACK) {
+            if (step && wrapped && w.rstar < 0) {
+                w.rstar = (int32_t)w.cnt;
+                w.nstar = w.n;
+            }
+        }
+        if (KIND == NCO_CARR)
+            go_on = go_on && !(w.stop_at_wrap && ((step && wrapped) || w.n > w.nstop));
+        w.active = go_on;
     }
 }
 
 /* the lanes of a wavefront by the sign of their step, each group in its own straight-line loop (the host's plan
  * keeps the signs apart, so a wavefront normally runs only one of the two) */
-template <int KIND>
+template <int KIND, bool TRACK>
 __device__ __forceinline__ void walk_both_signs(WalkLane<KIND> &w, int nsamp, unsigned long long *hz, uint32_t *status)
 {
     const bool on = w.active;
     const bool neg = w.s < 0.0;
     if (__ballot(on && !neg)) {
         w.active = on && !neg;
-        walk_lockstep<KIND, false>(w, nsamp, hz, status);
+        walk_lockstep<KIND, false, TRACK>(w, nsamp, hz, status);
     }
     if (KIND == NCO_CARR && __ballot(on && neg)) {
         w.active = on && neg;
-        walk_lockstep<KIND, true>(w, nsamp, hz, status);
+        walk_lockstep<KIND, true, TRACK>(w, nsamp, hz, status);
     }
 }
 
-/* Lane -> chain as planned in BatchDev::seed_order (code and carrier chains never share a wavefront). */
+/* a lane set up for chain k of its kind: block-channel k, rows region `chain` of the pool */
+template <int KIND>
+__device__ __forceinline__ WalkLane<KIND> walk_lane(const BatchDev &p, int chain, double x0, double s, bool on)
+{
+    WalkLane<KIND> w;
+    w.x = x0;
+    w.s = s;
+    w.n = 0;
+    w.nav = 0;
+    w.bits = 0;
+    w.dwrd = nullptr;
+    const uint64_t o0 = p.row_off[chain], o1 = p.row_off[chain + 1];
+    w.rows = p.rows + o0;
+    w.cap = (uint32_t)(o1 - o0);
+    w.cnt = 0;
+    w.active = on;
+    w.stuck = false;
+    w.store = true;
+    w.stop_at_wrap = false;
+    w.nstop = INT32_MAX;
+    w.rstar = w.nstar = -1;
+    w.margin = 1.0;
+    w.hz512 = 0;
+    return w;
+}
+
+/*
+ * Lane -> chain as planned in BatchDev::seed_order (code and carrier chains never share a wavefront).
+ * PASS: 0 = every block starts from its descriptor's carr_phase (independent blocks, or seeds resolved by the
+ * host); 1 = pass A of the device-side carrier chain: carrier chains only, from the rough start phases, end
+ * states only (ChainAux::endA); 2 = pass B: all chains, carriers from the refined start phases, rows, margins
+ * and the place of the first wrap (see k_chain_fix).
+ */
+template <int PASS>
 __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
 {
     __builtin_amdgcn_s_setprio(GPSBB_SEED_PRIO);
@@ -212,24 +268,16 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
     const int c = gid < p.seed_lanes ? p.seed_order[gid] : -1;
     const int nbc = p.nblocks * p.nch;
     const bool is_code = c >= 0 && c < nbc, is_carr = c >= nbc;
-    if (__ballot(is_code)) {
-        WalkLane<NCO_CODE> w;
+    if (PASS != 1 && __ballot(is_code)) {
         const int k = is_code ? c : 0;
         const gpsbb_chan_t &ch = p.ch[k];
         const bool on = is_code && ch.prn > 0;
-        w.x = ch.code_phase;
-        w.s = mul_rn(ch.f_code, p.delt); /* plutogpssim.c:2709: f_code * delt, rounded on its own */
-        w.n = 0;
+        /* plutogpssim.c:2709: f_code * delt, rounded on its own */
+        WalkLane<NCO_CODE> w = walk_lane<NCO_CODE>(p, k, ch.code_phase, mul_rn(ch.f_code, p.delt), on);
         w.nav = nav_pack(ch.icode, ch.ibit, ch.iword);
         w.dwrd = ch.dwrd;
         w.bits = on ? walk_dbits(ch.dwrd, w.nav, nav_bit(ch.dwrd, w.nav) < 0 ? 1u : 0u) : 0u;
-        const uint64_t o0 = p.row_off[k], o1 = p.row_off[k + 1];
-        w.rows = p.rows + o0;
-        w.cap = (uint32_t)(o1 - o0);
-        w.cnt = 0;
-        w.active = on;
-        w.stuck = false;
-        walk_both_signs<NCO_CODE>(w, p.nsamp, p.hazards, p.status);
+        walk_both_signs<NCO_CODE, false>(w, p.nsamp, p.hazards, p.status);
         if (is_code) {
             gpsbb_chan_state_t &e = p.end[k];
             p.row_cnt[k] = on ? (int32_t)(w.cnt < w.cap ? w.cnt : w.cap) : 0;
@@ -249,28 +297,197 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
         }
     }
     if (__ballot(is_carr)) {
-        WalkLane<NCO_CARR> w;
         const int k = is_carr ? c - nbc : 0;
         const gpsbb_chan_t &ch = p.ch[k];
         const bool on = is_carr && ch.prn > 0;
-        w.x = ch.carr_phase;
-        w.s = mul_rn(ch.f_carr, p.delt); /* plutogpssim.c:2741 */
-        w.n = 0;
-        w.nav = 0;
-        w.bits = 0;
-        w.dwrd = nullptr;
-        const uint64_t o0 = p.row_off[nbc + k], o1 = p.row_off[nbc + k + 1];
-        w.rows = p.rows + o0;
-        w.cap = (uint32_t)(o1 - o0);
-        w.cnt = 0;
-        w.active = on;
-        w.stuck = false;
-        walk_both_signs<NCO_CARR>(w, p.nsamp, p.hazards, p.status);
+        const double x0 = PASS == 1 ? p.aux[k].start0 : (PASS == 2 ? p.aux[k].start1 : ch.carr_phase);
+        WalkLane<NCO_CARR> w = walk_lane<NCO_CARR>(p, nbc + k, x0, mul_rn(ch.f_carr, p.delt) /* c:2741 */, on);
+        w.store = PASS != 1;
+        if (PASS == 2)
+            walk_both_signs<NCO_CARR, true>(w, p.nsamp, p.hazards, p.status);
+        else
+            walk_both_signs<NCO_CARR, false>(w, p.nsamp, p.hazards, p.status);
         if (is_carr) {
-            p.row_cnt[nbc + k] = on ? (int32_t)(w.cnt < w.cap ? w.cnt : w.cap) : 0;
-            p.end[k].carr_phase = on ? w.x : 0.0;
+            if (PASS == 1) {
+                p.aux[k].endA = on ? w.x : 0.0;
+            } else {
+                p.row_cnt[nbc + k] = on ? (int32_t)(w.cnt < w.cap ? w.cnt : w.cap) : 0;
+                p.end[k].carr_phase = on ? w.x : 0.0;
+                if (PASS == 2) {
+                    /* the trajectory walked here is not final: k_chain_fix decides what counts */
+                    p.aux[k].margin = w.margin;
+                    p.aux[k].rstar = w.rstar;
+                    p.aux[k].nstar = w.nstar;
+                    p.aux[k].delta = 0.0;
+                    p.aux[k].hz512 = on ? w.hz512 : 0u;
+                } else if (on && w.hz512) {
+                    atomicAdd(p.hazards, (unsigned long long)w.hz512);
+                }
+            }
         }
     }
+}
+
+/* does block b of channel i continue block b-1's carrier (GPSBB_CHAIN_CARRIER: same channel index, same prn)? */
+__device__ __forceinline__ bool chain_continues(const BatchDev &p, int b, int i)
+{
+    if (b == 0)
+        return false;
+    const int prn = p.ch[(size_t)b * p.nch + i].prn;
+    return prn > 0 && prn == p.ch[(size_t)(b - 1) * p.nch + i].prn;
+}
+
+/*
+ * Device-side carrier chain, step 2 of 4: start phases good to a few units in the last place from pass A.
+ * One lane per channel walks the blocks in order: the walk of block b from the rough start0 ended at endA;
+ * from a start that is d = start1 - start0 away it ends, up to a handful of roundings, d away from there
+ * (a trajectory is translated by a small change of its start phase: see k_chain_fix), and there the next
+ * block begins.
+ */
+__global__ void k_chain_prefix(BatchDev p)
+{
+    const int i = threadIdx.x;
+    if (i >= p.nch)
+        return;
+    double prev = 0.0;
+    for (int b = 0; b < p.nblocks; b++) {
+        const size_t k = (size_t)b * p.nch + i;
+        ChainAux &a = p.aux[k];
+        double st = p.ch[k].carr_phase;
+        if (chain_continues(p, b, i)) {
+            st = prev;
+            st = st >= 1.0 ? st - 1.0 : (st < 0.0 ? st + 1.0 : st);
+        }
+        a.start1 = st;
+        prev = a.endA + (st - a.start0);
+    }
+}
+
+/* rows of one exact walk of a whole block, as k_walk writes them (build_rows_f64 drives it) */
+struct FixRowSink {
+    SynRow *rows;
+    uint32_t cap, cnt;
+    bool overflow;
+    uint32_t hz512;
+    __device__ __forceinline__ void row(int32_t n0, uint32_t, double x, double S, bool)
+    {
+        if (cnt < cap) {
+            SynRow r;
+            r.n0 = n0;
+            r.nav = 0;
+            r.x = x;
+            r.S = S;
+            rows[cnt] = r;
+        } else {
+            overflow = true;
+        }
+        cnt++;
+    }
+    __device__ __forceinline__ void table_index_512() { hz512++; }
+    __device__ __forceinline__ void nav_fetch(uint32_t) {}
+};
+
+/*
+ * Device-side carrier chain, step 4 of 4: make it exact.  One lane per channel, blocks in order.
+ *
+ * Pass B walked block b from start1, a few units in the last place away from the true start phase x (the end
+ * of block b-1, known exactly only now).  The two trajectories are translates of each other once both have
+ * been through their first wrap: every step adds the step rounded to the grid of the binade the sum falls into,
+ * and after a wrap both states are multiples of 2^-52 (2^-53 for a falling phase), i.e. of every grid they
+ * will meet, so as long as the difference d never puts the two sums on different sides of a binade edge (or of
+ * the wrap threshold) each rounding commutes with the shift (ties: see below).  Pass B recorded how close its
+ * states came to a binade edge (margin).
+ * So: walk the true start exactly up to its first wrap (a lap at most: its rows replace pass B's), take d there,
+ * and if |d| < margin the rest of the block is pass B's plus d — rows (k_tiles adds d from row rstar on) and
+ * end state alike.  Otherwise (no wrap in the block, different row structure, a tie-prone or tiny step, d too
+ * large) the lane walks the block exactly on its own; that is the rare, slow way.
+ */
+__global__ void k_chain_fix(BatchDev p)
+{
+    const int i = threadIdx.x;
+    const bool lane_on = i < p.nch;
+    const int nbc = p.nblocks * p.nch;
+    double prev_end = 0.0;
+    unsigned long long n_fallback = 0, n_hz = 0;
+    for (int b = 0; b < p.nblocks; b++) {
+        const size_t k = (size_t)b * p.nch + (lane_on ? i : 0);
+        const gpsbb_chan_t &ch = p.ch[k];
+        const bool on = lane_on && ch.prn > 0;
+        ChainAux a = p.aux[k];
+        const double x = lane_on && chain_continues(p, b, i) ? prev_end : ch.carr_phase;
+        const double s = mul_rn(ch.f_carr, p.delt);
+        const uint64_t sb = f64_bits(s);
+        const int es = (int)((sb >> 52) & 0x7ff);
+        const bool same = f64_bits(x) == f64_bits(a.start1);
+        /* A tie (a sum exactly half-way between two grid points, rounded to the even one) commutes with the shift
+         * only if the shift is an even number of grid steps.  It is one in every binade below the one in which
+         * the sum just before a wrap is rounded: [1, 2) for a rising phase (grid 2^-52, shift a multiple of
+         * 2^-52), [0.5, 1) for a falling one (grid 2^-53, shift a multiple of 2^-53).  A tie there needs the
+         * step's bits below that grid to be all zero or exactly one half of it: such steps go the slow way. */
+        bool tie_prone = true;
+        {
+            const int dt = (s < 0.0 ? 1022 : 1023) - es; /* the step's last place is 2^dt times finer than that grid */
+            if (dt >= 1 && dt <= 52) {
+                const uint64_t low = ((sb & F64_MANT) | F64_HID) & ((1ull << dt) - 1);
+                tie_prone = low == 0ull || low == (1ull << (dt - 1));
+            } else if (dt <= 0) {
+                tie_prone = false; /* the step is a multiple of the grid: sums are never between grid points */
+            }
+        }
+        bool can = on && !same && a.rstar >= 0 && es >= 123 && !tie_prone && a.margin > 0x1p-50;
+        /* the exact walk up to the first wrap, over pass B's rows */
+        WalkLane<NCO_CARR> w = walk_lane<NCO_CARR>(p, nbc + (int)k, x, s, can);
+        w.stop_at_wrap = true;
+        w.nstop = a.nstar;
+        walk_both_signs<NCO_CARR, true>(w, p.nsamp, p.hazards, p.status);
+        double end = p.end[k].carr_phase;
+        uint32_t hz512 = a.hz512; /* pass B's trajectory is the true one, or a translate that met no edge */
+        if (can) {
+            can = w.rstar == a.rstar && w.nstar == a.nstar;
+            const double xb = a.nstar < p.nsamp ? w.rows[a.rstar < (int)w.cap ? a.rstar : 0].x : end;
+            const double d = w.x - xb;
+            can = can && (a.nstar >= p.nsamp || w.rows[a.rstar < (int)w.cap ? a.rstar : 0].n0 == a.nstar) &&
+                  fabs(d) < a.margin - 0x1p-51;
+            if (can) {
+                a.delta = d;
+                end = end + d; /* exact: the true end state is a double */
+            }
+        }
+        if (on && !same && !can) {
+            /* on its own: the whole block exactly, rows in place of pass B's */
+            FixRowSink sink;
+            sink.rows = w.rows;
+            sink.cap = w.cap;
+            sink.cnt = 0;
+            sink.overflow = false;
+            sink.hz512 = 0;
+            uint32_t nav = 0;
+            end = build_rows_f64<NCO_CARR>(x, s, nav, p.nsamp, sink);
+            hz512 = sink.hz512;
+            if (sink.overflow)
+                atomicOr(p.status, ST_ROW_OVERFLOW);
+            p.row_cnt[nbc + k] = (int32_t)(sink.cnt < sink.cap ? sink.cnt : sink.cap);
+            a.delta = 0.0;
+            a.rstar = 0;
+            n_fallback++;
+        }
+        if (lane_on) {
+            if (on && same) {
+                a.delta = 0.0;
+                a.rstar = 0;
+            }
+            p.aux[k].delta = a.delta;
+            p.aux[k].rstar = a.rstar;
+            p.end[k].carr_phase = on ? end : 0.0;
+            prev_end = end;
+            if (on)
+                n_hz += hz512;
+        }
+    }
+    if (n_hz)
+        atomicAdd(p.hazards, n_hz);
+    if (n_fallback)
+        atomicAdd(p.hazards + 4, n_fallback);
 }
 
 /*
@@ -291,6 +508,10 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
         return;
     const SynRow *__restrict__ rows = p.rows + p.row_off[chain];
     const int b = bi / p.nch, i = bi % p.nch;
+    /* carrier chained on the device: from row rstar on the true states are pass B's plus delta (k_chain_fix) */
+    const bool shifted = kind && p.aux && p.chain_dev;
+    const double delta = shifted ? p.aux[bi].delta : 0.0;
+    const int rstar = shifted ? p.aux[bi].rstar : 0;
     double *__restrict__ tx = p.tile_x + ((size_t)b * (2 * (size_t)p.nch) + 2 * i + kind) * (size_t)p.ntiles;
     uint32_t *__restrict__ tn = p.tile_nav + ((size_t)b * (size_t)p.nch + i) * (size_t)p.ntiles;
     /* four rows per lane and turn, their loads issued together: the kernel is bound by the latency of these
@@ -314,7 +535,9 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
             int t_end = (int)(((uint32_t)n_next[j] + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
             t_end = t_end < p.ntiles ? t_end : p.ntiles;
             for (; t < t_end; t++) {
-                const double v = __fma_rn((double)(t * TILE - row[j].n0), row[j].S, row[j].x);
+                double v = __fma_rn((double)(t * TILE - row[j].n0), row[j].S, row[j].x);
+                if (kind)
+                    v = r0 + j * GPSBB_TILES_WG >= rstar ? v + delta : v; /* exact: the sum is the true state */
                 tx[t] = kind ? mul_rn(v, 512.0) : v;
                 if (!kind)
                     tn[t] = row[j].nav;

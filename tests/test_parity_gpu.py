@@ -202,6 +202,57 @@ def test_batch_chained_carrier(pkg, synth, oracle):
     b2.close()
 
 
+
+def test_carrier_chained_on_the_device(pkg, synth, oracle, request):
+    """GPSBB_CHAIN_CARRIER at a sample rate the breakpoint kernel takes: the exact carrier chain runs on the
+    device, in parallel over the blocks (pass A, prefix, pass B, k_chain_fix: every block is walked from a
+    start phase a few units in the last place off and shifted onto the true trajectory after its first wrap).
+    Bit-exact against the oracle walking the blocks in order, for every kind of block the fix-up knows:
+    translated ones, channels too slow to wrap within a block (walked sequentially), a step that can tie,
+    a channel that does not move, channels that come and go."""
+    nb, nch = 24, 16
+    fs, nsamp = 25e6, 120000
+    ch = pkg.synth_descriptors(nb, nch=nch, seed=4242)
+    rng = np.random.default_rng(5)
+    # one Doppler per channel, drifting a little from block to block like a real pass
+    f0 = rng.uniform(-5000, 5000, nch)
+    f0[0], f0[1], f0[2], f0[3] = 3.0, -40.0, 0.0, fs * 2.0 ** -14       # no wrap in a block / none ever / tie-prone step
+    ch["f_carr"] = f0[None, :] + rng.uniform(-0.5, 0.5, (nb, nch)) * (np.abs(f0[None, :]) > 100)
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    ch["prn"] = np.arange(1, nch + 1)[None, :]
+    ch["prn"][7:, 5] = 31        # channel 5 re-allocated at block 7: restarts from its descriptor
+    ch["prn"][10:13, 9] = 0      # channel 9 off for three blocks
+    want_iq, want_st, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
+    fb0 = synth.info(pkg.INFO_CHAIN_FALLBACKS)
+    b = synth.batch(ch, 1 / fs, nsamp, flags=pkg.CHAIN_CARRIER)
+    for _ in range(2):           # two runs: the table sets alternate
+        b.run()
+    synth.sync()
+    iq, st = b.read()
+    b.close()
+    where, kernel = request.node.callspec.params["seed_mode"].split("+")
+    if where == "k_seed" and kernel == "auto":
+        assert synth.info(pkg.INFO_LAST_KERNEL) == 2 and synth.info(pkg.INFO_CHAIN_ON_DEVICE) == 1
+        # blocks the fix-up had to walk sequentially: at most those of the four special channels (often fewer:
+        # where pass A's prediction of a start phase is exact to the bit there is nothing to fix) plus a few
+        fb = synth.info(pkg.INFO_CHAIN_FALLBACKS) - fb0
+        assert fb <= 2 * (4 * (nb - 1) + 12), fb
+    assert (iq == want_iq).all()
+    for k in range(nb):
+        assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
+    # ... and forced onto host threads it is the same bytes
+    synth.set_option(pkg.OPT_CHAIN_WHERE, 1)
+    try:
+        b = synth.batch(ch, 1 / fs, nsamp, flags=pkg.CHAIN_CARRIER)
+        b.run()
+        synth.sync()
+        assert synth.info(pkg.INFO_CHAIN_ON_DEVICE) == 0
+        assert (b.read()[0] == want_iq).all()
+        b.close()
+    finally:
+        synth.set_option(pkg.OPT_CHAIN_WHERE, 0)
+
+
 def test_stream_ring_with_pinned_gather(pkg, synth, oracle):
     nch, delt, nsamp, bps = 8, 1 / 4.092e6, 50000, 2
     ch = pkg.synth_descriptors(10, nch=nch, seed=101)

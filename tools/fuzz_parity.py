@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--shapes", action="store_true", help="a few extreme shapes instead of random small ones")
+    ap.add_argument("--ev", action="store_true",
+                    help="only workloads the breakpoint kernel k_synth_ev is eligible for: sample rates above 16 MS/s, "
+                         "Doppler up to fs/2100 (four table-index changes per run of 16 samples), IEEE carrier")
     a = ap.parse_args()
     import torch  # noqa: F401  (first: the HIP runtime)
     from __graft_entry__ import load_package
@@ -47,11 +50,19 @@ def main():
             if a.shapes:
                 fs, nsamp, nch, nblocks = shapes[case // 2]
                 fixed, mode = False, 1 + case % 2
+            if a.ev:
+                fs = float(rng.choice([16e6, 16.368e6, 20e6, 25e6, 30e6, 2.0 ** 25, 50e6, 61.44e6]))
+                nsamp = int(rng.choice([rng.integers(1, 3000), rng.integers(3000, 300000), 1024 * int(rng.integers(1, 200))]))
+                fixed = False
             ch = pkg.synth_descriptors(nblocks, nch=nch, seed=int(rng.integers(1, 2 ** 31)))
-            scale = 10.0 ** rng.uniform(-3, np.log10(0.124 * fs), size=(nblocks, nch))
+            scale = 10.0 ** rng.uniform(-3, np.log10((1.0 / 2100.0 if a.ev else 0.124) * fs), size=(nblocks, nch))
             ch["f_carr"] = np.where(rng.random((nblocks, nch)) < 0.5, -1.0, 1.0) * scale
             if rng.random() < 0.3:                     # exact binary steps: phases land on boundaries
-                ch["f_carr"] = np.sign(ch["f_carr"]) * fs * 2.0 ** rng.integers(-20, -4, size=(nblocks, nch))
+                ch["f_carr"] = np.sign(ch["f_carr"]) * fs * 2.0 ** rng.integers(-20, -11 if a.ev else -4, size=(nblocks, nch))
+            if a.ev and rng.random() < 0.2:            # a channel that does not move at all, one that barely does
+                ch["f_carr"][:, 0] = 0.0
+                if nch > 1:
+                    ch["f_carr"][:, 1] = 1e-9 * fs
             ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
             if rng.random() < 0.2:
                 ch["code_phase"] = np.floor(ch["code_phase"])        # starts on chip boundaries

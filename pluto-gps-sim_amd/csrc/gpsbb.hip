@@ -362,6 +362,7 @@ struct gpsbb_batch {
     /* GPSBB_CHAIN_CARRIER resolved on the device (gpsbb_walk.hip.h: k_chain_prefix / k_chain_fix) */
     bool chain_dev = false;
     DevBuf<ChainAux> d_aux[NSETS];
+    DevBuf<SynRow> d_prefix[NSETS];
     std::vector<ChainAux> h_aux;
     int carr_lanes = 0; /* lanes of the seed plan that walk carrier chains (they come first) */
     hipEvent_t synth_done[NSETS] = {nullptr, nullptr, nullptr};
@@ -709,6 +710,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         }
         for (int set = 0; set < b->nsets; set++) {
             HIPCHK(h, (hipError_t)b->d_aux[set].reserve(nbc));
+            HIPCHK(h, (hipError_t)b->d_prefix[set].reserve(nbc * (size_t)CHAIN_PREFIX_CAP));
             HIPCHK(h, hipMemcpyAsync(b->d_aux[set].p, b->h_aux.data(), nbc * sizeof(ChainAux), hipMemcpyHostToDevice, upload_stream));
         }
     }
@@ -828,6 +830,7 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         b->d_tile_x[k].release();
         b->d_tile_nav[k].release();
         b->d_aux[k].release();
+        b->d_prefix[k].release();
         b->d_evc.release();
         if (b->synth_done[k])
             (void)hipEventDestroy(b->synth_done[k]);
@@ -1152,6 +1155,7 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.evc = b->d_evc.p;
     p.chain_dev = b->chain_dev ? 1 : 0;
     p.aux = b->chain_dev ? b->d_aux[set].p : nullptr;
+    p.prefix_rows = b->chain_dev ? b->d_prefix[set].p : nullptr;
     return p;
 }
 

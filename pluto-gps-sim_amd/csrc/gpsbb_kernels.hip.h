@@ -99,16 +99,28 @@ struct EvConst {
 static_assert(sizeof(EvConst) == 56, "EvConst layout");
 
 /* Per (block, channel) scratch of the device-side carrier chain (gpsbb_walk.hip.h, k_chain_fix). */
+constexpr int CHAIN_MAX_CROSS = 20;
+constexpr int CHAIN_PREFIX_CAP = 64; /* rows of one lap walked by k_chain_fix on its own */
 struct ChainAux {
     double start0; /* rough start phase (host: descriptor phase + sum of nsamp*step, in plain double arithmetic) */
     double start1; /* start phase pass B walks from: good to a few units in the last place                  */
     double endA;   /* end phase of pass A's walk from start0                                               */
     double margin; /* pass B: smallest distance of a row's first or last state to an edge of its binade    */
-    double delta;  /* true state minus pass B's state, from row rstar on                                   */
-    int32_t rstar; /* pass B: rows emitted when the first wrap had happened (-1: none)                     */
-    int32_t nstar; /* ... and samples done                                                                */
-    uint32_t hz512; /* pass B: samples whose phase was exactly 1.0                                         */
-    uint32_t _pad;
+    /* pass B: the rows, up to and including the one after the first wrap, whose first state came out of a sum
+     * rounded on a coarser grid than the states of the row before (a binade crossed upwards, or a wrap): only
+     * there can the offset between pass B's trajectory and the true one change */
+    int32_t ncross;                 /* -1: more than CHAIN_MAX_CROSS of them                              */
+    int32_t cross[CHAIN_MAX_CROSS]; /* row numbers, ascending                                             */
+    uint32_t hz512;                 /* pass B: samples whose phase was exactly 1.0                         */
+    int32_t wrap_row;               /* pass B: the row that follows the first wrap (-1: no wrap in the block) */
+    /* k_chain_fix, when it walked the block's first lap on its own: rows 0 .. prefix_cnt-1 of the chain's
+     * prefix region hold the samples before prefix_end (= the first sample of pass B's row wrap_row) and
+     * pass B's rows before wrap_row are void */
+    int32_t prefix_cnt, prefix_end;
+    int32_t _pad;
+    /* k_chain_fix: true state minus pass B's state, for rows cross[j-1] <= r < cross[j] (seg[0]: from row 0,
+     * seg[ncross]: to the end of the block) */
+    double seg[CHAIN_MAX_CROSS + 1];
 };
 
 /* Everything the kernels need about one batch; passed by value as the kernel argument. */
@@ -152,6 +164,7 @@ struct BatchDev {
     const EvConst *evc;             /* [nblocks*nch]                                                  */
     int chain_dev;                  /* 1: GPSBB_CHAIN_CARRIER is resolved on the device (k_chain_prefix / k_chain_fix) */
     ChainAux *aux;                  /* [nblocks*nch]                                                  */
+    SynRow *prefix_rows;            /* [nblocks*nch][CHAIN_PREFIX_CAP]: see ChainAux::prefix_cnt       */
 };
 
 __device__ __forceinline__ size_t tile_row_at(const BatchDev &p, int b, int t, int i, int kind)

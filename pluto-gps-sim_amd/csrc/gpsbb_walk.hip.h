@@ -40,9 +40,11 @@ struct WalkLane {
     bool stuck; /* x + s rounded back to x and nothing wrapped: the state is constant from here on */
     /* carrier chains of a batch whose carrier is chained on the device (see k_chain_fix) */
     bool store;        /* write rows (pass A of the chain only wants the end state) */
-    bool stop_at_wrap; /* end the walk right after the first wrap, or once past sample nstop */
-    int32_t nstop;
-    int32_t rstar, nstar; /* rows emitted / samples done when the first wrap had happened; -1: no wrap */
+    ChainAux *aux;     /* pass B: where the crossings go */
+    int32_t ncross;    /* crossings recorded so far; -1: too many */
+    int32_t prev_ex;   /* biased exponent of the previous row's states */
+    bool prev_wrapped; /* the step before this row wrapped */
+    bool wrap_seen;    /* the first wrap is behind: the offset is settled */
     double margin;     /* smallest distance of a row's first or last state to an edge of its binade */
     uint32_t hz512;    /* carrier: samples whose phase is exactly 1.0 (gpsbb_hazards_t.itable_512) */
 };
@@ -101,7 +103,7 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
         const int ex = (int)(hi >> 20); /* sign bit included: a negative state (-0.0) counts as beyond the range */
         const int d = ex - es;
         const bool weird = (unsigned)(ex - 1) >= (unsigned)(TOPEX - 1); /* zero, subnormal, negative, beyond the top */
-        const bool rare = w.active && !weird && (generic || d > 50 || w.stuck);
+        const bool rare = w.active && (w.stuck || (!weird && (generic || d > 50)));
         bool expl = weird || d < 2;
         if (any_tie)
             expl |= ((tiemask >> (d & 63)) & 1ull) != 0ull && (__double2loint(x) & 1);
@@ -135,6 +137,23 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
             const double lo = __hiloint2double((int)(hi & 0xfff00000u), 0);
             const double dl = add_rn(SNEG ? x1 : x, -lo), dh = add_rn(add_rn(lo, lo), -(SNEG ? x : x1));
             w.margin = w.active ? fmin(w.margin, (weird || rare) ? 0.0 : fmin(dl, dh)) : w.margin;
+            if (KIND == NCO_CARR) {
+                /* this row's states lie on a coarser grid than the previous row's (or the step wrapped): the
+                 * offset to the true trajectory may change here.  Few per block: only until the first wrap. */
+                const bool cross = w.active && !w.wrap_seen && (ex > w.prev_ex || w.prev_wrapped);
+                if (__builtin_expect(__ballot(cross) != 0ull, 0)) {
+                    if (cross) {
+                        if (w.ncross >= 0 && w.ncross < CHAIN_MAX_CROSS)
+                            w.aux->cross[w.ncross++] = (int32_t)w.cnt;
+                        else
+                            w.ncross = -1;
+                        w.wrap_seen = w.prev_wrapped;
+                        if (w.prev_wrapped)
+                            w.aux->wrap_row = (int32_t)w.cnt;
+                    }
+                }
+                w.prev_ex = w.active ? ex : w.prev_ex;
+            }
         }
         if (__builtin_expect(__ballot(rare || (w.active && weird)) != 0ull, 0)) {
             if (KIND == NCO_CARR && w.active && ex >= TOPEX && !(hi >> 31))
@@ -193,20 +212,14 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
                 }
             }
         }
-        if (__builtin_expect(__ballot(rare) != 0ull, 0)) /* only a state far above the step can stop moving */
-            w.stuck = rare && step && !wrapped && f64_bits(x2) == f64_bits(x1);
+        /* only a state far above the step, or a zero one with a zero step, can stop moving */
+        if (__builtin_expect(__ballot(rare || (w.active && weird)) != 0ull, 0))
+            w.stuck = (rare || weird) && step && !wrapped && f64_bits(x2) == f64_bits(x1);
         w.x = step ? x2 : (w.active ? x1 : w.x);
         w.n = step ? n1 + 1 : (w.active ? n1 : w.n); /* lanes waiting for the other direction's loop keep theirs */
-        bool go_on = step && w.n < nsamp;
-        if (KIND == NCO_CARR && TRACK) {
-            if (step && wrapped && w.rstar < 0) {
-                w.rstar = (int32_t)w.cnt;
-                w.nstar = w.n;
-            }
-        }
-        if (KIND == NCO_CARR)
-            go_on = go_on && !(w.stop_at_wrap && ((step && wrapped) || w.n > w.nstop));
-        w.active = go_on;
+        if (KIND == NCO_CARR && TRACK)
+            w.prev_wrapped = w.active ? (step && wrapped) : w.prev_wrapped;
+        w.active = step && w.n < nsamp;
     }
 }
 
@@ -245,9 +258,11 @@ __device__ __forceinline__ WalkLane<KIND> walk_lane(const BatchDev &p, int chain
     w.active = on;
     w.stuck = false;
     w.store = true;
-    w.stop_at_wrap = false;
-    w.nstop = INT32_MAX;
-    w.rstar = w.nstar = -1;
+    w.aux = nullptr;
+    w.ncross = 0;
+    w.prev_ex = 0x7fff;
+    w.prev_wrapped = false;
+    w.wrap_seen = false;
     w.margin = 1.0;
     w.hz512 = 0;
     return w;
@@ -303,6 +318,7 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
         const double x0 = PASS == 1 ? p.aux[k].start0 : (PASS == 2 ? p.aux[k].start1 : ch.carr_phase);
         WalkLane<NCO_CARR> w = walk_lane<NCO_CARR>(p, nbc + k, x0, mul_rn(ch.f_carr, p.delt) /* c:2741 */, on);
         w.store = PASS != 1;
+        w.aux = PASS == 2 ? &p.aux[k] : nullptr;
         if (PASS == 2)
             walk_both_signs<NCO_CARR, true>(w, p.nsamp, p.hazards, p.status);
         else
@@ -316,9 +332,10 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
                 if (PASS == 2) {
                     /* the trajectory walked here is not final: k_chain_fix decides what counts */
                     p.aux[k].margin = w.margin;
-                    p.aux[k].rstar = w.rstar;
-                    p.aux[k].nstar = w.nstar;
-                    p.aux[k].delta = 0.0;
+                    p.aux[k].ncross = on ? w.ncross : 0;
+                    if (!w.wrap_seen)
+                        p.aux[k].wrap_row = -1;
+                    p.aux[k].prefix_cnt = 0;
                     p.aux[k].hz512 = on ? w.hz512 : 0u;
                 } else if (on && w.hz512) {
                     atomicAdd(p.hazards, (unsigned long long)w.hz512);
@@ -390,17 +407,20 @@ struct FixRowSink {
 /*
  * Device-side carrier chain, step 4 of 4: make it exact.  One lane per channel, blocks in order.
  *
- * Pass B walked block b from start1, a few units in the last place away from the true start phase x (the end
- * of block b-1, known exactly only now).  The two trajectories are translates of each other once both have
- * been through their first wrap: every step adds the step rounded to the grid of the binade the sum falls into,
- * and after a wrap both states are multiples of 2^-52 (2^-53 for a falling phase), i.e. of every grid they
- * will meet, so as long as the difference d never puts the two sums on different sides of a binade edge (or of
- * the wrap threshold) each rounding commutes with the shift (ties: see below).  Pass B recorded how close its
- * states came to a binade edge (margin).
- * So: walk the true start exactly up to its first wrap (a lap at most: its rows replace pass B's), take d there,
- * and if |d| < margin the rest of the block is pass B's plus d — rows (k_tiles adds d from row rstar on) and
- * end state alike.  Otherwise (no wrap in the block, different row structure, a tie-prone or tiny step, d too
- * large) the lane walks the block exactly on its own; that is the rare, slow way.
+ * Pass B walked block b from start1, a few units in the last place away from the true start phase (the end of
+ * block b-1, known exactly only now).  Inside one of pass B's rows all states lie in one binade, on one grid,
+ * and every step adds the same multiple of it: the true trajectory is pass B's plus an offset d that is a
+ * multiple of that grid, for as long as the two stay in the same binade for the same steps — which pass B's
+ * margin (how close its rows' first and last states come to a binade edge) guarantees when |d| is smaller.
+ * d can only change where a sum is rounded on a COARSER grid: a binade crossed upwards, or a wrap.  Once a sum
+ * has been rounded on the coarsest grid there is (the one before a wrap: 2^-52 in [1,2) for a rising phase,
+ * 2^-53 in [0.5,1) for a falling one) d is a multiple of every grid the phase will ever meet and stays put
+ * (ties: see tie_prone below).  Pass B recorded those few rows; here, for each of them in turn: pass B's state
+ * at the last sample of the row before, plus d, is the true state there; one genuine IEEE step (c:2741-2746)
+ * gives the true first state of the row; minus pass B's, that is the new d.  k_tiles adds the offsets to the
+ * rows' states, the end state gets the last one.  A block whose step can tie on the coarsest grid, is tiny,
+ * has more crossings than the record holds, or whose margin is not larger than its offsets is walked exactly
+ * by the lane on its own (rare, slow).
  */
 __global__ void k_chain_fix(BatchDev p)
 {
@@ -413,51 +433,103 @@ __global__ void k_chain_fix(BatchDev p)
         const size_t k = (size_t)b * p.nch + (lane_on ? i : 0);
         const gpsbb_chan_t &ch = p.ch[k];
         const bool on = lane_on && ch.prn > 0;
-        ChainAux a = p.aux[k];
+        ChainAux &a = p.aux[k];
         const double x = lane_on && chain_continues(p, b, i) ? prev_end : ch.carr_phase;
         const double s = mul_rn(ch.f_carr, p.delt);
         const uint64_t sb = f64_bits(s);
         const int es = (int)((sb >> 52) & 0x7ff);
-        const bool same = f64_bits(x) == f64_bits(a.start1);
-        /* A tie (a sum exactly half-way between two grid points, rounded to the even one) commutes with the shift
-         * only if the shift is an even number of grid steps.  It is one in every binade below the one in which
-         * the sum just before a wrap is rounded: [1, 2) for a rising phase (grid 2^-52, shift a multiple of
-         * 2^-52), [0.5, 1) for a falling one (grid 2^-53, shift a multiple of 2^-53).  A tie there needs the
-         * step's bits below that grid to be all zero or exactly one half of it: such steps go the slow way. */
-        bool tie_prone = true;
-        {
-            const int dt = (s < 0.0 ? 1022 : 1023) - es; /* the step's last place is 2^dt times finer than that grid */
-            if (dt >= 1 && dt <= 52) {
-                const uint64_t low = ((sb & F64_MANT) | F64_HID) & ((1ull << dt) - 1);
-                tie_prone = low == 0ull || low == (1ull << (dt - 1));
-            } else if (dt <= 0) {
-                tie_prone = false; /* the step is a multiple of the grid: sums are never between grid points */
-            }
-        }
-        bool can = on && !same && a.rstar >= 0 && es >= 123 && !tie_prone && a.margin > 0x1p-50;
-        /* the exact walk up to the first wrap, over pass B's rows */
-        WalkLane<NCO_CARR> w = walk_lane<NCO_CARR>(p, nbc + (int)k, x, s, can);
-        w.stop_at_wrap = true;
-        w.nstop = a.nstar;
-        walk_both_signs<NCO_CARR, true>(w, p.nsamp, p.hazards, p.status);
+        const double margin = a.margin;
+        const int ncross = a.ncross;
+        const SynRow *rows = p.rows + p.row_off[nbc + k];
         double end = p.end[k].carr_phase;
         uint32_t hz512 = a.hz512; /* pass B's trajectory is the true one, or a translate that met no edge */
-        if (can) {
-            can = w.rstar == a.rstar && w.nstar == a.nstar;
-            const double xb = a.nstar < p.nsamp ? w.rows[a.rstar < (int)w.cap ? a.rstar : 0].x : end;
-            const double d = w.x - xb;
-            can = can && (a.nstar >= p.nsamp || w.rows[a.rstar < (int)w.cap ? a.rstar : 0].n0 == a.nstar) &&
-                  fabs(d) < a.margin - 0x1p-51;
-            if (can) {
-                a.delta = d;
-                end = end + d; /* exact: the true end state is a double */
+        const double d0 = x - a.start1; /* exact: both in the same binade, or the margin test below fails */
+        /* Ties.  A sum exactly half-way between two grid points goes to the even one, so a tie commutes with the
+         * shift only if the shift is an even number of steps of that grid.  It always is on grids finer than the
+         * one the offset was last rounded on.  That leaves (1) the binades the phase visits before its offset has
+         * been through the coarsest grid — from its start binade upwards if it rises, its start binade only if it
+         * falls: if the step can tie there (walk_tiemask) the lane walks the block's first lap on its own;
+         * (2) the coarsest grid itself, where a tie needs the step's bits below that grid to be all zero or exactly
+         * one half of it: then an ODD final offset sends the whole block the slow way. */
+        const bool fall = s < 0.0;
+        bool tie_top = true;
+        {
+            const int dt = (fall ? 1022 : 1023) - es; /* the step's last place is 2^dt times finer than that grid */
+            if (dt >= 1 && dt <= 52) {
+                const uint64_t low = ((sb & F64_MANT) | F64_HID) & ((1ull << dt) - 1);
+                tie_top = low == 0ull || low == (1ull << (dt - 1));
+            } else if (dt <= 0) {
+                tie_top = false; /* the step is a multiple of the grid: sums are never between grid points */
             }
         }
-        if (on && !same && !can) {
-            /* on its own: the whole block exactly, rows in place of pass B's */
+        bool tie_asc = false;
+        if (on && d0 != 0.0 && es >= 123) {
+            const int dstart = (int)((f64_bits(x) >> 52) & 0x7ff) - es;
+            const uint64_t tm = walk_tiemask(sb);
+            const uint64_t from = dstart <= 0 ? ~0ull : (dstart > 50 ? 0ull : ~((1ull << dstart) - 1));
+            tie_asc = (tm & (fall ? (dstart >= 2 && dstart <= 50 ? 1ull << dstart : 0ull) : from)) != 0ull;
+        }
+        const double gtop = fall ? 0x1p-53 : 0x1p-52;
+        const bool base = on && es >= 123 && ncross >= 0 && fabs(d0) < margin - 0x1p-51;
+        bool ok = on && d0 == 0.0;
+        double d = d0;
+        if (on)
+            a.seg[0] = d0;
+        if (base && !ok && !tie_asc) {
+            /* the usual way: one genuine step per recorded crossing */
+            ok = true;
+            for (int j = 0; ok && j < ncross; j++) {
+                const int r = a.cross[j];
+                const SynRow pre = rows[r - 1], post = rows[r];
+                /* pass B's state at the last sample of row r-1, the true one, one genuine step */
+                double xt = __fma_rn((double)(post.n0 - 1 - pre.n0), pre.S, pre.x) + d;
+                carr_step(xt, s);
+                d = xt - post.x;
+                ok = fabs(d) < margin - 0x1p-51;
+                a.seg[j + 1] = d;
+            }
+            /* an odd number of steps of the coarsest grid and a step that can tie there: not a translate */
+            if (ok && tie_top && a.wrap_row >= 0 && fmod(fabs(d) * (fall ? 0x1p+53 : 0x1p+52), 2.0) != 0.0)
+                ok = false;
+        } else if (base && !ok && a.wrap_row >= 0) {
+            /* a tie-prone binade on the way up: the first lap exactly, on its own rows; after the wrap that ends it
+             * the offset is a multiple of every grid and the rest of the block is pass B's plus it */
+            const int wr = a.wrap_row;
+            const int nstar = rows[wr].n0; /* a wrap always starts a row */
             FixRowSink sink;
-            sink.rows = w.rows;
-            sink.cap = w.cap;
+            sink.rows = p.prefix_rows + k * CHAIN_PREFIX_CAP;
+            sink.cap = CHAIN_PREFIX_CAP;
+            sink.cnt = 0;
+            sink.overflow = false;
+            sink.hz512 = 0;
+            uint32_t nav = 0;
+            const double xs = build_rows_f64<NCO_CARR>(x, s, nav, nstar, sink);
+            d = xs - rows[wr].x;
+            ok = !sink.overflow && sink.hz512 == 0 && fabs(d) < margin - 0x1p-51 &&
+                 !(tie_top && fmod(fabs(d) * (fall ? 0x1p+53 : 0x1p+52), 2.0) != 0.0);
+            if (ok) {
+                a.prefix_cnt = (int32_t)sink.cnt;
+                a.prefix_end = nstar;
+                /* pass B's rows from wrap_row on: one segment */
+                a.ncross = 1;
+                a.cross[0] = wr;
+                a.seg[0] = 0.0;
+                a.seg[1] = d;
+            }
+        }
+        (void)gtop;
+        if (on && ok && d0 != 0.0)
+            end = end + d; /* exact: the true end state is a double */
+#ifdef GPSBB_CHAIN_DEBUG
+        if (on && !ok)
+            printf("chain fallback: block %d ch %d d0 %.3e d %.3e margin %.3e ncross %d es %d tie_top %d tie_asc %d wrap_row %d\n", b,
+                   i, d0, d, margin, ncross, es, (int)tie_top, (int)tie_asc, a.wrap_row);
+#endif
+        if (on && !ok) {
+            /* on its own: the whole block exactly, rows in place of pass B's, no offsets */
+            FixRowSink sink;
+            sink.rows = p.rows + p.row_off[nbc + k];
+            sink.cap = (uint32_t)(p.row_off[nbc + k + 1] - p.row_off[nbc + k]);
             sink.cnt = 0;
             sink.overflow = false;
             sink.hz512 = 0;
@@ -467,17 +539,12 @@ __global__ void k_chain_fix(BatchDev p)
             if (sink.overflow)
                 atomicOr(p.status, ST_ROW_OVERFLOW);
             p.row_cnt[nbc + k] = (int32_t)(sink.cnt < sink.cap ? sink.cnt : sink.cap);
-            a.delta = 0.0;
-            a.rstar = 0;
+            a.ncross = 0;
+            a.seg[0] = 0.0;
+            a.prefix_cnt = 0;
             n_fallback++;
         }
         if (lane_on) {
-            if (on && same) {
-                a.delta = 0.0;
-                a.rstar = 0;
-            }
-            p.aux[k].delta = a.delta;
-            p.aux[k].rstar = a.rstar;
             p.end[k].carr_phase = on ? end : 0.0;
             prev_end = end;
             if (on)
@@ -508,16 +575,33 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
         return;
     const SynRow *__restrict__ rows = p.rows + p.row_off[chain];
     const int b = bi / p.nch, i = bi % p.nch;
-    /* carrier chained on the device: from row rstar on the true states are pass B's plus delta (k_chain_fix) */
-    const bool shifted = kind && p.aux && p.chain_dev;
-    const double delta = shifted ? p.aux[bi].delta : 0.0;
-    const int rstar = shifted ? p.aux[bi].rstar : 0;
     double *__restrict__ tx = p.tile_x + ((size_t)b * (2 * (size_t)p.nch) + 2 * i + kind) * (size_t)p.ntiles;
     uint32_t *__restrict__ tn = p.tile_nav + ((size_t)b * (size_t)p.nch + i) * (size_t)p.ntiles;
+    /* carrier chained on the device: the true states are pass B's plus an offset per stretch of rows (k_chain_fix) */
+    const bool shifted = kind && p.aux && p.chain_dev;
+    const ChainAux *aux = shifted ? &p.aux[bi] : nullptr;
+    const int ncross = shifted ? (aux->ncross > 0 ? aux->ncross : 0) : 0;
+    /* k_chain_fix walked the first lap on its own: those rows (in the chain's prefix region) hold the samples
+     * before prefix_end, pass B's rows before wrap_row are void */
+    const int prefix_cnt = shifted ? aux->prefix_cnt : 0;
+    const int first_row = prefix_cnt > 0 ? aux->wrap_row : 0;
+    if (prefix_cnt > 0) {
+        const SynRow *pr = p.prefix_rows + (size_t)bi * CHAIN_PREFIX_CAP;
+        const int pend = aux->prefix_end;
+        for (int r = threadIdx.x; r < prefix_cnt; r += blockDim.x) {
+            const SynRow row = pr[r];
+            const int n_next = r + 1 < prefix_cnt ? pr[r + 1].n0 : pend;
+            int t = (int)(((uint32_t)row.n0 + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
+            int t_end = (int)(((uint32_t)n_next + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
+            t_end = t_end < p.ntiles ? t_end : p.ntiles;
+            for (; t < t_end; t++)
+                tx[t] = mul_rn(__fma_rn((double)(t * TILE - row.n0), row.S, row.x), 512.0);
+        }
+    }
     /* four rows per lane and turn, their loads issued together: the kernel is bound by the latency of these
      * loads, not by their number */
     constexpr int U = 4;
-    for (int r0 = threadIdx.x; r0 < cnt; r0 += U * GPSBB_TILES_WG) {
+    for (int r0 = first_row + threadIdx.x; r0 < cnt; r0 += U * GPSBB_TILES_WG) {
         SynRow row[U];
         int n_next[U];
 #pragma unroll
@@ -529,6 +613,17 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
             if (r >= cnt)
                 n_next[j] = row[j].n0; /* past the chain's last row: no tiles */
         }
+        double off[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            off[j] = 0.0;
+            if (shifted) {
+                int g = 0; /* the row's segment: the crossings at or before it */
+                while (g < ncross && aux->cross[g] <= r0 + j * GPSBB_TILES_WG)
+                    g++;
+                off[j] = aux->seg[g];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < U; j++) {
             int t = (int)(((uint32_t)row[j].n0 + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
@@ -536,8 +631,7 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
             t_end = t_end < p.ntiles ? t_end : p.ntiles;
             for (; t < t_end; t++) {
                 double v = __fma_rn((double)(t * TILE - row[j].n0), row[j].S, row[j].x);
-                if (kind)
-                    v = r0 + j * GPSBB_TILES_WG >= rstar ? v + delta : v; /* exact: the sum is the true state */
+                v = shifted ? v + off[j] : v; /* exact: the sum is the true state, a double */
                 tx[t] = kind ? mul_rn(v, 512.0) : v;
                 if (!kind)
                     tn[t] = row[j].nav;

@@ -77,7 +77,14 @@ def main():
             synth.set_option(pkg.OPT_SYNTH_KERNEL, kern)
             b = synth.batch(ch, 1.0 / fs, nsamp, flags=flags)
             b.run()
-            synth.sync()
+            try:
+                synth.sync()
+            except Exception:
+                np.save("gpurun_out/fuzz_fail_ch.npy", ch)
+                print("FAILED in sync:", dict(case=case, fs=fs, nsamp=nsamp, nch=nch, nblocks=nblocks, fixed=fixed, chain=chain,
+                                              mode=mode, kern=kern), "f_carr", ch["f_carr"].tolist(), "prn", ch["prn"].tolist(),
+                      "carr_phase", ch["carr_phase"].tolist())
+                raise
             iq, st = b.read()
             b.close()
             used[synth.info(pkg.INFO_LAST_KERNEL)] = used.get(synth.info(pkg.INFO_LAST_KERNEL), 0) + 1

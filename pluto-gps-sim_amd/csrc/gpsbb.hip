@@ -263,6 +263,7 @@ struct gpsbb {
     int device = 0;
     hipStream_t s_seed = nullptr;    /* NCO seeding pre-pass (k_seed) and descriptor uploads            */
     hipStream_t s_seed2 = nullptr;   /* ... of every other batch / slot of a streaming ring (created on first use) */
+    hipStream_t s_seed3 = nullptr;   /* ... a third one: batches whose carrier is chained on the device keep three pre-passes in flight */
     unsigned batches_created = 0;
     hipStream_t s_compute = nullptr; /* synthesis kernel (k_synth)                                      */
     hipStream_t s_copy = nullptr;    /* device-to-host gather                                            */
@@ -319,8 +320,9 @@ struct DevBuf {
  * that last read that set has finished.  Per-sample kernel: two sets (the pre-pass of run k+1 overlaps the
  * synthesis of run k).  Breakpoint kernel: three, and consecutive runs seed on alternating streams: its
  * pre-pass (k_walk) is as long as its longest chain whatever the batch size — longer than the synthesis it
- * feeds — so two of them have to be in flight for the synthesis kernel to set the pace. */
-constexpr int NSETS = 3;
+ * feeds — so two of them have to be in flight for the synthesis kernel to set the pace; four, three pre-passes in
+ * flight on three streams, where the carrier is chained on the device (two walks and the fix-up per run). */
+constexpr int NSETS = 4;
 
 struct gpsbb_batch {
     gpsbb *h = nullptr;
@@ -365,8 +367,8 @@ struct gpsbb_batch {
     DevBuf<SynRow> d_prefix[NSETS];
     std::vector<ChainAux> h_aux;
     int carr_lanes = 0; /* lanes of the seed plan that walk carrier chains (they come first) */
-    hipEvent_t synth_done[NSETS] = {nullptr, nullptr, nullptr};
-    bool synth_pending[NSETS] = {false, false, false};
+    hipEvent_t synth_done[NSETS] = {nullptr, nullptr, nullptr, nullptr};
+    bool synth_pending[NSETS] = {false, false, false, false};
     hipEvent_t upload_done = nullptr; /* descriptors and plans of the last set-up are on the device */
     int nsets = 2;                    /* table sets in use: run k works on set k % nsets */
     unsigned run_count = 0;
@@ -492,6 +494,8 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
         (void)hipStreamSynchronize(h->s_seed);
     if (h->s_seed2)
         (void)hipStreamSynchronize(h->s_seed2);
+    if (h->s_seed3)
+        (void)hipStreamSynchronize(h->s_seed3);
     if (h->s_compute)
         (void)hipStreamSynchronize(h->s_compute);
     if (h->s_copy)
@@ -510,6 +514,8 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
         (void)hipStreamDestroy(h->s_seed);
     if (h->s_seed2)
         (void)hipStreamDestroy(h->s_seed2);
+    if (h->s_seed3)
+        (void)hipStreamDestroy(h->s_seed3);
     if (h->s_compute)
         (void)hipStreamDestroy(h->s_compute);
     if (h->s_copy)
@@ -634,7 +640,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     HIPCHK(h, (hipError_t)b->d_ch.reserve(nbc));
     HIPCHK(h, (hipError_t)b->d_row_off.reserve(2 * nbc + 1));
     HIPCHK(h, (hipError_t)b->d_tile_ctr.reserve((size_t)nblocks));
-    b->nsets = b->ev ? NSETS : 2;
+    b->nsets = b->ev ? ((flags & GPSBB_CHAIN_CARRIER) && nblocks > 1 && h->opt_chain_where == 0 ? 4 : 3) : 2;
     for (int set = 0; set < b->nsets; set++) {
         HIPCHK(h, (hipError_t)b->d_end[set].reserve(nbc));
         if (b->ev) {
@@ -813,6 +819,8 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
     (void)hipStreamSynchronize(b->h->s_seed);
     if (b->h->s_seed2)
         (void)hipStreamSynchronize(b->h->s_seed2);
+    if (b->h->s_seed3)
+        (void)hipStreamSynchronize(b->h->s_seed3);
     (void)hipStreamSynchronize(b->h->s_compute);
     b->d_ch.release();
     b->d_row_off.release();
@@ -1181,10 +1189,14 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
      * read this table set has finished, i.e. it overlaps the synthesis of the runs before it.  With three sets
      * consecutive runs take the handle's two seeding streams in turn, so that two pre-passes are in flight. */
     hipStream_t ss = b->seed_stream;
-    if (b->nsets > 2 && (b->run_count & 1u)) {
+    if (b->nsets > 2) {
         if (!h->s_seed2)
             HIPCHK(h, hipStreamCreateWithFlags(&h->s_seed2, hipStreamNonBlocking));
-        ss = b->seed_stream == h->s_seed ? h->s_seed2 : h->s_seed;
+        if (b->nsets > 3 && !h->s_seed3)
+            HIPCHK(h, hipStreamCreateWithFlags(&h->s_seed3, hipStreamNonBlocking));
+        hipStream_t pool[3] = {h->s_seed, h->s_seed2, h->s_seed3};
+        const unsigned base = b->seed_stream == h->s_seed ? 0u : 1u;
+        ss = pool[(base + b->run_count) % (unsigned)(b->nsets - 1)];
     }
     if (b->upload_done)
         HIPCHK(h, hipStreamWaitEvent(ss, b->upload_done, 0));
@@ -1212,7 +1224,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
                 BatchDev pa = p; /* pass A: the carrier chains only (they come first in the plan) */
                 pa.seed_lanes = b->carr_lanes;
                 hipLaunchKernelGGL(k_walk<1>, dim3((b->carr_lanes + GPSBB_WALK_WG - 1) / GPSBB_WALK_WG), dim3(GPSBB_WALK_WG), 0, ss, pa);
-                hipLaunchKernelGGL(k_chain_prefix, dim3(1), dim3(64), 0, ss, p);
+                hipLaunchKernelGGL(k_chain_prefix, dim3(b->nch), dim3(64), 0, ss, p);
                 hipLaunchKernelGGL(k_walk<2>, wg_all, dim3(GPSBB_WALK_WG), 0, ss, p);
                 hipLaunchKernelGGL(k_chain_fix, dim3(1), dim3(64), 0, ss, p);
             } else {
@@ -1296,6 +1308,8 @@ extern "C" int gpsbb_sync(gpsbb_t *h)
     HIPCHK(h, hipStreamSynchronize(h->s_seed));
     if (h->s_seed2)
         HIPCHK(h, hipStreamSynchronize(h->s_seed2));
+    if (h->s_seed3)
+        HIPCHK(h, hipStreamSynchronize(h->s_seed3));
     HIPCHK(h, hipStreamSynchronize(h->s_compute));
     HIPCHK(h, hipStreamSynchronize(h->s_copy));
     uint32_t st = 0;
@@ -1526,6 +1540,8 @@ extern "C" void gpsbb_stream_destroy(gpsbb_stream_t *s)
     (void)hipStreamSynchronize(s->h->s_seed);
     if (s->h->s_seed2)
         (void)hipStreamSynchronize(s->h->s_seed2);
+    if (s->h->s_seed3)
+        (void)hipStreamSynchronize(s->h->s_seed3);
     (void)hipStreamSynchronize(s->h->s_compute);
     (void)hipStreamSynchronize(s->h->s_copy);
     delete s->carry;

@@ -118,6 +118,9 @@ struct ChainAux {
      * pass B's rows before wrap_row are void */
     int32_t prefix_cnt, prefix_end;
     int32_t _pad;
+    /* pass B, for crossing j: its state at the last sample of row cross[j]-1 and at the first of row cross[j] */
+    double pre[CHAIN_MAX_CROSS], post[CHAIN_MAX_CROSS];
+    double endB;   /* pass B's end state */
     /* k_chain_fix: true state minus pass B's state, for rows cross[j-1] <= r < cross[j] (seg[0]: from row 0,
      * seg[ncross]: to the end of the block) */
     double seg[CHAIN_MAX_CROSS + 1];

@@ -57,17 +57,19 @@ __device__ __forceinline__ uint32_t walk_dbits(const uint32_t *dwrd, uint32_t na
     return (cur ? 1u : 0u) | nxt;
 }
 
-/* bit d (2 <= d <= 50) set: rounding s to a multiple of 2^d units of its own last place is a tie — the low d
- * bits of its mantissa are exactly 1 followed by zeros.  A state d binades above s then only takes a regular
- * run from an even mantissa (gpsbb_nco.h: "half-way case on an odd mantissa"). */
-__device__ __forceinline__ uint64_t walk_tiemask(uint64_t sb)
+/* The one d for which rounding s to a multiple of 2^d units of its own last place is a tie — the low d bits of
+ * its mantissa are exactly 1 followed by zeros: d = (trailing zeros) + 1.  A state d binades above s only takes
+ * a regular run from an even mantissa (gpsbb_nco.h: "half-way case on an odd mantissa"). */
+__device__ __forceinline__ int walk_tie_d(uint64_t sb)
 {
     const uint64_t Ms = (sb & F64_MANT) | F64_HID;
-    uint64_t m = 0;
-    for (int d = 2; d <= 50; d++)
-        if ((Ms & ((1ull << d) - 1)) == (1ull << (d - 1)))
-            m |= 1ull << d;
-    return m;
+    return __builtin_ctzll(Ms) + 1;
+}
+/* as a mask over d = 2..50 (bit d) */
+__device__ __forceinline__ uint64_t walk_tiemask(uint64_t sb)
+{
+    const int d = walk_tie_d(sb);
+    return d >= 2 && d <= 50 ? 1ull << d : 0ull;
 }
 
 /*
@@ -217,8 +219,21 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
             w.stuck = (rare || weird) && step && !wrapped && f64_bits(x2) == f64_bits(x1);
         w.x = step ? x2 : (w.active ? x1 : w.x);
         w.n = step ? n1 + 1 : (w.active ? n1 : w.n); /* lanes waiting for the other direction's loop keep theirs */
-        if (KIND == NCO_CARR && TRACK)
+        if (KIND == NCO_CARR && TRACK) {
             w.prev_wrapped = w.active ? (step && wrapped) : w.prev_wrapped;
+            /* the block's last step has no row after it: if it crossed upwards or wrapped, the crossing is
+             * recorded here, its "row" being the end state */
+            const bool last_cross = step && !(w.n < nsamp) && !w.wrap_seen &&
+                                    (wrapped || (int)((uint32_t)__double2hiint(x2) >> 20) > ex);
+            if (__builtin_expect(__ballot(last_cross) != 0ull, 0)) {
+                if (last_cross) {
+                    if (w.ncross >= 0 && w.ncross < CHAIN_MAX_CROSS)
+                        w.aux->cross[w.ncross++] = (int32_t)w.cnt;
+                    else
+                        w.ncross = -1;
+                }
+            }
+        }
         w.active = step && w.n < nsamp;
     }
 }
@@ -331,11 +346,22 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
                 p.end[k].carr_phase = on ? w.x : 0.0;
                 if (PASS == 2) {
                     /* the trajectory walked here is not final: k_chain_fix decides what counts */
-                    p.aux[k].margin = w.margin;
-                    p.aux[k].ncross = on ? w.ncross : 0;
+                    ChainAux &a = p.aux[k];
+                    a.margin = w.margin;
+                    a.ncross = on ? w.ncross : 0;
                     if (!w.wrap_seen)
-                        p.aux[k].wrap_row = -1;
-                    p.aux[k].prefix_cnt = 0;
+                        a.wrap_row = -1;
+                    a.prefix_cnt = 0;
+                    a.endB = on ? w.x : 0.0;
+                    /* what k_chain_fix needs of the rows around the crossings, so that it does not have to
+                     * fetch them one dependent load after the other */
+                    for (int j = 0; on && j < w.ncross; j++) {
+                        const int r = a.cross[j];
+                        const SynRow pre = w.rows[r - 1];
+                        const int n_post = r < (int)w.cnt ? w.rows[r].n0 : p.nsamp;
+                        a.pre[j] = __fma_rn((double)(n_post - 1 - pre.n0), pre.S, pre.x);
+                        a.post[j] = r < (int)w.cnt ? w.rows[r].x : w.x;
+                    }
                     p.aux[k].hz512 = on ? w.hz512 : 0u;
                 } else if (on && w.hz512) {
                     atomicAdd(p.hazards, (unsigned long long)w.hz512);
@@ -356,27 +382,50 @@ __device__ __forceinline__ bool chain_continues(const BatchDev &p, int b, int i)
 
 /*
  * Device-side carrier chain, step 2 of 4: start phases good to a few units in the last place from pass A.
- * One lane per channel walks the blocks in order: the walk of block b from the rough start0 ended at endA;
- * from a start that is d = start1 - start0 away it ends, up to a handful of roundings, d away from there
- * (a trajectory is translated by a small change of its start phase: see k_chain_fix), and there the next
- * block begins.
+ * The walk of block b from the rough start0 ended at endA; from a start that is e = start1 - start0 away it
+ * ends, up to a handful of roundings, e away from there (a trajectory is translated by a small change of its
+ * start phase: see k_chain_fix), and there the next block begins: e[b+1] = e[b] + (endA[b] - start0[b+1]),
+ * restarting from 0 where a block does not continue the one before.  One wavefront per channel: a segmented
+ * inclusive scan over the blocks, 64 at a time.
  */
 __global__ void k_chain_prefix(BatchDev p)
 {
-    const int i = threadIdx.x;
+    const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= p.nch)
         return;
-    double prev = 0.0;
-    for (int b = 0; b < p.nblocks; b++) {
-        const size_t k = (size_t)b * p.nch + i;
-        ChainAux &a = p.aux[k];
-        double st = p.ch[k].carr_phase;
-        if (chain_continues(p, b, i)) {
-            st = prev;
-            st = st >= 1.0 ? st - 1.0 : (st < 0.0 ? st + 1.0 : st);
+    double carry = 0.0; /* e of the block before the chunk's first */
+    for (int b0 = 0; b0 < p.nblocks; b0 += 64) {
+        const int b = b0 + lane;
+        const bool in = b < p.nblocks;
+        const size_t k = (size_t)(in ? b : 0) * p.nch + i;
+        const bool cont = in && chain_continues(p, b, i);
+        /* the increment this block adds to the correction of the block before it: the phase lost between the end
+         * of pass A's walk of block b-1 and the rough start of block b (a wrap of the unit interval apart at most) */
+        double c = 0.0;
+        if (cont) {
+            c = p.aux[k - p.nch].endA - p.aux[k].start0;
+            c = c > 0.5 ? c - 1.0 : (c < -0.5 ? c + 1.0 : c);
         }
-        a.start1 = st;
-        prev = a.endA + (st - a.start0);
+        /* segmented inclusive scan: (flag, value) pairs, flag = the sum restarts here */
+        double v = c;
+        bool f = !cont;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double vu = __shfl_up(v, o);
+            const int fu = __shfl_up((int)f, o);
+            if (lane >= o) {
+                v = f ? v : v + vu;
+                f = f || fu;
+            }
+        }
+        const double e = f ? v : v + carry;
+        if (in) {
+            ChainAux &a = p.aux[k];
+            double st = cont ? a.start0 + e : p.ch[k].carr_phase;
+            st = st >= 1.0 ? st - 1.0 : (st < 0.0 ? st + 1.0 : st);
+            a.start1 = st;
+        }
+        carry = __shfl(e, 63);
     }
 }
 
@@ -422,28 +471,61 @@ struct FixRowSink {
  * has more crossings than the record holds, or whose margin is not larger than its offsets is walked exactly
  * by the lane on its own (rare, slow).
  */
+/* what one turn of k_chain_fix's loop reads: fetched a block ahead, because the loop itself is one long chain of
+ * dependent arithmetic (each block starts where the one before ended) and must not wait for memory as well */
+struct FixIn {
+    int prn, prn_prev, ncross, wrap_row;
+    uint32_t hz512;
+    double carr_phase, f_carr, start1, margin, endB, pre0, post0, pre1, post1;
+};
+__device__ __forceinline__ FixIn fix_load(const BatchDev &p, int b, int i)
+{
+    const size_t k = (size_t)b * p.nch + i;
+    const gpsbb_chan_t &ch = p.ch[k];
+    const ChainAux &a = p.aux[k];
+    FixIn f;
+    f.prn = ch.prn;
+    f.prn_prev = b > 0 ? p.ch[k - p.nch].prn : 0;
+    f.carr_phase = ch.carr_phase;
+    f.f_carr = ch.f_carr;
+    f.start1 = a.start1;
+    f.margin = a.margin;
+    f.endB = a.endB;
+    f.ncross = a.ncross;
+    f.wrap_row = a.wrap_row;
+    f.hz512 = a.hz512;
+    f.pre0 = a.pre[0];
+    f.post0 = a.post[0];
+    f.pre1 = a.pre[1];
+    f.post1 = a.post[1];
+    return f;
+}
+
 __global__ void k_chain_fix(BatchDev p)
 {
     const int i = threadIdx.x;
     const bool lane_on = i < p.nch;
+    const int il = lane_on ? i : 0;
     const int nbc = p.nblocks * p.nch;
     double prev_end = 0.0;
     unsigned long long n_fallback = 0, n_hz = 0;
+    FixIn nxt = fix_load(p, 0, il);
     for (int b = 0; b < p.nblocks; b++) {
-        const size_t k = (size_t)b * p.nch + (lane_on ? i : 0);
-        const gpsbb_chan_t &ch = p.ch[k];
-        const bool on = lane_on && ch.prn > 0;
+        const FixIn in = nxt;
+        nxt = fix_load(p, b + 1 < p.nblocks ? b + 1 : b, il);
+        const size_t k = (size_t)b * p.nch + il;
+        const bool on = lane_on && in.prn > 0;
         ChainAux &a = p.aux[k];
-        const double x = lane_on && chain_continues(p, b, i) ? prev_end : ch.carr_phase;
-        const double s = mul_rn(ch.f_carr, p.delt);
+        const double x = lane_on && b > 0 && in.prn > 0 && in.prn == in.prn_prev ? prev_end : in.carr_phase;
+        const double s = mul_rn(in.f_carr, p.delt);
         const uint64_t sb = f64_bits(s);
         const int es = (int)((sb >> 52) & 0x7ff);
-        const double margin = a.margin;
-        const int ncross = a.ncross;
+        const double margin = in.margin;
+        const int ncross = in.ncross;
         const SynRow *rows = p.rows + p.row_off[nbc + k];
-        double end = p.end[k].carr_phase;
-        uint32_t hz512 = a.hz512; /* pass B's trajectory is the true one, or a translate that met no edge */
-        const double d0 = x - a.start1; /* exact: both in the same binade, or the margin test below fails */
+        double end = in.endB;
+        uint32_t hz512 = in.hz512; /* pass B's trajectory is the true one, or a translate that met no edge */
+        const double d0 = x - in.start1; /* exact: both in the same binade, or the margin test below fails */
         /* Ties.  A sum exactly half-way between two grid points goes to the even one, so a tie commutes with the
          * shift only if the shift is an even number of steps of that grid.  It always is on grids finer than the
          * one the offset was last rounded on.  That leaves (1) the binades the phase visits before its offset has
@@ -465,9 +547,8 @@ __global__ void k_chain_fix(BatchDev p)
         bool tie_asc = false;
         if (on && d0 != 0.0 && es >= 123) {
             const int dstart = (int)((f64_bits(x) >> 52) & 0x7ff) - es;
-            const uint64_t tm = walk_tiemask(sb);
-            const uint64_t from = dstart <= 0 ? ~0ull : (dstart > 50 ? 0ull : ~((1ull << dstart) - 1));
-            tie_asc = (tm & (fall ? (dstart >= 2 && dstart <= 50 ? 1ull << dstart : 0ull) : from)) != 0ull;
+            const int dtie = walk_tie_d(sb); /* the one binade (above the step's) in which the step ties */
+            tie_asc = dtie >= 2 && dtie <= 50 && (fall ? dtie == dstart : dtie >= dstart);
         }
         const double gtop = fall ? 0x1p-53 : 0x1p-52;
         const bool base = on && es >= 123 && ncross >= 0 && fabs(d0) < margin - 0x1p-51;
@@ -479,22 +560,20 @@ __global__ void k_chain_fix(BatchDev p)
             /* the usual way: one genuine step per recorded crossing */
             ok = true;
             for (int j = 0; ok && j < ncross; j++) {
-                const int r = a.cross[j];
-                const SynRow pre = rows[r - 1], post = rows[r];
-                /* pass B's state at the last sample of row r-1, the true one, one genuine step */
-                double xt = __fma_rn((double)(post.n0 - 1 - pre.n0), pre.S, pre.x) + d;
+                /* pass B's state at the last sample before the crossing, the true one, one genuine step */
+                double xt = (j == 0 ? in.pre0 : (j == 1 ? in.pre1 : a.pre[j])) + d;
                 carr_step(xt, s);
-                d = xt - post.x;
+                d = xt - (j == 0 ? in.post0 : (j == 1 ? in.post1 : a.post[j]));
                 ok = fabs(d) < margin - 0x1p-51;
                 a.seg[j + 1] = d;
             }
             /* an odd number of steps of the coarsest grid and a step that can tie there: not a translate */
-            if (ok && tie_top && a.wrap_row >= 0 && fmod(fabs(d) * (fall ? 0x1p+53 : 0x1p+52), 2.0) != 0.0)
+            if (ok && tie_top && in.wrap_row >= 0 && fmod(fabs(d) * (fall ? 0x1p+53 : 0x1p+52), 2.0) != 0.0)
                 ok = false;
-        } else if (base && !ok && a.wrap_row >= 0) {
+        } else if (base && !ok && in.wrap_row >= 0) {
             /* a tie-prone binade on the way up: the first lap exactly, on its own rows; after the wrap that ends it
              * the offset is a multiple of every grid and the rest of the block is pass B's plus it */
-            const int wr = a.wrap_row;
+            const int wr = in.wrap_row;
             const int nstar = rows[wr].n0; /* a wrap always starts a row */
             FixRowSink sink;
             sink.rows = p.prefix_rows + k * CHAIN_PREFIX_CAP;
@@ -523,7 +602,7 @@ __global__ void k_chain_fix(BatchDev p)
 #ifdef GPSBB_CHAIN_DEBUG
         if (on && !ok)
             printf("chain fallback: block %d ch %d d0 %.3e d %.3e margin %.3e ncross %d es %d tie_top %d tie_asc %d wrap_row %d\n", b,
-                   i, d0, d, margin, ncross, es, (int)tie_top, (int)tie_asc, a.wrap_row);
+                   i, d0, d, margin, ncross, es, (int)tie_top, (int)tie_asc, in.wrap_row);
 #endif
         if (on && !ok) {
             /* on its own: the whole block exactly, rows in place of pass B's, no offsets */

@@ -35,6 +35,7 @@ assert CHAN_DTYPE.itemsize == 296 and STATE_DTYPE.itemsize == 40 and ROW_DTYPE.i
 
 CHAIN_CARRIER = 1
 FIXED_CARRIER = 2
+STREAM_DEVICE_ONLY = 4
 OPT_SEED_WHERE, OPT_SYNTH_KERNEL, OPT_SKIP_SEED, OPT_CHAIN_WHERE = 1, 2, 3, 4
 INFO_LAST_KERNEL, INFO_EXACT_RUNS, INFO_CHAIN_ON_DEVICE, INFO_CHAIN_FALLBACKS = 1, 2, 3, 4
 
@@ -287,6 +288,7 @@ class Stream:
     def __init__(self, synth, nch, delt, nsamp, blocks_per_slot, depth=3, flags=0):
         self.synth = synth
         self.nch, self.nsamp, self.bps = nch, nsamp, blocks_per_slot
+        self.device_only = bool(flags & STREAM_DEVICE_ONLY)
         self._s = C.c_void_p()
         _chk(lib().gpsbb_stream_create(synth._h, nch, delt, nsamp, blocks_per_slot, depth, flags,
                                        C.byref(self._s)), "gpsbb_stream_create")
@@ -309,9 +311,13 @@ class Stream:
         _chk(lib().gpsbb_stream_push(self._s, ch.ctypes.data), "gpsbb_stream_push")
 
     def pop(self, copy=True):
+        """(IQ [blocks_per_slot, nsamp, 2] int16 in the slot's pinned host buffer, end states); a stream created with
+        STREAM_DEVICE_ONLY returns the slot's device pointer (an int) instead of the array."""
         p = C.c_void_p()
         st = np.zeros((self.bps, self.nch), STATE_DTYPE)
         _chk(lib().gpsbb_stream_pop(self._s, C.byref(p), st.ctypes.data), "gpsbb_stream_pop")
+        if self.device_only:
+            return p.value, st
         n = self.bps * self.nsamp * 2
         view = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int16)), (n,)).reshape(self.bps, self.nsamp, 2)
         return (view.copy() if copy else view), st

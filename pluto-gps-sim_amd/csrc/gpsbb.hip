@@ -367,6 +367,14 @@ struct gpsbb_batch {
     DevBuf<SynRow> d_prefix[NSETS];
     std::vector<ChainAux> h_aux;
     int carr_lanes = 0; /* lanes of the seed plan that walk carrier chains (they come first) */
+    /* a stream's slot: the carrier continues from the push before (set by gpsbb_stream_push around set-up / launch) */
+    ChainCarryDev *d_carry = nullptr;
+    const int *carry_prn = nullptr;        /* in: prn per channel in the last block pushed before */
+    double *carry_phase = nullptr;         /* in/out: the host's rough idea of the phase there / after this push */
+    uint32_t cont0_mask = 0;
+    hipEvent_t ev_prefix = nullptr, ev_fix = nullptr; /* the stream's: order k_chain_prefix / k_chain_fix across pushes */
+    int max_sets = NSETS;
+    unsigned stream_turn = 0; /* the stream's push count */
     hipEvent_t synth_done[NSETS] = {nullptr, nullptr, nullptr, nullptr};
     bool synth_pending[NSETS] = {false, false, false, false};
     hipEvent_t upload_done = nullptr; /* descriptors and plans of the last set-up are on the device */
@@ -641,6 +649,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     HIPCHK(h, (hipError_t)b->d_row_off.reserve(2 * nbc + 1));
     HIPCHK(h, (hipError_t)b->d_tile_ctr.reserve((size_t)nblocks));
     b->nsets = b->ev ? ((flags & GPSBB_CHAIN_CARRIER) && nblocks > 1 && h->opt_chain_where == 0 ? 4 : 3) : 2;
+    b->nsets = b->nsets > b->max_sets ? b->max_sets : b->nsets;
     for (int set = 0; set < b->nsets; set++) {
         HIPCHK(h, (hipError_t)b->d_end[set].reserve(nbc));
         if (b->ev) {
@@ -689,7 +698,9 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         HIPCHK(h, hipMemcpyAsync(b->d_kstep.p, b->h_kstep.data(), nbc * 4, hipMemcpyHostToDevice, upload_stream));
     }
     b->h_ch.assign(ch, ch + nbc);
-    b->chain_dev = b->ev && (flags & GPSBB_CHAIN_CARRIER) && nblocks > 1 && h->opt_chain_where == 0 && !host_seeding_wanted(b);
+    b->chain_dev = b->ev && (flags & GPSBB_CHAIN_CARRIER) && (nblocks > 1 || b->d_carry) && h->opt_chain_where == 0 &&
+                   !host_seeding_wanted(b);
+    b->cont0_mask = 0;
     if (b->chain_dev) {
         /* The carrier chain is resolved exactly on the device, in parallel over the blocks (k_walk pass A,
          * k_chain_prefix, k_walk pass B, k_chain_fix).  All the host contributes is a rough start phase per block:
@@ -697,8 +708,8 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
          * after a few hundred blocks; pass A takes it from there). */
         b->h_aux.assign(nbc, ChainAux());
         for (int i = 0; i < nch; i++) {
-            double x = 0.0;
-            int prev_prn = 0;
+            double x = b->d_carry && b->carry_phase ? b->carry_phase[i] : 0.0;
+            int prev_prn = b->d_carry && b->carry_prn ? b->carry_prn[i] : 0;
             for (int blk = 0; blk < nblocks; blk++) {
                 const gpsbb_chan_t &c = ch[(size_t)blk * nch + i];
                 ChainAux &a = b->h_aux[(size_t)blk * nch + i];
@@ -706,6 +717,8 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
                 if (c.prn > 0) {
                     if (c.prn != prev_prn)
                         x = c.carr_phase;
+                    else if (blk == 0)
+                        b->cont0_mask |= 1u << i;
                     a.start0 = x;
                     const volatile double sk = c.f_carr * delt;
                     x = x + (double)nsamp * sk;
@@ -713,6 +726,8 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
                 }
                 prev_prn = c.prn > 0 ? c.prn : 0;
             }
+            if (b->d_carry && b->carry_phase)
+                b->carry_phase[i] = x;
         }
         for (int set = 0; set < b->nsets; set++) {
             HIPCHK(h, (hipError_t)b->d_aux[set].reserve(nbc));
@@ -1164,6 +1179,8 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.chain_dev = b->chain_dev ? 1 : 0;
     p.aux = b->chain_dev ? b->d_aux[set].p : nullptr;
     p.prefix_rows = b->chain_dev ? b->d_prefix[set].p : nullptr;
+    p.carry = b->chain_dev ? b->d_carry : nullptr;
+    p.cont0_mask = b->cont0_mask;
     return p;
 }
 
@@ -1197,6 +1214,14 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         hipStream_t pool[3] = {h->s_seed, h->s_seed2, h->s_seed3};
         const unsigned base = b->seed_stream == h->s_seed ? 0u : 1u;
         ss = pool[(base + b->run_count) % (unsigned)(b->nsets - 1)];
+    } else if (b->d_carry && b->chain_dev) {
+        /* a stream's slot (one table set): consecutive pushes take the three seeding streams in turn */
+        if (!h->s_seed2)
+            HIPCHK(h, hipStreamCreateWithFlags(&h->s_seed2, hipStreamNonBlocking));
+        if (!h->s_seed3)
+            HIPCHK(h, hipStreamCreateWithFlags(&h->s_seed3, hipStreamNonBlocking));
+        hipStream_t pool[3] = {h->s_seed, h->s_seed2, h->s_seed3};
+        ss = pool[b->stream_turn % 3u];
     }
     if (b->upload_done)
         HIPCHK(h, hipStreamWaitEvent(ss, b->upload_done, 0));
@@ -1224,9 +1249,18 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
                 BatchDev pa = p; /* pass A: the carrier chains only (they come first in the plan) */
                 pa.seed_lanes = b->carr_lanes;
                 hipLaunchKernelGGL(k_walk<1>, dim3((b->carr_lanes + GPSBB_WALK_WG - 1) / GPSBB_WALK_WG), dim3(GPSBB_WALK_WG), 0, ss, pa);
+                /* a stream: this push's prefix / fix-up follow the ones of the push before (other seeding stream) */
+                if (b->d_carry && b->ev_prefix)
+                    HIPCHK(h, hipStreamWaitEvent(ss, b->ev_prefix, 0));
                 hipLaunchKernelGGL(k_chain_prefix, dim3(b->nch), dim3(64), 0, ss, p);
+                if (b->d_carry && b->ev_prefix)
+                    HIPCHK(h, hipEventRecord(b->ev_prefix, ss));
                 hipLaunchKernelGGL(k_walk<2>, wg_all, dim3(GPSBB_WALK_WG), 0, ss, p);
+                if (b->d_carry && b->ev_fix)
+                    HIPCHK(h, hipStreamWaitEvent(ss, b->ev_fix, 0));
                 hipLaunchKernelGGL(k_chain_fix, dim3(1), dim3(64), 0, ss, p);
+                if (b->d_carry && b->ev_fix)
+                    HIPCHK(h, hipEventRecord(b->ev_fix, ss));
             } else {
                 hipLaunchKernelGGL(k_walk<0>, wg_all, dim3(GPSBB_WALK_WG), 0, ss, p);
             }
@@ -1526,6 +1560,12 @@ struct gpsbb_stream {
     std::vector<Slot> slots;
     uint64_t head = 0, tail = 0; /* pushes / pops so far */
     ChainCarry *carry = nullptr;               /* IEEE carrier chained on the host across pushes */
+    /* ... or on the device (gpsbb_walk.hip.h): the exact phase never leaves it */
+    ChainCarryDev *d_carry = nullptr;
+    hipEvent_t ev_prefix = nullptr, ev_fix = nullptr;
+    int last_prn[GPSBB_MAX_CHAN] = {0};        /* prn per channel in the last block pushed */
+    double rough_phase[GPSBB_MAX_CHAN] = {0};  /* the host's rough idea of the carrier phase after it */
+    bool carry_on_device = false;              /* where the authoritative carry is right now */
     std::vector<gpsbb_chan_t> seeded;
     std::vector<double> seeds;
     int fx_prn[GPSBB_MAX_CHAN] = {0};          /* fixed-point carrier: channel state after the last push */
@@ -1545,6 +1585,12 @@ extern "C" void gpsbb_stream_destroy(gpsbb_stream_t *s)
     (void)hipStreamSynchronize(s->h->s_compute);
     (void)hipStreamSynchronize(s->h->s_copy);
     delete s->carry;
+    if (s->d_carry)
+        (void)hipFree(s->d_carry);
+    if (s->ev_prefix)
+        (void)hipEventDestroy(s->ev_prefix);
+    if (s->ev_fix)
+        (void)hipEventDestroy(s->ev_fix);
     for (auto &sl : s->slots) {
         if (sl.batch) gpsbb_batch_destroy(sl.batch);
         if (sl.h_iq) (void)hipHostFree(sl.h_iq);
@@ -1559,7 +1605,7 @@ extern "C" int gpsbb_stream_create(gpsbb_t *h, int nch, double delt, int nsamp, 
                                    int depth, unsigned flags, gpsbb_stream_t **out)
 {
     if (!h || !out || nch < 1 || nch > GPSBB_MAX_CHAN || nsamp < 1 || blocks_per_slot < 1 || depth < 2 ||
-        depth > 64 || !(delt > 0.0) || (flags & ~(GPSBB_CHAIN_CARRIER | GPSBB_FIXED_CARRIER)))
+        depth > 64 || !(delt > 0.0) || (flags & ~(GPSBB_CHAIN_CARRIER | GPSBB_FIXED_CARRIER | GPSBB_STREAM_DEVICE_ONLY)))
         return GPSBB_E_BADARG;
     *out = nullptr;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1581,8 +1627,10 @@ extern "C" int gpsbb_stream_create(gpsbb_t *h, int nch, double delt, int nsamp, 
         hipError_t e = sl.batch ? hipSuccess : hipErrorOutOfMemory;
         if (e == hipSuccess && ((&sl - &s->slots[0]) & 1))
             e = use_second_seed_stream(sl.batch);
+        if (e == hipSuccess) sl.batch->max_sets = 1; /* consecutive pushes use different slots: one table set each */
         if (e == hipSuccess) e = (hipError_t)sl.batch->d_iq.reserve(iq_bytes / 2);
-        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_iq, iq_bytes, hipHostMallocDefault);
+        if (e == hipSuccess && !(flags & GPSBB_STREAM_DEVICE_ONLY))
+            e = hipHostMalloc((void **)&sl.h_iq, iq_bytes, hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_end, end_bytes, hipHostMallocDefault);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.computed, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming);
@@ -1612,25 +1660,79 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
      * computed here on host threads with the same jump-ahead the device uses (it depends on descriptors
      * only), so the device sees independent blocks and the pre-pass stays fully parallel.  Chaining on the
      * device (one lane per channel walking the slot's blocks in order) is ~12x slower for a 16-block slot. */
-    unsigned run_flags = s->flags;
+    unsigned run_flags = s->flags & (GPSBB_CHAIN_CARRIER | GPSBB_FIXED_CARRIER);
+    const size_t nbc = (size_t)s->bps * s->nch;
+    b->d_carry = nullptr;
     if ((s->flags & GPSBB_CHAIN_CARRIER) && !(s->flags & GPSBB_FIXED_CARRIER)) {
-        const size_t nbc = (size_t)s->bps * s->nch;
         for (size_t k = 0; k < nbc; k++)
             if (!chan_ok(ch[k], s->delt))
                 return GPSBB_E_BADCHAN;
+        /* Where the carrier is chained: on the device wherever the breakpoint kernel and the device pre-pass take
+         * the push (exactly, in parallel over the blocks, the phase carried from push to push in device memory),
+         * else on host threads (sequential per channel).  A stream may change sides between pushes: the carry
+         * then moves across, which costs a synchronisation. */
+        std::vector<EvConst> tmp;
+        static const size_t host_lim = getenv("GPSBB_HOST_SEED_MAX") ? (size_t)atol(getenv("GPSBB_HOST_SEED_MAX")) : HOST_SEED_MAX_CHANNELS;
+        static const bool dev_only = getenv("GPSBB_DEVICE_SEED_ONLY") != nullptr;
+        const bool dev = h->opt_chain_where == 0 && h->opt_synth_kernel != 1 &&
+                         (h->opt_seed_where == 1 || (h->opt_seed_where == 0 && (dev_only || nbc > host_lim))) &&
+                         ev_plan(ch, s->bps, s->nch, s->delt, tmp);
         if (!s->carry) {
             s->carry = new (std::nothrow) ChainCarry();
             if (!s->carry)
                 return GPSBB_E_NOMEM;
             memset(s->carry, 0, sizeof *s->carry);
         }
-        s->seeded.assign(ch, ch + nbc);
-        s->seeds.resize(nbc);
-        chain_carrier_host(ch, s->bps, s->nch, s->delt, s->nsamp, s->seeds.data(), 0, s->carry);
-        for (size_t k = 0; k < nbc; k++)
-            s->seeded[k].carr_phase = s->seeds[k];
-        ch = s->seeded.data();
-        run_flags &= ~GPSBB_CHAIN_CARRIER;
+        if (dev) {
+            if (!s->d_carry) {
+                HIPCHK(h, hipMalloc((void **)&s->d_carry, sizeof(ChainCarryDev)));
+                HIPCHK(h, hipMemset(s->d_carry, 0, sizeof(ChainCarryDev)));
+                HIPCHK(h, hipEventCreateWithFlags(&s->ev_prefix, hipEventDisableTiming));
+                HIPCHK(h, hipEventCreateWithFlags(&s->ev_fix, hipEventDisableTiming));
+            }
+            if (!s->carry_on_device && s->head > 0) {
+                /* host -> device: the exact phases as both the prediction and the truth */
+                ChainCarryDev c;
+                for (int i = 0; i < GPSBB_MAX_CHAN; i++)
+                    c.approx_end[i] = c.exact_end[i] = s->carry->phase[i];
+                const int rc_ = gpsbb_sync(h);
+                if (rc_ != GPSBB_OK)
+                    return rc_;
+                HIPCHK(h, hipMemcpy(s->d_carry, &c, sizeof c, hipMemcpyHostToDevice));
+                for (int i = 0; i < s->nch; i++) {
+                    s->last_prn[i] = s->carry->prn[i];
+                    s->rough_phase[i] = s->carry->phase[i];
+                }
+            }
+            s->carry_on_device = true;
+            b->d_carry = s->d_carry;
+            b->carry_prn = s->last_prn;
+            b->carry_phase = s->rough_phase;
+            b->ev_prefix = s->ev_prefix;
+            b->ev_fix = s->ev_fix;
+            b->stream_turn = (unsigned)s->head;
+        } else {
+            if (s->carry_on_device) {
+                /* device -> host */
+                ChainCarryDev c;
+                const int rc_ = gpsbb_sync(h);
+                if (rc_ != GPSBB_OK)
+                    return rc_;
+                HIPCHK(h, hipMemcpy(&c, s->d_carry, sizeof c, hipMemcpyDeviceToHost));
+                for (int i = 0; i < s->nch; i++) {
+                    s->carry->prn[i] = s->last_prn[i];
+                    s->carry->phase[i] = c.exact_end[i];
+                }
+                s->carry_on_device = false;
+            }
+            s->seeded.assign(ch, ch + nbc);
+            s->seeds.resize(nbc);
+            chain_carrier_host(ch, s->bps, s->nch, s->delt, s->nsamp, s->seeds.data(), 0, s->carry);
+            for (size_t k = 0; k < nbc; k++)
+                s->seeded[k].carr_phase = s->seeds[k];
+            ch = s->seeded.data();
+            run_flags &= ~GPSBB_CHAIN_CARRIER;
+        }
     }
     /* the slot's previous D2H copy was waited for by the pop that freed it */
     const bool fx_chain = (s->flags & GPSBB_FIXED_CARRIER) && (s->flags & GPSBB_CHAIN_CARRIER) && s->head > 0;
@@ -1639,8 +1741,14 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     int rc = batch_setup(b, ch, s->bps, s->nch, s->delt, s->nsamp, run_flags, b->seed_stream);
     b->fixed_prev_prn = nullptr;
     b->fixed_prev_phase = nullptr;
-    if (rc != GPSBB_OK)
+    if (rc != GPSBB_OK) {
+        b->d_carry = nullptr;
         return rc;
+    }
+    if (b->d_carry && !b->chain_dev) { /* the push was promised a device-side chain */
+        b->d_carry = nullptr;
+        return GPSBB_E_INTERNAL;
+    }
     if (s->flags & GPSBB_FIXED_CARRIER)
         for (int i = 0; i < s->nch; i++) {
             const size_t k = (size_t)(s->bps - 1) * s->nch + i;
@@ -1649,13 +1757,20 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
         }
     b->last_iq = b->d_iq.p;
     rc = batch_launch(b, b->d_iq.p);
+    b->d_carry = nullptr;
     if (rc != GPSBB_OK)
         return rc;
+    if (s->carry_on_device && (s->flags & GPSBB_CHAIN_CARRIER) && !(s->flags & GPSBB_FIXED_CARRIER))
+        for (int i = 0; i < s->nch; i++) {
+            const int prn = ch[(size_t)(s->bps - 1) * s->nch + i].prn;
+            s->last_prn[i] = prn > 0 ? prn : 0;
+        }
     HIPCHK(h, hipEventRecord(sl.computed, h->s_compute));
     /* gather on the side stream: pinned, asynchronous, overlaps the next push's kernels */
     hipStream_t cs = h->s_copy;
     HIPCHK(h, hipStreamWaitEvent(cs, sl.computed, 0));
-    HIPCHK(h, hipMemcpyAsync(sl.h_iq, b->d_iq.p, (size_t)s->bps * s->nsamp * 4, hipMemcpyDeviceToHost, cs));
+    if (sl.h_iq)
+        HIPCHK(h, hipMemcpyAsync(sl.h_iq, b->d_iq.p, (size_t)s->bps * s->nsamp * 4, hipMemcpyDeviceToHost, cs));
     HIPCHK(h, hipMemcpyAsync(sl.h_end, b->d_end[b->last_set].p, (size_t)s->bps * s->nch * sizeof(gpsbb_chan_state_t),
                              hipMemcpyDeviceToHost, cs));
     HIPCHK(h, hipEventRecord(sl.copied, cs));
@@ -1673,7 +1788,7 @@ extern "C" int gpsbb_stream_pop(gpsbb_stream_t *s, const int16_t **iq, gpsbb_cha
     HIPCHK(h, hipSetDevice(h->device));
     auto &sl = s->slots[s->tail % s->depth];
     HIPCHK(h, hipEventSynchronize(sl.copied));
-    *iq = sl.h_iq;
+    *iq = sl.h_iq ? sl.h_iq : sl.batch->d_iq.p; /* GPSBB_STREAM_DEVICE_ONLY: the slot's buffer in HBM */
     if (end_state)
         memcpy(end_state, sl.h_end, (size_t)s->bps * s->nch * sizeof(gpsbb_chan_state_t));
     s->tail++;

@@ -126,6 +126,13 @@ struct ChainAux {
     double seg[CHAIN_MAX_CROSS + 1];
 };
 
+/* The carrier of a stream (gpsbb_stream_*) from one push to the next, on the device. */
+struct ChainCarryDev {
+    double approx_end[GPSBB_MAX_CHAN];    /* channel i's carrier phase after the last block pushed so far: as
+                                             k_chain_prefix of that push predicts it ...                          */
+    double exact_end[GPSBB_MAX_CHAN];     /* ... and exactly, once its k_chain_fix has run                         */
+};
+
 /* Everything the kernels need about one batch; passed by value as the kernel argument. */
 struct BatchDev {
     const gpsbb_chan_t *ch;         /* [nblocks*nch] descriptors, block-major                        */
@@ -168,6 +175,8 @@ struct BatchDev {
     int chain_dev;                  /* 1: GPSBB_CHAIN_CARRIER is resolved on the device (k_chain_prefix / k_chain_fix) */
     ChainAux *aux;                  /* [nblocks*nch]                                                  */
     SynRow *prefix_rows;            /* [nblocks*nch][CHAIN_PREFIX_CAP]: see ChainAux::prefix_cnt       */
+    ChainCarryDev *carry;           /* stream: block 0 continues the previous push's last block; else NULL */
+    uint32_t cont0_mask;            /* ... for the channels of this mask (same prn as in that block: the host knows) */
 };
 
 __device__ __forceinline__ size_t tile_row_at(const BatchDev &p, int b, int t, int i, int kind)

@@ -374,9 +374,9 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
 /* does block b of channel i continue block b-1's carrier (GPSBB_CHAIN_CARRIER: same channel index, same prn)? */
 __device__ __forceinline__ bool chain_continues(const BatchDev &p, int b, int i)
 {
-    if (b == 0)
-        return false;
     const int prn = p.ch[(size_t)b * p.nch + i].prn;
+    if (b == 0) /* a stream's push continues the push before it */
+        return p.carry && prn > 0 && ((p.cont0_mask >> i) & 1u);
     return prn > 0 && prn == p.ch[(size_t)(b - 1) * p.nch + i].prn;
 }
 
@@ -403,7 +403,7 @@ __global__ void k_chain_prefix(BatchDev p)
          * of pass A's walk of block b-1 and the rough start of block b (a wrap of the unit interval apart at most) */
         double c = 0.0;
         if (cont) {
-            c = p.aux[k - p.nch].endA - p.aux[k].start0;
+            c = (b == 0 ? p.carry->approx_end[i] : p.aux[k - p.nch].endA) - p.aux[k].start0;
             c = c > 0.5 ? c - 1.0 : (c < -0.5 ? c + 1.0 : c);
         }
         /* segmented inclusive scan: (flag, value) pairs, flag = the sum restarts here */
@@ -424,6 +424,12 @@ __global__ void k_chain_prefix(BatchDev p)
             double st = cont ? a.start0 + e : p.ch[k].carr_phase;
             st = st >= 1.0 ? st - 1.0 : (st < 0.0 ? st + 1.0 : st);
             a.start1 = st;
+            if (p.carry && b == p.nblocks - 1) {
+                /* where the stream's next push will start, as far as pass A can tell */
+                double en = a.endA + (st - a.start0);
+                en = en >= 1.0 ? en - 1.0 : (en < 0.0 ? en + 1.0 : en);
+                p.carry->approx_end[i] = en;
+            }
         }
         carry = __shfl(e, 63);
     }
@@ -507,7 +513,7 @@ __global__ void k_chain_fix(BatchDev p)
     const bool lane_on = i < p.nch;
     const int il = lane_on ? i : 0;
     const int nbc = p.nblocks * p.nch;
-    double prev_end = 0.0;
+    double prev_end = p.carry ? p.carry->exact_end[il] : 0.0; /* a stream: where the push before this one ended */
     unsigned long long n_fallback = 0, n_hz = 0;
     FixIn nxt = fix_load(p, 0, il);
     for (int b = 0; b < p.nblocks; b++) {
@@ -516,7 +522,8 @@ __global__ void k_chain_fix(BatchDev p)
         const size_t k = (size_t)b * p.nch + il;
         const bool on = lane_on && in.prn > 0;
         ChainAux &a = p.aux[k];
-        const double x = lane_on && b > 0 && in.prn > 0 && in.prn == in.prn_prev ? prev_end : in.carr_phase;
+        const bool cont = lane_on && in.prn > 0 && (b > 0 ? in.prn == in.prn_prev : (p.carry && ((p.cont0_mask >> il) & 1u)));
+        const double x = cont ? prev_end : in.carr_phase;
         const double s = mul_rn(in.f_carr, p.delt);
         const uint64_t sb = f64_bits(s);
         const int es = (int)((sb >> 52) & 0x7ff);
@@ -630,6 +637,8 @@ __global__ void k_chain_fix(BatchDev p)
                 n_hz += hz512;
         }
     }
+    if (p.carry && lane_on)
+        p.carry->exact_end[i] = prev_end;
     if (n_hz)
         atomicAdd(p.hazards, n_hz);
     if (n_fallback)

@@ -277,6 +277,43 @@ def test_stream_ring_with_pinned_gather(pkg, synth, oracle):
     s.close()
 
 
+
+def test_stream_carrier_carried_on_the_device(pkg, synth, oracle, request):
+    """A chained stream at 25 MS/s: the exact carrier phase is carried from push to push in device memory (no host
+    chain), channels come and go between pushes, and the bytes are those of the oracle walking all blocks in
+    order.  Also with the ring rendering into HBM only (STREAM_DEVICE_ONLY)."""
+    nch, fs, nsamp, bps, npush = 16, 25e6, 60000, 5, 6
+    ch = pkg.synth_descriptors(bps * npush, nch=nch, seed=777)
+    ch["prn"] = np.arange(1, nch + 1)[None, :]
+    f0 = np.linspace(-4800, 4800, nch)
+    f0[3], f0[8] = 2.0, 0.0
+    ch["f_carr"] = f0[None, :]
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    ch["prn"][bps * 2:, 6] = 29            # re-allocated exactly at a push boundary
+    ch["prn"][bps * 3 + 2:bps * 4 + 1, 11] = 0
+    want_iq, want_st, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
+    where, kernel = request.node.callspec.params["seed_mode"].split("+")
+    for flags in (pkg.CHAIN_CARRIER, pkg.CHAIN_CARRIER | pkg.STREAM_DEVICE_ONLY):
+        st_ = synth.stream(nch, 1 / fs, nsamp, bps, depth=3, flags=flags)
+        got, gst = [], []
+        for k in range(npush):
+            if st_.pending == 3:
+                a, b = st_.pop()
+                got.append(a), gst.append(b)
+            st_.push(ch[k * bps:(k + 1) * bps])
+        while st_.pending:
+            a, b = st_.pop()
+            got.append(a), gst.append(b)
+        if where == "k_seed" and kernel == "auto":
+            assert synth.info(pkg.INFO_CHAIN_ON_DEVICE) == 1
+        gst = np.concatenate(gst)
+        for k in range(bps * npush):
+            assert_state_equal(gst[k], want_st[k], ch["prn"][k] > 0)
+        if not (flags & pkg.STREAM_DEVICE_ONLY):
+            assert (np.concatenate(got) == want_iq).all()
+        st_.close()
+
+
 def test_external_device_buffer(pkg, synth, oracle):
     import torch
     ch = pkg.synth_descriptors(2, nch=16, seed=111)

@@ -2,25 +2,38 @@
 """bench.py — the GPS L1 C/A IQ buffer-fill path on MI355X, BASELINE.json's metric.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...
 
-Workload (config.workload = "synth16-S", BASELINE configs[2]): a seeded
-descriptor-level constellation of 16 channels at fs = 25 MS/s in 0.1 s blocks of 2.5 M samples.  One
-"step" is one pass of the hot path (NCO seeding pre-pass + synthesis kernel) over one batch of
---blocks such blocks whose descriptors are already resident in HBM; the int16 IQ lands in HBM.  With
-N > 1 each rank owns one GPU and a contiguous time shard of the stream (blocks [r*B, (r+1)*B) of the same
-seeded descriptor sequence): no data-path collective, weak scaling; torch.distributed (RCCL) is used for
-the barrier and the max-over-ranks time only.
+Workload (config.workload = "synth16-S as one stream", BASELINE configs[2] in the shape of configs[4]): ONE
+time-continuous 16-channel stream at fs = 25 MS/s in 0.1 s blocks of 2.5 M samples — seeded descriptors
+ with a slowly varying Doppler per channel, |f_carr| <= 5 kHz — whose carrier is chained
+exactly from block to block (GPSBB_CHAIN_CARRIER, c:2741-2746 never re-seeds carr_phase).  One "step" is one
+pass of the hot path over the next 3200 blocks of that stream (8e9 IQ samples, 32 GB of int16 IQ), every block
+rendered once, from descriptors the library has not seen before: per 400-block push the host validates and plans
+the descriptors and uploads them, the device chains the carrier exactly in parallel over the blocks (k_walk pass A,
+k_chain_prefix, k_walk pass B, k_chain_fix), expands the tile states (k_tiles) and synthesises (k_synth_ev); the
+IQ lands in the ring's HBM slots (GPSBB_STREAM_DEVICE_ONLY).  With N ranks the stream is cut into N contiguous
+time shards (rank r renders blocks [r*T/N, (r+1)*T/N) of the same T = K*3200 blocks: strong scaling, no data-path
+collective); a shard starts from the stream's exact carrier phase there (host chain, timed, reported as
+shard_seed_s); torch.distributed (RCCL) carries the barrier, the max-over-ranks time and the digests only.
 
-Prints ONE JSON line on rank 0 (see the keys below): value = IQ samples/s over all GPUs,
-roofline = algorithmic HBM bytes (4 B per IQ sample) of the synthesis kernel / its HIP-event duration
-against the 8 TB/s HBM peak, cpu_baseline = the CPU restatement (oracle, 1 core) timed on a bounded
-sample of the same workload in the same run.
+Prints ONE JSON line on rank 0.  `value` = IQ samples/s over all GPUs, from the MEDIAN of --repeats timed regions
+of K steps each, every region bracketed by barrier + synchronize on both sides with the ring drained (min / max
+beside it).  `roofline` = algorithmic HBM bytes (4 B per IQ sample) of the synthesis kernel / its HIP-event
+duration against the 8 TB/s HBM peak.  Beside it, measured in the same invocation:
+  resident      re-runs of one 400-block batch whose descriptors and plans stay in HBM (independent blocks and
+                chained): what round 1 reported as its value
+  gather        the same shard through a ring with the pinned D2H gather (PCIe-inclusive; never `value`)
+  m1            BASELINE.md section 3's other leg: 12 ch, 2.6 MS/s, 300 000-sample blocks (GPU, and the CPU port)
+  cpu_baseline  the CPU restatement (oracle, 1 core) on a bounded sample of the same blocks
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -28,13 +41,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PUSH_BLOCKS = 400      # blocks per push (1e9 samples, 4 GB of IQ)
+STEP_PUSHES = 8        # pushes per step over all ranks: a step is 3200 blocks
 
 
-def cpu_baseline(pkg, ch, delt, nsamp, budget_s=12.0):
+def stream_descriptors(pkg, nblocks, nch, seed=0x5EED, max_doppler=5000.0):
+    """A stream continuous in time: everything from the seeded generator (M2) except the Doppler, which moves
+    slowly and smoothly per channel like a satellite pass (period 1-2 h, both signs, through zero)."""
+    ch = pkg.synth_descriptors(nblocks, nch=nch, seed=seed, max_doppler=max_doppler)
+    g = pkg.SplitMix64(seed ^ 0xD0BB1E5)
+    ph = g.u01((nch,)) * 2.0 * np.pi
+    per = 36000.0 * (1.0 + g.u01((nch,)))
+    amp = max_doppler * (0.35 + 0.65 * g.u01((nch,)))
+    b = np.arange(nblocks, dtype=np.float64)[:, None]
+    ch["f_carr"] = amp[None, :] * np.sin(ph[None, :] + 2.0 * np.pi * b / per[None, :])
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    return ch
+
+
+def cpu_baseline(ob, ch, delt, nsamp, budget_s=10.0):
     """The oracle (kind "port": bit-identical CPU restatement of plutogpssim.c:2690-2756, gcc -O2
-    -ffp-contract=off, 1 thread) on as many leading blocks of the same batch as fit the time budget."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle_binding as ob
+    -ffp-contract=off, 1 thread) on as many leading blocks of the stream as fit the time budget."""
     orc = ob.Oracle()
     orc.fill_blocks(ch[:1], delt, min(nsamp, 1000))  # one-time table/code generation out of the timing
     t0 = time.perf_counter()
@@ -48,7 +75,7 @@ def cpu_baseline(pkg, ch, delt, nsamp, budget_s=12.0):
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     out = {"value": nb * nsamp / best, "unit": "IQ samples/s", "cores": 1, "kind": "port",
-           "sample": "%d of the step's blocks (%d ch x %d samples each), best of 2, gcc -O2 -ffp-contract=off" %
+           "sample": "%d of the stream's blocks (%d ch x %d samples each), best of 2, gcc -O2 -ffp-contract=off" %
                      (nb, ch.shape[1], nsamp)}
     if ob.have_ref():
         # the reference's own loop statements, built with its Makefile's flags (-O0), on a smaller sample
@@ -60,22 +87,75 @@ def cpu_baseline(pkg, ch, delt, nsamp, budget_s=12.0):
     return out
 
 
+def block_digest(a):
+    """32-bit digest of (a 1 MiB prefix of) one block as it sits in host memory: proof of arrival, cheap enough not to
+    bound the gather (full-length digests are the tests' business)."""
+    return zlib.crc32(memoryview(a).cast("B")[:1 << 20])
+
+
+def resident_leg(pkg, synth, torch, ch, delt, nsamp, flags, steps, warmup, dev):
+    """round 1's measurement: one batch resident in HBM, run again and again"""
+    out = torch.empty(ch.shape[0] * nsamp * 2, dtype=torch.int16, device=dev)
+    batch = synth.batch(ch, delt, nsamp, flags=flags)
+    for _ in range(warmup):
+        batch.run(out.data_ptr())
+    synth.sync()
+    torch.cuda.synchronize()
+    batch.timing_stats(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.run(out.data_ptr())
+    synth.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = batch.timing_stats(reset=True)
+    ceil_ms = synth.fill_ceiling(out.data_ptr(), out.numel() * 2, iters=10)
+    batch.close()
+    del out
+    n = ch.shape[0] * nsamp
+    return {"value": n * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "synth_kernel_ms": st["ms_synth_sum"] / max(st["runs"], 1), "prepass_ms": st["ms_seed_sum"] / max(st["runs"], 1),
+            "chained": bool(flags & pkg.CHAIN_CARRIER)}, n * 4 / (ceil_ms * 1e-3) / 1e9
+
+
+def dry_run(args, pkg, dist, world, rank):
+    """No GPU: the sharding, the shard seeds and the digest exchange of the N > 1 path with the CPU oracle rendering
+    (tiny blocks).  What tests/test_shard_gloo.py runs under gloo with world_size 2."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import hashlib
+    import oracle_binding as ob
+    delt, nsamp, nch = 1.0 / args.fs, args.nsamp, args.nch
+    total = args.steps * STEP_PUSHES * args.push_blocks
+    ch = stream_descriptors(pkg, total, nch)
+    b0, b1 = pkg.shard_blocks(total, rank, world)
+    seeds = pkg.chain_carrier_host(ch[:b0 + 1], delt, nsamp)
+    mine = ch[b0:b1].copy()
+    mine["carr_phase"][0] = seeds[b0]
+    iq, _, _ = ob.Oracle().fill_blocks(mine, delt, nsamp, chain=True)
+    dig = [hashlib.sha256(iq[k].tobytes()).digest() for k in range(b1 - b0)]
+    if world > 1:
+        allg = [None] * world
+        dist.all_gather_object(allg, dig)
+        dig = [d for part in allg for d in part]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_ranks": world, "blocks": total,
+                          "stream_digest": hashlib.sha256(b"".join(dig)).hexdigest()}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps per region; a step is 3200 blocks of the stream")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--blocks", type=int, default=400, help="0.1 s blocks per step and GPU")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median is reported")
+    ap.add_argument("--push-blocks", type=int, default=PUSH_BLOCKS, help="0.1 s blocks per push")
+    ap.add_argument("--depth", type=int, default=4, help="ring slots")
     ap.add_argument("--nch", type=int, default=16)
     ap.add_argument("--fs", type=float, default=25e6)
     ap.add_argument("--nsamp", type=int, default=2500000)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--fixed-carrier", action="store_true",
-                    help="the reference's fixed-point carrier variant (GPSBB_FIXED_CARRIER); not the headline config")
-    ap.add_argument("--chain", action="store_true",
-                    help="the blocks of a step are consecutive in time (GPSBB_CHAIN_CARRIER): carrier chained exactly")
-    ap.add_argument("--synth-only", action="store_true",
-                    help="measurement aid: after warm-up re-run only k_synth on the tables already built")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling runs)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: sharding / seeds / digest exchange with the CPU oracle")
     args = ap.parse_args()
 
     import torch  # first: it brings the HIP runtime the library then shares
@@ -86,110 +166,194 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    # one rank per GPU; GPSBB_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a box with fewer GPUs
-    # than ranks (functional check only: ranks then share devices)
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if STEP_PUSHES % world:
+        raise SystemExit("the number of ranks must divide %d" % STEP_PUSHES)
+    # one rank per GPU; GPSBB_BENCH_BACKEND=gloo lets the N>1 code path be exercised where ranks share a device
     backend = os.environ.get("GPSBB_BENCH_BACKEND", "nccl")
+    if args.dry_run:
+        backend = "gloo"
     ndev = torch.cuda.device_count()
     if backend == "nccl" and world > ndev:
         raise SystemExit("%d ranks but %d GPUs" % (world, ndev))
     local = local % max(ndev, 1)
-    torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
+            torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+    if args.dry_run:
+        dry_run(args, pkg, dist, world, rank)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    torch.cuda.set_device(local)
+    dev = "cuda:%d" % local
 
-    delt = 1.0 / args.fs
-    B = args.blocks
-    # time shards: rank r gets blocks [r*B, (r+1)*B) of one seeded descriptor sequence
-    ch_all = pkg.synth_descriptors(B * world, nch=args.nch, seed=0x5EED)
-    ch = ch_all[rank * B:(rank + 1) * B]
+    delt, nsamp, nch, PB = 1.0 / args.fs, args.nsamp, args.nch, args.push_blocks
+    K, W, R = args.steps, args.warmup, args.repeats
+    ppr = STEP_PUSHES // world                 # pushes per rank and step
+    total = K * STEP_PUSHES * PB               # blocks of the stream
+    # ---- the stream and this rank's shard of it (set-up, not timed as throughput; the seed is timed on its own) ----
+    t_gen = time.perf_counter()
+    ch_all = stream_descriptors(pkg, total, nch)
+    t_gen = time.perf_counter() - t_gen
+    b0, b1 = pkg.shard_blocks(total, rank, world)
+    t_seed = time.perf_counter()
+    seed0 = pkg.chain_carrier_host(ch_all[:b0 + 1], delt, nsamp)[b0] if b0 > 0 else ch_all["carr_phase"][0]
+    t_seed = time.perf_counter() - t_seed
+    mine = ch_all[b0:b1].copy()
+    mine["carr_phase"][0] = seed0              # the shard starts from the stream's exact phase
+    npush = mine.shape[0] // PB                # = K * ppr
+    del ch_all
 
-    flags = 0
-    if args.fixed_carrier:
-        ch = ch.copy()
-        ch["carr_phase"] = np.floor(ch["carr_phase"] * 2.0 ** 32)
-        flags = pkg.FIXED_CARRIER
-    if args.chain:
-        flags |= pkg.CHAIN_CARRIER
     synth = pkg.Synth(local)
-    batch = synth.batch(ch, delt, args.nsamp, flags=flags)
-    out = torch.empty(B * args.nsamp * 2, dtype=torch.int16, device="cuda:%d" % local)
 
     def barrier():
-        torch.cuda.synchronize()
         synth.sync()
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
-    if args.synth_only:
-        synth.set_option(pkg.OPT_SKIP_SEED, 1)
-        args.warmup = max(args.warmup, 2)
-    for _ in range(args.warmup):
-        batch.run(out.data_ptr())
+    def run_ring(st, first, count, depth):
+        """`count` pushes starting at push number `first` of the shard (cyclically), every slot popped; the ring ends drained"""
+        for j in range(count):
+            if st.pending >= depth:
+                st.pop(copy=False)
+            k = (first + j) % npush
+            st.push(mine[k * PB:(k + 1) * PB])
+        while st.pending:
+            st.pop(copy=False)
+
+    # ---- headline: K steps of fresh pushes, chained on the device, IQ into HBM ----
+    st = synth.stream(nch, delt, nsamp, PB, depth=args.depth, flags=pkg.CHAIN_CARRIER | pkg.STREAM_DEVICE_ONLY)
+    run_ring(st, 0, W * ppr, args.depth)
+    pos = W * ppr
     barrier()
-    batch.timing_stats(reset=True)
-
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.run(out.data_ptr())
-    synth.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=("cuda:%d" % local) if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
-
-    stats = batch.timing_stats(reset=True)
-    samples_per_step = B * args.nsamp
+    st.timing_stats(reset=True)
+    times = []
+    for _ in range(R):
+        barrier()
+        t0 = time.perf_counter()
+        run_ring(st, pos, K * ppr, args.depth)
+        synth.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        times.append(dt)
+        pos += K * ppr
+    barrier()
+    stats = st.timing_stats(reset=True)
+    chain_dev = synth.info(pkg.INFO_CHAIN_ON_DEVICE)
+    last_kernel = synth.info(pkg.INFO_LAST_KERNEL)
+    st.close()
+    elapsed = statistics.median(times)
+    samples_per_step = STEP_PUSHES * PB * nsamp
+    samples_per_launch = PB * nsamp
     ms_synth = stats["ms_synth_sum"] / max(stats["runs"], 1)
     ms_seed = stats["ms_seed_sum"] / max(stats["runs"], 1)
-    achieved = 4.0 * samples_per_step / (ms_synth * 1e-3) / 1e9  # GB/s, algorithmic bytes / kernel time
+    achieved = 4.0 * samples_per_launch / (ms_synth * 1e-3) / 1e9  # GB/s, algorithmic bytes / kernel time
 
-    # empirical write ceiling: a pure int16x2 fill of the same buffer
-    ceil_ms = synth.fill_ceiling(out.data_ptr(), out.numel() * 2, iters=10)
-    ceil_gbs = out.numel() * 2 / (ceil_ms * 1e-3) / 1e9
+    # ---- PCIe-inclusive: the same shard through a ring with the pinned gather (never `value`) ----
+    gather = None
+    if not args.no_extras:
+        gb, gdepth, gslots = 32, 5, 16
+        gst = synth.stream(nch, delt, nsamp, gb, depth=gdepth, flags=pkg.CHAIN_CARRIER)
+        dig = []
 
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("k_synth_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+        def gather_run(nslots, keep):
+            pushed = popped = 0
+            while popped < nslots:
+                while pushed < nslots and gst.pending < gdepth:
+                    k = pushed % (mine.shape[0] // gb)
+                    gst.push(mine[k * gb:(k + 1) * gb])
+                    pushed += 1
+                iq, _ = gst.pop(copy=False)
+                if keep:
+                    dig.extend(block_digest(iq[j]) for j in range(gb))
+                popped += 1
+        gather_run(gdepth, False)
+        barrier()
+        t0 = time.perf_counter()
+        gather_run(gslots, True)
+        gdt = time.perf_counter() - t0
+        gst.close()
+        per_rank = gslots * gb * nsamp * 4 / gdt / 1e9
+        mydig = zlib.crc32(np.asarray(dig, np.uint32).tobytes())
+        if world > 1:
+            allg = [None] * world
+            dist.all_gather_object(allg, (per_rank, mydig))
+            rates, digs = [a[0] for a in allg], [a[1] for a in allg]
+        else:
+            rates, digs = [per_rank], [mydig]
+        gather = {"value": sum(rates) / 4.0 * 1e9, "unit": "IQ samples/s", "per_rank_GBps_to_host": rates,
+                  "slot_blocks": gb, "depth": gdepth, "slots": gslots, "chained": True,
+                  "digest_of_block_digests": zlib.crc32(np.asarray(digs, np.uint32).tobytes()),
+                  "note": "pinned hipMemcpyAsync on the side stream, 1 MiB of every block digested on arrival; PCIe Gen5 x16 = 63 GB/s"}
 
+    res = None
     if rank == 0:
         res = {
             "metric": "IQ samples/sec (whole node) at 16 channels; bit-exact int16 IQ vs CPU ref",
-            "value": world * samples_per_step * args.steps / elapsed,
+            "value": samples_per_step * K / elapsed,
             "unit": "IQ samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64 NCO + int16x2 accumulate", "data": "synthetic",
-            "config": {"carrier_nco": "fixed-point 32-bit (variant)" if args.fixed_carrier else "IEEE double (reference default)",
-                       "workload": "synth16-S: %d ch, fs %.3g S/s, %d-sample blocks, %d blocks per step per GPU, "
-                                   "seeded descriptors (splitmix64 0x5EED), time-sharded by rank" %
-                                   (args.nch, args.fs, args.nsamp, B),
-                       "global_samples_per_step": world * samples_per_step, "parallelism": "time-shard x%d" % world},
+            "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64 NCOs (exact), i32 accumulate of packed int16 I/Q", "data": "synthetic",
+            "config": {"carrier_nco": "IEEE double (reference default), chained across all blocks of the stream",
+                       "workload": "synth16-S as one stream: %d ch, fs %.3g S/s, %d-sample blocks, seeded descriptors "
+                                   "(splitmix64 0x5EED) with a slowly varying Doppler, %d blocks per step (%d pushes of %d "
+                                   "fresh blocks), %d blocks in all, cut into %d contiguous time shards" %
+                                   (nch, args.fs, nsamp, STEP_PUSHES * PB, STEP_PUSHES, PB, total, world),
+                       "global_samples_per_step": samples_per_step, "parallelism": "time-shard x%d" % world,
+                       "ring_depth": args.depth, "carrier_chain": "device" if chain_dev else "host threads",
+                       "synthesis_kernel": "k_synth_ev" if last_kernel == 2 else "k_synth"},
+            "repeats": {"n": R, "seconds": times, "ms_per_step_min": min(times) / K * 1e3,
+                        "ms_per_step_max": max(times) / K * 1e3, "value_min": samples_per_step * K / max(times),
+                        "value_max": samples_per_step * K / min(times)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_synth", "ms_per_launch": ms_synth, "algorithmic_bytes_per_launch": 4 * samples_per_step,
-                         "write_ceiling_measured_GBs": ceil_gbs, "frac_of_measured_ceiling": achieved / ceil_gbs,
-                         "note": "VALU-bound (FP64 NCO adds + LUT/sign integer ops), not HBM-bound; see DESIGN.md"},
-            "seed_kernel_ms_per_launch": ms_seed,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_synth_ev" if last_kernel == 2 else "k_synth", "ms_per_launch": ms_synth,
+                         "launches_timed": stats["runs"], "algorithmic_bytes_per_launch": 4 * samples_per_launch,
+                         "note": "VALU-issue-bound, not HBM-bound: see DESIGN.md"},
+            "prepass_ms_per_launch": ms_seed,
+            "shard_seed_s": t_seed, "descriptor_generation_s": t_gen,
         }
-        if not args.no_cpu and world == 1:
-            res["cpu_baseline"] = cpu_baseline(pkg, ch, delt, args.nsamp)
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                res["roofline"]["traffic"] = json.load(open(pmc)).get("k_synth_hbm_bytes_per_launch")
+            except Exception:
+                pass
+        if gather:
+            res["gather"] = gather
+    if world == 1 and not args.no_extras:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        rch = pkg.synth_descriptors(PB, nch=nch, seed=0x5EED)
+        r0, ceil_gbs = resident_leg(pkg, synth, torch, rch, delt, nsamp, 0, 20, 4, dev)
+        r1, _ = resident_leg(pkg, synth, torch, rch, delt, nsamp, pkg.CHAIN_CARRIER, 20, 5, dev)
+        res["resident"] = {"independent_blocks": r0, "chained": r1, "unit": "IQ samples/s",
+                           "note": "one 400-block batch re-run 20 times, descriptors and plans resident in HBM (round 1's value)"}
+        res["roofline"]["write_ceiling_measured_GBs"] = ceil_gbs
+        res["roofline"]["frac_of_measured_ceiling"] = achieved / ceil_gbs
+        # BASELINE.md section 3: the reference-faithful geometry (12 ch, 2.6 MS/s, 300 000-sample blocks)
+        mch = pkg.synth_descriptors(1000, nch=12, seed=0xF00D)
+        m1, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, 0, 10, 3, dev)
+        res["m1"] = {"gpu": m1, "unit": "IQ samples/s",
+                     "workload": "12 ch, fs 2.6e6 S/s, 300000-sample blocks, 1000 independent blocks per step (per-sample kernel k_synth)"}
+        if not args.no_cpu:
+            import oracle_binding as ob
+            res["cpu_baseline"] = cpu_baseline(ob, mine, delt, nsamp)
+            res["m1"]["cpu"] = cpu_baseline(ob, mch, 1.0 / 2.6e6, 300000, budget_s=5.0)
+    if rank == 0:
         print(json.dumps(res))
-    batch.close()
     synth.close()
     if world > 1:
         dist.destroy_process_group()

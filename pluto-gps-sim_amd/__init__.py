@@ -37,7 +37,7 @@ CHAIN_CARRIER = 1
 FIXED_CARRIER = 2
 STREAM_DEVICE_ONLY = 4
 OPT_SEED_WHERE, OPT_SYNTH_KERNEL, OPT_SKIP_SEED, OPT_CHAIN_WHERE = 1, 2, 3, 4
-INFO_LAST_KERNEL, INFO_EXACT_RUNS, INFO_CHAIN_ON_DEVICE, INFO_CHAIN_FALLBACKS = 1, 2, 3, 4
+INFO_LAST_KERNEL, INFO_EXACT_RUNS, INFO_CHAIN_ON_DEVICE, INFO_CHAIN_FALLBACKS, INFO_CHAIN_TIES = 1, 2, 3, 4, 5
 
 ERRORS = {0: "GPSBB_OK", -1: "GPSBB_E_BADARG", -2: "GPSBB_E_BADCHAN", -3: "GPSBB_E_HIP", -4: "GPSBB_E_NOMEM",
           -5: "GPSBB_E_INTERNAL", -6: "GPSBB_E_NODEVICE", -7: "GPSBB_E_STATE"}
@@ -48,7 +48,7 @@ API_SYMBOLS = [
     "gpsbb_fill_block", "gpsbb_fill_block_ex", "gpsbb_fill_block_ref", "gpsbb_batch_create", "gpsbb_batch_destroy",
     "gpsbb_batch_iq_bytes", "gpsbb_batch_run", "gpsbb_sync", "gpsbb_batch_read", "gpsbb_batch_device_iq",
     "gpsbb_get_hazards", "gpsbb_batch_last_timing", "gpsbb_batch_timing_stats", "gpsbb_fill_ceiling", "gpsbb_stream_create",
-    "gpsbb_stream_destroy", "gpsbb_stream_push", "gpsbb_stream_pop", "gpsbb_stream_pending",
+    "gpsbb_stream_destroy", "gpsbb_stream_push", "gpsbb_stream_pop", "gpsbb_stream_pending", "gpsbb_stream_timing_stats",
     "gpsbb_codegen", "gpsbb_sincos_tables", "gpsbb_chain_carrier_host", "gpsbb_set_option", "gpsbb_get_info",
 ]
 
@@ -111,6 +111,7 @@ def lib():
         L.gpsbb_stream_push.argtypes = [vp, vp]
         L.gpsbb_stream_pop.argtypes = [vp, C.POINTER(vp), vp]
         L.gpsbb_stream_pending.argtypes = [vp]
+        L.gpsbb_stream_timing_stats.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_float), C.POINTER(C.c_float), i]
         L.gpsbb_codegen.argtypes = [i, vp]
         L.gpsbb_sincos_tables.argtypes = [vp, vp]
         L.gpsbb_chain_carrier_host.argtypes = [vp, i, i, d, i, vp, i]
@@ -325,6 +326,12 @@ class Stream:
     @property
     def pending(self):
         return lib().gpsbb_stream_pending(self._s)
+
+    def timing_stats(self, reset=True):
+        n, a, b = C.c_int(), C.c_float(), C.c_float()
+        _chk(lib().gpsbb_stream_timing_stats(self._s, C.byref(n), C.byref(a), C.byref(b), int(reset)),
+             "gpsbb_stream_timing_stats")
+        return {"runs": n.value, "ms_seed_sum": a.value, "ms_synth_sum": b.value}
 
 
 # ---- synthetic descriptors (BASELINE / SURVEY section 8d, workload M2) -------------------------------

@@ -374,6 +374,10 @@ struct gpsbb_batch {
     uint32_t cont0_mask = 0;
     hipEvent_t ev_prefix = nullptr, ev_fix = nullptr; /* the stream's: order k_chain_prefix / k_chain_fix across pushes */
     int max_sets = NSETS;
+    /* pinned staging arena of the uploads of one set-up: hipMemcpyAsync from pageable memory is not asynchronous
+     * (it waits for the stream's earlier work — the previous push's pre-pass — before it returns) */
+    char *stage = nullptr;
+    size_t stage_cap = 0, stage_used = 0;
     unsigned stream_turn = 0; /* the stream's push count */
     hipEvent_t synth_done[NSETS] = {nullptr, nullptr, nullptr, nullptr};
     bool synth_pending[NSETS] = {false, false, false, false};
@@ -461,10 +465,12 @@ extern "C" int gpsbb_get_info(gpsbb_t *h, int what, uint64_t *out)
         *out = (uint64_t)h->last_kernel;
         return GPSBB_OK;
     case GPSBB_INFO_EXACT_RUNS:
-    case GPSBB_INFO_CHAIN_FALLBACKS: {
+    case GPSBB_INFO_CHAIN_FALLBACKS:
+    case GPSBB_INFO_CHAIN_TIES: {
         HIPCHK(h, hipSetDevice(h->device));
         unsigned long long v = 0;
-        HIPCHK(h, hipMemcpy(&v, h->d_hz + (what == GPSBB_INFO_EXACT_RUNS ? 2 : 4), 8, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(&v, h->d_hz + (what == GPSBB_INFO_EXACT_RUNS ? 2 : (what == GPSBB_INFO_CHAIN_FALLBACKS ? 4 : 5)), 8,
+                            hipMemcpyDeviceToHost));
         *out = v;
         return GPSBB_OK;
     }
@@ -597,6 +603,17 @@ static void chain_carrier_host(const gpsbb_chan_t *ch, int nblocks, int nch, dou
 
 static bool host_seeding_wanted(const gpsbb_batch *b);
 
+/* upload `bytes` from pageable `src` through the batch's pinned arena (grown at the start of a set-up) */
+static hipError_t stage_upload(gpsbb_batch *b, void *dst, const void *src, size_t bytes, hipStream_t stream)
+{
+    const size_t at = (b->stage_used + 63) & ~(size_t)63;
+    if (at + bytes > b->stage_cap) /* cannot happen: the arena was sized for this set-up */
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+    memcpy(b->stage + at, src, bytes);
+    b->stage_used = at + bytes;
+    return hipMemcpyAsync(dst, b->stage + at, bytes, hipMemcpyHostToDevice, stream);
+}
+
 /* ---- batch planning -------------------------------------------------------------------------------- */
 
 static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int nch, double delt,
@@ -612,6 +629,22 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         if (!chan_ok(ch[k], delt, fixed))
             return GPSBB_E_BADCHAN;
 
+    {
+        /* everything a set-up uploads, with room to spare: descriptors, plans, per-channel constants, chain scratch */
+        const size_t need = nbc * (sizeof(gpsbb_chan_t) + sizeof(EvConst) + (size_t)NSETS * sizeof(ChainAux) + 2 * 8 + 2 * 4 + 4 * 4) +
+                            64 * 1024;
+        if (b->upload_done) /* the previous set-up's copies out of the arena are long done; make sure */
+            HIPCHK(h, hipEventSynchronize(b->upload_done));
+        if (need > b->stage_cap) {
+            if (b->stage)
+                (void)hipHostFree(b->stage);
+            b->stage = nullptr;
+            b->stage_cap = 0;
+            HIPCHK(h, hipHostMalloc((void **)&b->stage, need + need / 4, hipHostMallocDefault));
+            b->stage_cap = need + need / 4;
+        }
+        b->stage_used = 0;
+    }
     b->nblocks = nblocks;
     b->nch = nch;
     b->nsamp = nsamp;
@@ -667,7 +700,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     }
     if (b->ev) {
         HIPCHK(h, (hipError_t)b->d_evc.reserve(nbc));
-        HIPCHK(h, hipMemcpyAsync(b->d_evc.p, b->h_evc.data(), nbc * sizeof(EvConst), hipMemcpyHostToDevice, upload_stream));
+        HIPCHK(h, stage_upload(b, b->d_evc.p, b->h_evc.data(), nbc * sizeof(EvConst), upload_stream));
     }
     if (fixed) {
         /* start phase and step of the 32-bit accumulator per (block, channel); the chain across blocks is
@@ -694,8 +727,8 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         }
         HIPCHK(h, (hipError_t)b->d_kph0.reserve(nbc));
         HIPCHK(h, (hipError_t)b->d_kstep.reserve(nbc));
-        HIPCHK(h, hipMemcpyAsync(b->d_kph0.p, b->h_kph0.data(), nbc * 4, hipMemcpyHostToDevice, upload_stream));
-        HIPCHK(h, hipMemcpyAsync(b->d_kstep.p, b->h_kstep.data(), nbc * 4, hipMemcpyHostToDevice, upload_stream));
+        HIPCHK(h, stage_upload(b, b->d_kph0.p, b->h_kph0.data(), nbc * 4, upload_stream));
+        HIPCHK(h, stage_upload(b, b->d_kstep.p, b->h_kstep.data(), nbc * 4, upload_stream));
     }
     b->h_ch.assign(ch, ch + nbc);
     b->chain_dev = b->ev && (flags & GPSBB_CHAIN_CARRIER) && (nblocks > 1 || b->d_carry) && h->opt_chain_where == 0 &&
@@ -732,7 +765,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         for (int set = 0; set < b->nsets; set++) {
             HIPCHK(h, (hipError_t)b->d_aux[set].reserve(nbc));
             HIPCHK(h, (hipError_t)b->d_prefix[set].reserve(nbc * (size_t)CHAIN_PREFIX_CAP));
-            HIPCHK(h, hipMemcpyAsync(b->d_aux[set].p, b->h_aux.data(), nbc * sizeof(ChainAux), hipMemcpyHostToDevice, upload_stream));
+            HIPCHK(h, stage_upload(b, b->d_aux[set].p, b->h_aux.data(), nbc * sizeof(ChainAux), upload_stream));
         }
     }
     if ((flags & GPSBB_CHAIN_CARRIER) && !fixed && nblocks > 1 && !b->chain_dev) {
@@ -745,8 +778,8 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
             if (b->h_ch[k].prn > 0)
                 b->h_ch[k].carr_phase = seeds[k];
     }
-    HIPCHK(h, hipMemcpyAsync(b->d_ch.p, b->h_ch.data(), nbc * sizeof(gpsbb_chan_t), hipMemcpyHostToDevice, upload_stream));
-    HIPCHK(h, hipMemcpyAsync(b->d_row_off.p, b->row_off.data(), (2 * nbc + 1) * 8, hipMemcpyHostToDevice, upload_stream));
+    HIPCHK(h, stage_upload(b, b->d_ch.p, b->h_ch.data(), nbc * sizeof(gpsbb_chan_t), upload_stream));
+    HIPCHK(h, stage_upload(b, b->d_row_off.p, b->row_off.data(), (2 * nbc + 1) * 8, upload_stream));
     {
         /* which chain each lane of k_seed walks (BatchDev::seed_order).  k_seed takes as long as its slowest
          * wavefront: rows of its longest chain x the time of one turn of the loop, which grows with the
@@ -794,7 +827,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
             waves_of(carr.data() + n8 + n16 + n32, nbc - n8 - n16 - n32, 64, (int32_t)nbc);
         }
         HIPCHK(h, (hipError_t)b->d_seed_order.reserve(order.size()));
-        HIPCHK(h, hipMemcpyAsync(b->d_seed_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, upload_stream));
+        HIPCHK(h, stage_upload(b, b->d_seed_order.p, order.data(), order.size() * 4, upload_stream));
     }
     if (!b->upload_done)
         HIPCHK(h, hipEventCreateWithFlags(&b->upload_done, hipEventDisableTiming));
@@ -864,6 +897,8 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         (void)hipHostFree(b->hs_tile_row);
     if (b->hs_end)
         (void)hipHostFree(b->hs_end);
+    if (b->stage)
+        (void)hipHostFree(b->stage);
     if (b->hs_tile_x)
         (void)hipHostFree(b->hs_tile_x);
     if (b->hs_tile_nav)
@@ -1645,6 +1680,28 @@ extern "C" int gpsbb_stream_create(gpsbb_t *h, int nch, double delt, int nsamp, 
 }
 
 extern "C" int gpsbb_stream_pending(const gpsbb_stream_t *s) { return s ? (int)(s->head - s->tail) : 0; }
+
+extern "C" int gpsbb_stream_timing_stats(gpsbb_stream_t *s, int *nruns, float *ms_seed_sum, float *ms_synth_sum, int reset)
+{
+    if (!s)
+        return GPSBB_E_BADARG;
+    int n = 0;
+    float a = 0, c = 0;
+    for (auto &sl : s->slots) {
+        int k = 0;
+        float x = 0, y = 0, z = 0;
+        const int rc = gpsbb_batch_timing_stats(sl.batch, &k, &x, &y, &z, reset);
+        if (rc != GPSBB_OK)
+            return rc;
+        n += k;
+        a += x;
+        c += y;
+    }
+    if (nruns) *nruns = n;
+    if (ms_seed_sum) *ms_seed_sum = a;
+    if (ms_synth_sum) *ms_synth_sum = c;
+    return GPSBB_OK;
+}
 
 extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
 {

@@ -161,7 +161,8 @@ struct BatchDev {
     uint32_t *status;               /* self-check word                                               */
     unsigned long long *hazards;    /* [0] itable_512, [1] dwrd_oob, [2] lane-runs k_synth_ev recomputed exactly,
                                        [3] scratch (hazards seen by walks whose rows are not the final ones),
-                                       [4] blocks k_chain_fix walked on its own                          */
+                                       [4] blocks k_chain_fix walked on its own, [5] wraps of falling phases whose
+                                       "+ 1.0" was an exact tie (pass B)                                  */
     /* breakpoint kernel (k_synth_ev): instead of rows and a tile index, k_seed leaves the exact state of every
      * chain at the first sample of every tile */
     int ev;                         /* 1: this batch runs on k_synth_ev                               */

@@ -44,6 +44,7 @@ struct WalkLane {
     int32_t ncross;    /* crossings recorded so far; -1: too many */
     int32_t prev_ex;   /* biased exponent of the previous row's states */
     bool prev_wrapped; /* the step before this row wrapped */
+    bool prev_tie;     /* ... and its "+ 1.0" was an exact tie (falling phase) */
     bool wrap_seen;    /* the first wrap is behind: the offset is settled */
     double margin;     /* smallest distance of a row's first or last state to an edge of its binade */
     uint32_t hz512;    /* carrier: samples whose phase is exactly 1.0 (gpsbb_hazards_t.itable_512) */
@@ -142,16 +143,20 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
             if (KIND == NCO_CARR) {
                 /* this row's states lie on a coarser grid than the previous row's (or the step wrapped): the
                  * offset to the true trajectory may change here.  Few per block: only until the first wrap. */
-                const bool cross = w.active && !w.wrap_seen && (ex > w.prev_ex || w.prev_wrapped);
+                /* ... and, for a falling phase, wherever the "+ 1.0" of a wrap was an exact tie: the sum then goes to
+                 * the even neighbour, which for an offset of an odd number of grid steps is the other one */
+                const bool cross = w.active && ((!w.wrap_seen && (ex > w.prev_ex || w.prev_wrapped)) || w.prev_tie);
                 if (__builtin_expect(__ballot(cross) != 0ull, 0)) {
+                    if (cross && w.prev_tie)
+                        atomicAdd(hz + 5, 1ull);
                     if (cross) {
                         if (w.ncross >= 0 && w.ncross < CHAIN_MAX_CROSS)
                             w.aux->cross[w.ncross++] = (int32_t)w.cnt;
                         else
                             w.ncross = -1;
-                        w.wrap_seen = w.prev_wrapped;
-                        if (w.prev_wrapped)
+                        if (w.prev_wrapped && !w.wrap_seen)
                             w.aux->wrap_row = (int32_t)w.cnt;
+                        w.wrap_seen = w.wrap_seen || w.prev_wrapped;
                     }
                 }
                 w.prev_ex = w.active ? ex : w.prev_ex;
@@ -192,11 +197,16 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
         const int n1 = w.n + k;
         const bool step = w.active && n1 < nsamp;
         double x2 = add_rn(x1, s);
-        bool wrapped;
+        bool wrapped, tie = false;
         if (KIND == NCO_CARR) {
             /* c:2743-2746; a rising phase can only pass 1.0, a falling one only 0.0 */
             wrapped = SNEG ? x2 < 0.0 : x2 >= 1.0;
             const double xw = add_rn(x2, SNEG ? 1.0 : -1.0);
+            if (SNEG && TRACK) /* exactly half-way?  xw - 1 and the difference are exact (|1.0| >= |x2|) */
+                tie = wrapped && fabs(add_rn(add_rn(xw, -1.0), -x2)) == 0x1p-54;
+#ifdef GPSBB_EXP_NOTIE /* experiment: what the test suite says when the ties are not looked for */
+            tie = false;
+#endif
             x2 = wrapped ? xw : x2;
         } else {
             wrapped = x2 >= 1023.0;
@@ -221,10 +231,11 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
         w.n = step ? n1 + 1 : (w.active ? n1 : w.n); /* lanes waiting for the other direction's loop keep theirs */
         if (KIND == NCO_CARR && TRACK) {
             w.prev_wrapped = w.active ? (step && wrapped) : w.prev_wrapped;
+            w.prev_tie = w.active ? (step && tie) : w.prev_tie;
             /* the block's last step has no row after it: if it crossed upwards or wrapped, the crossing is
              * recorded here, its "row" being the end state */
-            const bool last_cross = step && !(w.n < nsamp) && !w.wrap_seen &&
-                                    (wrapped || (int)((uint32_t)__double2hiint(x2) >> 20) > ex);
+            const bool last_cross = step && !(w.n < nsamp) &&
+                                    ((!w.wrap_seen && (wrapped || (int)((uint32_t)__double2hiint(x2) >> 20) > ex)) || tie);
             if (__builtin_expect(__ballot(last_cross) != 0ull, 0)) {
                 if (last_cross) {
                     if (w.ncross >= 0 && w.ncross < CHAIN_MAX_CROSS)
@@ -277,6 +288,7 @@ __device__ __forceinline__ WalkLane<KIND> walk_lane(const BatchDev &p, int chain
     w.ncross = 0;
     w.prev_ex = 0x7fff;
     w.prev_wrapped = false;
+    w.prev_tie = false;
     w.wrap_seen = false;
     w.margin = 1.0;
     w.hz512 = 0;
@@ -469,8 +481,10 @@ struct FixRowSink {
  * margin (how close its rows' first and last states come to a binade edge) guarantees when |d| is smaller.
  * d can only change where a sum is rounded on a COARSER grid: a binade crossed upwards, or a wrap.  Once a sum
  * has been rounded on the coarsest grid there is (the one before a wrap: 2^-52 in [1,2) for a rising phase,
- * 2^-53 in [0.5,1) for a falling one) d is a multiple of every grid the phase will ever meet and stays put
- * (ties: see tie_prone below).  Pass B recorded those few rows; here, for each of them in turn: pass B's state
+ * 2^-53 in [0.5,1) for a falling one) d is a multiple of every grid the phase will ever meet and stays put —
+ * except at a later rounding on that coarsest grid that is an exact TIE while d is an odd number of its steps
+ * (see below: a rising phase's step decides whether its wrap sums can tie at all; a falling phase's "+ 1.0"
+ * ties or not depending on the state's low bits, so pass B tests every wrap and records the ties as well).  Pass B recorded those few rows; here, for each of them in turn: pass B's state
  * at the last sample of the row before, plus d, is the true state there; one genuine IEEE step (c:2741-2746)
  * gives the true first state of the row; minus pass B's, that is the new d.  k_tiles adds the offsets to the
  * rows' states, the end state gets the last one.  A block whose step can tie on the coarsest grid, is tiny,
@@ -573,10 +587,11 @@ __global__ void k_chain_fix(BatchDev p)
                 d = xt - (j == 0 ? in.post0 : (j == 1 ? in.post1 : a.post[j]));
                 ok = fabs(d) < margin - 0x1p-51;
                 a.seg[j + 1] = d;
+                /* from the first wrap on: an odd number of steps of the coarsest grid and a step that can tie there
+                 * (at every wrap if the phase rises, at every step in the top binade if it falls): not a translate */
+                if (tie_top && in.wrap_row >= 0 && a.cross[j] >= in.wrap_row && fmod(fabs(d) * (fall ? 0x1p+53 : 0x1p+52), 2.0) != 0.0)
+                    ok = false;
             }
-            /* an odd number of steps of the coarsest grid and a step that can tie there: not a translate */
-            if (ok && tie_top && in.wrap_row >= 0 && fmod(fabs(d) * (fall ? 0x1p+53 : 0x1p+52), 2.0) != 0.0)
-                ok = false;
         } else if (base && !ok && in.wrap_row >= 0) {
             /* a tie-prone binade on the way up: the first lap exactly, on its own rows; after the wrap that ends it
              * the offset is a multiple of every grid and the rest of the block is pass B's plus it */

@@ -278,6 +278,35 @@ def test_stream_ring_with_pinned_gather(pkg, synth, oracle):
 
 
 
+
+def test_device_chain_through_wraps_that_tie(pkg, synth, oracle, request):
+    """Falling carriers at high Doppler over full-size blocks: ~750 wraps per block and channel, and about one in
+    8000 of them adds 1.0 to a phase whose low bits put the sum exactly half-way between two doubles.  Such a tie
+    goes to the even neighbour — a different one for the true trajectory than for pass B's when they are an odd
+    number of grid steps apart — so pass B has to find and record them and k_chain_fix has to step through them.
+    Bit-exact end states and IQ against the oracle walking the blocks in order."""
+    nb, nch = 8, 16
+    fs, nsamp = 25e6, 2500000
+    ch = pkg.synth_descriptors(nb, nch=nch, seed=2718)
+    rng = np.random.default_rng(11)
+    ch["f_carr"] = -rng.uniform(3000.0, 12000.0, nch)[None, :] + rng.uniform(-0.5, 0.5, (nb, nch))
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    want_iq, want_st, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
+    ties0 = synth.info(pkg.INFO_CHAIN_TIES)
+    b = synth.batch(ch, 1 / fs, nsamp, flags=pkg.CHAIN_CARRIER)
+    b.run()
+    synth.sync()
+    iq, st = b.read()
+    b.close()
+    where, kernel = request.node.callspec.params["seed_mode"].split("+")
+    if where == "k_seed" and kernel == "auto":
+        assert synth.info(pkg.INFO_CHAIN_ON_DEVICE) == 1
+        assert synth.info(pkg.INFO_CHAIN_TIES) - ties0 >= 3      # ~12 expected: the case is really exercised
+    for k in range(nb):
+        assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
+    assert sha(iq) == sha(want_iq)
+
+
 def test_stream_carrier_carried_on_the_device(pkg, synth, oracle, request):
     """A chained stream at 25 MS/s: the exact carrier phase is carried from push to push in device memory (no host
     chain), channels come and go between pushes, and the bytes are those of the oracle walking all blocks in

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Kernel-tuning helper (not the bench contract): one batch resident in HBM, run again and again.
+   python tools/kbench.py [--blocks 400] [--steps 10] [--warmup 4] [--chain] [--synth-only] [--per-sample]
+Prints one JSON line with value (IQ samples/s), ms_per_step, roofline.ms_per_launch (synthesis kernel, HIP events)
+and seed_kernel_ms_per_launch (pre-pass, HIP events)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--blocks", type=int, default=400)
+    ap.add_argument("--nch", type=int, default=16)
+    ap.add_argument("--fs", type=float, default=25e6)
+    ap.add_argument("--nsamp", type=int, default=2500000)
+    ap.add_argument("--chain", action="store_true")
+    ap.add_argument("--synth-only", action="store_true", help="after warm-up re-run only the synthesis kernel on the tables already built")
+    ap.add_argument("--per-sample", action="store_true", help="force the per-sample kernel k_synth")
+    ap.add_argument("--no-cpu", action="store_true", help="ignored (compatibility with older scripts)")
+    a = ap.parse_args()
+    import torch
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    ch = pkg.synth_descriptors(a.blocks, nch=a.nch, seed=0x5EED)
+    synth = pkg.Synth(0)
+    if a.per_sample:
+        synth.set_option(pkg.OPT_SYNTH_KERNEL, 1)
+    batch = synth.batch(ch, 1.0 / a.fs, a.nsamp, flags=pkg.CHAIN_CARRIER if a.chain else 0)
+    out = torch.empty(a.blocks * a.nsamp * 2, dtype=torch.int16, device="cuda:0")
+    if a.synth_only:
+        synth.set_option(pkg.OPT_SKIP_SEED, 1)
+        a.warmup = max(a.warmup, 5)
+    for _ in range(a.warmup):
+        batch.run(out.data_ptr())
+    synth.sync()
+    torch.cuda.synchronize()
+    batch.timing_stats(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        batch.run(out.data_ptr())
+    synth.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = batch.timing_stats(reset=True)
+    n = a.blocks * a.nsamp
+    print(json.dumps({"value": n * a.steps / dt, "ms_per_step": dt / a.steps * 1e3,
+                      "roofline": {"ms_per_launch": st["ms_synth_sum"] / max(st["runs"], 1)},
+                      "seed_kernel_ms_per_launch": st["ms_seed_sum"] / max(st["runs"], 1),
+                      "kernel": synth.info(pkg.INFO_LAST_KERNEL), "chain_on_device": synth.info(pkg.INFO_CHAIN_ON_DEVICE)}))
+    synth.set_option(pkg.OPT_SKIP_SEED, 0)
+    batch.close()
+    synth.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,9 +6,9 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS -d "$OUT/sq1" -o pmc -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu --blocks 40 > "$OUT/sq1.log" 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -d "$OUT/sq2" -o pmc -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu --blocks 40 > "$OUT/sq2.log" 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_F64 -d "$OUT/sq3" -o pmc -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu --blocks 40 > "$OUT/sq3.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS -d "$OUT/sq1" -o pmc -- python /root/repo/tools/kbench.py --steps 2 --warmup 1 --no-cpu --blocks 40 > "$OUT/sq1.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -d "$OUT/sq2" -o pmc -- python /root/repo/tools/kbench.py --steps 2 --warmup 1 --no-cpu --blocks 40 > "$OUT/sq2.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_F64 -d "$OUT/sq3" -o pmc -- python /root/repo/tools/kbench.py --steps 2 --warmup 1 --no-cpu --blocks 40 > "$OUT/sq3.log" 2>&1
 cd /root/repo
 python - "$OUT" <<'PY'
 import sqlite3, glob, sys, os

@@ -6,7 +6,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 ROOT=$PWD
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o trace -- python "$ROOT/bench.py" --no-cpu "$@" > "$OUT/prof_stdout.log" 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o trace -- python "$ROOT/tools/kbench.py" "$@" > "$OUT/prof_stdout.log" 2>&1 )
 python - "$OUT" <<'PY'
 import sqlite3, glob, sys, os
 for db in glob.glob(os.path.join(sys.argv[1], "prof", "*.db")):

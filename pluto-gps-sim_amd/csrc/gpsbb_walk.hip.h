@@ -45,6 +45,8 @@ struct WalkLane {
     int32_t prev_ex;   /* biased exponent of the previous row's states */
     bool prev_wrapped; /* the step before this row wrapped */
     bool prev_tie;     /* ... and its "+ 1.0" was an exact tie (falling phase) */
+    bool tie_done;     /* a tie has been recorded: both trajectories left it with an even mantissa, the offset is an
+                          even number of grid steps from there on and no later tie can change it */
     bool wrap_seen;    /* the first wrap is behind: the offset is settled */
     double margin;     /* smallest distance of a row's first or last state to an edge of its binade */
     uint32_t hz512;    /* carrier: samples whose phase is exactly 1.0 (gpsbb_hazards_t.itable_512) */
@@ -100,6 +102,12 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
     const bool generic = es < 123; /* tiny or zero step: every run through the integer version */
     const uint64_t tiemask = generic ? 0ull : walk_tiemask(sb);
     const bool any_tie = __ballot(w.active && tiemask != 0ull) != 0ull;
+    /* pass B, falling phase whose step ties on the top binade's grid (its low bits are exactly half of 2^-53): there
+     * EVERY step in [0.5, 1) is a tie, taken from an even mantissa by a regular run and from an odd one by one
+     * explicit step first.  A true trajectory an odd number of grid steps away does the other of the two at the
+     * first sample after the first wrap — and is an even number away ever after.  That sample gets a row of its
+     * own and the row after it is recorded like a tie, so that k_chain_fix steps through it. */
+    const bool ttf = TRACK && SNEG && KIND == NCO_CARR && !generic && walk_tie_d(sb) == 1022 - es;
     while (__ballot(w.active)) {
         const double x = w.x;
         const uint32_t hi = (uint32_t)__double2hiint(x);
@@ -108,6 +116,9 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
         const bool weird = (unsigned)(ex - 1) >= (unsigned)(TOPEX - 1); /* zero, subnormal, negative, beyond the top */
         const bool rare = w.active && (w.stuck || (!weird && (generic || d > 50)));
         bool expl = weird || d < 2;
+        const bool first_wrap_row = TRACK && KIND == NCO_CARR && w.active && w.prev_wrapped && !w.wrap_seen;
+        if (TRACK && SNEG)
+            expl |= ttf && first_wrap_row;
         if (any_tie)
             expl |= ((tiemask >> (d & 63)) & 1ull) != 0ull && (__double2loint(x) & 1);
         /* S = s rounded to a multiple of ulp(x), ties to even: adding and subtracting 1.5 * 2^e */
@@ -145,10 +156,12 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
                  * offset to the true trajectory may change here.  Few per block: only until the first wrap. */
                 /* ... and, for a falling phase, wherever the "+ 1.0" of a wrap was an exact tie: the sum then goes to
                  * the even neighbour, which for an offset of an odd number of grid steps is the other one */
-                const bool cross = w.active && ((!w.wrap_seen && (ex > w.prev_ex || w.prev_wrapped)) || w.prev_tie);
+                const bool cross = w.active && ((!w.wrap_seen && (ex > w.prev_ex || w.prev_wrapped)) || (w.prev_tie && !w.tie_done));
                 if (__builtin_expect(__ballot(cross) != 0ull, 0)) {
-                    if (cross && w.prev_tie)
+                    if (cross && w.prev_tie) {
                         atomicAdd(hz + 5, 1ull);
+                        w.tie_done = true;
+                    }
                     if (cross) {
                         if (w.ncross >= 0 && w.ncross < CHAIN_MAX_CROSS)
                             w.aux->cross[w.ncross++] = (int32_t)w.cnt;
@@ -202,8 +215,12 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
             /* c:2743-2746; a rising phase can only pass 1.0, a falling one only 0.0 */
             wrapped = SNEG ? x2 < 0.0 : x2 >= 1.0;
             const double xw = add_rn(x2, SNEG ? 1.0 : -1.0);
-            if (SNEG && TRACK) /* exactly half-way?  xw - 1 and the difference are exact (|1.0| >= |x2|) */
-                tie = wrapped && fabs(add_rn(add_rn(xw, -1.0), -x2)) == 0x1p-54;
+            /* was the sum rounded on the coarsest grid exactly half-way?  (Fast2Sum: both differences are exact.)
+             * Falling: x2 + 1.0 on the 2^-53 grid; rising: x1 + s on the 2^-52 grid of [1, 2). */
+            if (SNEG && TRACK)
+                tie = (wrapped && fabs(add_rn(add_rn(xw, -1.0), -x2)) == 0x1p-54) || (ttf && first_wrap_row);
+            if (!SNEG && TRACK)
+                tie = wrapped && fabs(add_rn(add_rn(x2, -x1), -s)) == 0x1p-53;
 #ifdef GPSBB_EXP_NOTIE /* experiment: what the test suite says when the ties are not looked for */
             tie = false;
 #endif
@@ -235,7 +252,7 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
             /* the block's last step has no row after it: if it crossed upwards or wrapped, the crossing is
              * recorded here, its "row" being the end state */
             const bool last_cross = step && !(w.n < nsamp) &&
-                                    ((!w.wrap_seen && (wrapped || (int)((uint32_t)__double2hiint(x2) >> 20) > ex)) || tie);
+                                    ((!w.wrap_seen && (wrapped || (int)((uint32_t)__double2hiint(x2) >> 20) > ex)) || (tie && !w.tie_done));
             if (__builtin_expect(__ballot(last_cross) != 0ull, 0)) {
                 if (last_cross) {
                     if (w.ncross >= 0 && w.ncross < CHAIN_MAX_CROSS)
@@ -289,6 +306,7 @@ __device__ __forceinline__ WalkLane<KIND> walk_lane(const BatchDev &p, int chain
     w.prev_ex = 0x7fff;
     w.prev_wrapped = false;
     w.prev_tie = false;
+    w.tie_done = false;
     w.wrap_seen = false;
     w.margin = 1.0;
     w.hz512 = 0;
@@ -552,8 +570,10 @@ __global__ void k_chain_fix(BatchDev p)
          * one the offset was last rounded on.  That leaves (1) the binades the phase visits before its offset has
          * been through the coarsest grid — from its start binade upwards if it rises, its start binade only if it
          * falls: if the step can tie there (walk_tiemask) the lane walks the block's first lap on its own;
-         * (2) the coarsest grid itself, where a tie needs the step's bits below that grid to be all zero or exactly
-         * one half of it: then an ODD final offset sends the whole block the slow way. */
+         * (2) the coarsest grid itself: pass B finds the first tie there after the first wrap (a wrap sum exactly
+         * half-way; for a falling phase whose step ties on the top binade's grid, the first step after the wrap) and
+         * records it as a crossing: both trajectories leave a tie with an even mantissa, so the offset is an even
+         * number of grid steps from there on and no later tie can change it. */
         const bool fall = s < 0.0;
         bool tie_top = true;
         {
@@ -587,10 +607,6 @@ __global__ void k_chain_fix(BatchDev p)
                 d = xt - (j == 0 ? in.post0 : (j == 1 ? in.post1 : a.post[j]));
                 ok = fabs(d) < margin - 0x1p-51;
                 a.seg[j + 1] = d;
-                /* from the first wrap on: an odd number of steps of the coarsest grid and a step that can tie there
-                 * (at every wrap if the phase rises, at every step in the top binade if it falls): not a translate */
-                if (tie_top && in.wrap_row >= 0 && a.cross[j] >= in.wrap_row && fmod(fabs(d) * (fall ? 0x1p+53 : 0x1p+52), 2.0) != 0.0)
-                    ok = false;
             }
         } else if (base && !ok && in.wrap_row >= 0) {
             /* a tie-prone binade on the way up: the first lap exactly, on its own rows; after the wrap that ends it
@@ -606,6 +622,7 @@ __global__ void k_chain_fix(BatchDev p)
             uint32_t nav = 0;
             const double xs = build_rows_f64<NCO_CARR>(x, s, nav, nstar, sink);
             d = xs - rows[wr].x;
+            /* (a tie-prone coarsest grid and an odd offset there: pass B's recorded tie is not part of this path) */
             ok = !sink.overflow && sink.hz512 == 0 && fabs(d) < margin - 0x1p-51 &&
                  !(tie_top && fmod(fabs(d) * (fall ? 0x1p+53 : 0x1p+52), 2.0) != 0.0);
             if (ok) {

@@ -1,0 +1,64 @@
+"""bench.py's N > 1 path: one stream cut into contiguous time shards, each rank starting from the stream's exact
+carrier phase at its shard, digests exchanged, no data-path collective.
+
+  * on the CPU box: `bench.py --dry-run` under torch.distributed.run with the gloo backend, world sizes 1 and 2 — the
+    sharding, the shard seeds (gpsbb_chain_carrier_host) and the digest exchange are the product's, the rendering is
+    the CPU oracle's; the digest of the whole stream must not depend on the number of ranks;
+  * on the GPU box (-m gpu): the real thing, two ranks sharing the one device (GPSBB_BENCH_BACKEND=gloo), through the
+    device-only ring and the pinned gather, small blocks."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, extra, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    if world == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + extra
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+               os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]      # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_dry_run_digest_does_not_depend_on_the_number_of_ranks(pkg):
+    args = ["--dry-run", "--steps", "1", "--push-blocks", "1", "--nsamp", "20000", "--fs", "25e6"]
+    one = _run(1, args)
+    two = _run(2, args)
+    assert one["blocks"] == two["blocks"] == 8
+    assert one["n_ranks"] == 1 and two["n_ranks"] == 2
+    assert one["stream_digest"] == two["stream_digest"]
+
+
+@pytest.mark.gpu
+def test_two_ranks_through_the_device_path(pkg):
+    args = ["--steps", "2", "--warmup", "1", "--repeats", "2", "--push-blocks", "8", "--nsamp", "200000", "--depth", "3", "--no-cpu"]
+    env = {"GPSBB_BENCH_BACKEND": "gloo", "GPSBB_DEVICE_SEED_ONLY": "1"}
+    one = _run(1, args, env)
+    two = _run(2, args, env)
+    for r, n in ((one, 1), (two, 2)):
+        assert r["n_gpus"] == n and r["scaling"] == "strong" and r["steps"] == 2
+        assert r["config"]["carrier_chain"] == "device" and r["config"]["synthesis_kernel"] == "k_synth_ev"
+        assert r["value"] > 0 and r["roofline"]["frac"] > 0 and len(r["repeats"]["seconds"]) == 2
+        assert len(r["gather"]["per_rank_GBps_to_host"]) == n
+    assert one["config"]["global_samples_per_step"] == two["config"]["global_samples_per_step"]

@@ -16,6 +16,6 @@ with pkg.Synth(0) as s:
         b.run()
         s.sync()
         t = b.timing()
-        print("run %d: seed %.3f ms synth %.3f ms; chained on device %d; fallbacks %d of %d" %
-              (k, t["ms_seed"], t["ms_synth"], s.info(pkg.INFO_CHAIN_ON_DEVICE), s.info(pkg.INFO_CHAIN_FALLBACKS) - f0, nb * 16))
+        print("run %d: seed %.3f ms synth %.3f ms; chained on device %d; fallbacks %d of %d; ties so far %d" %
+              (k, t["ms_seed"], t["ms_synth"], s.info(pkg.INFO_CHAIN_ON_DEVICE), s.info(pkg.INFO_CHAIN_FALLBACKS) - f0, nb * 16, s.info(pkg.INFO_CHAIN_TIES)))
     b.close()

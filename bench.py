@@ -37,6 +37,11 @@ import zlib
 
 import numpy as np
 
+# The library keeps up to seven HIP streams busy (three pre-pass streams, upload, compute, gather, the null stream); the
+# runtime's default of four hardware queues would make unrelated streams share a queue and run one after the other.
+# Must be set before the HIP runtime starts (import torch).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -149,7 +154,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median is reported")
     ap.add_argument("--push-blocks", type=int, default=PUSH_BLOCKS, help="0.1 s blocks per push")
-    ap.add_argument("--depth", type=int, default=4, help="ring slots")
+    ap.add_argument("--depth", type=int, default=6, help="ring slots")
     ap.add_argument("--nch", type=int, default=16)
     ap.add_argument("--fs", type=float, default=25e6)
     ap.add_argument("--nsamp", type=int, default=2500000)

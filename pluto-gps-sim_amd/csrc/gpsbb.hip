@@ -264,6 +264,8 @@ struct gpsbb {
     hipStream_t s_seed = nullptr;    /* NCO seeding pre-pass (k_seed) and descriptor uploads            */
     hipStream_t s_seed2 = nullptr;   /* ... of every other batch / slot of a streaming ring (created on first use) */
     hipStream_t s_seed3 = nullptr;   /* ... a third one: batches whose carrier is chained on the device keep three pre-passes in flight */
+    hipStream_t s_upload = nullptr;  /* descriptors and plans of a set-up: a stream of their own, so that they never queue
+                                        behind an older push's pre-pass */
     unsigned batches_created = 0;
     hipStream_t s_compute = nullptr; /* synthesis kernel (k_synth)                                      */
     hipStream_t s_copy = nullptr;    /* device-to-host gather                                            */
@@ -510,6 +512,8 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
         (void)hipStreamSynchronize(h->s_seed2);
     if (h->s_seed3)
         (void)hipStreamSynchronize(h->s_seed3);
+    if (h->s_upload)
+        (void)hipStreamSynchronize(h->s_upload);
     if (h->s_compute)
         (void)hipStreamSynchronize(h->s_compute);
     if (h->s_copy)
@@ -530,6 +534,8 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
         (void)hipStreamDestroy(h->s_seed2);
     if (h->s_seed3)
         (void)hipStreamDestroy(h->s_seed3);
+    if (h->s_upload)
+        (void)hipStreamDestroy(h->s_upload);
     if (h->s_compute)
         (void)hipStreamDestroy(h->s_compute);
     if (h->s_copy)
@@ -542,6 +548,11 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     if (!out)
         return GPSBB_E_BADARG;
     *out = nullptr;
+    /* Up to seven streams carry work at the same time (three pre-pass streams, upload, compute, gather, the null
+     * stream).  The runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share one
+     * run one after the other: ask for eight, unless the host has said otherwise.  Only takes effect if this is the
+     * process's first HIP call; a host that initialises HIP earlier (e.g. through torch) sets it itself. */
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
         return GPSBB_E_NODEVICE;
@@ -574,6 +585,7 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     h->sm_count = prop.multiProcessorCount;
     if ((e = hipStreamCreateWithFlags(&h->s_seed, hipStreamNonBlocking)) != hipSuccess) return fail(e);
     if ((e = hipStreamCreateWithFlags(&h->s_compute, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+    if ((e = hipStreamCreateWithFlags(&h->s_upload, hipStreamNonBlocking)) != hipSuccess) return fail(e);
     if ((e = hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&h->d_tabs, sizeof tabs)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&h->d_ca, ca.size() * 4)) != hipSuccess) return fail(e);
@@ -923,12 +935,12 @@ extern "C" int gpsbb_batch_create(gpsbb_t *h, const gpsbb_chan_t *ch, int nblock
         return GPSBB_E_NOMEM;
     if (h->batches_created++ & 1) /* batches created one after the other seed side by side */
         HIPCHK(h, use_second_seed_stream(b));
-    int rc = batch_setup(b, ch, nblocks, nch, delt, nsamp, flags, b->seed_stream);
+    int rc = batch_setup(b, ch, nblocks, nch, delt, nsamp, flags, h->s_upload);
     if (rc != GPSBB_OK) {
         gpsbb_batch_destroy(b);
         return rc;
     }
-    HIPCHK(h, hipStreamSynchronize(b->seed_stream));
+    HIPCHK(h, hipStreamSynchronize(h->s_upload));
     *out = b;
     return GPSBB_OK;
 }
@@ -1374,6 +1386,7 @@ extern "C" int gpsbb_sync(gpsbb_t *h)
     if (!h)
         return GPSBB_E_BADARG;
     HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->s_upload));
     HIPCHK(h, hipStreamSynchronize(h->s_seed));
     if (h->s_seed2)
         HIPCHK(h, hipStreamSynchronize(h->s_seed2));
@@ -1795,7 +1808,7 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     const bool fx_chain = (s->flags & GPSBB_FIXED_CARRIER) && (s->flags & GPSBB_CHAIN_CARRIER) && s->head > 0;
     b->fixed_prev_prn = fx_chain ? s->fx_prn : nullptr;
     b->fixed_prev_phase = fx_chain ? s->fx_phase : nullptr;
-    int rc = batch_setup(b, ch, s->bps, s->nch, s->delt, s->nsamp, run_flags, b->seed_stream);
+    int rc = batch_setup(b, ch, s->bps, s->nch, s->delt, s->nsamp, run_flags, h->s_upload);
     b->fixed_prev_prn = nullptr;
     b->fixed_prev_phase = nullptr;
     if (rc != GPSBB_OK) {

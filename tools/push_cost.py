@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """host time of gpsbb_stream_push (400-block pushes, chained on the device, HBM-only ring)"""
 import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa
@@ -8,12 +9,12 @@ from __graft_entry__ import load_package
 pkg = load_package()
 import bench
 PB = 400
-ch = bench.stream_descriptors(pkg, PB * 12, 16)
+ch = bench.stream_descriptors(pkg, PB * 24, 16)
 with pkg.Synth(0) as s:
     st = s.stream(16, 1 / 25e6, 2500000, PB, depth=4, flags=pkg.CHAIN_CARRIER | pkg.STREAM_DEVICE_ONLY)
     tp, tq = [], []
     t_all = time.perf_counter()
-    for k in range(12):
+    for k in range(24):
         if st.pending >= 4:
             t0 = time.perf_counter(); st.pop(copy=False); tq.append(time.perf_counter() - t0)
         t0 = time.perf_counter(); st.push(ch[k * PB:(k + 1) * PB]); tp.append(time.perf_counter() - t0)
@@ -23,5 +24,5 @@ with pkg.Synth(0) as s:
     t_all = time.perf_counter() - t_all
     print("push ms:", " ".join("%.2f" % (t * 1e3) for t in tp))
     print("pop  ms:", " ".join("%.2f" % (t * 1e3) for t in tq))
-    print("total %.1f ms for 12 pushes" % (t_all * 1e3))
+    print("total %.1f ms for 24 pushes" % (t_all * 1e3))
     st.close()

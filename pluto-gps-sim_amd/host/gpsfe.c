@@ -85,6 +85,7 @@ typedef struct {  /* the host-side part of channel_t h:152-174 */
 
 struct gpsfe {
     int max_chan;
+    int emitted_prn[GPSBB_MAX_CHAN]; /* prn of each channel in the descriptors gpsfe_next_block last handed out */
     int fixed_carrier; /* the reference's `#ifndef FLOAT_CARR_PHASE` variant: 32-bit phase accumulator */
     eph_t eph[N_EPH_SETS + 1][N_SAT]; /* one spare, always-invalid set: the reference peeks at set ieph+1 (c:2777) */
     int neph, ieph;
@@ -988,6 +989,7 @@ int gpsfe_next_block(gpsfe_t *fe, gpsbb_chan_t *ch)
         chan_t *c = &fe->chan[i];
         gpsbb_chan_t *d = &ch[i];
         memset(d, 0, sizeof *d);
+        fe->emitted_prn[i] = c->prn > 0 ? c->prn : 0;
         if (c->prn <= 0)
             continue;
         range_t rho;
@@ -1039,10 +1041,12 @@ int gpsfe_feed_back(gpsfe_t *fe, const gpsbb_chan_state_t *end_state)
 {
     if (!fe || !end_state)
         return GPSFE_E_BADARG;
-    /* Only channels that were active in the block just rendered and are still allocated keep their phase;
-     * a channel (re)allocated by the maintenance step of that block starts from allocateChannel's value. */
+    /* Only a channel that still carries the satellite it carried in the block just rendered keeps that block's end
+     * phase.  gpsfe_next_block has already run the block's 30 s maintenance (the reference runs it after the fill,
+     * c:2764-2798): a slot freed and given to a newly risen satellite in the same pass holds allocateChannel's
+     * phase (c:1956-1964) and must not inherit the departed satellite's. */
     for (int i = 0; i < fe->max_chan; i++)
-        if (fe->chan[i].prn > 0 && end_state[i].dataBit != 0)
+        if (fe->chan[i].prn > 0 && fe->chan[i].prn == fe->emitted_prn[i] && end_state[i].dataBit != 0)
             fe->chan[i].carr_phase = end_state[i].carr_phase;
     return GPSFE_OK;
 }

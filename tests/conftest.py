@@ -52,3 +52,15 @@ def synth(pkg):
 
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+# The reference's channel_t (plutogpssim.h:152-174, FLOAT_CARR_PHASE build, LP64) as a numpy record: what a caller
+# that kept the reference's structures hands to gpsbb_fill_block_ref.  tests/test_ref_layout.py checks every offset
+# against offsetof() on the real header (in the build container, where /root/reference exists).
+import numpy as _np
+
+REF_CHANNEL_DTYPE = _np.dtype([("prn", "<i4"), ("ca", "<i4", (1023,)), ("f_carr", "<f8"), ("f_code", "<f8"),
+                               ("carr_phase", "<f8"), ("code_phase", "<f8"), ("g0_week", "<i4"), ("_p0", "<i4"),
+                               ("g0_sec", "<f8"), ("sbf", "<u8", (50,)), ("dwrd", "<u8", (60,)), ("iword", "<i4"),
+                               ("ibit", "<i4"), ("icode", "<i4"), ("dataBit", "<i4"), ("codeCA", "<i4"), ("_p1", "<i4"),
+                               ("azel", "<f8", (2,)), ("rho0", "<f8", (8,))])

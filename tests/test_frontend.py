@@ -32,18 +32,27 @@ def assert_desc_equal(got, want, what):
         assert a.tobytes() == b.tobytes(), "%s: field %s differs" % (what, f)
 
 
-@pytest.mark.parametrize("name,nav,motion,max_chan", [
-    ("static_F", "synth3540.14n", None, 12),
-    ("motion_F", "synth3540.14n", "circle_motion.csv", 12),
-    ("dense_S", "dense3540.14n", None, 16)])
-def test_descriptors_match_the_reference_dumps(fe_pkg, name, nav, motion, max_chan):
+# golden file, nav file, motion file, MAX_CHAN, further FrontEnd options
+SCENARIOS = [
+    ("static_F", "synth3540.14n", None, 12, {}),
+    ("motion_F", "synth3540.14n", "circle_motion.csv", 12, {}),
+    ("dense_S", "dense3540.14n", None, 16, {}),
+    ("rinex3_F", "synth3540_v3.rnx", None, 12, {"rinex3": True}),                    # readRinex3, c:1241-1610
+    ("toverwrite_F", "synth3540.14n", None, 12, {"start": (2014, 12, 21, 10, 0, 0.0), "time_overwrite": True}),  # c:2523-2553
+    ("motion_ref_F", "synth3540.14n", "circle.csv", 12, {}),                         # the reference's own circle.csv
+    ("swap_S", "dense3540.14n", None, 16, {"start": (2014, 12, 20, 1, 20, 0.0)}),    # a slot changes hands at block 1500
+]
+
+
+@pytest.mark.parametrize("name,nav,motion,max_chan,kw", SCENARIOS)
+def test_descriptors_match_the_reference_dumps(fe_pkg, name, nav, motion, max_chan, kw):
     pkg = fe_pkg
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     fs, nsamp = float(z["fs"]), int(z["nsamp"])
     blocks = [int(b) for b in z["blocks"]]
     want = z["desc"].view(pkg.CHAN_DTYPE).reshape(len(blocks), -1)
     fe = pkg.FrontEnd(os.path.join(GOLDEN, nav), llh=SITE, motion=os.path.join(GOLDEN, motion) if motion else None,
-                      max_chan=max_chan)
+                      max_chan=max_chan, **kw)
     ch = chained(pkg, fe.generate(max(blocks) + 1), fs, nsamp)
     fe.close()
     for k, b in enumerate(blocks):
@@ -145,3 +154,31 @@ def test_fixed_carrier_descriptors(fe_pkg):
     ch["carr_phase"] = ph.astype(np.float64)
     for k, b in enumerate(blocks):
         assert_desc_equal(ch[b], want[k], "fixed block %d" % b)
+
+
+def test_feed_back_keeps_a_newly_allocated_channels_own_phase(fe_pkg):
+    """The drop-in loop (gpsfe_next_block / render / gpsfe_feed_back) across the 30 s maintenance of block 1499, which
+    frees channel 10 (PRN 11 has set) and gives it to PRN 18 in the same pass: the new satellite starts from
+    allocateChannel's phase (c:1956-1964), not from the end phase of the block PRN 11 was rendered in.  The render is
+    replaced by the exact carrier jump-ahead (the end phase is all feed_back looks at); descriptors against the
+    reference's dump around the hand-over."""
+    pkg = fe_pkg
+    z = np.load(os.path.join(GOLDEN, "swap_S.npz"))
+    fs, nsamp = float(z["fs"]), int(z["nsamp"])
+    blocks = [int(b) for b in z["blocks"]]
+    want = z["desc"].view(pkg.CHAN_DTYPE).reshape(len(blocks), -1)
+    assert want["prn"][1][10] == 11 and want["prn"][2][10] == 18
+    fe = pkg.FrontEnd(os.path.join(GOLDEN, "dense3540.14n"), llh=SITE, max_chan=16, start=(2014, 12, 20, 1, 20, 0.0))
+    lib = pkg.lib()
+    for b in range(max(blocks) + 1):
+        ch = fe.next_block()
+        if b in blocks:
+            assert_desc_equal(ch, want[blocks.index(b)], "feed-back loop, block %d" % b)
+        st = np.zeros(16, pkg.STATE_DTYPE)
+        for i in range(16):
+            if ch["prn"][i] > 0:
+                s = float(np.float64(ch["f_carr"][i]) * np.float64(1.0 / fs))
+                st["carr_phase"][i] = lib.gpsbb_test_carr_jump(float(ch["carr_phase"][i]), s, nsamp)
+                st["dataBit"][i] = 1
+        fe.feed_back(st)
+    fe.close()

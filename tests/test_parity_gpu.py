@@ -387,11 +387,7 @@ def test_reference_struct_layout_entry_point(pkg, synth, oracle):
     layout here (LP64: int prn; int ca[1023]; double f_carr, f_code, carr_phase, code_phase; gpstime_t g0;
     unsigned long sbf[5][10]; unsigned long dwrd[60]; int iword, ibit, icode, dataBit, codeCA; ...)."""
     import ctypes as C
-    chan_t = np.dtype([("prn", "<i4"), ("ca", "<i4", (1023,)), ("f_carr", "<f8"), ("f_code", "<f8"),
-                       ("carr_phase", "<f8"), ("code_phase", "<f8"), ("g0_week", "<i4"), ("_p0", "<i4"),
-                       ("g0_sec", "<f8"), ("sbf", "<u8", (50,)), ("dwrd", "<u8", (60,)), ("iword", "<i4"),
-                       ("ibit", "<i4"), ("icode", "<i4"), ("dataBit", "<i4"), ("codeCA", "<i4"), ("_p1", "<i4"),
-                       ("azel", "<f8", (2,)), ("rho0", "<f8", (8,))])
+    from conftest import REF_CHANNEL_DTYPE as chan_t   # checked against offsetof() on the real header: test_ref_layout.py
     d = pkg.synth_descriptors(1, nch=12, seed=121)[0]
     d["prn"][5] = 0
     chan = np.zeros(12, chan_t)
@@ -443,11 +439,15 @@ def test_full_size_blocks_and_linearity(pkg, synth, oracle):
     assert (total == iq[0]).all()
 
 
-@pytest.mark.parametrize("name,nav,motion,max_chan", [
-    ("static_F", "synth3540.14n", None, 12),            # BASELINE configs 1/2
-    ("motion_F", "synth3540.14n", "circle_motion.csv", 12),   # config 4: 10 Hz user motion
-    ("dense_S", "dense3540.14n", None, 16)])            # config 3 geometry through the front end
-def test_end_to_end_from_rinex(pkg, synth, name, nav, motion, max_chan):
+@pytest.mark.parametrize("name,nav,motion,max_chan,kw", [
+    ("static_F", "synth3540.14n", None, 12, {}),            # BASELINE configs 1/2
+    ("motion_F", "synth3540.14n", "circle_motion.csv", 12, {}),   # config 4: 10 Hz user motion
+    ("dense_S", "dense3540.14n", None, 16, {}),             # config 3 geometry through the front end
+    ("rinex3_F", "synth3540_v3.rnx", None, 12, {"rinex3": True}),                  # readRinex3, c:1241-1610
+    ("toverwrite_F", "synth3540.14n", None, 12, {"start": (2014, 12, 21, 10, 0, 0.0), "time_overwrite": True}),  # -T
+    ("motion_ref_F", "synth3540.14n", "circle.csv", 12, {}),                       # config 4 on the reference's circle.csv
+    ("swap_S", "dense3540.14n", None, 16, {"start": (2014, 12, 20, 1, 20, 0.0)})])  # a channel changes hands at block 1500
+def test_end_to_end_from_rinex(pkg, synth, name, nav, motion, max_chan, kw):
     """RINEX file + position/motion -> from-scratch host front end -> device (carrier chained on the GPU)
     -> int16 IQ, against the golden vectors of the reference's own code: the same bytes, block for block."""
     pkg.build_frontend()
@@ -455,7 +455,7 @@ def test_end_to_end_from_rinex(pkg, synth, name, nav, motion, max_chan):
     fs, nsamp = float(z["fs"]), int(z["nsamp"])
     blocks = [int(b) for b in z["blocks"]]
     fe = pkg.FrontEnd(os.path.join(GOLDEN, nav), llh=(30.286502, 120.032669, 100.0),
-                      motion=os.path.join(GOLDEN, motion) if motion else None, max_chan=max_chan)
+                      motion=os.path.join(GOLDEN, motion) if motion else None, max_chan=max_chan, **kw)
     ch = fe.generate(max(blocks) + 1)
     fe.close()
     b = synth.batch(ch, 1.0 / fs, nsamp, flags=pkg.CHAIN_CARRIER)
@@ -469,6 +469,25 @@ def test_end_to_end_from_rinex(pkg, synth, name, nav, motion, max_chan):
         assert sha(iq[blk]) == str(z["iq_sha256"][k]), (name, blk)
         assert_state_equal(st[blk], want_st[k], ch["prn"][blk] > 0)
     assert synth.hazards(reset=True) == {"itable_512": 0, "dwrd_oob": 0}
+
+
+def test_feedback_loop_across_a_channel_hand_over(pkg, synth):
+    """One gpsbb_fill_block per block with gpsfe_feed_back, across the 30 s maintenance that hands channel 10 from PRN 11
+    to PRN 18 in one pass (swap_S): the IQ of the blocks around it equals the reference's, i.e. the new satellite did
+    not inherit the old one's carrier phase."""
+    pkg.build_frontend()
+    z = np.load(os.path.join(GOLDEN, "swap_S.npz"))
+    fs, nsamp = float(z["fs"]), int(z["nsamp"])
+    blocks = [int(b) for b in z["blocks"]]
+    fe = pkg.FrontEnd(os.path.join(GOLDEN, "dense3540.14n"), llh=(30.286502, 120.032669, 100.0), max_chan=16,
+                      start=(2014, 12, 20, 1, 20, 0.0))
+    for blk in range(max(blocks) + 1):
+        ch = fe.next_block()
+        iq, st = synth.fill_block(ch, 1.0 / fs, nsamp)
+        fe.feed_back(st)
+        if blk in blocks:
+            assert (iq == z["iq_prefix"][blocks.index(blk)]).all(), blk
+    fe.close()
 
 
 def test_single_block_feedback_loop_like_the_reference(pkg, synth):
@@ -634,6 +653,57 @@ def test_time_shards_through_the_ring_give_one_digest(pkg, synth, oracle):
             d, _ = ss.shard_digests(pkg, synth, ch, seeds, b0, b1, delt, nsamp, bps)
             got += d
         assert got == want, (world, bps)
+
+
+
+def test_config5_at_full_block_size_in_1_2_and_4_time_shards(pkg, synth, oracle, request):
+    """BASELINE configs[4] at its real block size: 360 s of the 16-channel 25 MS/s stream (3600 blocks of 2.5 M samples,
+    9e9 samples, 36 GB) through the ring with the pinned gather, on one GPU, as 1, 2 and 4 contiguous time shards.  A
+    shard starts from the stream's exact carrier phase there (gpsbb_chain_carrier_host) and chains on the device from
+    then on; every block is digested as it lands in pinned host memory.  The digest of the block digests must not
+    depend on the number of shards, two blocks are compared with the CPU oracle in full, and no hazard may have
+    been counted.  (Run once: the seeding variants are covered at small sizes.)"""
+    if request.node.callspec.params["seed_mode"] != "k_seed+auto":
+        pytest.skip("full-size run: once")
+    import xxhash
+    import bench
+    nch, fs, nsamp, nb, bps, depth = 16, 25e6, 2500000, 3600, 36, 4
+    delt = 1.0 / fs
+    ch = bench.stream_descriptors(pkg, nb, nch)
+    seeds = pkg.chain_carrier_host(ch, delt, nsamp)
+    synth.hazards(reset=True)
+
+    def render(nshards):
+        digs = []
+        for r in range(nshards):
+            b0, b1 = pkg.shard_blocks(nb, r, nshards)
+            mine = ch[b0:b1].copy()
+            mine["carr_phase"][0] = seeds[b0]
+            st = synth.stream(nch, delt, nsamp, bps, depth=depth, flags=pkg.CHAIN_CARRIER)
+            nslots = (b1 - b0) // bps
+            pushed = popped = 0
+            while popped < nslots:
+                while pushed < nslots and st.pending < depth:
+                    st.push(mine[pushed * bps:(pushed + 1) * bps])
+                    pushed += 1
+                iq, _ = st.pop(copy=False)
+                digs.extend(xxhash.xxh3_64_intdigest(memoryview(iq[k]).cast("B")) for k in range(bps))
+                popped += 1
+            st.close()
+        return digs
+
+    one = render(1)
+    assert synth.info(pkg.INFO_CHAIN_ON_DEVICE) == 1 and synth.info(pkg.INFO_LAST_KERNEL) == 2
+    assert len(one) == nb
+    for n in (2, 4):
+        assert render(n) == one, "%d shards" % n
+    assert synth.hazards(reset=True) == {"itable_512": 0, "dwrd_oob": 0}
+    # two blocks in full against the CPU oracle, started from the host chain's exact phase
+    for b in (2700, 3599):
+        d = ch[b:b + 1].copy()
+        d["carr_phase"][0] = seeds[b]
+        want, _, _ = oracle.fill_blocks(d, delt, nsamp)
+        assert xxhash.xxh3_64_intdigest(memoryview(np.ascontiguousarray(want[0])).cast("B")) == one[b], b
 
 
 def test_handle_and_batch_lifecycle(pkg, oracle):

@@ -39,6 +39,9 @@ int gpsbb_tx_create(gpsbb_tx_t **out, size_t nsamp, gpsbb_tx_push_fn push, void 
  * gpsbb_tx_end returns 0, or 1 once the consumer has stopped (push returned < 0): plutotx.exit. */
 int16_t *gpsbb_tx_begin(gpsbb_tx_t *tx);
 int gpsbb_tx_end(gpsbb_tx_t *tx);
+/* instead of gpsbb_tx_end when the fill failed: releases the buffer WITHOUT handing it to the consumer (it holds
+ * the previous block, or half of a new one) */
+void gpsbb_tx_cancel(gpsbb_tx_t *tx);
 
 /* stop the TX thread (after it has delivered everything submitted) and free the surface */
 void gpsbb_tx_destroy(gpsbb_tx_t *tx);

@@ -400,6 +400,7 @@ struct gpsbb_batch {
     size_t ev_used = 0;
     bool ran = false;
     int16_t *last_iq = nullptr;
+    int16_t *last_ext_iq = nullptr; /* the caller's device buffer of the last run, if it used one */
 };
 
 #define HIPCHK(h, call)                                                                            \
@@ -933,8 +934,14 @@ extern "C" int gpsbb_batch_create(gpsbb_t *h, const gpsbb_chan_t *ch, int nblock
     gpsbb_batch *b = batch_new(h);
     if (!b)
         return GPSBB_E_NOMEM;
-    if (h->batches_created++ & 1) /* batches created one after the other seed side by side */
-        HIPCHK(h, use_second_seed_stream(b));
+    if (h->batches_created++ & 1) { /* batches created one after the other seed side by side */
+        const hipError_t e2 = use_second_seed_stream(b);
+        if (e2 != hipSuccess) {
+            gpsbb_batch_destroy(b);
+            h->last_hip = (int)e2;
+            return e2 == hipErrorOutOfMemory ? GPSBB_E_NOMEM : GPSBB_E_HIP;
+        }
+    }
     int rc = batch_setup(b, ch, nblocks, nch, delt, nsamp, flags, h->s_upload);
     if (rc != GPSBB_OK) {
         gpsbb_batch_destroy(b);
@@ -1375,6 +1382,7 @@ extern "C" int gpsbb_batch_run(gpsbb_batch_t *b, int16_t *d_iq)
         b->last_iq = d_iq;
     } else {
         b->last_iq = nullptr;
+        b->last_ext_iq = d_iq; /* gpsbb_batch_read copies from it for as long as the caller keeps it alive */
     }
     return batch_launch(b, d_iq);
 }
@@ -1410,9 +1418,10 @@ extern "C" int gpsbb_batch_read(gpsbb_batch_t *b, int16_t *iq_out, gpsbb_chan_st
     gpsbb *h = b->h;
     HIPCHK(h, hipSetDevice(h->device));
     if (iq_out) {
-        if (!b->last_iq)
+        const int16_t *src = b->last_iq ? b->last_iq : b->last_ext_iq;
+        if (!src)
             return GPSBB_E_STATE;
-        HIPCHK(h, hipMemcpy(iq_out, b->last_iq, gpsbb_batch_iq_bytes(b), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(iq_out, src, gpsbb_batch_iq_bytes(b), hipMemcpyDeviceToHost));
     }
     if (end_state)
         HIPCHK(h, hipMemcpy(end_state, b->d_end[b->last_set].p, (size_t)b->nblocks * b->nch * sizeof(gpsbb_chan_state_t),
@@ -1733,6 +1742,15 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     unsigned run_flags = s->flags & (GPSBB_CHAIN_CARRIER | GPSBB_FIXED_CARRIER);
     const size_t nbc = (size_t)s->bps * s->nch;
     b->d_carry = nullptr;
+    /* the chaining state only moves on once every enqueue of this push has succeeded: a failed push can be retried */
+    ChainCarry carry_next;
+    bool carry_host = false;
+    double rough_next[GPSBB_MAX_CHAN];
+    memcpy(rough_next, s->rough_phase, sizeof rough_next);
+    int fx_prn_next[GPSBB_MAX_CHAN];
+    uint32_t fx_phase_next[GPSBB_MAX_CHAN];
+    memcpy(fx_prn_next, s->fx_prn, sizeof fx_prn_next);
+    memcpy(fx_phase_next, s->fx_phase, sizeof fx_phase_next);
     if ((s->flags & GPSBB_CHAIN_CARRIER) && !(s->flags & GPSBB_FIXED_CARRIER)) {
         for (size_t k = 0; k < nbc; k++)
             if (!chan_ok(ch[k], s->delt))
@@ -1777,7 +1795,7 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
             s->carry_on_device = true;
             b->d_carry = s->d_carry;
             b->carry_prn = s->last_prn;
-            b->carry_phase = s->rough_phase;
+            b->carry_phase = rough_next;
             b->ev_prefix = s->ev_prefix;
             b->ev_fix = s->ev_fix;
             b->stream_turn = (unsigned)s->head;
@@ -1797,7 +1815,9 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
             }
             s->seeded.assign(ch, ch + nbc);
             s->seeds.resize(nbc);
-            chain_carrier_host(ch, s->bps, s->nch, s->delt, s->nsamp, s->seeds.data(), 0, s->carry);
+            carry_next = *s->carry; /* committed only when the push has been enqueued in full */
+            carry_host = true;
+            chain_carrier_host(ch, s->bps, s->nch, s->delt, s->nsamp, s->seeds.data(), 0, &carry_next);
             for (size_t k = 0; k < nbc; k++)
                 s->seeded[k].carr_phase = s->seeds[k];
             ch = s->seeded.data();
@@ -1822,19 +1842,14 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     if (s->flags & GPSBB_FIXED_CARRIER)
         for (int i = 0; i < s->nch; i++) {
             const size_t k = (size_t)(s->bps - 1) * s->nch + i;
-            s->fx_prn[i] = ch[k].prn > 0 ? ch[k].prn : 0;
-            s->fx_phase[i] = b->h_kph0[k] + (uint32_t)s->nsamp * (uint32_t)b->h_kstep[k];
+            fx_prn_next[i] = ch[k].prn > 0 ? ch[k].prn : 0;
+            fx_phase_next[i] = b->h_kph0[k] + (uint32_t)s->nsamp * (uint32_t)b->h_kstep[k];
         }
     b->last_iq = b->d_iq.p;
     rc = batch_launch(b, b->d_iq.p);
     b->d_carry = nullptr;
     if (rc != GPSBB_OK)
         return rc;
-    if (s->carry_on_device && (s->flags & GPSBB_CHAIN_CARRIER) && !(s->flags & GPSBB_FIXED_CARRIER))
-        for (int i = 0; i < s->nch; i++) {
-            const int prn = ch[(size_t)(s->bps - 1) * s->nch + i].prn;
-            s->last_prn[i] = prn > 0 ? prn : 0;
-        }
     HIPCHK(h, hipEventRecord(sl.computed, h->s_compute));
     /* gather on the side stream: pinned, asynchronous, overlaps the next push's kernels */
     hipStream_t cs = h->s_copy;
@@ -1844,6 +1859,17 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     HIPCHK(h, hipMemcpyAsync(sl.h_end, b->d_end[b->last_set].p, (size_t)s->bps * s->nch * sizeof(gpsbb_chan_state_t),
                              hipMemcpyDeviceToHost, cs));
     HIPCHK(h, hipEventRecord(sl.copied, cs));
+    /* commit */
+    if (carry_host)
+        *s->carry = carry_next;
+    if (s->carry_on_device && (s->flags & GPSBB_CHAIN_CARRIER) && !(s->flags & GPSBB_FIXED_CARRIER))
+        for (int i = 0; i < s->nch; i++) {
+            const int prn = ch[(size_t)(s->bps - 1) * s->nch + i].prn;
+            s->last_prn[i] = prn > 0 ? prn : 0;
+        }
+    memcpy(s->rough_phase, rough_next, sizeof rough_next);
+    memcpy(s->fx_prn, fx_prn_next, sizeof fx_prn_next);
+    memcpy(s->fx_phase, fx_phase_next, sizeof fx_phase_next);
     s->head++;
     return GPSBB_OK;
 }
@@ -1903,10 +1929,15 @@ static void chain_carrier_host(const gpsbb_chan_t *ch, int nblocks, int nch, dou
     if (nthreads == 1) {
         work(0, nch);
     } else {
+        /* a thread that cannot be started (no exception may cross the C boundary) leaves its share to the caller */
         std::vector<std::thread> th;
         for (int t = 0; t < nthreads; t++) {
             const int i0 = (int)((long)nch * t / nthreads), i1 = (int)((long)nch * (t + 1) / nthreads);
-            th.emplace_back(work, i0, i1);
+            try {
+                th.emplace_back(work, i0, i1);
+            } catch (...) {
+                work(i0, i1);
+            }
         }
         for (auto &t : th)
             t.join();

@@ -47,8 +47,14 @@ int main(int argc, char **argv)
         switch (opt) {
         case 'e': cfg.navfile = optarg; break;
         case 'u': cfg.motion_file = optarg; break;
-        case 'c': cfg.use_ecef = 1; sscanf(optarg, "%lf,%lf,%lf", &cfg.pos[0], &cfg.pos[1], &cfg.pos[2]); break;
-        case 'l': cfg.use_ecef = 0; sscanf(optarg, "%lf,%lf,%lf", &cfg.pos[0], &cfg.pos[1], &cfg.pos[2]); break;
+        case 'c':
+        case 'l':
+            cfg.use_ecef = opt == 'c';
+            if (sscanf(optarg, "%lf,%lf,%lf", &cfg.pos[0], &cfg.pos[1], &cfg.pos[2]) != 3) {
+                fprintf(stderr, "ERROR: -%c wants three comma-separated numbers\n", opt);
+                return 1;
+            }
+            break;
         case 's':
             fs_hz = atol(optarg);
             if (fs_hz < 1000000) { /* c:2326 */
@@ -59,7 +65,10 @@ int main(int argc, char **argv)
         case 'T': cfg.time_overwrite = 1; break;
         case 't':
             cfg.have_start = 1;
-            sscanf(optarg, "%d/%d/%d,%d:%d:%lf", &cfg.y, &cfg.m, &cfg.d, &cfg.hh, &cfg.mm, &cfg.sec);
+            if (sscanf(optarg, "%d/%d/%d,%d:%d:%lf", &cfg.y, &cfg.m, &cfg.d, &cfg.hh, &cfg.mm, &cfg.sec) != 6) {
+                fprintf(stderr, "ERROR: -t wants YYYY/MM/DD,hh:mm:ss\n");
+                return 1;
+            }
             break;
         case 'i': cfg.iono_disable = 1; break;
         case '3': cfg.rinex3 = 1; break; /* the reference declares -3 with an argument (c:2296); here it is a flag */
@@ -103,7 +112,7 @@ int main(int argc, char **argv)
         const int bps = nblocks < 16 ? (int)(nblocks > 0 ? nblocks : 1) : 16, depth = 3;
         gpsbb_stream_t *st = NULL;
         gpsbb_chan_t *slot = malloc((size_t)bps * cfg.max_chan * sizeof *slot);
-        rc = gpsbb_stream_create(bb, cfg.max_chan, delt, (int)nsamp, bps, depth, GPSBB_CHAIN_CARRIER, &st);
+        rc = slot ? gpsbb_stream_create(bb, cfg.max_chan, delt, (int)nsamp, bps, depth, GPSBB_CHAIN_CARRIER, &st) : GPSBB_E_NOMEM;
         long pushed = 0, written = 0;
         while (rc == GPSBB_OK && slot && written < nblocks) {
             while (rc == GPSBB_OK && pushed < nblocks && gpsbb_stream_pending(st) < depth) {
@@ -157,11 +166,12 @@ int main(int argc, char **argv)
         gpsfe_next_block(fe, ch);                                   /* c:2656-2687 (+ c:2764-2805) */
         int16_t *iq = gpsbb_tx_begin(tx);                           /* c:2689 */
         rc = gpsbb_fill_block(bb, ch, cfg.max_chan, delt, (int)nsamp, iq, st); /* replaces c:2690-2756 */
-        const int stopped = gpsbb_tx_end(tx);                       /* c:2757-2759 */
-        if (rc != GPSBB_OK) {
+        if (rc != GPSBB_OK) { /* the buffer holds no valid block: it must not reach the sink */
+            gpsbb_tx_cancel(tx);
             fprintf(stderr, "ERROR: gpsbb_fill_block: %s\n", gpsbb_strerror(rc));
             break;
         }
+        const int stopped = gpsbb_tx_end(tx);                       /* c:2757-2759 */
         gpsfe_feed_back(fe, st); /* the loop's in-place update of chan[i].carr_phase */
         if (stopped)
             break;

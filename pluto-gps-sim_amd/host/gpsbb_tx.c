@@ -100,6 +100,11 @@ int gpsbb_tx_end(gpsbb_tx_t *tx)
     return stopped ? 1 : 0;
 }
 
+void gpsbb_tx_cancel(gpsbb_tx_t *tx)
+{
+    pthread_mutex_unlock(&tx->data_mutex); /* nothing submitted: the TX thread keeps waiting */
+}
+
 unsigned long gpsbb_tx_delivered(gpsbb_tx_t *tx)
 {
     pthread_mutex_lock(&tx->data_mutex);

@@ -257,6 +257,9 @@ def main():
     stats = st.timing_stats(reset=True)
     chain_dev = synth.info(pkg.INFO_CHAIN_ON_DEVICE)
     last_kernel = synth.info(pkg.INFO_LAST_KERNEL)
+    chain_info = {"blocks_walked_sequentially": synth.info(pkg.INFO_CHAIN_FALLBACKS), "of_block_channels": pos * PB * nch,
+                  "wrap_ties_recorded": synth.info(pkg.INFO_CHAIN_TIES),
+                  "lane_runs_recomputed_exactly_by_k_synth_ev": synth.info(pkg.INFO_EXACT_RUNS)}
     st.close()
     elapsed = statistics.median(times)
     samples_per_step = STEP_PUSHES * PB * nsamp
@@ -329,6 +332,7 @@ def main():
                          "launches_timed": stats["runs"], "algorithmic_bytes_per_launch": 4 * samples_per_launch,
                          "note": "VALU-issue-bound, not HBM-bound: see DESIGN.md"},
             "prepass_ms_per_launch": ms_seed,
+            "device_chain": chain_info,
             "shard_seed_s": t_seed, "descriptor_generation_s": t_gen,
         }
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")

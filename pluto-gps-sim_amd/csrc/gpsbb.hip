@@ -264,6 +264,7 @@ struct gpsbb {
     hipStream_t s_seed = nullptr;    /* NCO seeding pre-pass (k_seed) and descriptor uploads            */
     hipStream_t s_seed2 = nullptr;   /* ... of every other batch / slot of a streaming ring (created on first use) */
     hipStream_t s_seed3 = nullptr;   /* ... a third one: batches whose carrier is chained on the device keep three pre-passes in flight */
+    hipStream_t s_seed4 = nullptr;   /* ... and a fourth, for the pushes of a stream (see batch_launch) */
     hipStream_t s_upload = nullptr;  /* descriptors and plans of a set-up: a stream of their own, so that they never queue
                                         behind an older push's pre-pass */
     unsigned batches_created = 0;
@@ -513,6 +514,8 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
         (void)hipStreamSynchronize(h->s_seed2);
     if (h->s_seed3)
         (void)hipStreamSynchronize(h->s_seed3);
+    if (h->s_seed4)
+        (void)hipStreamSynchronize(h->s_seed4);
     if (h->s_upload)
         (void)hipStreamSynchronize(h->s_upload);
     if (h->s_compute)
@@ -535,6 +538,8 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
         (void)hipStreamDestroy(h->s_seed2);
     if (h->s_seed3)
         (void)hipStreamDestroy(h->s_seed3);
+    if (h->s_seed4)
+        (void)hipStreamDestroy(h->s_seed4);
     if (h->s_upload)
         (void)hipStreamDestroy(h->s_upload);
     if (h->s_compute)
@@ -882,6 +887,8 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         (void)hipStreamSynchronize(b->h->s_seed2);
     if (b->h->s_seed3)
         (void)hipStreamSynchronize(b->h->s_seed3);
+    if (b->h->s_seed4)
+        (void)hipStreamSynchronize(b->h->s_seed4);
     (void)hipStreamSynchronize(b->h->s_compute);
     b->d_ch.release();
     b->d_row_off.release();
@@ -1269,13 +1276,16 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         const unsigned base = b->seed_stream == h->s_seed ? 0u : 1u;
         ss = pool[(base + b->run_count) % (unsigned)(b->nsets - 1)];
     } else if (b->d_carry && b->chain_dev) {
-        /* a stream's slot (one table set): consecutive pushes take the three seeding streams in turn */
+        /* a stream's slot (one table set): consecutive pushes take the four seeding streams in turn */
         if (!h->s_seed2)
             HIPCHK(h, hipStreamCreateWithFlags(&h->s_seed2, hipStreamNonBlocking));
         if (!h->s_seed3)
             HIPCHK(h, hipStreamCreateWithFlags(&h->s_seed3, hipStreamNonBlocking));
-        hipStream_t pool[3] = {h->s_seed, h->s_seed2, h->s_seed3};
-        ss = pool[b->stream_turn % 3u];
+        if (!h->s_seed4)
+            HIPCHK(h, hipStreamCreateWithFlags(&h->s_seed4, hipStreamNonBlocking));
+        static const unsigned nseed = getenv("GPSBB_STREAM_SEED_STREAMS") ? (unsigned)atoi(getenv("GPSBB_STREAM_SEED_STREAMS")) : 4u;
+        hipStream_t pool[4] = {h->s_seed, h->s_seed2, h->s_seed3, h->s_seed4};
+        ss = pool[b->stream_turn % (nseed >= 1 && nseed <= 4 ? nseed : 4u)];
     }
     if (b->upload_done)
         HIPCHK(h, hipStreamWaitEvent(ss, b->upload_done, 0));
@@ -1400,6 +1410,8 @@ extern "C" int gpsbb_sync(gpsbb_t *h)
         HIPCHK(h, hipStreamSynchronize(h->s_seed2));
     if (h->s_seed3)
         HIPCHK(h, hipStreamSynchronize(h->s_seed3));
+    if (h->s_seed4)
+        HIPCHK(h, hipStreamSynchronize(h->s_seed4));
     HIPCHK(h, hipStreamSynchronize(h->s_compute));
     HIPCHK(h, hipStreamSynchronize(h->s_copy));
     uint32_t st = 0;
@@ -1639,6 +1651,8 @@ extern "C" void gpsbb_stream_destroy(gpsbb_stream_t *s)
         (void)hipStreamSynchronize(s->h->s_seed2);
     if (s->h->s_seed3)
         (void)hipStreamSynchronize(s->h->s_seed3);
+    if (s->h->s_seed4)
+        (void)hipStreamSynchronize(s->h->s_seed4);
     (void)hipStreamSynchronize(s->h->s_compute);
     (void)hipStreamSynchronize(s->h->s_copy);
     delete s->carry;

@@ -24,12 +24,18 @@ def main():
     ap.add_argument("--chain", action="store_true")
     ap.add_argument("--synth-only", action="store_true", help="after warm-up re-run only the synthesis kernel on the tables already built")
     ap.add_argument("--per-sample", action="store_true", help="force the per-sample kernel k_synth")
+    ap.add_argument("--smooth", action="store_true", help="bench.py's stream descriptors (slowly varying Doppler) instead of M2's")
     ap.add_argument("--no-cpu", action="store_true", help="ignored (compatibility with older scripts)")
+    ap.add_argument("--fill-ceiling", action="store_true", help="also run the pure write kernel over the output buffer (counter calibration)")
     a = ap.parse_args()
     import torch
     from __graft_entry__ import load_package
     pkg = load_package()
-    ch = pkg.synth_descriptors(a.blocks, nch=a.nch, seed=0x5EED)
+    if a.smooth:
+        import bench
+        ch = bench.stream_descriptors(pkg, a.blocks, a.nch)
+    else:
+        ch = pkg.synth_descriptors(a.blocks, nch=a.nch, seed=0x5EED)
     synth = pkg.Synth(0)
     if a.per_sample:
         synth.set_option(pkg.OPT_SYNTH_KERNEL, 1)
@@ -51,6 +57,8 @@ def main():
     dt = time.perf_counter() - t0
     st = batch.timing_stats(reset=True)
     n = a.blocks * a.nsamp
+    if a.fill_ceiling:
+        synth.fill_ceiling(out.data_ptr(), out.numel() * 2, iters=10)
     print(json.dumps({"value": n * a.steps / dt, "ms_per_step": dt / a.steps * 1e3,
                       "roofline": {"ms_per_launch": st["ms_synth_sum"] / max(st["runs"], 1)},
                       "seed_kernel_ms_per_launch": st["ms_seed_sum"] / max(st["runs"], 1),

@@ -26,7 +26,8 @@ def q(db, sql):
 
 
 def short(name):
-    for k in ("k_synth", "k_seed", "k_fill_ceiling"):
+    for k in ("k_synth_ev", "k_synth", "k_walk<1>", "k_walk<2>", "k_walk<0>", "k_tiles", "k_chain_fix", "k_chain_prefix", "k_seed",
+              "k_fill_ceiling"):
         if k in name:
             return k
     return None
@@ -65,15 +66,18 @@ def main():
     if "k_fill_ceiling" in k and "WRITE_SIZE_KiB_per_launch" in k["k_fill_ceiling"] and bench:
         known = bench["roofline"]["algorithmic_bytes_per_launch"]  # the fill writes the same buffer
         res["write_size_calibration"] = k["k_fill_ceiling"]["WRITE_SIZE_KiB_per_launch"] * 1024.0 / known
-    if "k_synth" in k and "WRITE_SIZE_KiB_per_launch" in k["k_synth"]:
+    dom = "k_synth_ev" if "k_synth_ev" in k else "k_synth"   # the dominant kernel of the bench workload
+    res["dominant_kernel"] = dom
+    if dom in k and "WRITE_SIZE_KiB_per_launch" in k[dom]:
         cal = res.get("write_size_calibration", 1.0) or 1.0
-        w = k["k_synth"]["WRITE_SIZE_KiB_per_launch"] * 1024.0 / cal
-        r = 2.0 * k["k_synth"].get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024.0
+        w = k[dom]["WRITE_SIZE_KiB_per_launch"] * 1024.0 / cal
+        r = 2.0 * k[dom].get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024.0
         res["k_synth_hbm_write_bytes_per_launch"] = w
         res["k_synth_hbm_read_bytes_per_launch"] = r
         res["k_synth_hbm_bytes_per_launch"] = w + r
     if bench:
-        res["bench"] = {kk: bench[kk] for kk in ("value", "ms_per_step", "roofline", "seed_kernel_ms_per_launch") if kk in bench}
+        res["bench"] = {kk: bench[kk] for kk in ("value", "ms_per_step", "steps", "warmup", "repeats", "roofline",
+                                                 "prepass_ms_per_launch", "config") if kk in bench}
     print(json.dumps(res, indent=1))
     if prefix:
         with open(prefix + "_kernel_stats.txt", "w") as f:

@@ -18,6 +18,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 #include "gpsbb.h"
@@ -259,12 +260,15 @@ struct WorkPool {
     }
 };
 
+constexpr int SEED_STREAMS_MAX = 8;
+constexpr unsigned STREAM_SEED_STREAMS = 6; /* pre-passes of a stream's pushes in flight (GPSBB_STREAM_SEED_STREAMS) */
+
 struct gpsbb {
     int device = 0;
     hipStream_t s_seed = nullptr;    /* NCO seeding pre-pass (k_seed) and descriptor uploads            */
-    hipStream_t s_seed2 = nullptr;   /* ... of every other batch / slot of a streaming ring (created on first use) */
-    hipStream_t s_seed3 = nullptr;   /* ... a third one: batches whose carrier is chained on the device keep three pre-passes in flight */
-    hipStream_t s_seed4 = nullptr;   /* ... and a fourth, for the pushes of a stream (see batch_launch) */
+    hipStream_t s_more[SEED_STREAMS_MAX - 1] = {}; /* ... further ones, created on first use: every other batch, batches
+                                                      that keep several pre-passes in flight, the pushes of a stream
+                                                      (see batch_launch and seed_stream_at) */
     hipStream_t s_upload = nullptr;  /* descriptors and plans of a set-up: a stream of their own, so that they never queue
                                         behind an older push's pre-pass */
     unsigned batches_created = 0;
@@ -293,10 +297,13 @@ template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t cap = 0; /* elements */
-    int reserve(size_t n)
+    /* room: a first allocation that expects to be outgrown (the row pool of a ring slot, whose pushes see different
+     * Dopplers) takes that much more than asked, so that the stream does not stall on re-allocations later */
+    int reserve(size_t n, size_t room = 0)
     {
         if (n <= cap)
             return hipSuccess;
+        n += room;
         if (p) {
             (void)hipFree(p); /* synchronises the device: grow with head-room so that a ring whose slots see
                                  slightly different row counts stops re-allocating after a few pushes */
@@ -510,12 +517,9 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
         gpsbb_batch_destroy(h->scratch);
     if (h->s_seed)
         (void)hipStreamSynchronize(h->s_seed);
-    if (h->s_seed2)
-        (void)hipStreamSynchronize(h->s_seed2);
-    if (h->s_seed3)
-        (void)hipStreamSynchronize(h->s_seed3);
-    if (h->s_seed4)
-        (void)hipStreamSynchronize(h->s_seed4);
+    for (hipStream_t st : h->s_more)
+        if (st)
+            (void)hipStreamSynchronize(st);
     if (h->s_upload)
         (void)hipStreamSynchronize(h->s_upload);
     if (h->s_compute)
@@ -534,12 +538,9 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
     h->pool = nullptr;
     if (h->s_seed)
         (void)hipStreamDestroy(h->s_seed);
-    if (h->s_seed2)
-        (void)hipStreamDestroy(h->s_seed2);
-    if (h->s_seed3)
-        (void)hipStreamDestroy(h->s_seed3);
-    if (h->s_seed4)
-        (void)hipStreamDestroy(h->s_seed4);
+    for (hipStream_t st : h->s_more)
+        if (st)
+            (void)hipStreamDestroy(st);
     if (h->s_upload)
         (void)hipStreamDestroy(h->s_upload);
     if (h->s_compute)
@@ -556,9 +557,9 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     *out = nullptr;
     /* Up to seven streams carry work at the same time (three pre-pass streams, upload, compute, gather, the null
      * stream).  The runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share one
-     * run one after the other: ask for eight, unless the host has said otherwise.  Only takes effect if this is the
+     * run one after the other: ask for twelve, unless the host has said otherwise.  Only takes effect if this is the
      * process's first HIP call; a host that initialises HIP earlier (e.g. through torch) sets it itself. */
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    setenv("GPU_MAX_HW_QUEUES", "12", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
         return GPSBB_E_NODEVICE;
@@ -622,6 +623,43 @@ static void chain_carrier_host(const gpsbb_chan_t *ch, int nblocks, int nch, dou
 static bool host_seeding_wanted(const gpsbb_batch *b);
 
 /* upload `bytes` from pageable `src` through the batch's pinned arena (grown at the start of a set-up) */
+/* GPSBB_PUSH_TRACE=<ms>: where the host time of a stream push goes, printed for pushes that take longer than <ms> */
+struct PushTrace {
+    double limit_ms = -1.0;
+    int n = 0;
+    const char *what[32];
+    std::chrono::steady_clock::time_point t[32];
+    PushTrace()
+    {
+        const char *e = getenv("GPSBB_PUSH_TRACE");
+        if (e)
+            limit_ms = atof(e);
+    }
+    void start() { n = 0; mark("start"); }
+    void mark(const char *w)
+    {
+        if (limit_ms < 0.0 || n >= 32)
+            return;
+        what[n] = w;
+        t[n++] = std::chrono::steady_clock::now();
+    }
+    void end()
+    {
+        if (limit_ms < 0.0 || n < 2)
+            return;
+        mark("end");
+        const double tot = std::chrono::duration<double, std::milli>(t[n - 1] - t[0]).count();
+        if (tot < limit_ms)
+            return;
+        fprintf(stderr, "[gpsbb push %.2f ms]", tot);
+        for (int i = 1; i < n; i++)
+            fprintf(stderr, " %s %.2f", what[i], std::chrono::duration<double, std::milli>(t[i] - t[i - 1]).count());
+        fprintf(stderr, "\n");
+    }
+};
+static thread_local PushTrace g_push_trace;
+#define PUSH_MARK(w) g_push_trace.mark(w)
+
 static hipError_t stage_upload(gpsbb_batch *b, void *dst, const void *src, size_t bytes, hipStream_t stream)
 {
     const size_t at = (b->stage_used + 63) & ~(size_t)63;
@@ -653,6 +691,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
                             64 * 1024;
         if (b->upload_done) /* the previous set-up's copies out of the arena are long done; make sure */
             HIPCHK(h, hipEventSynchronize(b->upload_done));
+        PUSH_MARK("arena");
         if (need > b->stage_cap) {
             if (b->stage)
                 (void)hipHostFree(b->stage);
@@ -675,6 +714,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     /* Which synthesis kernel: the breakpoint kernel (gpsbb_events.hip.h) where every run of SPT samples holds
      * at most one chip change and at most EV_KC_MAX table-index changes and the I sums stay below 2^15. */
     b->ev = !fixed && h->opt_synth_kernel != 1 && ev_plan(ch, nblocks, nch, delt, b->h_evc);
+    PUSH_MARK("ev_plan");
 
     /* row pool plan: chain id = kind*nbc + block*nch + channel */
     b->row_off.assign(2 * nbc + 1, 0);
@@ -706,7 +746,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         if (b->ev) {
             HIPCHK(h, (hipError_t)b->d_tile_x[set].reserve(2 * nbc * (size_t)b->ntiles));
             HIPCHK(h, (hipError_t)b->d_tile_nav[set].reserve(nbc * (size_t)b->ntiles));
-            HIPCHK(h, (hipError_t)b->d_rows[set].reserve(b->total_rows + 4));
+            HIPCHK(h, (hipError_t)b->d_rows[set].reserve(b->total_rows + 4, b->max_sets == 1 ? (size_t)(b->total_rows / 2) : 0));
             HIPCHK(h, (hipError_t)b->d_row_cnt[set].reserve(2 * nbc));
         } else {
             HIPCHK(h, (hipError_t)b->d_rows[set].reserve(b->total_rows + 4)); /* + slack: k_synth prefetches one row past a chain */
@@ -796,7 +836,9 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
             if (b->h_ch[k].prn > 0)
                 b->h_ch[k].carr_phase = seeds[k];
     }
+    PUSH_MARK("aux");
     HIPCHK(h, stage_upload(b, b->d_ch.p, b->h_ch.data(), nbc * sizeof(gpsbb_chan_t), upload_stream));
+    PUSH_MARK("up_ch");
     HIPCHK(h, stage_upload(b, b->d_row_off.p, b->row_off.data(), (2 * nbc + 1) * 8, upload_stream));
     {
         /* which chain each lane of k_seed walks (BatchDev::seed_order).  k_seed takes as long as its slowest
@@ -845,6 +887,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
             waves_of(carr.data() + n8 + n16 + n32, nbc - n8 - n16 - n32, 64, (int32_t)nbc);
         }
         HIPCHK(h, (hipError_t)b->d_seed_order.reserve(order.size()));
+        PUSH_MARK("order");
         HIPCHK(h, stage_upload(b, b->d_seed_order.p, order.data(), order.size() * 4, upload_stream));
     }
     if (!b->upload_done)
@@ -864,17 +907,27 @@ static gpsbb_batch *batch_new(gpsbb *h)
     return b;
 }
 
-/* every other batch (and every other slot of a ring) seeds on the handle's second stream, created on first use */
-static hipError_t use_second_seed_stream(gpsbb_batch *b)
+/* seeding stream k of the handle (0 = s_seed), created on first use */
+static hipError_t seed_stream_at(gpsbb *h, unsigned k, hipStream_t *out)
 {
-    gpsbb *h = b->h;
-    if (!h->s_seed2) {
-        hipError_t e = hipStreamCreateWithFlags(&h->s_seed2, hipStreamNonBlocking);
+    if (k == 0 || k >= (unsigned)SEED_STREAMS_MAX) {
+        *out = h->s_seed;
+        return hipSuccess;
+    }
+    hipStream_t &st = h->s_more[k - 1];
+    if (!st) {
+        hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
         if (e != hipSuccess)
             return e;
     }
-    b->seed_stream = h->s_seed2;
+    *out = st;
     return hipSuccess;
+}
+
+/* every other batch (and every other slot of a ring) seeds on the handle's second stream */
+static hipError_t use_second_seed_stream(gpsbb_batch *b)
+{
+    return seed_stream_at(b->h, 1, &b->seed_stream);
 }
 
 extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
@@ -883,12 +936,9 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         return;
     (void)hipSetDevice(b->h->device);
     (void)hipStreamSynchronize(b->h->s_seed);
-    if (b->h->s_seed2)
-        (void)hipStreamSynchronize(b->h->s_seed2);
-    if (b->h->s_seed3)
-        (void)hipStreamSynchronize(b->h->s_seed3);
-    if (b->h->s_seed4)
-        (void)hipStreamSynchronize(b->h->s_seed4);
+    for (hipStream_t st : b->h->s_more)
+        if (st)
+            (void)hipStreamSynchronize(st);
     (void)hipStreamSynchronize(b->h->s_compute);
     b->d_ch.release();
     b->d_row_off.release();
@@ -1262,30 +1312,21 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         }
     }
     hipEvent_t *ev = b->evs[b->ev_used++].e;
+    PUSH_MARK("l_ev");
 
     /* The pre-pass runs on a seeding stream of its own: it may start as soon as the synthesis kernel that last
      * read this table set has finished, i.e. it overlaps the synthesis of the runs before it.  With three sets
      * consecutive runs take the handle's two seeding streams in turn, so that two pre-passes are in flight. */
     hipStream_t ss = b->seed_stream;
     if (b->nsets > 2) {
-        if (!h->s_seed2)
-            HIPCHK(h, hipStreamCreateWithFlags(&h->s_seed2, hipStreamNonBlocking));
-        if (b->nsets > 3 && !h->s_seed3)
-            HIPCHK(h, hipStreamCreateWithFlags(&h->s_seed3, hipStreamNonBlocking));
-        hipStream_t pool[3] = {h->s_seed, h->s_seed2, h->s_seed3};
         const unsigned base = b->seed_stream == h->s_seed ? 0u : 1u;
-        ss = pool[(base + b->run_count) % (unsigned)(b->nsets - 1)];
+        HIPCHK(h, seed_stream_at(h, (base + b->run_count) % (unsigned)(b->nsets - 1), &ss));
     } else if (b->d_carry && b->chain_dev) {
-        /* a stream's slot (one table set): consecutive pushes take the four seeding streams in turn */
-        if (!h->s_seed2)
-            HIPCHK(h, hipStreamCreateWithFlags(&h->s_seed2, hipStreamNonBlocking));
-        if (!h->s_seed3)
-            HIPCHK(h, hipStreamCreateWithFlags(&h->s_seed3, hipStreamNonBlocking));
-        if (!h->s_seed4)
-            HIPCHK(h, hipStreamCreateWithFlags(&h->s_seed4, hipStreamNonBlocking));
-        static const unsigned nseed = getenv("GPSBB_STREAM_SEED_STREAMS") ? (unsigned)atoi(getenv("GPSBB_STREAM_SEED_STREAMS")) : 4u;
-        hipStream_t pool[4] = {h->s_seed, h->s_seed2, h->s_seed3, h->s_seed4};
-        ss = pool[b->stream_turn % (nseed >= 1 && nseed <= 4 ? nseed : 4u)];
+        /* a stream's slot (one table set): consecutive pushes take the seeding streams in turn, so that as many
+         * pre-passes are in flight (a pre-pass is a chain of latency-bound kernels: ~12 ms whatever the size of the
+         * push, and the ring delivers one push per (that / streams)) */
+        static const unsigned nseed = getenv("GPSBB_STREAM_SEED_STREAMS") ? (unsigned)atoi(getenv("GPSBB_STREAM_SEED_STREAMS")) : STREAM_SEED_STREAMS;
+        HIPCHK(h, seed_stream_at(h, b->stream_turn % (nseed >= 1 && nseed <= (unsigned)SEED_STREAMS_MAX ? nseed : STREAM_SEED_STREAMS), &ss));
     }
     if (b->upload_done)
         HIPCHK(h, hipStreamWaitEvent(ss, b->upload_done, 0));
@@ -1335,6 +1376,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(ev[1], ss));
+    PUSH_MARK("l_pre");
 
     HIPCHK(h, hipStreamWaitEvent(h->s_compute, ev[1], 0));
     HIPCHK(h, hipMemsetAsync(b->d_tile_ctr.p, 0, (size_t)b->nblocks * sizeof(int32_t), h->s_compute));
@@ -1406,12 +1448,9 @@ extern "C" int gpsbb_sync(gpsbb_t *h)
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->s_upload));
     HIPCHK(h, hipStreamSynchronize(h->s_seed));
-    if (h->s_seed2)
-        HIPCHK(h, hipStreamSynchronize(h->s_seed2));
-    if (h->s_seed3)
-        HIPCHK(h, hipStreamSynchronize(h->s_seed3));
-    if (h->s_seed4)
-        HIPCHK(h, hipStreamSynchronize(h->s_seed4));
+    for (hipStream_t st : h->s_more)
+        if (st)
+            HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipStreamSynchronize(h->s_compute));
     HIPCHK(h, hipStreamSynchronize(h->s_copy));
     uint32_t st = 0;
@@ -1647,12 +1686,9 @@ extern "C" void gpsbb_stream_destroy(gpsbb_stream_t *s)
         return;
     (void)hipSetDevice(s->h->device);
     (void)hipStreamSynchronize(s->h->s_seed);
-    if (s->h->s_seed2)
-        (void)hipStreamSynchronize(s->h->s_seed2);
-    if (s->h->s_seed3)
-        (void)hipStreamSynchronize(s->h->s_seed3);
-    if (s->h->s_seed4)
-        (void)hipStreamSynchronize(s->h->s_seed4);
+    for (hipStream_t st : s->h->s_more)
+        if (st)
+            (void)hipStreamSynchronize(st);
     (void)hipStreamSynchronize(s->h->s_compute);
     (void)hipStreamSynchronize(s->h->s_copy);
     delete s->carry;
@@ -1702,7 +1738,7 @@ extern "C" int gpsbb_stream_create(gpsbb_t *h, int nch, double delt, int nsamp, 
         if (e == hipSuccess) e = (hipError_t)sl.batch->d_iq.reserve(iq_bytes / 2);
         if (e == hipSuccess && !(flags & GPSBB_STREAM_DEVICE_ONLY))
             e = hipHostMalloc((void **)&sl.h_iq, iq_bytes, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_end, end_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_end, end_bytes + 32, hipHostMallocDefault); /* + the status word */
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.computed, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming);
         if (e != hipSuccess) {
@@ -1746,6 +1782,7 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     if (s->head - s->tail >= (uint64_t)s->depth)
         return GPSBB_E_STATE; /* ring full: pop first */
     gpsbb *h = s->h;
+    g_push_trace.start();
     HIPCHK(h, hipSetDevice(h->device));
     auto &sl = s->slots[s->head % s->depth];
     gpsbb_batch *b = sl.batch;
@@ -1842,7 +1879,9 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     const bool fx_chain = (s->flags & GPSBB_FIXED_CARRIER) && (s->flags & GPSBB_CHAIN_CARRIER) && s->head > 0;
     b->fixed_prev_prn = fx_chain ? s->fx_prn : nullptr;
     b->fixed_prev_phase = fx_chain ? s->fx_phase : nullptr;
+    PUSH_MARK("plan");
     int rc = batch_setup(b, ch, s->bps, s->nch, s->delt, s->nsamp, run_flags, h->s_upload);
+    PUSH_MARK("setup");
     b->fixed_prev_prn = nullptr;
     b->fixed_prev_phase = nullptr;
     if (rc != GPSBB_OK) {
@@ -1861,17 +1900,37 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
         }
     b->last_iq = b->d_iq.p;
     rc = batch_launch(b, b->d_iq.p);
+    PUSH_MARK("launch");
     b->d_carry = nullptr;
     if (rc != GPSBB_OK)
         return rc;
     HIPCHK(h, hipEventRecord(sl.computed, h->s_compute));
+    PUSH_MARK("rec");
     /* gather on the side stream: pinned, asynchronous, overlaps the next push's kernels */
     hipStream_t cs = h->s_copy;
     HIPCHK(h, hipStreamWaitEvent(cs, sl.computed, 0));
-    if (sl.h_iq)
-        HIPCHK(h, hipMemcpyAsync(sl.h_iq, b->d_iq.p, (size_t)s->bps * s->nsamp * 4, hipMemcpyDeviceToHost, cs));
-    HIPCHK(h, hipMemcpyAsync(sl.h_end, b->d_end[b->last_set].p, (size_t)s->bps * s->nch * sizeof(gpsbb_chan_state_t),
-                             hipMemcpyDeviceToHost, cs));
+    PUSH_MARK("wait");
+    if (sl.h_iq) {
+        static const bool sdma = getenv("GPSBB_GATHER_SDMA") != nullptr; /* experiment: the runtime's copy instead */
+        static const int gwg = getenv("GPSBB_GATHER_WGS") ? atoi(getenv("GPSBB_GATHER_WGS")) : 32;
+        if (sdma) {
+            HIPCHK(h, hipMemcpyAsync(sl.h_iq, b->d_iq.p, (size_t)s->bps * s->nsamp * 4, hipMemcpyDeviceToHost, cs));
+        } else {
+            hipLaunchKernelGGL(k_gather_to_host, dim3(gwg), dim3(256), 0, cs, (const gather_u32x4 *)b->d_iq.p, (gather_u32x4 *)sl.h_iq,
+                               ((size_t)s->bps * s->nsamp * 4 + 15) / 16);
+            HIPCHK(h, hipGetLastError());
+        }
+    }
+    PUSH_MARK("iq");
+    {
+        /* end states (40 B each: a multiple of 16 bytes for any even count; odd counts are rounded up into the
+         * allocation's slack) + the self-check word, by a small kernel: see k_end_states_to_host */
+        const size_t bytes = (size_t)s->bps * s->nch * sizeof(gpsbb_chan_state_t);
+        hipLaunchKernelGGL(k_end_states_to_host, dim3(64), dim3(256), 0, cs, (const uint4 *)b->d_end[b->last_set].p,
+                           (uint4 *)sl.h_end, (bytes + 15) / 16, h->d_status, (uint32_t *)((char *)sl.h_end + ((bytes + 15) & ~(size_t)15)));
+        HIPCHK(h, hipGetLastError());
+    }
+    PUSH_MARK("endst");
     HIPCHK(h, hipEventRecord(sl.copied, cs));
     /* commit */
     if (carry_host)
@@ -1885,6 +1944,7 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     memcpy(s->fx_prn, fx_prn_next, sizeof fx_prn_next);
     memcpy(s->fx_phase, fx_phase_next, sizeof fx_phase_next);
     s->head++;
+    g_push_trace.end();
     return GPSBB_OK;
 }
 
@@ -1903,7 +1963,7 @@ extern "C" int gpsbb_stream_pop(gpsbb_stream_t *s, const int16_t **iq, gpsbb_cha
         memcpy(end_state, sl.h_end, (size_t)s->bps * s->nch * sizeof(gpsbb_chan_state_t));
     s->tail++;
     uint32_t st = 0;
-    HIPCHK(h, hipMemcpy(&st, h->d_status, 4, hipMemcpyDeviceToHost));
+    memcpy(&st, (const char *)sl.h_end + (((size_t)s->bps * s->nch * sizeof(gpsbb_chan_state_t) + 15) & ~(size_t)15), 4);
     if (st) {
         HIPCHK(h, hipMemset(h->d_status, 0, 4));
         return GPSBB_E_INTERNAL;

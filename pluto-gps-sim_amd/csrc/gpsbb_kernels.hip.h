@@ -1205,5 +1205,41 @@ __global__ __launch_bounds__(256) void k_fill_ceiling(uint4 *__restrict__ dst, s
     }
 }
 
+/* A stream slot's end-of-block states and the handle's self-check word, written straight into the slot's pinned
+ * host memory (device-visible): a few hundred KB per push.  A hipMemcpyAsync of that size stalls the calling host
+ * thread for milliseconds whenever the copy stream still waits for its event; a kernel launch never does. */
+__global__ __launch_bounds__(256) void k_end_states_to_host(const uint4 *__restrict__ src, uint4 *__restrict__ dst_host, size_t n16,
+                                                            const uint32_t *__restrict__ status, uint32_t *__restrict__ status_host)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+        dst_host[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *status_host = *status;
+}
+
+/* The gather of a stream slot's IQ into its pinned host buffer as a kernel (stores that leave over PCIe): unlike
+ * hipMemcpyAsync — which makes the calling thread wait until the copy stream's pending event wait is satisfied, i.e.
+ * for the whole pre-pass and synthesis of the push — a launch returns at once, so the host keeps the ring full.
+ * A workgroup moves 16 KB at a time, contiguous, so that the stores of a wavefront form full PCIe write bursts. */
+typedef unsigned int gather_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_gather_to_host(const gather_u32x4 *__restrict__ src, gather_u32x4 *__restrict__ dst_host, size_t n16)
+{
+    const size_t per = 256 * 4;
+    const size_t nchunk = (n16 + per - 1) / per;
+    for (size_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+        const size_t base = c * per + threadIdx.x;
+        gather_u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (base + (size_t)u * 256 < n16)
+                v[u] = __builtin_nontemporal_load(src + base + (size_t)u * 256);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (base + (size_t)u * 256 < n16)
+                __builtin_nontemporal_store(v[u], dst_host + base + (size_t)u * 256);
+    }
+}
+
 } /* namespace gpsbb_impl */
 #endif

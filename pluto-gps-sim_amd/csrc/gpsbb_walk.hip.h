@@ -541,6 +541,11 @@ __device__ __forceinline__ FixIn fix_load(const BatchDev &p, int b, int i)
 
 __global__ void k_chain_fix(BatchDev p)
 {
+#ifndef GPSBB_EXP_NOPRIO
+    /* one wavefront on whose latency every later push of the stream waits: let it win the issue arbitration
+     * against the synthesis wavefronts it shares its SIMD with */
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const int i = threadIdx.x;
     const bool lane_on = i < p.nch;
     const int il = lane_on ? i : 0;

@@ -738,7 +738,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
      * a free synchronises the device) */
     HIPCHK(h, (hipError_t)b->d_ch.reserve(nbc));
     HIPCHK(h, (hipError_t)b->d_row_off.reserve(2 * nbc + 1));
-    HIPCHK(h, (hipError_t)b->d_tile_ctr.reserve((size_t)nblocks));
+    HIPCHK(h, (hipError_t)b->d_tile_ctr.reserve((size_t)NSETS * (size_t)nblocks)); /* one set of counters per table set */
     b->nsets = b->ev ? ((flags & GPSBB_CHAIN_CARRIER) && nblocks > 1 && h->opt_chain_where == 0 ? 4 : 3) : 2;
     b->nsets = b->nsets > b->max_sets ? b->max_sets : b->nsets;
     for (int set = 0; set < b->nsets; set++) {
@@ -1273,7 +1273,7 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.row_off = b->d_row_off.p;
     p.tile_row = b->d_tile_row[set].p;
     p.row_cnt = b->d_row_cnt[set].p;
-    p.tile_ctr = b->d_tile_ctr.p;
+    p.tile_ctr = b->d_tile_ctr.p + (size_t)set * (size_t)b->nblocks;
     p.kph0 = (b->flags & GPSBB_FIXED_CARRIER) ? b->d_kph0.p : nullptr;
     p.kstep = (b->flags & GPSBB_FIXED_CARRIER) ? b->d_kstep.p : nullptr;
     p.end = b->d_end[set].p;
@@ -1333,6 +1333,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     if (b->synth_pending[set])
         HIPCHK(h, hipStreamWaitEvent(ss, b->synth_done[set], 0));
     HIPCHK(h, hipEventRecord(ev[0], ss));
+    bool ctr_reset_by_prepass = false;
     if (h->opt_skip_seed && b->run_count >= (unsigned)b->nsets) {
         /* measurement hook: time the synthesis kernel alone on tables already built */
     } else if (host_seeding_wanted(b)) {
@@ -1370,6 +1371,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
                 hipLaunchKernelGGL(k_walk<0>, wg_all, dim3(GPSBB_WALK_WG), 0, ss, p);
             }
             hipLaunchKernelGGL(k_tiles, dim3(2 * b->nblocks * b->nch), dim3(GPSBB_TILES_WG), 0, ss, p);
+            ctr_reset_by_prepass = true; /* k_tiles zeroes the set's tile counters */
         }
     } else {
         hipLaunchKernelGGL(k_seed<false>, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, ss, p);
@@ -1379,7 +1381,8 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     PUSH_MARK("l_pre");
 
     HIPCHK(h, hipStreamWaitEvent(h->s_compute, ev[1], 0));
-    HIPCHK(h, hipMemsetAsync(b->d_tile_ctr.p, 0, (size_t)b->nblocks * sizeof(int32_t), h->s_compute));
+    if (!ctr_reset_by_prepass)
+        HIPCHK(h, hipMemsetAsync(p.tile_ctr, 0, (size_t)b->nblocks * sizeof(int32_t), h->s_compute));
     HIPCHK(h, hipEventRecord(ev[2], h->s_compute));
     if (b->ev) {
         /* One workgroup of EV_WG lanes fits a CU (its LDS image takes ~140 KB).  Grid = (blocks, workgroups per

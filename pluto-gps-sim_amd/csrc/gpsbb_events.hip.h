@@ -153,7 +153,8 @@ struct EvHalf {
     int jk[KC]; /* row of D (= sample - 1) of the k-th index change, 15 = not in this run */
     int jc;     /* ... of the chip change */
     int c0;     /* chip of the first sample, not reduced modulo 1023 */
-    bool unsafe;
+    unsigned long long um; /* lanes that cannot rule out a disagreement between the model and the reference (wave mask:
+                              the comparisons land in scalar registers and are combined there) */
     uint32_t A[KC + 1];
     uint32_t ch2;
 };
@@ -167,12 +168,12 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK 
     const double y0 = __fma_rn(off, K.S, yt); /* >= 0 */
     const double fr = __builtin_amdgcn_fract(y0);
     const int it0 = (int)y0 & 511;
-    h.unsafe = fr < b; /* the previous change lies within the model error of sample 0 */
-    double t = (1.0 - fr) * K.rS; /* samples until the next index change */
+    h.um = __builtin_amdgcn_fcmp(fr, b, 4 /* olt */); /* the previous change lies within the model error of sample 0 */
+    double t = __fma_rn(-fr, K.rS, K.rS); /* (1 - fr) / |step|: samples until the next index change */
 #pragma unroll
     for (int k = 0; k < KC; k++) {
         const double tq = fmin(t, 15.5);
-        h.unsafe |= fabs(__builtin_amdgcn_fract(tq) - 0.5) > K.thrK;
+        h.um |= __builtin_amdgcn_fcmp(fabs(__builtin_amdgcn_fract(tq) - 0.5), K.thrK, 2 /* ogt */);
         h.jk[k] = (int)tq; /* the change shows at sample (int)tq + 1: rows 0..14, or 15 */
         t += K.rS;
     }
@@ -184,9 +185,9 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK 
     const double x0 = __fma_rn(off, K.sc, xt);
     const double frc = __builtin_amdgcn_fract(x0);
     h.c0 = (int)x0;
-    h.unsafe |= frc < b;
-    const double tc = fmin((1.0 - frc) * K.rsc, 15.5);
-    h.unsafe |= fabs(__builtin_amdgcn_fract(tc) - 0.5) > K.thrC;
+    h.um |= __builtin_amdgcn_fcmp(frc, b, 4);
+    const double tc = fmin(__fma_rn(-frc, K.rsc, K.rsc), 15.5);
+    h.um |= __builtin_amdgcn_fcmp(fabs(__builtin_amdgcn_fract(tc) - 0.5), K.thrC, 2);
     h.jc = (int)tc;
     h.ch2 = L.chip2[i][h.c0];
     return h;
@@ -199,7 +200,7 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK 
  */
 template <int KC, bool DF>
 __device__ __forceinline__ void ev_second(EvLds &L, int wave, int lane, int i, EvHalf<KC> &h, uint32_t db, uint32_t db_next,
-                                          bool always_exact, bool lane_live, const EvConst *kb, const double *tile_x,
+                                          bool always_exact, unsigned long long live_mask, const EvConst *kb, const double *tile_x,
                                           int ntiles, uint32_t nb, double off, uint32_t &acc0, unsigned long long *n_exact)
 {
     const uint32_t ma = (uint32_t)(int32_t)(int8_t)(h.ch2 & 0xffu), mb = (uint32_t)(int32_t)(int8_t)(h.ch2 >> 8);
@@ -214,9 +215,9 @@ __device__ __forceinline__ void ev_second(EvLds &L, int wave, int lane, int i, E
     int jc = m0 == m1 ? EV_ROW_DISCARD : h.jc; /* equal neighbours: nothing changes at the chip boundary */
 
     /* ---- rare: this lane cannot rule out that the model and the reference disagree ---- */
-    const bool unsafe = (h.unsafe || always_exact) && lane_live;
-    if (__builtin_expect(__ballot(unsafe) != 0ull, 0)) {
-        if (unsafe) {
+    const unsigned long long um = (always_exact ? ~0ull : h.um) & live_mask;
+    if (__builtin_expect(um != 0ull, 0)) {
+        if ((um >> lane) & 1ull) {
             /* its fast-path contribution becomes nothing ... */
 #pragma unroll
             for (int k = 0; k < KC; k++)
@@ -258,7 +259,7 @@ struct EvTile {
  * arithmetic covers the other's LDS latency */
 template <int KC, bool DF>
 __device__ __forceinline__ void ev_channels(EvLds &L, int wave, int lane, uint32_t mask, const EvConst *kb, const EvTile &T,
-                                            double off, bool lane_live, uint32_t &acc0, unsigned long long *n_exact)
+                                            double off, unsigned long long live_mask, uint32_t &acc0, unsigned long long *n_exact)
 {
 #define GPSBB_EV_IN(i)                                                                                                 \
     const EvK K##i = ev_load_k(kb, i);                                                                                 \
@@ -267,7 +268,7 @@ __device__ __forceinline__ void ev_channels(EvLds &L, int wave, int lane, uint32
     {                                                                                                                  \
         const uint32_t db_ = 0u - ((T.dbits >> i) & 1u), dn_ = 0u - ((T.dnext >> i) & 1u);                             \
         const uint32_t nb_ = ((T.dbits >> i) & 1u) | (((T.dnext >> i) & 1u) << 1);                                     \
-        ev_second<KC, DF>(L, wave, lane, i, h, db_, dn_, ((T.exact_mask >> i) & 1u) != 0, lane_live, kb, T.tile_x,      \
+        ev_second<KC, DF>(L, wave, lane, i, h, db_, dn_, ((T.exact_mask >> i) & 1u) != 0, live_mask, kb, T.tile_x,      \
                           T.ntiles, nb_,                                                                               \
                           off, acc0, n_exact);                                                                         \
     }
@@ -310,38 +311,43 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
     const gpsbb_chan_t *__restrict__ cb = p.ch + (size_t)b * p.nch;
     const EvConst *__restrict__ kb = p.evc + (size_t)b * p.nch;
     /* ---- stage the block's per-channel tables in LDS (once per workgroup) ---- */
-    for (int e = tid; e < p.nch * EV_AMP_STRIDE; e += EV_WG) {
-        const int i = e / EV_AMP_STRIDE;
-        int k = (e % EV_AMP_STRIDE) & 511;
-        uint32_t v = 0;
-        if (cb[i].prn > 0) {
-            if (kb[i].down)
-                k = 511 - k; /* falling carrier: the table back to front (see ev_first) */
-            const double g = cb[i].gain;
-            /* (int)(table * gain): one IEEE multiply, truncation toward zero (plutogpssim.c:2701-2702) */
-            const int ip = (int)mul_rn((double)p.tabs[k], g);
-            const int qp = (int)mul_rn((double)p.tabs[512 + k], g);
-            v = ((uint32_t)qp << 16) + (uint32_t)ip;
-        }
-        L.amp[i][e % EV_AMP_STRIDE] = v;
-    }
-    for (int e = tid; e < p.nch * EV_CHIP_LEN; e += EV_WG) {
-        const int i = e / EV_CHIP_LEN, c = e % EV_CHIP_LEN;
+    /* wavefront w stages channels w, w + 16, ...: what depends on the channel alone is wave-uniform */
+    for (int i = __builtin_amdgcn_readfirstlane(tid >> 6); i < p.nch; i += EV_WAVES) {
         const int prn = cb[i].prn;
-        const int ca = c % GPSBB_CA_LEN, cb1 = (c + 1) % GPSBB_CA_LEN;
-        uint32_t v = 0;
-        if (prn > 0) {
-            const uint32_t b0 = (p.ca_bits[prn * 32 + (ca >> 5)] >> (ca & 31)) & 1u;
-            const uint32_t b1 = (p.ca_bits[prn * 32 + (cb1 >> 5)] >> (cb1 & 31)) & 1u;
-            v = (b0 ? 0x00u : 0xffu) | (b1 ? 0x0000u : 0xff00u);
+        const bool down = kb[i].down != 0; /* falling carrier: the table back to front (see ev_first) */
+        const double g = cb[i].gain;
+        for (int e = tid & 63; e < EV_AMP_STRIDE; e += 64) {
+            const int k = down ? 511 - (e & 511) : (e & 511);
+            uint32_t v = 0;
+            if (prn > 0) {
+                /* (int)(table * gain): one IEEE multiply, truncation toward zero (plutogpssim.c:2701-2702) */
+                const int ip = (int)mul_rn((double)p.tabs[k], g);
+                const int qp = (int)mul_rn((double)p.tabs[512 + k], g);
+                v = ((uint32_t)qp << 16) + (uint32_t)ip;
+            }
+            L.amp[i][e] = v;
         }
-        L.chip2[i][c] = (uint16_t)v;
+        const uint32_t *__restrict__ bits = p.ca_bits + (prn > 0 ? prn : 0) * 32;
+        for (int c = tid & 63; c < EV_CHIP_LEN; c += 64) {
+            const int ca = c >= GPSBB_CA_LEN ? c - GPSBB_CA_LEN : c; /* c < 2 * 1023 */
+            const int cb1 = c + 1 >= GPSBB_CA_LEN ? c + 1 - GPSBB_CA_LEN : c + 1;
+            uint32_t v = 0;
+            if (prn > 0) {
+                const uint32_t b0 = (bits[ca >> 5] >> (ca & 31)) & 1u;
+                const uint32_t b1 = (bits[cb1 >> 5] >> (cb1 & 31)) & 1u;
+                v = (b0 ? 0x00u : 0xffu) | (b1 ? 0x0000u : 0xff00u);
+            }
+            L.chip2[i][c] = (uint16_t)v;
+        }
     }
     for (int e = tid; e < EV_WAVES * 16 * 64; e += EV_WG)
         (&L.D[0][0][0])[e] = 0u;
     __syncthreads();
 
     /* ---- from here on every wavefront works alone ---- */
+#ifdef GPSBB_EV_PRIO
+    __builtin_amdgcn_s_setprio(GPSBB_EV_PRIO);
+#endif
     const int wave = tid >> 6, lane = tid & 63;
     const int ntw = p.ntiles;
     const int nch2 = 2 * p.nch;
@@ -415,16 +421,17 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
         const int n0 = wt * TILE + lane * SPT;
         const int nvalid = p.nsamp - n0 < SPT ? p.nsamp - n0 : SPT;
         const bool lane_live = nvalid > 0;
+        const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(lane_live);
         uint32_t acc0 = 0;
-        ev_channels<1, false>(L, wave, lane, mk[0] & ~dflip, kb, T, off, lane_live, acc0, n_exact);
-        ev_channels<2, false>(L, wave, lane, mk[1] & ~dflip, kb, T, off, lane_live, acc0, n_exact);
+        ev_channels<1, false>(L, wave, lane, mk[0] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
+        ev_channels<2, false>(L, wave, lane, mk[1] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
         if (__builtin_expect((mk[2] | mk[3] | dflip) != 0u, 0)) {
-            ev_channels<3, false>(L, wave, lane, mk[2] & ~dflip, kb, T, off, lane_live, acc0, n_exact);
-            ev_channels<4, false>(L, wave, lane, mk[3] & ~dflip, kb, T, off, lane_live, acc0, n_exact);
-            ev_channels<1, true>(L, wave, lane, mk[0] & dflip, kb, T, off, lane_live, acc0, n_exact);
-            ev_channels<2, true>(L, wave, lane, mk[1] & dflip, kb, T, off, lane_live, acc0, n_exact);
-            ev_channels<3, true>(L, wave, lane, mk[2] & dflip, kb, T, off, lane_live, acc0, n_exact);
-            ev_channels<4, true>(L, wave, lane, mk[3] & dflip, kb, T, off, lane_live, acc0, n_exact);
+            ev_channels<3, false>(L, wave, lane, mk[2] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
+            ev_channels<4, false>(L, wave, lane, mk[3] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
+            ev_channels<1, true>(L, wave, lane, mk[0] & dflip, kb, T, off, live_mask, acc0, n_exact);
+            ev_channels<2, true>(L, wave, lane, mk[1] & dflip, kb, T, off, live_mask, acc0, n_exact);
+            ev_channels<3, true>(L, wave, lane, mk[2] & dflip, kb, T, off, live_mask, acc0, n_exact);
+            ev_channels<4, true>(L, wave, lane, mk[3] & dflip, kb, T, off, live_mask, acc0, n_exact);
         }
         /* ---- prefix sum over the run, back to int16 pairs, store (c:2754-2755) ---- */
         uint32_t o[SPT];
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
             if (j)
                 P += __hip_atomic_exchange(&L.D[wave][j - 1][lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const uint32_t t = P + 0x8000u; /* undoes the borrow of a negative I in the high half */
-            o[j] = ((P ^ t) & 0xffffu) ^ t; /* low half of P, high half of t */
+            o[j] = __builtin_amdgcn_perm(t, P, 0x07060100u); /* low half of P, high half of t (v_perm_b32) */
         }
         uint32_t *out = reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + n0;
         if (nvalid == SPT && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) {

@@ -695,6 +695,10 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
     const int chain = blockIdx.x;
     const int nbc = p.nblocks * p.nch;
     const int kind = chain >= nbc ? 1 : 0, bi = chain - kind * nbc;
+    /* the tile counters of this table set, for the synthesis kernel that follows (the one that last used them has
+     * finished: the pre-pass waited for it): saves a memset and its launch gap on the synthesis stream */
+    if (chain < p.nblocks && threadIdx.x == 0)
+        p.tile_ctr[chain] = 0;
     const int cnt = p.row_cnt[chain];
     if (cnt <= 0)
         return;

@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <vector>
 
-#define ITER 2048
+#define ITER 16384
 template <int OP>
 __global__ __launch_bounds__(256) void k(double *out, double s, int n)
 {
@@ -44,6 +44,22 @@ __global__ __launch_bounds__(256) void k(double *out, double s, int n)
             if (OP == 22) { asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(b[i]) : "v"(raddr), "n"(i * 4)); }
             if (OP == 23) { asm volatile("ds_read_b32 %0, %3 offset:%4\n\tv_xor_b32 %1, %1, %2\n\tv_xor_b32 %2, %1, %2\n\tv_xor_b32 %1, %1, %2\n\tv_xor_b32 %2, %1, %2" : "=v"(b[i]), "+v"(x0), "+v"(x1) : "v"(laddr), "n"(i * 4)); }
             if (OP == 24) { asm volatile("v_xor_b32 %0, %0, %1\n\tv_xor_b32 %1, %0, %1\n\tv_xor_b32 %0, %0, %1\n\tv_xor_b32 %1, %0, %1" : "+v"(x0), "+v"(x1)); }
+            if (OP == 30) { asm volatile("v_fract_f64 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7])); }
+            if (OP == 31) { asm volatile("v_min_f64 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7])); }
+            if (OP == 32) { asm volatile("v_cmp_lt_f64 vcc, %0, %1" : : "v"(a[i]), "v"(a[(i + 1) & 7]) : "vcc"); }
+            if (OP == 33) { float f = __int_as_float(b[i]), g = __int_as_float(b[(i + 1) & 7]); asm volatile("v_fract_f32 %0, %1" : "=v"(f) : "v"(g)); b[i] = __float_as_int(f); }
+            if (OP == 34) { float f = __int_as_float(b[i]), g = __int_as_float(b[(i + 1) & 7]); asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(f) : "v"(g)); b[i] = __float_as_int(f); }
+            if (OP == 35) { asm volatile("v_bfe_i32 %0, %1, 8, 8" : "=v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 36) { asm volatile("v_cmp_lt_i32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7]) : "vcc"); }
+            if (OP == 37) { asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(b[i]) : "v"(a[(i + 1) & 7])); }
+            if (OP == 38) { asm volatile("v_sub_u32 %0, %1, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 39) { asm volatile("v_add_f64 %0, %1, -0.5" : "=v"(a[i]) : "v"(a[(i + 1) & 7])); }
+            if (OP == 40) { asm volatile("v_cmp_gt_f64 vcc, |%0|, %1" : : "v"(a[i]), "v"(a[(i + 1) & 7]) : "vcc"); }
+            if (OP == 41) { asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 42) { asm volatile("v_and_or_b32 %0, %1, %2, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7])); }
+            if (OP == 43) { asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(b[i]) : "v"(b[(i + 1) & 7]) : "vcc"); }
+            if (OP == 44) { asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7])); }
+            if (OP == 45) { asm volatile("v_rndne_f64 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7])); }
             if (OP == 17) { scratch[(threadIdx.x & 63) * 17 + ((b[i] + it) & 15) + (threadIdx.x >> 6) * 1088] = (unsigned)i; }
             if (OP == 18) { b[i] += scratch[(threadIdx.x & 63) * 17 + ((b[(i+1)&7] + it) & 15) + (threadIdx.x >> 6) * 1088]; }
         }
@@ -102,5 +118,21 @@ int main()
     run<24>("4x v_xor", 4);
     run<23>("ds_read_b32 + 4x v_xor (per group)", 1);
     run<18>("addr calc + ds_read_b32 + add", 1);
+    run<30>("v_fract_f64", 1);
+    run<31>("v_min_f64", 1);
+    run<32>("v_cmp_lt_f64", 1);
+    run<39>("v_add_f64 (inline const)", 1);
+    run<40>("v_cmp_gt_f64 |abs|", 1);
+    run<45>("v_rndne_f64", 1);
+    run<37>("v_cvt_f32_f64", 1);
+    run<33>("v_fract_f32", 1);
+    run<34>("v_fma_f32", 1);
+    run<44>("v_pk_fma_f32", 1);
+    run<41>("v_cvt_i32_f32", 1);
+    run<35>("v_bfe_i32", 1);
+    run<36>("v_cmp_lt_i32 + v_cndmask", 2);
+    run<43>("v_cndmask_b32", 1);
+    run<38>("v_sub_u32", 1);
+    run<42>("v_and_or_b32", 1);
     return 0;
 }

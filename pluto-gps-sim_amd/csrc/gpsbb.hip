@@ -273,6 +273,9 @@ struct gpsbb {
                                         behind an older push's pre-pass */
     unsigned batches_created = 0;
     hipStream_t s_compute = nullptr; /* synthesis kernel (k_synth)                                      */
+    hipStream_t s_compute2 = nullptr; /* ... of every other launch: consecutive synthesis kernels work on different table sets and
+                                         output ranges, so the head of one may fill the CUs the tail of the other leaves idle */
+    unsigned compute_turn = 0;
     hipStream_t s_copy = nullptr;    /* device-to-host gather                                            */
     std::vector<uint32_t> h_ca;      /* host copy of the C/A chips (seeding of small batches on the host)  */
     unsigned long long host_dwrd_oob = 0, host_itable_512 = 0; /* hazards counted by host-side seeding      */
@@ -341,6 +344,7 @@ struct gpsbb_batch {
      * 6.6e9 -> 7.3e9 samples/s at depth 3, 8.4e9 at depth 4).  Two, not one per slot: with the compute and
      * copy streams that makes four, and streams beyond the hardware queues share them. */
     hipStream_t seed_stream = nullptr;
+    hipStream_t last_cs = nullptr; /* the synthesis stream of the last launch */
     int nblocks = 0, nch = 0, nsamp = 0, ntiles = 0;
     double delt = 0.0;
     unsigned flags = 0;
@@ -524,6 +528,8 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
         (void)hipStreamSynchronize(h->s_upload);
     if (h->s_compute)
         (void)hipStreamSynchronize(h->s_compute);
+    if (h->s_compute2)
+        (void)hipStreamSynchronize(h->s_compute2);
     if (h->s_copy)
         (void)hipStreamSynchronize(h->s_copy);
     if (h->d_tabs)
@@ -545,6 +551,8 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
         (void)hipStreamDestroy(h->s_upload);
     if (h->s_compute)
         (void)hipStreamDestroy(h->s_compute);
+    if (h->s_compute2)
+        (void)hipStreamDestroy(h->s_compute2);
     if (h->s_copy)
         (void)hipStreamDestroy(h->s_copy);
     delete h;
@@ -592,6 +600,7 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     h->sm_count = prop.multiProcessorCount;
     if ((e = hipStreamCreateWithFlags(&h->s_seed, hipStreamNonBlocking)) != hipSuccess) return fail(e);
     if ((e = hipStreamCreateWithFlags(&h->s_compute, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+    if ((e = hipStreamCreateWithFlags(&h->s_compute2, hipStreamNonBlocking)) != hipSuccess) return fail(e);
     if ((e = hipStreamCreateWithFlags(&h->s_upload, hipStreamNonBlocking)) != hipSuccess) return fail(e);
     if ((e = hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&h->d_tabs, sizeof tabs)) != hipSuccess) return fail(e);
@@ -940,6 +949,7 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         if (st)
             (void)hipStreamSynchronize(st);
     (void)hipStreamSynchronize(b->h->s_compute);
+    (void)hipStreamSynchronize(b->h->s_compute2);
     b->d_ch.release();
     b->d_row_off.release();
     if (b->upload_done)
@@ -1380,10 +1390,19 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     HIPCHK(h, hipEventRecord(ev[1], ss));
     PUSH_MARK("l_pre");
 
-    HIPCHK(h, hipStreamWaitEvent(h->s_compute, ev[1], 0));
+    /* off by default: +2 % on a stream of pushes, but overlapping kernels make the per-launch time (the roofline figure)
+     * meaningless and re-runs of a resident batch get slower */
+    static const bool one_cs = getenv("GPSBB_TWO_COMPUTE_STREAMS") == nullptr;
+    /* consecutive launches take the two synthesis streams in turn — they work on different table sets (or, slots of
+     * a ring, different batches) — except re-runs of a batch that has a single table set */
+    hipStream_t sc = h->s_compute;
+    if (!one_cs && (b->nsets >= 2 || b->max_sets == 1) && ((h->compute_turn++) & 1u))
+        sc = h->s_compute2;
+    b->last_cs = sc;
+    HIPCHK(h, hipStreamWaitEvent(sc, ev[1], 0));
     if (!ctr_reset_by_prepass)
-        HIPCHK(h, hipMemsetAsync(p.tile_ctr, 0, (size_t)b->nblocks * sizeof(int32_t), h->s_compute));
-    HIPCHK(h, hipEventRecord(ev[2], h->s_compute));
+        HIPCHK(h, hipMemsetAsync(p.tile_ctr, 0, (size_t)b->nblocks * sizeof(int32_t), sc));
+    HIPCHK(h, hipEventRecord(ev[2], sc));
     if (b->ev) {
         /* One workgroup of EV_WG lanes fits a CU (its LDS image takes ~140 KB).  Grid = (blocks, workgroups per
          * block) with the block as the fast dimension, see k_synth_ev: enough workgroups per block that the
@@ -1397,7 +1416,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         long want = (wg_slots * oversub + b->nblocks - 1) / b->nblocks;
         want = want < min_wg ? min_wg : want;
         want = want > max_useful ? max_useful : want;
-        hipLaunchKernelGGL(k_synth_ev, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), h->s_compute, p, d_iq);
+        hipLaunchKernelGGL(k_synth_ev, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), sc, p, d_iq);
         h->last_kernel = 2;
         h->last_chain_dev = b->chain_dev ? 1 : 0;
     } else {
@@ -1413,11 +1432,11 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         long want = (wg_slots * oversub + b->nblocks - 1) / b->nblocks;
         want = want < 1 ? 1 : (want > max_useful ? max_useful : want);
         const int gx = (int)want;
-        hipLaunchKernelGGL(k_synth, dim3(gx, b->nblocks), dim3(TILE_THREADS), sizeof(SynthLds), h->s_compute, p, d_iq);
+        hipLaunchKernelGGL(k_synth, dim3(gx, b->nblocks), dim3(TILE_THREADS), sizeof(SynthLds), sc, p, d_iq);
     }
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(ev[3], h->s_compute));
-    HIPCHK(h, hipEventRecord(b->synth_done[set], h->s_compute));
+    HIPCHK(h, hipEventRecord(ev[3], sc));
+    HIPCHK(h, hipEventRecord(b->synth_done[set], sc));
     b->synth_pending[set] = true;
     b->last_set = set;
     b->run_count++;
@@ -1455,6 +1474,7 @@ extern "C" int gpsbb_sync(gpsbb_t *h)
         if (st)
             HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipStreamSynchronize(h->s_compute));
+    HIPCHK(h, hipStreamSynchronize(h->s_compute2));
     HIPCHK(h, hipStreamSynchronize(h->s_copy));
     uint32_t st = 0;
     HIPCHK(h, hipMemcpy(&st, h->d_status, 4, hipMemcpyDeviceToHost));
@@ -1595,10 +1615,10 @@ extern "C" int gpsbb_fill_block_ex(gpsbb_t *h, const gpsbb_chan_t *ch, int nch, 
     rc = gpsbb_batch_run(b, nullptr);
     if (rc != GPSBB_OK)
         return rc;
-    HIPCHK(h, hipMemcpyAsync(iq_out, b->last_iq, (size_t)nsamp * 4, hipMemcpyDeviceToHost, h->s_compute));
+    HIPCHK(h, hipMemcpyAsync(iq_out, b->last_iq, (size_t)nsamp * 4, hipMemcpyDeviceToHost, b->last_cs));
     if (end_state)
         HIPCHK(h, hipMemcpyAsync(end_state, b->d_end[b->last_set].p, (size_t)nch * sizeof(gpsbb_chan_state_t),
-                                 hipMemcpyDeviceToHost, h->s_compute));
+                                 hipMemcpyDeviceToHost, b->last_cs));
     return gpsbb_sync(h);
 }
 
@@ -1693,6 +1713,7 @@ extern "C" void gpsbb_stream_destroy(gpsbb_stream_t *s)
         if (st)
             (void)hipStreamSynchronize(st);
     (void)hipStreamSynchronize(s->h->s_compute);
+    (void)hipStreamSynchronize(s->h->s_compute2);
     (void)hipStreamSynchronize(s->h->s_copy);
     delete s->carry;
     if (s->d_carry)
@@ -1907,7 +1928,7 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     b->d_carry = nullptr;
     if (rc != GPSBB_OK)
         return rc;
-    HIPCHK(h, hipEventRecord(sl.computed, h->s_compute));
+    HIPCHK(h, hipEventRecord(sl.computed, b->last_cs));
     PUSH_MARK("rec");
     /* gather on the side stream: pinned, asynchronous, overlaps the next push's kernels */
     hipStream_t cs = h->s_copy;

@@ -345,9 +345,6 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
     __syncthreads();
 
     /* ---- from here on every wavefront works alone ---- */
-#ifdef GPSBB_EV_PRIO
-    __builtin_amdgcn_s_setprio(GPSBB_EV_PRIO);
-#endif
     const int wave = tid >> 6, lane = tid & 63;
     const int ntw = p.ntiles;
     const int nch2 = 2 * p.nch;

@@ -45,8 +45,8 @@ struct WalkLane {
     int32_t prev_ex;   /* biased exponent of the previous row's states */
     bool prev_wrapped; /* the step before this row wrapped */
     bool prev_tie;     /* ... and its "+ 1.0" was an exact tie (falling phase) */
-    bool tie_done;     /* a tie has been recorded: both trajectories left it with an even mantissa, the offset is an
-                          even number of grid steps from there on and no later tie can change it */
+    bool tie_done;     /* a tie after the first wrap has been recorded: both trajectories left it with an even mantissa, the
+                          offset is an even number of grid steps from there on and no later tie can change it */
     bool wrap_seen;    /* the first wrap is behind: the offset is settled */
     double margin;     /* smallest distance of a row's first or last state to an edge of its binade */
     uint32_t hz512;    /* carrier: samples whose phase is exactly 1.0 (gpsbb_hazards_t.itable_512) */
@@ -160,7 +160,11 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
                 if (__builtin_expect(__ballot(cross) != 0ull, 0)) {
                     if (cross && w.prev_tie) {
                         atomicAdd(hz + 5, 1ull);
-                        w.tie_done = true;
+                        /* A tie settles the parity of the offset only if BOTH trajectories tied, i.e. if the offset
+                         * already was a multiple of the coarsest grid: true from the first wrap on.  At the first
+                         * wrap itself the offset may still be half a step of that grid — pass B ties, the true
+                         * trajectory lands on a grid point (odd or even) — so later ties still have to be looked at. */
+                        w.tie_done = w.wrap_seen;
                     }
                     if (cross) {
                         if (w.ncross >= 0 && w.ncross < CHAIN_MAX_CROSS)
@@ -644,6 +648,12 @@ __global__ void k_chain_fix(BatchDev p)
         if (on && ok && d0 != 0.0)
             end = end + d; /* exact: the true end state is a double */
 #ifdef GPSBB_CHAIN_DEBUG
+        if (on && p.nch == 1) {
+            printf("fix b %d x %.17g start1 %.17g d0 %.3e margin %.3e ncross %d wrap_row %d tie_top %d tie_asc %d ok %d endB %.17g end %.17g s %.17g\n", b, x,
+                   in.start1, d0, margin, ncross, in.wrap_row, (int)tie_top, (int)tie_asc, (int)ok, in.endB, end, s);
+            for (int j = 0; j < ncross && j < CHAIN_MAX_CROSS; j++)
+                printf("    cross %d row %d pre %.17g post %.17g seg %.3e\n", j, a.cross[j], a.pre[j], a.post[j], a.seg[j + 1]);
+        }
         if (on && !ok)
             printf("chain fallback: block %d ch %d d0 %.3e d %.3e margin %.3e ncross %d es %d tie_top %d tie_asc %d wrap_row %d\n", b,
                    i, d0, d, margin, ncross, es, (int)tie_top, (int)tie_asc, in.wrap_row);

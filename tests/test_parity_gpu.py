@@ -333,6 +333,34 @@ def test_device_chain_with_steps_that_tie_on_the_coarsest_grid(pkg, synth, oracl
     assert (iq == want_iq).all()
 
 
+def test_device_chain_tie_at_the_first_wrap_of_pass_b_only(pkg, synth, oracle, request):
+    """Found by the stream soak (tools/fuzz_parity.py --stream, seed 3 case 28): a falling carrier at 30 MS/s whose
+    pass B starts half a step of the coarsest grid below the true phase.  At the block's first wrap pass B's "+ 1.0"
+    is an exact tie while the true sum lands on a grid point, which leaves the two an ODD number of grid steps apart —
+    so the tie at the block's second wrap (both trajectories tie there) still changes the offset and has to be
+    recorded.  Pushed through a ring in pushes of 33 blocks, as it failed; bit-exact end states and IQ."""
+    ch = np.load(os.path.join(GOLDEN, "chain_first_wrap_tie_desc.npy"))
+    fs, nsamp, bps = 30e6, 24607, 33
+    nb = ch.shape[0]
+    want_iq, want_st, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
+    for depth in (2, 4):
+        st_ = synth.stream(1, 1 / fs, nsamp, bps, depth=depth, flags=pkg.CHAIN_CARRIER)
+        got, gst = [], []
+        for k in range(nb // bps):
+            if st_.pending == depth:
+                a, b = st_.pop()
+                got.append(a), gst.append(b)
+            st_.push(ch[k * bps:(k + 1) * bps])
+        while st_.pending:
+            a, b = st_.pop()
+            got.append(a), gst.append(b)
+        st_.close()
+        gst = np.concatenate(gst)
+        for k in range(nb):
+            assert_state_equal(gst[k], want_st[k], ch["prn"][k] > 0)
+        assert (np.concatenate(got) == want_iq).all()
+
+
 def test_stream_carrier_carried_on_the_device(pkg, synth, oracle, request):
     """A chained stream at 25 MS/s: the exact carrier phase is carried from push to push in device memory (no host
     chain), channels come and go between pushes, and the bytes are those of the oracle walking all blocks in

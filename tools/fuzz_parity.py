@@ -16,6 +16,80 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
+def stream_soak(a):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+    import torch  # noqa: F401
+    from __graft_entry__ import load_package
+    import oracle_binding as ob
+    pkg = load_package()
+    oracle = ob.Oracle()
+    rng = np.random.default_rng(a.seed)
+    fallbacks = ties = 0
+    with pkg.Synth(0) as synth:
+        for case in range(a.cases):
+            fs = float(rng.choice([16.368e6, 20e6, 25e6, 30e6, 2.0 ** 25, 50e6]))
+            nch = int(rng.integers(1, 17))
+            bps = int(rng.choice([4, 16, 33, 64, 100]))
+            pushes = int(rng.integers(2, 6))
+            nsamp = int(rng.integers(2000, max(2001, min(200000, int(3e7 / (bps * pushes * nch))))))
+            nb = bps * pushes
+            ch = pkg.synth_descriptors(nb, nch=nch, seed=int(rng.integers(1, 2 ** 31)))
+            # Doppler: a slow drift per channel (what a real stream looks like) or independent per block
+            f0 = rng.uniform(-1.0, 1.0, size=nch) * fs / 2100.0 * 10.0 ** rng.uniform(-4, 0, size=nch)
+            if rng.random() < 0.6:
+                drift = rng.uniform(-1e-3, 1e-3, size=nch) * np.abs(f0)
+                f = f0[None, :] + drift[None, :] * np.arange(nb)[:, None]
+            else:
+                f = f0[None, :] * rng.uniform(0.5, 1.0, size=(nb, nch)) * np.where(rng.random((nb, nch)) < 0.1, -1.0, 1.0)
+            if rng.random() < 0.3:                     # exact binary steps: ties on coarse grids
+                f[:, 0] = np.sign(f[0, 0] if f[0, 0] != 0 else 1.0) * fs * 2.0 ** float(rng.integers(-20, -11))
+            if rng.random() < 0.2:
+                f[:, -1] = 0.0
+            ch["f_carr"] = f
+            ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+            # satellites come and go: a channel changes PRN or goes idle for a stretch of blocks
+            for _ in range(int(rng.integers(0, 4))):
+                i = int(rng.integers(0, nch)); b0 = int(rng.integers(0, nb)); b1 = int(rng.integers(b0, nb + 1))
+                ch["prn"][b0:b1, i] = 0 if rng.random() < 0.5 else int(rng.integers(1, 33))
+            delt = 1.0 / fs
+            want_iq, want_st, _ = oracle.fill_blocks(ch, delt, nsamp, chain=True, fixed=False)
+            depth = int(rng.integers(2, 5))
+            dev_only = bool(rng.integers(0, 2))
+            st = synth.stream(nch, delt, nsamp, bps, depth=depth,
+                              flags=pkg.CHAIN_CARRIER | (pkg.STREAM_DEVICE_ONLY if dev_only else 0))
+            got = []
+            k = 0
+            popped = 0
+            while popped < pushes:
+                while k < pushes and st.pending < depth:
+                    st.push(ch[k * bps:(k + 1) * bps]); k += 1
+                iq, es = st.pop(copy=True)
+                got.append((None if dev_only else np.asarray(iq).reshape(bps, -1), es))  # HBM-only ring: end states only
+                popped += 1
+            st.close()
+            what = dict(case=case, fs=fs, nsamp=nsamp, nch=nch, bps=bps, pushes=pushes, depth=depth, dev_only=dev_only)
+            for j, (iq, es) in enumerate(got):
+                w = want_iq[j * bps:(j + 1) * bps].reshape(bps, -1)
+                if iq is not None and not (iq == w).all():
+                    bad = np.argwhere(iq != w)[0]
+                    np.save("gpurun_out/fuzz_stream_fail_ch.npy", ch)
+                    raise SystemExit("STREAM MISMATCH %r push %d first at block %d element %d" % (what, j, bad[0], bad[1]))
+                act = ch["prn"][j * bps:(j + 1) * bps] > 0
+                wcp = want_st["carr_phase"][j * bps:(j + 1) * bps]
+                if es["carr_phase"][act].tobytes() != wcp[act].tobytes():
+                    bad = np.argwhere((es["carr_phase"] != wcp) & act)
+                    np.save("gpurun_out/fuzz_stream_fail_ch.npy", ch)
+                    raise SystemExit("STREAM END STATE MISMATCH %r push %d: %d block-channels, first (block, channel) %r got %r want %r; "
+                                     "f_carr there %r prn column %r" %
+                                     (what, j, len(bad), bad[0].tolist(), es["carr_phase"][tuple(bad[0])], wcp[tuple(bad[0])],
+                                      ch["f_carr"][j * bps + bad[0][0], bad[0][1]], ch["prn"][:, bad[0][1]].tolist()))
+        fallbacks = synth.info(pkg.INFO_CHAIN_FALLBACKS)
+        ties = synth.info(pkg.INFO_CHAIN_TIES)
+        on_dev = synth.info(pkg.INFO_CHAIN_ON_DEVICE)
+    print("fuzz_parity --stream: %d chained streams bit-exact (seed %d); last push chained on the device: %d; blocks walked "
+          "sequentially by k_chain_fix: %d; wrap ties recorded: %d" % (a.cases, a.seed, on_dev, fallbacks, ties))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=300)
@@ -24,7 +98,13 @@ def main():
     ap.add_argument("--ev", action="store_true",
                     help="only workloads the breakpoint kernel k_synth_ev is eligible for: sample rates above 16 MS/s, "
                          "Doppler up to fs/2100 (four table-index changes per run of 16 samples), IEEE carrier")
+    ap.add_argument("--stream", action="store_true",
+                    help="chained streams instead of batches: several pushes of many short blocks through a ring, the carrier "
+                         "chained on the device from push to push (PRN changes, idle channels, steps that tie), against the "
+                         "oracle's sequential render of the whole stream")
     a = ap.parse_args()
+    if a.stream:
+        return stream_soak(a)
     import torch  # noqa: F401  (first: the HIP runtime)
     from __graft_entry__ import load_package
     import oracle_binding as ob

@@ -29,9 +29,9 @@ def stream_soak(a):
         for case in range(a.cases):
             fs = float(rng.choice([16.368e6, 20e6, 25e6, 30e6, 2.0 ** 25, 50e6]))
             nch = int(rng.integers(1, 17))
-            bps = int(rng.choice([4, 16, 33, 64, 100]))
-            pushes = int(rng.integers(2, 6))
-            nsamp = int(rng.integers(2000, max(2001, min(200000, int(3e7 / (bps * pushes * nch))))))
+            bps = int(rng.choice([4, 16, 33, 64, 100] if a.nsamp_max <= 1000000 else [2, 3, 5]))
+            pushes = int(rng.integers(2, 6 if a.nsamp_max <= 1000000 else 4))
+            nsamp = int(rng.integers(2000, max(2001, min(a.nsamp_max, int(a.budget / (bps * pushes * nch))))))
             nb = bps * pushes
             ch = pkg.synth_descriptors(nb, nch=nch, seed=int(rng.integers(1, 2 ** 31)))
             # Doppler: a slow drift per channel (what a real stream looks like) or independent per block
@@ -55,6 +55,7 @@ def stream_soak(a):
             want_iq, want_st, _ = oracle.fill_blocks(ch, delt, nsamp, chain=True, fixed=False)
             depth = int(rng.integers(2, 5))
             dev_only = bool(rng.integers(0, 2))
+            synth.set_option(pkg.OPT_SEED_WHERE, 1 if rng.random() < 0.85 else 0)  # mostly: pre-pass and chain on the device
             st = synth.stream(nch, delt, nsamp, bps, depth=depth,
                               flags=pkg.CHAIN_CARRIER | (pkg.STREAM_DEVICE_ONLY if dev_only else 0))
             got = []
@@ -102,6 +103,8 @@ def main():
                     help="chained streams instead of batches: several pushes of many short blocks through a ring, the carrier "
                          "chained on the device from push to push (PRN changes, idle channels, steps that tie), against the "
                          "oracle's sequential render of the whole stream")
+    ap.add_argument("--nsamp-max", type=int, default=200000, help="--stream: longest block")
+    ap.add_argument("--budget", type=float, default=3e7, help="--stream: channel-samples per case (what the CPU oracle has to walk)")
     a = ap.parse_args()
     if a.stream:
         return stream_soak(a)

@@ -99,13 +99,16 @@ def block_digest(a):
     return zlib.crc32(m[-(1 << 16):], zlib.crc32(m[:1 << 16]))
 
 
-def resident_leg(pkg, synth, torch, ch, delt, nsamp, flags, steps, warmup, dev):
-    """round 1's measurement: one batch resident in HBM, run again and again"""
+def resident_leg(pkg, synth, torch, ch, delt, nsamp, flags, steps, warmup, dev, synth_only=False):
+    """round 1's measurement: one batch resident in HBM, run again and again; synth_only: the pre-pass is skipped once
+    every table set has been built (GPSBB_OPT_SKIP_SEED), i.e. the synthesis kernel with the GPU to itself"""
     out = torch.empty(ch.shape[0] * nsamp * 2, dtype=torch.int16, device=dev)
     batch = synth.batch(ch, delt, nsamp, flags=flags)
     for _ in range(warmup):
         batch.run(out.data_ptr())
     synth.sync()
+    if synth_only:
+        synth.set_option(pkg.OPT_SKIP_SEED, 1)
     torch.cuda.synchronize()
     batch.timing_stats(reset=True)
     t0 = time.perf_counter()
@@ -115,6 +118,8 @@ def resident_leg(pkg, synth, torch, ch, delt, nsamp, flags, steps, warmup, dev):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     st = batch.timing_stats(reset=True)
+    if synth_only:
+        synth.set_option(pkg.OPT_SKIP_SEED, 0)
     ceil_ms = synth.fill_ceiling(out.data_ptr(), out.numel() * 2, iters=10)
     batch.close()
     del out
@@ -353,6 +358,11 @@ def main():
                            "note": "one 400-block batch re-run 20 times, descriptors and plans resident in HBM (round 1's value)"}
         res["roofline"]["write_ceiling_measured_GBs"] = ceil_gbs
         res["roofline"]["frac_of_measured_ceiling"] = achieved / ceil_gbs
+        # the same kernel with the GPU to itself (tables already built): what the pre-passes running beside it cost
+        r2, _ = resident_leg(pkg, synth, torch, rch, delt, nsamp, 0, 20, 5, dev, synth_only=True)
+        alone = 4.0 * samples_per_launch / (r2["synth_kernel_ms"] * 1e-3) / 1e9
+        res["roofline"]["alone"] = {"ms_per_launch": r2["synth_kernel_ms"], "achieved": alone, "frac": alone / HBM_PEAK_GBS,
+                                    "note": "k_synth_ev on resident tables, no pre-pass running beside it"}
         # the reference-faithful geometry (12 ch, 2.6 MS/s, 300 000-sample blocks)
         mch = pkg.synth_descriptors(1000, nch=12, seed=0xF00D)
         m1, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, 0, 10, 3, dev)

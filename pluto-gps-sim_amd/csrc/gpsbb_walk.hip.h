@@ -26,6 +26,26 @@ namespace gpsbb_impl {
 #endif
 constexpr int WALK_ROW_MAX = 4 * TILE - 1; /* steps of one regular run (see walk_lockstep) */
 
+/* A row as this pre-pass keeps it: 16 bytes, one store per turn of the walk.  The increment S of SynRow is not stored:
+ * it is a function of the row's first state and the chain's step — s rounded to a multiple of ulp(x), ties to even
+ * (walk_row_step) — and k_tiles recomputes it.  (The scattered row stores of the walk are what the kernels running
+ * beside it feel most; the chain's region of the pool is addressed in units of these rows.) */
+struct WalkRow {
+    int32_t n0;   /* first sample of the row */
+    uint32_t nav; /* code chains: the data bits in force (walk_dbits) */
+    double x;     /* state at n0 */
+};
+static_assert(sizeof(WalkRow) == 16 && sizeof(WalkRow) <= sizeof(SynRow), "rows of the walk live in the SynRow pool");
+
+/* the increment of a regular run that starts at x: s rounded to a multiple of ulp(x), ties to even — adding and
+ * subtracting 1.5 * 2^e (exact for every x, s of the NCOs; 0 where the state does not move) */
+__device__ __forceinline__ double walk_row_step(double x, double s)
+{
+    const uint32_t hi = (uint32_t)__double2hiint(x);
+    const double C = __hiloint2double((int)((hi & 0xfff00000u) | 0x80000u), 0);
+    return add_rn(add_rn(s, C), -C);
+}
+
 /* what a lane carries through the walk */
 template <int KIND>
 struct WalkLane {
@@ -34,12 +54,11 @@ struct WalkLane {
     uint32_t nav;  /* code: packed nav counters */
     uint32_t bits; /* code: bit 0 = data bit in force is -1, bit 1 = the one after the next roll-over is -1 */
     const uint32_t *dwrd;
-    SynRow *rows;
+    WalkRow *rows;
     uint32_t cap, cnt;
     bool active;
     bool stuck; /* x + s rounded back to x and nothing wrapped: the state is constant from here on */
     /* carrier chains of a batch whose carrier is chained on the device (see k_chain_fix) */
-    bool store;        /* write rows (pass A of the chain only wants the end state) */
     ChainAux *aux;     /* pass B: where the crossings go */
     int32_t ncross;    /* crossings recorded so far; -1: too many */
     int32_t prev_ex;   /* biased exponent of the previous row's states */
@@ -92,7 +111,7 @@ __device__ __forceinline__ uint64_t walk_tiemask(uint64_t sb)
  * The rare cases — tiny or zero steps (es < 123), states more than 50 binades above the step, a state that
  * no longer moves — go through the integer version of the regular run (gpsbb_nco.h) behind a wave-uniform test.
  */
-template <int KIND, bool SNEG, bool TRACK>
+template <int KIND, bool SNEG, bool TRACK, bool STORE = true>
 __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsigned long long *hz, uint32_t *status)
 {
     constexpr int TOPEX = KIND == NCO_CARR ? 1023 : 1023 + 10;
@@ -197,13 +216,12 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
             }
         }
         /* the row of this turn: samples n .. n + k */
-        if (w.active) {
+        if (STORE && w.active) { /* pass A of the carrier chain only wants the end state */
             if (w.cnt < w.cap) {
-                SynRow row;
+                WalkRow row;
                 row.n0 = w.n;
                 row.nav = w.bits;
                 row.x = x;
-                row.S = S;
                 w.rows[w.cnt] = row;
             } else {
                 atomicOr(status, ST_ROW_OVERFLOW);
@@ -272,18 +290,18 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
 
 /* the lanes of a wavefront by the sign of their step, each group in its own straight-line loop (the host's plan
  * keeps the signs apart, so a wavefront normally runs only one of the two) */
-template <int KIND, bool TRACK>
+template <int KIND, bool TRACK, bool STORE = true>
 __device__ __forceinline__ void walk_both_signs(WalkLane<KIND> &w, int nsamp, unsigned long long *hz, uint32_t *status)
 {
     const bool on = w.active;
     const bool neg = w.s < 0.0;
     if (__ballot(on && !neg)) {
         w.active = on && !neg;
-        walk_lockstep<KIND, false, TRACK>(w, nsamp, hz, status);
+        walk_lockstep<KIND, false, TRACK, STORE>(w, nsamp, hz, status);
     }
     if (KIND == NCO_CARR && __ballot(on && neg)) {
         w.active = on && neg;
-        walk_lockstep<KIND, true, TRACK>(w, nsamp, hz, status);
+        walk_lockstep<KIND, true, TRACK, STORE>(w, nsamp, hz, status);
     }
 }
 
@@ -299,12 +317,11 @@ __device__ __forceinline__ WalkLane<KIND> walk_lane(const BatchDev &p, int chain
     w.bits = 0;
     w.dwrd = nullptr;
     const uint64_t o0 = p.row_off[chain], o1 = p.row_off[chain + 1];
-    w.rows = p.rows + o0;
+    w.rows = reinterpret_cast<WalkRow *>(p.rows) + o0;
     w.cap = (uint32_t)(o1 - o0);
     w.cnt = 0;
     w.active = on;
     w.stuck = false;
-    w.store = true;
     w.aux = nullptr;
     w.ncross = 0;
     w.prev_ex = 0x7fff;
@@ -366,12 +383,11 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
         const bool on = is_carr && ch.prn > 0;
         const double x0 = PASS == 1 ? p.aux[k].start0 : (PASS == 2 ? p.aux[k].start1 : ch.carr_phase);
         WalkLane<NCO_CARR> w = walk_lane<NCO_CARR>(p, nbc + k, x0, mul_rn(ch.f_carr, p.delt) /* c:2741 */, on);
-        w.store = PASS != 1;
         w.aux = PASS == 2 ? &p.aux[k] : nullptr;
         if (PASS == 2)
             walk_both_signs<NCO_CARR, true>(w, p.nsamp, p.hazards, p.status);
         else
-            walk_both_signs<NCO_CARR, false>(w, p.nsamp, p.hazards, p.status);
+            walk_both_signs<NCO_CARR, false, PASS != 1>(w, p.nsamp, p.hazards, p.status);
         if (is_carr) {
             if (PASS == 1) {
                 p.aux[k].endA = on ? w.x : 0.0;
@@ -391,9 +407,9 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
                      * fetch them one dependent load after the other */
                     for (int j = 0; on && j < w.ncross; j++) {
                         const int r = a.cross[j];
-                        const SynRow pre = w.rows[r - 1];
+                        const WalkRow pre = w.rows[r - 1];
                         const int n_post = r < (int)w.cnt ? w.rows[r].n0 : p.nsamp;
-                        a.pre[j] = __fma_rn((double)(n_post - 1 - pre.n0), pre.S, pre.x);
+                        a.pre[j] = __fma_rn((double)(n_post - 1 - pre.n0), walk_row_step(pre.x, w.s), pre.x);
                         a.post[j] = r < (int)w.cnt ? w.rows[r].x : w.x;
                     }
                     p.aux[k].hz512 = on ? w.hz512 : 0u;
@@ -471,18 +487,17 @@ __global__ void k_chain_prefix(BatchDev p)
 
 /* rows of one exact walk of a whole block, as k_walk writes them (build_rows_f64 drives it) */
 struct FixRowSink {
-    SynRow *rows;
+    WalkRow *rows;
     uint32_t cap, cnt;
     bool overflow;
     uint32_t hz512;
-    __device__ __forceinline__ void row(int32_t n0, uint32_t, double x, double S, bool)
+    __device__ __forceinline__ void row(int32_t n0, uint32_t, double x, double, bool)
     {
         if (cnt < cap) {
-            SynRow r;
+            WalkRow r;
             r.n0 = n0;
             r.nav = 0;
             r.x = x;
-            r.S = S;
             rows[cnt] = r;
         } else {
             overflow = true;
@@ -570,7 +585,7 @@ __global__ void k_chain_fix(BatchDev p)
         const int es = (int)((sb >> 52) & 0x7ff);
         const double margin = in.margin;
         const int ncross = in.ncross;
-        const SynRow *rows = p.rows + p.row_off[nbc + k];
+        const WalkRow *rows = reinterpret_cast<const WalkRow *>(p.rows) + p.row_off[nbc + k];
         double end = in.endB;
         uint32_t hz512 = in.hz512; /* pass B's trajectory is the true one, or a translate that met no edge */
         const double d0 = x - in.start1; /* exact: both in the same binade, or the margin test below fails */
@@ -623,7 +638,7 @@ __global__ void k_chain_fix(BatchDev p)
             const int wr = in.wrap_row;
             const int nstar = rows[wr].n0; /* a wrap always starts a row */
             FixRowSink sink;
-            sink.rows = p.prefix_rows + k * CHAIN_PREFIX_CAP;
+            sink.rows = reinterpret_cast<WalkRow *>(p.prefix_rows) + k * CHAIN_PREFIX_CAP;
             sink.cap = CHAIN_PREFIX_CAP;
             sink.cnt = 0;
             sink.overflow = false;
@@ -661,7 +676,7 @@ __global__ void k_chain_fix(BatchDev p)
         if (on && !ok) {
             /* on its own: the whole block exactly, rows in place of pass B's, no offsets */
             FixRowSink sink;
-            sink.rows = p.rows + p.row_off[nbc + k];
+            sink.rows = reinterpret_cast<WalkRow *>(p.rows) + p.row_off[nbc + k];
             sink.cap = (uint32_t)(p.row_off[nbc + k + 1] - p.row_off[nbc + k]);
             sink.cnt = 0;
             sink.overflow = false;
@@ -712,8 +727,10 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
     const int cnt = p.row_cnt[chain];
     if (cnt <= 0)
         return;
-    const SynRow *__restrict__ rows = p.rows + p.row_off[chain];
+    const WalkRow *__restrict__ rows = reinterpret_cast<const WalkRow *>(p.rows) + p.row_off[chain];
     const int b = bi / p.nch, i = bi % p.nch;
+    /* the chain's step (c:2709 / c:2741), from which every row's increment follows (walk_row_step) */
+    const double s = kind ? mul_rn(p.ch[bi].f_carr, p.delt) : mul_rn(p.ch[bi].f_code, p.delt);
     double *__restrict__ tx = p.tile_x + ((size_t)b * (2 * (size_t)p.nch) + 2 * i + kind) * (size_t)p.ntiles;
     uint32_t *__restrict__ tn = p.tile_nav + ((size_t)b * (size_t)p.nch + i) * (size_t)p.ntiles;
     /* carrier chained on the device: the true states are pass B's plus an offset per stretch of rows (k_chain_fix) */
@@ -725,23 +742,23 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
     const int prefix_cnt = shifted ? aux->prefix_cnt : 0;
     const int first_row = prefix_cnt > 0 ? aux->wrap_row : 0;
     if (prefix_cnt > 0) {
-        const SynRow *pr = p.prefix_rows + (size_t)bi * CHAIN_PREFIX_CAP;
+        const WalkRow *pr = reinterpret_cast<const WalkRow *>(p.prefix_rows) + (size_t)bi * CHAIN_PREFIX_CAP;
         const int pend = aux->prefix_end;
         for (int r = threadIdx.x; r < prefix_cnt; r += blockDim.x) {
-            const SynRow row = pr[r];
+            const WalkRow row = pr[r];
             const int n_next = r + 1 < prefix_cnt ? pr[r + 1].n0 : pend;
             int t = (int)(((uint32_t)row.n0 + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
             int t_end = (int)(((uint32_t)n_next + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
             t_end = t_end < p.ntiles ? t_end : p.ntiles;
             for (; t < t_end; t++)
-                tx[t] = mul_rn(__fma_rn((double)(t * TILE - row.n0), row.S, row.x), 512.0);
+                tx[t] = mul_rn(__fma_rn((double)(t * TILE - row.n0), walk_row_step(row.x, s), row.x), 512.0);
         }
     }
     /* four rows per lane and turn, their loads issued together: the kernel is bound by the latency of these
      * loads, not by their number */
     constexpr int U = 4;
     for (int r0 = first_row + threadIdx.x; r0 < cnt; r0 += U * GPSBB_TILES_WG) {
-        SynRow row[U];
+        WalkRow row[U];
         int n_next[U];
 #pragma unroll
         for (int j = 0; j < U; j++) {
@@ -768,8 +785,9 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
             int t = (int)(((uint32_t)row[j].n0 + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
             int t_end = (int)(((uint32_t)n_next[j] + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
             t_end = t_end < p.ntiles ? t_end : p.ntiles;
+            const double S = walk_row_step(row[j].x, s);
             for (; t < t_end; t++) {
-                double v = __fma_rn((double)(t * TILE - row[j].n0), row[j].S, row[j].x);
+                double v = __fma_rn((double)(t * TILE - row[j].n0), S, row[j].x);
                 v = shifted ? v + off[j] : v; /* exact: the sum is the true state, a double */
                 tx[t] = kind ? mul_rn(v, 512.0) : v;
                 if (!kind)

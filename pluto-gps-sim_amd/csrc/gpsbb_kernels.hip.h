@@ -110,20 +110,20 @@ struct ChainAux {
      * rounded on a coarser grid than the states of the row before (a binade crossed upwards, or a wrap): only
      * there can the offset between pass B's trajectory and the true one change */
     int32_t ncross;                 /* -1: more than CHAIN_MAX_CROSS of them                              */
-    int32_t cross[CHAIN_MAX_CROSS]; /* row numbers, ascending                                             */
+    int32_t cross[CHAIN_MAX_CROSS]; /* the first sample of each such row, ascending (nsamp: the block's last step) */
     uint32_t hz512;                 /* pass B: samples whose phase was exactly 1.0                         */
-    int32_t wrap_row;               /* pass B: the row that follows the first wrap (-1: no wrap in the block) */
+    int32_t wrap_row;               /* pass B: the first sample after the first wrap (-1: no wrap in the block) */
     /* k_chain_fix, when it walked the block's first lap on its own: rows 0 .. prefix_cnt-1 of the chain's
-     * prefix region hold the samples before prefix_end (= the first sample of pass B's row wrap_row) and
-     * pass B's rows before wrap_row are void */
+     * prefix region hold the samples before prefix_end (= wrap_row) and pass B's rows before it are void */
     int32_t prefix_cnt, prefix_end;
     int32_t _pad;
-    /* pass B, for crossing j: its state at the last sample of row cross[j]-1 and at the first of row cross[j] */
+    /* pass B, for crossing j: its state at sample cross[j]-1 and at sample cross[j] */
     double pre[CHAIN_MAX_CROSS], post[CHAIN_MAX_CROSS];
     double endB;   /* pass B's end state */
-    /* k_chain_fix: true state minus pass B's state, for rows cross[j-1] <= r < cross[j] (seg[0]: from row 0,
+    /* k_chain_fix: true state minus pass B's state, for samples cross[j-1] <= n < cross[j] (seg[0]: from sample 0,
      * seg[ncross]: to the end of the block) */
     double seg[CHAIN_MAX_CROSS + 1];
+    double wrap_x; /* pass B's state at sample wrap_row */
 };
 
 /* The carrier of a stream (gpsbb_stream_*) from one push to the next, on the device. */

@@ -62,6 +62,7 @@ struct WalkLane {
     ChainAux *aux;     /* pass B: where the crossings go */
     int32_t ncross;    /* crossings recorded so far; -1: too many */
     int32_t prev_ex;   /* biased exponent of the previous row's states */
+    double prev_x1;    /* the state before the last step taken (the last sample of the previous row) */
     bool prev_wrapped; /* the step before this row wrapped */
     bool prev_tie;     /* ... and its "+ 1.0" was an exact tie (falling phase) */
     bool tie_done;     /* a tie after the first wrap has been recorded: both trajectories left it with an even mantissa, the
@@ -186,12 +187,19 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
                         w.tie_done = w.wrap_seen;
                     }
                     if (cross) {
-                        if (w.ncross >= 0 && w.ncross < CHAIN_MAX_CROSS)
-                            w.aux->cross[w.ncross++] = (int32_t)w.cnt;
-                        else
+                        /* what k_chain_fix needs of it: where, and pass B's states either side of the step */
+                        if (w.ncross >= 0 && w.ncross < CHAIN_MAX_CROSS) {
+                            w.aux->cross[w.ncross] = w.n;
+                            w.aux->pre[w.ncross] = w.prev_x1;
+                            w.aux->post[w.ncross] = x;
+                            w.ncross++;
+                        } else {
                             w.ncross = -1;
-                        if (w.prev_wrapped && !w.wrap_seen)
-                            w.aux->wrap_row = (int32_t)w.cnt;
+                        }
+                        if (w.prev_wrapped && !w.wrap_seen) {
+                            w.aux->wrap_row = w.n;
+                            w.aux->wrap_x = x;
+                        }
                         w.wrap_seen = w.wrap_seen || w.prev_wrapped;
                     }
                 }
@@ -216,7 +224,11 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
             }
         }
         /* the row of this turn: samples n .. n + k */
-        if (STORE && w.active) { /* pass A of the carrier chain only wants the end state */
+        /* Only rows that hold the first sample of a tile are kept: k_tiles reads nothing else of them (most rows
+         * of a fast chain are the few-sample ones of the low binades after every wrap), and the scattered row
+         * stores are what the kernels running beside the walk feel most.  Pass A keeps none. */
+        const bool keeps = w.n == 0 || ((uint32_t)(w.n + k) / (uint32_t)TILE) != ((uint32_t)(w.n - 1) / (uint32_t)TILE);
+        if (STORE && w.active && keeps) {
             if (w.cnt < w.cap) {
                 WalkRow row;
                 row.n0 = w.n;
@@ -277,12 +289,17 @@ __device__ __forceinline__ void walk_lockstep(WalkLane<KIND> &w, int nsamp, unsi
                                     ((!w.wrap_seen && (wrapped || (int)((uint32_t)__double2hiint(x2) >> 20) > ex)) || (tie && !w.tie_done));
             if (__builtin_expect(__ballot(last_cross) != 0ull, 0)) {
                 if (last_cross) {
-                    if (w.ncross >= 0 && w.ncross < CHAIN_MAX_CROSS)
-                        w.aux->cross[w.ncross++] = (int32_t)w.cnt;
-                    else
+                    if (w.ncross >= 0 && w.ncross < CHAIN_MAX_CROSS) {
+                        w.aux->cross[w.ncross] = nsamp;
+                        w.aux->pre[w.ncross] = x1;
+                        w.aux->post[w.ncross] = x2;
+                        w.ncross++;
+                    } else {
                         w.ncross = -1;
+                    }
                 }
             }
+            w.prev_x1 = w.active ? x1 : w.prev_x1;
         }
         w.active = step && w.n < nsamp;
     }
@@ -325,6 +342,7 @@ __device__ __forceinline__ WalkLane<KIND> walk_lane(const BatchDev &p, int chain
     w.aux = nullptr;
     w.ncross = 0;
     w.prev_ex = 0x7fff;
+    w.prev_x1 = 0.0;
     w.prev_wrapped = false;
     w.prev_tie = false;
     w.tie_done = false;
@@ -403,15 +421,6 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
                         a.wrap_row = -1;
                     a.prefix_cnt = 0;
                     a.endB = on ? w.x : 0.0;
-                    /* what k_chain_fix needs of the rows around the crossings, so that it does not have to
-                     * fetch them one dependent load after the other */
-                    for (int j = 0; on && j < w.ncross; j++) {
-                        const int r = a.cross[j];
-                        const WalkRow pre = w.rows[r - 1];
-                        const int n_post = r < (int)w.cnt ? w.rows[r].n0 : p.nsamp;
-                        a.pre[j] = __fma_rn((double)(n_post - 1 - pre.n0), walk_row_step(pre.x, w.s), pre.x);
-                        a.post[j] = r < (int)w.cnt ? w.rows[r].x : w.x;
-                    }
                     p.aux[k].hz512 = on ? w.hz512 : 0u;
                 } else if (on && w.hz512) {
                     atomicAdd(p.hazards, (unsigned long long)w.hz512);
@@ -533,7 +542,7 @@ struct FixRowSink {
 struct FixIn {
     int prn, prn_prev, ncross, wrap_row;
     uint32_t hz512;
-    double carr_phase, f_carr, start1, margin, endB, pre0, post0, pre1, post1;
+    double carr_phase, f_carr, start1, margin, endB, pre0, post0, pre1, post1, wrap_x;
 };
 __device__ __forceinline__ FixIn fix_load(const BatchDev &p, int b, int i)
 {
@@ -550,6 +559,7 @@ __device__ __forceinline__ FixIn fix_load(const BatchDev &p, int b, int i)
     f.endB = a.endB;
     f.ncross = a.ncross;
     f.wrap_row = a.wrap_row;
+    f.wrap_x = a.wrap_x;
     f.hz512 = a.hz512;
     f.pre0 = a.pre[0];
     f.post0 = a.post[0];
@@ -585,7 +595,6 @@ __global__ void k_chain_fix(BatchDev p)
         const int es = (int)((sb >> 52) & 0x7ff);
         const double margin = in.margin;
         const int ncross = in.ncross;
-        const WalkRow *rows = reinterpret_cast<const WalkRow *>(p.rows) + p.row_off[nbc + k];
         double end = in.endB;
         uint32_t hz512 = in.hz512; /* pass B's trajectory is the true one, or a translate that met no edge */
         const double d0 = x - in.start1; /* exact: both in the same binade, or the margin test below fails */
@@ -635,8 +644,7 @@ __global__ void k_chain_fix(BatchDev p)
         } else if (base && !ok && in.wrap_row >= 0) {
             /* a tie-prone binade on the way up: the first lap exactly, on its own rows; after the wrap that ends it
              * the offset is a multiple of every grid and the rest of the block is pass B's plus it */
-            const int wr = in.wrap_row;
-            const int nstar = rows[wr].n0; /* a wrap always starts a row */
+            const int nstar = in.wrap_row; /* a wrap always starts a row */
             FixRowSink sink;
             sink.rows = reinterpret_cast<WalkRow *>(p.prefix_rows) + k * CHAIN_PREFIX_CAP;
             sink.cap = CHAIN_PREFIX_CAP;
@@ -645,7 +653,7 @@ __global__ void k_chain_fix(BatchDev p)
             sink.hz512 = 0;
             uint32_t nav = 0;
             const double xs = build_rows_f64<NCO_CARR>(x, s, nav, nstar, sink);
-            d = xs - rows[wr].x;
+            d = xs - in.wrap_x;
             /* (a tie-prone coarsest grid and an odd offset there: pass B's recorded tie is not part of this path) */
             ok = !sink.overflow && sink.hz512 == 0 && fabs(d) < margin - 0x1p-51 &&
                  !(tie_top && fmod(fabs(d) * (fall ? 0x1p+53 : 0x1p+52), 2.0) != 0.0);
@@ -654,7 +662,7 @@ __global__ void k_chain_fix(BatchDev p)
                 a.prefix_end = nstar;
                 /* pass B's rows from wrap_row on: one segment */
                 a.ncross = 1;
-                a.cross[0] = wr;
+                a.cross[0] = nstar;
                 a.seg[0] = 0.0;
                 a.seg[1] = d;
             }
@@ -667,7 +675,7 @@ __global__ void k_chain_fix(BatchDev p)
             printf("fix b %d x %.17g start1 %.17g d0 %.3e margin %.3e ncross %d wrap_row %d tie_top %d tie_asc %d ok %d endB %.17g end %.17g s %.17g\n", b, x,
                    in.start1, d0, margin, ncross, in.wrap_row, (int)tie_top, (int)tie_asc, (int)ok, in.endB, end, s);
             for (int j = 0; j < ncross && j < CHAIN_MAX_CROSS; j++)
-                printf("    cross %d row %d pre %.17g post %.17g seg %.3e\n", j, a.cross[j], a.pre[j], a.post[j], a.seg[j + 1]);
+                printf("    cross %d sample %d pre %.17g post %.17g seg %.3e\n", j, a.cross[j], a.pre[j], a.post[j], a.seg[j + 1]);
         }
         if (on && !ok)
             printf("chain fallback: block %d ch %d d0 %.3e d %.3e margin %.3e ncross %d es %d tie_top %d tie_asc %d wrap_row %d\n", b,
@@ -740,7 +748,7 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
     /* k_chain_fix walked the first lap on its own: those rows (in the chain's prefix region) hold the samples
      * before prefix_end, pass B's rows before wrap_row are void */
     const int prefix_cnt = shifted ? aux->prefix_cnt : 0;
-    const int first_row = prefix_cnt > 0 ? aux->wrap_row : 0;
+    const int void_before = prefix_cnt > 0 ? aux->prefix_end : 0; /* pass B's rows before this sample are void */
     if (prefix_cnt > 0) {
         const WalkRow *pr = reinterpret_cast<const WalkRow *>(p.prefix_rows) + (size_t)bi * CHAIN_PREFIX_CAP;
         const int pend = aux->prefix_end;
@@ -757,7 +765,7 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
     /* four rows per lane and turn, their loads issued together: the kernel is bound by the latency of these
      * loads, not by their number */
     constexpr int U = 4;
-    for (int r0 = first_row + threadIdx.x; r0 < cnt; r0 += U * GPSBB_TILES_WG) {
+    for (int r0 = threadIdx.x; r0 < cnt; r0 += U * GPSBB_TILES_WG) {
         WalkRow row[U];
         int n_next[U];
 #pragma unroll
@@ -766,16 +774,16 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
             const int rc = r < cnt ? r : cnt - 1;
             row[j] = rows[rc];
             n_next[j] = rc + 1 < cnt ? rows[rc + 1].n0 : INT32_MAX - TILE;
-            if (r >= cnt)
-                n_next[j] = row[j].n0; /* past the chain's last row: no tiles */
+            if (r >= cnt || row[j].n0 < void_before)
+                n_next[j] = row[j].n0; /* past the chain's last row, or replaced by the prefix rows: no tiles */
         }
         double off[U];
 #pragma unroll
         for (int j = 0; j < U; j++) {
             off[j] = 0.0;
             if (shifted) {
-                int g = 0; /* the row's segment: the crossings at or before it */
-                while (g < ncross && aux->cross[g] <= r0 + j * GPSBB_TILES_WG)
+                int g = 0; /* the row's segment: the crossings at or before its first sample */
+                while (g < ncross && aux->cross[g] <= row[j].n0)
                     g++;
                 off[j] = aux->seg[g];
             }

@@ -393,7 +393,8 @@ struct gpsbb_batch {
     char *stage = nullptr;
     size_t stage_cap = 0, stage_used = 0;
     unsigned stream_turn = 0; /* the stream's push count */
-    hipEvent_t synth_done[NSETS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t synth_done_ref[NSETS] = {nullptr, nullptr, nullptr, nullptr}; /* not owned: the run's ev[3] */
+    hipEvent_t last_done = nullptr;
     bool synth_pending[NSETS] = {false, false, false, false};
     hipEvent_t upload_done = nullptr; /* descriptors and plans of the last set-up are on the device */
     int nsets = 2;                    /* table sets in use: run k works on set k % nsets */
@@ -762,8 +763,6 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
             HIPCHK(h, (hipError_t)b->d_tile_row[set].reserve(2 * nbc * ((size_t)b->ntiles + 1)));
             HIPCHK(h, (hipError_t)b->d_row_cnt[set].reserve(2 * nbc));
         }
-        if (!b->synth_done[set])
-            HIPCHK(h, hipEventCreateWithFlags(&b->synth_done[set], hipEventDisableTiming));
     }
     if (b->ev) {
         HIPCHK(h, (hipError_t)b->d_evc.reserve(nbc));
@@ -968,8 +967,6 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         b->d_aux[k].release();
         b->d_prefix[k].release();
         b->d_evc.release();
-        if (b->synth_done[k])
-            (void)hipEventDestroy(b->synth_done[k]);
     }
     if (b->hs_rows)
         (void)hipHostFree(b->hs_rows);
@@ -1341,7 +1338,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     if (b->upload_done)
         HIPCHK(h, hipStreamWaitEvent(ss, b->upload_done, 0));
     if (b->synth_pending[set])
-        HIPCHK(h, hipStreamWaitEvent(ss, b->synth_done[set], 0));
+        HIPCHK(h, hipStreamWaitEvent(ss, b->synth_done_ref[set], 0));
     HIPCHK(h, hipEventRecord(ev[0], ss));
     bool ctr_reset_by_prepass = false;
     if (h->opt_skip_seed && b->run_count >= (unsigned)b->nsets) {
@@ -1351,7 +1348,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
          * followed by the synthesis kernel, which synth_done[] of that set covers */
         const int prev = (set + b->nsets - 1) % b->nsets;
         if (b->synth_pending[prev])
-            HIPCHK(h, hipEventSynchronize(b->synth_done[prev]));
+            HIPCHK(h, hipEventSynchronize(b->synth_done_ref[prev]));
         const int rc = host_seed_run(b, set, ss);
         if (rc != GPSBB_OK)
             return rc;
@@ -1436,7 +1433,10 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(ev[3], sc));
-    HIPCHK(h, hipEventRecord(b->synth_done[set], sc));
+    /* the run's end-of-synthesis event doubles as "this table set is free again" and as what a stream's copy stream
+     * waits for: every further record on the synthesis stream is another packet between two kernels */
+    b->synth_done_ref[set] = ev[3];
+    b->last_done = ev[3];
     b->synth_pending[set] = true;
     b->last_set = set;
     b->run_count++;
@@ -1928,11 +1928,10 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     b->d_carry = nullptr;
     if (rc != GPSBB_OK)
         return rc;
-    HIPCHK(h, hipEventRecord(sl.computed, b->last_cs));
     PUSH_MARK("rec");
     /* gather on the side stream: pinned, asynchronous, overlaps the next push's kernels */
     hipStream_t cs = h->s_copy;
-    HIPCHK(h, hipStreamWaitEvent(cs, sl.computed, 0));
+    HIPCHK(h, hipStreamWaitEvent(cs, b->last_done, 0));
     PUSH_MARK("wait");
     if (sl.h_iq) {
         static const bool sdma = getenv("GPSBB_GATHER_SDMA") != nullptr; /* experiment: the runtime's copy instead */

@@ -539,10 +539,12 @@ struct FixRowSink {
  */
 /* what one turn of k_chain_fix's loop reads: fetched a block ahead, because the loop itself is one long chain of
  * dependent arithmetic (each block starts where the one before ended) and must not wait for memory as well */
+constexpr int FIX_PREFETCH_CROSS = 6;
 struct FixIn {
     int prn, prn_prev, ncross, wrap_row;
     uint32_t hz512;
-    double carr_phase, f_carr, start1, margin, endB, pre0, post0, pre1, post1, wrap_x;
+    double carr_phase, f_carr, start1, margin, endB, wrap_x;
+    double pre[FIX_PREFETCH_CROSS], post[FIX_PREFETCH_CROSS]; /* the first crossings (a block has about five) */
 };
 __device__ __forceinline__ FixIn fix_load(const BatchDev &p, int b, int i)
 {
@@ -561,14 +563,15 @@ __device__ __forceinline__ FixIn fix_load(const BatchDev &p, int b, int i)
     f.wrap_row = a.wrap_row;
     f.wrap_x = a.wrap_x;
     f.hz512 = a.hz512;
-    f.pre0 = a.pre[0];
-    f.post0 = a.post[0];
-    f.pre1 = a.pre[1];
-    f.post1 = a.post[1];
+#pragma unroll
+    for (int j = 0; j < FIX_PREFETCH_CROSS; j++) {
+        f.pre[j] = a.pre[j];
+        f.post[j] = a.post[j];
+    }
     return f;
 }
 
-__global__ void k_chain_fix(BatchDev p)
+__global__ __launch_bounds__(64) void k_chain_fix(BatchDev p)
 {
 #ifndef GPSBB_EXP_NOPRIO
     /* one wavefront on whose latency every later push of the stream waits: let it win the issue arbitration
@@ -581,10 +584,14 @@ __global__ void k_chain_fix(BatchDev p)
     const int nbc = p.nblocks * p.nch;
     double prev_end = p.carry ? p.carry->exact_end[il] : 0.0; /* a stream: where the push before this one ended */
     unsigned long long n_fallback = 0, n_hz = 0;
+    /* two blocks ahead: a turn of this loop is a few hundred cycles of dependent arithmetic, a load from HBM beside
+     * the other kernels takes longer than that */
     FixIn nxt = fix_load(p, 0, il);
+    FixIn nxt2 = fix_load(p, p.nblocks > 1 ? 1 : 0, il);
     for (int b = 0; b < p.nblocks; b++) {
         const FixIn in = nxt;
-        nxt = fix_load(p, b + 1 < p.nblocks ? b + 1 : b, il);
+        nxt = nxt2;
+        nxt2 = fix_load(p, b + 2 < p.nblocks ? b + 2 : p.nblocks - 1, il);
         const size_t k = (size_t)b * p.nch + il;
         const bool on = lane_on && in.prn > 0;
         ChainAux &a = p.aux[k];
@@ -635,9 +642,20 @@ __global__ void k_chain_fix(BatchDev p)
             ok = true;
             for (int j = 0; ok && j < ncross; j++) {
                 /* pass B's state at the last sample before the crossing, the true one, one genuine step */
-                double xt = (j == 0 ? in.pre0 : (j == 1 ? in.pre1 : a.pre[j])) + d;
+                double pre_j = 0.0, post_j = 0.0;
+                if (j >= FIX_PREFETCH_CROSS) { /* rare: beyond what was fetched ahead */
+                    pre_j = a.pre[j];
+                    post_j = a.post[j];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < FIX_PREFETCH_CROSS; q++) {
+                        pre_j = j == q ? in.pre[q] : pre_j;
+                        post_j = j == q ? in.post[q] : post_j;
+                    }
+                }
+                double xt = pre_j + d;
                 carr_step(xt, s);
-                d = xt - (j == 0 ? in.post0 : (j == 1 ? in.post1 : a.post[j]));
+                d = xt - post_j;
                 ok = fabs(d) < margin - 0x1p-51;
                 a.seg[j + 1] = d;
             }

@@ -156,7 +156,7 @@ def dry_run(args, pkg, dist, world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20, help="timed steps per region; a step is 3200 blocks of the stream")
+    ap.add_argument("--steps", type=int, default=40, help="timed steps per region; a step is 3200 blocks of the stream")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median is reported")
     ap.add_argument("--push-blocks", type=int, default=PUSH_BLOCKS, help="0.1 s blocks per push")

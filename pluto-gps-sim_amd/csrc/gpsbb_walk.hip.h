@@ -676,13 +676,31 @@ __global__ __launch_bounds__(64) void k_chain_fix(BatchDev p)
             ok = !sink.overflow && sink.hz512 == 0 && fabs(d) < margin - 0x1p-51 &&
                  !(tie_top && fmod(fabs(d) * (fall ? 0x1p+53 : 0x1p+52), 2.0) != 0.0);
             if (ok) {
-                a.prefix_cnt = (int32_t)sink.cnt;
-                a.prefix_end = nstar;
-                /* pass B's rows from wrap_row on: one segment */
-                a.ncross = 1;
-                a.cross[0] = nstar;
-                a.seg[0] = 0.0;
-                a.seg[1] = d;
+                /* pass B's rows from the wrap on: its offset there, then — as on the usual way — one genuine step
+                 * through every crossing pass B recorded after it (ties at later wraps, the block's last step);
+                 * the list is compacted in place (entry m is written after entry j >= m has been read) */
+                const double d_wrap = d;
+                int m = 1;
+                for (int j = 0; ok && j < ncross; j++) {
+                    const int cj = a.cross[j];
+                    if (cj <= nstar)
+                        continue;
+                    double xt = a.pre[j] + d;
+                    carr_step(xt, s);
+                    d = xt - a.post[j];
+                    ok = fabs(d) < margin - 0x1p-51;
+                    a.cross[m] = cj;
+                    a.seg[m + 1] = d;
+                    m++;
+                }
+                if (ok) {
+                    a.prefix_cnt = (int32_t)sink.cnt;
+                    a.prefix_end = nstar;
+                    a.ncross = m;
+                    a.cross[0] = nstar;
+                    a.seg[0] = 0.0;
+                    a.seg[1] = d_wrap;
+                }
             }
         }
         (void)gtop;

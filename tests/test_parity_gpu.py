@@ -2,12 +2,13 @@
 real reference.  Everything here is bit-exact: int16 IQ, end-of-block doubles compared by their bytes."""
 import hashlib
 import os
+import sys
 
 import numpy as np
 import pytest
 
 import oracle_binding as ob
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -333,14 +334,17 @@ def test_device_chain_with_steps_that_tie_on_the_coarsest_grid(pkg, synth, oracl
     assert (iq == want_iq).all()
 
 
-def test_device_chain_tie_at_the_first_wrap_of_pass_b_only(pkg, synth, oracle, request):
-    """Found by the stream soak (tools/fuzz_parity.py --stream, seed 3 case 28): a falling carrier at 30 MS/s whose
-    pass B starts half a step of the coarsest grid below the true phase.  At the block's first wrap pass B's "+ 1.0"
-    is an exact tie while the true sum lands on a grid point, which leaves the two an ODD number of grid steps apart —
-    so the tie at the block's second wrap (both trajectories tie there) still changes the offset and has to be
-    recorded.  Pushed through a ring in pushes of 33 blocks, as it failed; bit-exact end states and IQ."""
-    ch = np.load(os.path.join(GOLDEN, "chain_first_wrap_tie_desc.npy"))
-    fs, nsamp, bps = 30e6, 24607, 33
+@pytest.mark.parametrize("fixture,fs,nsamp,bps", [("chain_first_wrap_tie_desc.npy", 30e6, 24607, 33),
+                                                  ("chain_prefix_then_tie_desc.npy", 50e6, 3507, 100)])
+def test_device_chain_cases_found_by_the_stream_soak(pkg, synth, oracle, request, fixture, fs, nsamp, bps):
+    """Two single-channel streams on which the device-side chain was once off by one grid step (tools/fuzz_parity.py
+    --stream).  (1) A falling carrier whose pass B starts half a step of the coarsest grid below the true phase: at
+    the block's first wrap pass B's "+ 1.0" is an exact tie while the true sum lands on a grid point, which leaves the
+    two an ODD number of grid steps apart — so the tie at the block's second wrap still changes the offset and has to
+    be recorded.  (2) A block whose first lap k_chain_fix walks on its own (a tie-prone binade on the way up) and
+    that has a tie at a later wrap: the crossings pass B recorded after the first wrap count on that path too.
+    Pushed through a ring as they failed; bit-exact end states and IQ."""
+    ch = np.load(os.path.join(GOLDEN, fixture))
     nb = ch.shape[0]
     want_iq, want_st, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
     for depth in (2, 4):
@@ -359,6 +363,15 @@ def test_device_chain_tie_at_the_first_wrap_of_pass_b_only(pkg, synth, oracle, r
         for k in range(nb):
             assert_state_equal(gst[k], want_st[k], ch["prn"][k] > 0)
         assert (np.concatenate(got) == want_iq).all()
+    # and as one batch
+    b = synth.batch(ch, 1 / fs, nsamp, flags=pkg.CHAIN_CARRIER)
+    b.run()
+    synth.sync()
+    iq, st = b.read()
+    b.close()
+    for k in range(nb):
+        assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
+    assert (iq == want_iq).all()
 
 
 def test_stream_carrier_carried_on_the_device(pkg, synth, oracle, request):
@@ -654,6 +667,16 @@ def test_randomised_shapes_and_dopplers(pkg, synth, oracle):
         for k in range(nblocks):
             assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
     synth.hazards(reset=True)
+
+
+def test_stream_soak_small(pkg):
+    """A slice of the stream soak (tools/fuzz_parity.py --stream): 30 random chained streams — pushes of many short
+    blocks through rings of random depth, Dopplers that drift or jump, exact binary steps, channels that change PRN
+    or go idle, pre-pass and chain on the device — every one bit-exact against the oracle's sequential render."""
+    import types
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity
+    fuzz_parity.stream_soak(types.SimpleNamespace(cases=30, seed=3, nsamp_max=200000, budget=3e7))
 
 
 def test_time_shards_through_the_ring_give_one_digest(pkg, synth, oracle):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the BASELINE.json configs other than the headline one, end to end from the RINEX file:
-host front end (libgpsfe) -> exact carrier seeds on the host -> batches on one MI355X.
+host front end (libgpsfe) -> a chained stream of pushes on one MI355X (IQ left in HBM).
 Writes one JSON object; quoted in DESIGN.md (the headline config is bench.py's)."""
 import json
 import os
@@ -17,32 +17,40 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 SITE = (30.286502, 120.032669, 100.0)
 
 
-def run(pkg, synth, name, nav, motion, max_chan, fs, nsamp, nblocks, batch_blocks):
+def run(pkg, synth, name, nav, motion, max_chan, fs, nsamp, nblocks, push_blocks):
+    """front end on the host, then the descriptors through a chained stream (IQ left in HBM): the carrier is chained
+    inside the stream — on the device where the breakpoint kernel takes the push, on host threads otherwise"""
     t0 = time.perf_counter()
     fe = pkg.FrontEnd(os.path.join(GOLD, nav), llh=SITE, motion=os.path.join(GOLD, motion) if motion else None,
                       max_chan=max_chan)
     ch = fe.generate(nblocks)
     fe.close()
     t_fe = time.perf_counter() - t0
+    depth = 4
+    st = synth.stream(ch.shape[1], 1.0 / fs, nsamp, push_blocks, depth=depth, flags=pkg.CHAIN_CARRIER | pkg.STREAM_DEVICE_ONLY)
+
+    def render():
+        pushed = popped = 0
+        n = nblocks // push_blocks
+        while popped < n:
+            while pushed < n and st.pending < depth:
+                st.push(ch[pushed * push_blocks:(pushed + 1) * push_blocks])
+                pushed += 1
+            st.pop(copy=False)
+            popped += 1
+        synth.sync()
+
+    render()  # once before the clock starts: device buffers are allocated on first use
     t0 = time.perf_counter()
-    ch["carr_phase"] = pkg.chain_carrier_host(ch, 1.0 / fs, nsamp, 16)
-    ch["carr_phase"][ch["prn"] <= 0] = 0.0
-    t_chain = time.perf_counter() - t0
-    batches = [synth.batch(ch[k:k + batch_blocks], 1.0 / fs, nsamp) for k in range(0, nblocks, batch_blocks)]
-    for b in batches:  # every batch once before the clock starts: its device buffers are allocated on first use
-        b.run()
-        b.run()
-    synth.sync()
-    t0 = time.perf_counter()
-    for b in batches:
-        b.run()
-    synth.sync()
+    render()
     dt = time.perf_counter() - t0
-    for b in batches:
-        b.close()
+    on_dev = synth.info(pkg.INFO_CHAIN_ON_DEVICE)
+    st.close()
     return {"config": name, "channels": int((ch["prn"][0] > 0).sum()), "fs": fs, "nsamp_per_block": nsamp,
-            "blocks": nblocks, "signal_seconds": nblocks * 0.1, "front_end_s": t_fe, "host_carrier_chain_s": t_chain,
-            "gpu_s": dt, "iq_samples_per_s": nblocks * nsamp / dt, "x_realtime": nblocks * 0.1 / dt}
+            "blocks": nblocks, "signal_seconds": nblocks * 0.1, "front_end_s": t_fe, "render_s": dt,
+            "carrier_chain": "device" if on_dev else "host threads inside push()",
+            "render_iq_samples_per_s": nblocks * nsamp / dt,
+            "end_to_end_iq_samples_per_s": nblocks * nsamp / (dt + t_fe), "x_realtime_end_to_end": nblocks * 0.1 / (dt + t_fe)}
 
 
 def main():

@@ -377,6 +377,9 @@ struct gpsbb_batch {
     size_t hs_tx_cap = 0, hs_tn_cap = 0;
     /* GPSBB_CHAIN_CARRIER resolved on the device (gpsbb_walk.hip.h: k_chain_prefix / k_chain_fix) */
     bool chain_dev = false;
+    bool chain_starts = false; /* ... with the per-sample kernel: the chain kernels only fix the blocks' start phases */
+    DevBuf<int32_t> d_chain_order; /* chain_starts: the carrier chains, as k_walk's passes take them */
+    int chain_lanes = 0;
     DevBuf<ChainAux> d_aux[NSETS];
     DevBuf<SynRow> d_prefix[NSETS];
     std::vector<ChainAux> h_aux;
@@ -697,7 +700,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
 
     {
         /* everything a set-up uploads, with room to spare: descriptors, plans, per-channel constants, chain scratch */
-        const size_t need = nbc * (sizeof(gpsbb_chan_t) + sizeof(EvConst) + (size_t)NSETS * sizeof(ChainAux) + 2 * 8 + 2 * 4 + 4 * 4) +
+        const size_t need = nbc * (sizeof(gpsbb_chan_t) + sizeof(EvConst) + (size_t)NSETS * sizeof(ChainAux) + 2 * 8 + 2 * 4 + 5 * 4) +
                             64 * 1024;
         if (b->upload_done) /* the previous set-up's copies out of the arena are long done; make sure */
             HIPCHK(h, hipEventSynchronize(b->upload_done));
@@ -797,8 +800,9 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         HIPCHK(h, stage_upload(b, b->d_kstep.p, b->h_kstep.data(), nbc * 4, upload_stream));
     }
     b->h_ch.assign(ch, ch + nbc);
-    b->chain_dev = b->ev && (flags & GPSBB_CHAIN_CARRIER) && (nblocks > 1 || b->d_carry) && h->opt_chain_where == 0 &&
+    b->chain_dev = !fixed && (flags & GPSBB_CHAIN_CARRIER) && (nblocks > 1 || b->d_carry) && h->opt_chain_where == 0 &&
                    !host_seeding_wanted(b);
+    b->chain_starts = b->chain_dev && !b->ev;
     b->cont0_mask = 0;
     if (b->chain_dev) {
         /* The carrier chain is resolved exactly on the device, in parallel over the blocks (k_walk pass A,
@@ -830,7 +834,8 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         }
         for (int set = 0; set < b->nsets; set++) {
             HIPCHK(h, (hipError_t)b->d_aux[set].reserve(nbc));
-            HIPCHK(h, (hipError_t)b->d_prefix[set].reserve(nbc * (size_t)CHAIN_PREFIX_CAP));
+            if (!b->chain_starts)
+                HIPCHK(h, (hipError_t)b->d_prefix[set].reserve(nbc * (size_t)CHAIN_PREFIX_CAP));
             HIPCHK(h, stage_upload(b, b->d_aux[set].p, b->h_aux.data(), nbc * sizeof(ChainAux), upload_stream));
         }
     }
@@ -897,6 +902,23 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         HIPCHK(h, (hipError_t)b->d_seed_order.reserve(order.size()));
         PUSH_MARK("order");
         HIPCHK(h, stage_upload(b, b->d_seed_order.p, order.data(), order.size() * 4, upload_stream));
+        if (b->chain_starts) {
+            /* the chain's two walks take the carrier chains alone, in lockstep: by direction, then by |f_carr| */
+            std::sort(carr.begin(), carr.end(), [hc](int32_t x, int32_t y) {
+                const double fx = hc[x].prn > 0 ? std::fabs(hc[x].f_carr) : -1.0, fy = hc[y].prn > 0 ? std::fabs(hc[y].f_carr) : -1.0;
+                const bool nx = hc[x].prn > 0 && std::signbit(hc[x].f_carr), ny = hc[y].prn > 0 && std::signbit(hc[y].f_carr);
+                if (nx != ny)
+                    return ny;
+                return fx > fy || (fx == fy && x < y);
+            });
+            std::vector<int32_t> co;
+            for (size_t c = 0; c < nbc; c += 64)
+                for (size_t l = 0; l < 64; l++)
+                    co.push_back(c + l < nbc ? carr[c + l] + (int32_t)nbc : -1);
+            b->chain_lanes = (int)co.size();
+            HIPCHK(h, (hipError_t)b->d_chain_order.reserve(co.size()));
+            HIPCHK(h, stage_upload(b, b->d_chain_order.p, co.data(), co.size() * 4, upload_stream));
+        }
     }
     if (!b->upload_done)
         HIPCHK(h, hipEventCreateWithFlags(&b->upload_done, hipEventDisableTiming));
@@ -966,6 +988,7 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         b->d_tile_nav[k].release();
         b->d_aux[k].release();
         b->d_prefix[k].release();
+        b->d_chain_order.release();
         b->d_evc.release();
     }
     if (b->hs_rows)
@@ -1295,8 +1318,9 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.tile_nav = b->d_tile_nav[set].p;
     p.evc = b->d_evc.p;
     p.chain_dev = b->chain_dev ? 1 : 0;
+    p.chain_starts = b->chain_starts ? 1 : 0;
     p.aux = b->chain_dev ? b->d_aux[set].p : nullptr;
-    p.prefix_rows = b->chain_dev ? b->d_prefix[set].p : nullptr;
+    p.prefix_rows = b->chain_dev && !b->chain_starts ? b->d_prefix[set].p : nullptr;
     p.carry = b->chain_dev ? b->d_carry : nullptr;
     p.cont0_mask = b->cont0_mask;
     return p;
@@ -1381,6 +1405,26 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
             ctr_reset_by_prepass = true; /* k_tiles zeroes the set's tile counters */
         }
     } else {
+        if (b->chain_starts) {
+            /* the carrier chained on the device for the per-sample kernel: pass A, prefix, pass B without rows and the
+             * fix-up put the exact start phase of every block into its descriptor; k_seed then sees independent blocks */
+            BatchDev pc = p;
+            pc.seed_order = b->d_chain_order.p;
+            pc.seed_lanes = b->chain_lanes;
+            const dim3 wg_c((b->chain_lanes + GPSBB_WALK_WG - 1) / GPSBB_WALK_WG);
+            hipLaunchKernelGGL(k_walk<1>, wg_c, dim3(GPSBB_WALK_WG), 0, ss, pc);
+            if (b->d_carry && b->ev_prefix)
+                HIPCHK(h, hipStreamWaitEvent(ss, b->ev_prefix, 0));
+            hipLaunchKernelGGL(k_chain_prefix, dim3(b->nch), dim3(64), 0, ss, pc);
+            if (b->d_carry && b->ev_prefix)
+                HIPCHK(h, hipEventRecord(b->ev_prefix, ss));
+            hipLaunchKernelGGL(k_walk<3>, wg_c, dim3(GPSBB_WALK_WG), 0, ss, pc);
+            if (b->d_carry && b->ev_fix)
+                HIPCHK(h, hipStreamWaitEvent(ss, b->ev_fix, 0));
+            hipLaunchKernelGGL(k_chain_fix, dim3(1), dim3(64), 0, ss, pc);
+            if (b->d_carry && b->ev_fix)
+                HIPCHK(h, hipEventRecord(b->ev_fix, ss));
+        }
         hipLaunchKernelGGL(k_seed<false>, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, ss, p);
     }
     HIPCHK(h, hipGetLastError());
@@ -1418,7 +1462,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         h->last_chain_dev = b->chain_dev ? 1 : 0;
     } else {
         h->last_kernel = 1;
-        h->last_chain_dev = 0;
+        h->last_chain_dev = b->chain_dev ? 1 : 0;
         /* Workgroups per block: enough of them to oversubscribe the chip ~3x (tiles are handed out
          * dynamically in chunks, so the tail is short), never more than there are chunks; the per-block
          * LDS tables (amplitude LUT, chips, nav words) are then built few times per block. */
@@ -1834,12 +1878,10 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
          * the push (exactly, in parallel over the blocks, the phase carried from push to push in device memory),
          * else on host threads (sequential per channel).  A stream may change sides between pushes: the carry
          * then moves across, which costs a synchronisation. */
-        std::vector<EvConst> tmp;
         static const size_t host_lim = getenv("GPSBB_HOST_SEED_MAX") ? (size_t)atol(getenv("GPSBB_HOST_SEED_MAX")) : HOST_SEED_MAX_CHANNELS;
         static const bool dev_only = getenv("GPSBB_DEVICE_SEED_ONLY") != nullptr;
-        const bool dev = h->opt_chain_where == 0 && h->opt_synth_kernel != 1 &&
-                         (h->opt_seed_where == 1 || (h->opt_seed_where == 0 && (dev_only || nbc > host_lim))) &&
-                         ev_plan(ch, s->bps, s->nch, s->delt, tmp);
+        const bool dev = h->opt_chain_where == 0 &&
+                         (h->opt_seed_where == 1 || (h->opt_seed_where == 0 && (dev_only || nbc > host_lim)));
         if (!s->carry) {
             s->carry = new (std::nothrow) ChainCarry();
             if (!s->carry)

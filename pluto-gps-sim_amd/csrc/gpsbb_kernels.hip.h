@@ -174,6 +174,8 @@ struct BatchDev {
                                        bit after the next code roll-over is -1                         */
     const EvConst *evc;             /* [nblocks*nch]                                                  */
     int chain_dev;                  /* 1: GPSBB_CHAIN_CARRIER is resolved on the device (k_chain_prefix / k_chain_fix) */
+    int chain_starts;               /* ... for the per-sample kernel: the chain kernels only put the exact start phase of every
+                                       block into its descriptor (no rows, no offsets); k_seed then sees independent blocks */
     ChainAux *aux;                  /* [nblocks*nch]                                                  */
     SynRow *prefix_rows;            /* [nblocks*nch][CHAIN_PREFIX_CAP]: see ChainAux::prefix_cnt       */
     ChainCarryDev *carry;           /* stream: block 0 continues the previous push's last block; else NULL */

@@ -357,7 +357,8 @@ __device__ __forceinline__ WalkLane<KIND> walk_lane(const BatchDev &p, int chain
  * PASS: 0 = every block starts from its descriptor's carr_phase (independent blocks, or seeds resolved by the
  * host); 1 = pass A of the device-side carrier chain: carrier chains only, from the rough start phases, end
  * states only (ChainAux::endA); 2 = pass B: all chains, carriers from the refined start phases, rows, margins
- * and the place of the first wrap (see k_chain_fix).
+ * and the place of the first wrap (see k_chain_fix); 3 = pass B where only the blocks' exact start phases are wanted
+ * (the per-sample kernel's pre-pass follows and sees independent blocks): carrier chains only, no rows.
  */
 template <int PASS>
 __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
     const int c = gid < p.seed_lanes ? p.seed_order[gid] : -1;
     const int nbc = p.nblocks * p.nch;
     const bool is_code = c >= 0 && c < nbc, is_carr = c >= nbc;
-    if (PASS != 1 && __ballot(is_code)) {
+    if (PASS != 1 && PASS != 3 && __ballot(is_code)) {
         const int k = is_code ? c : 0;
         const gpsbb_chan_t &ch = p.ch[k];
         const bool on = is_code && ch.prn > 0;
@@ -399,20 +400,22 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
         const int k = is_carr ? c - nbc : 0;
         const gpsbb_chan_t &ch = p.ch[k];
         const bool on = is_carr && ch.prn > 0;
-        const double x0 = PASS == 1 ? p.aux[k].start0 : (PASS == 2 ? p.aux[k].start1 : ch.carr_phase);
+        const double x0 = PASS == 1 ? p.aux[k].start0 : (PASS >= 2 ? p.aux[k].start1 : ch.carr_phase);
         WalkLane<NCO_CARR> w = walk_lane<NCO_CARR>(p, nbc + k, x0, mul_rn(ch.f_carr, p.delt) /* c:2741 */, on);
-        w.aux = PASS == 2 ? &p.aux[k] : nullptr;
-        if (PASS == 2)
-            walk_both_signs<NCO_CARR, true>(w, p.nsamp, p.hazards, p.status);
+        w.aux = PASS >= 2 ? &p.aux[k] : nullptr;
+        if (PASS >= 2)
+            walk_both_signs<NCO_CARR, true, PASS == 2>(w, p.nsamp, p.hazards, p.status);
         else
             walk_both_signs<NCO_CARR, false, PASS != 1>(w, p.nsamp, p.hazards, p.status);
         if (is_carr) {
             if (PASS == 1) {
                 p.aux[k].endA = on ? w.x : 0.0;
             } else {
-                p.row_cnt[nbc + k] = on ? (int32_t)(w.cnt < w.cap ? w.cnt : w.cap) : 0;
-                p.end[k].carr_phase = on ? w.x : 0.0;
-                if (PASS == 2) {
+                if (PASS != 3) {
+                    p.row_cnt[nbc + k] = on ? (int32_t)(w.cnt < w.cap ? w.cnt : w.cap) : 0;
+                    p.end[k].carr_phase = on ? w.x : 0.0;
+                }
+                if (PASS >= 2) {
                     /* the trajectory walked here is not final: k_chain_fix decides what counts */
                     ChainAux &a = p.aux[k];
                     a.margin = w.margin;
@@ -493,6 +496,14 @@ __global__ void k_chain_prefix(BatchDev p)
         carry = __shfl(e, 63);
     }
 }
+
+/* an exact walk of which only the end state and the hazard count are wanted */
+struct FixNullSink {
+    uint32_t hz512;
+    __device__ __forceinline__ void row(int32_t, uint32_t, double, double, bool) {}
+    __device__ __forceinline__ void table_index_512() { hz512++; }
+    __device__ __forceinline__ void nav_fetch(uint32_t) {}
+};
 
 /* rows of one exact walk of a whole block, as k_walk writes them (build_rows_f64 drives it) */
 struct FixRowSink {
@@ -664,13 +675,21 @@ __global__ __launch_bounds__(64) void k_chain_fix(BatchDev p)
              * the offset is a multiple of every grid and the rest of the block is pass B's plus it */
             const int nstar = in.wrap_row; /* a wrap always starts a row */
             FixRowSink sink;
-            sink.rows = reinterpret_cast<WalkRow *>(p.prefix_rows) + k * CHAIN_PREFIX_CAP;
-            sink.cap = CHAIN_PREFIX_CAP;
+            sink.rows = p.chain_starts ? nullptr : reinterpret_cast<WalkRow *>(p.prefix_rows) + k * CHAIN_PREFIX_CAP;
+            sink.cap = p.chain_starts ? 0 : CHAIN_PREFIX_CAP;
             sink.cnt = 0;
             sink.overflow = false;
             sink.hz512 = 0;
             uint32_t nav = 0;
-            const double xs = build_rows_f64<NCO_CARR>(x, s, nav, nstar, sink);
+            double xs;
+            if (p.chain_starts) { /* only the state at the wrap is wanted */
+                FixNullSink ns;
+                ns.hz512 = 0;
+                xs = build_rows_f64<NCO_CARR>(x, s, nav, nstar, ns);
+                sink.hz512 = ns.hz512;
+            } else {
+                xs = build_rows_f64<NCO_CARR>(x, s, nav, nstar, sink);
+            }
             d = xs - in.wrap_x;
             /* (a tie-prone coarsest grid and an odd offset there: pass B's recorded tie is not part of this path) */
             ok = !sink.overflow && sink.hz512 == 0 && fabs(d) < margin - 0x1p-51 &&
@@ -717,7 +736,14 @@ __global__ __launch_bounds__(64) void k_chain_fix(BatchDev p)
             printf("chain fallback: block %d ch %d d0 %.3e d %.3e margin %.3e ncross %d es %d tie_top %d tie_asc %d wrap_row %d\n", b,
                    i, d0, d, margin, ncross, es, (int)tie_top, (int)tie_asc, in.wrap_row);
 #endif
-        if (on && !ok) {
+        if (on && !ok && p.chain_starts) {
+            /* on its own: the whole block exactly; only its end state is wanted */
+            FixNullSink ns;
+            ns.hz512 = 0;
+            uint32_t nav = 0;
+            end = build_rows_f64<NCO_CARR>(x, s, nav, p.nsamp, ns);
+            n_fallback++;
+        } else if (on && !ok) {
             /* on its own: the whole block exactly, rows in place of pass B's, no offsets */
             FixRowSink sink;
             sink.rows = reinterpret_cast<WalkRow *>(p.rows) + p.row_off[nbc + k];
@@ -736,7 +762,13 @@ __global__ __launch_bounds__(64) void k_chain_fix(BatchDev p)
             a.prefix_cnt = 0;
             n_fallback++;
         }
-        if (lane_on) {
+        if (lane_on && p.chain_starts) {
+            /* the per-sample kernel's pre-pass comes next: all it needs is where this block starts (it counts the
+             * hazards and writes the end states itself) */
+            if (on && cont)
+                const_cast<gpsbb_chan_t *>(p.ch)[k].carr_phase = x;
+            prev_end = end;
+        } else if (lane_on) {
             p.end[k].carr_phase = on ? end : 0.0;
             prev_end = end;
             if (on)

@@ -28,6 +28,9 @@ def stream_soak(a):
     with pkg.Synth(0) as synth:
         for case in range(a.cases):
             fs = float(rng.choice([16.368e6, 20e6, 25e6, 30e6, 2.0 ** 25, 50e6]))
+            low_rate = rng.random() < 0.25          # a rate only the per-sample kernel takes
+            if low_rate:
+                fs = float(rng.choice([1e6, 2.6e6, 4.092e6, 10e6]))
             nch = int(rng.integers(1, 17))
             bps = int(rng.choice([4, 16, 33, 64, 100] if a.nsamp_max <= 1000000 else [2, 3, 5]))
             pushes = int(rng.integers(2, 6 if a.nsamp_max <= 1000000 else 4))
@@ -35,7 +38,7 @@ def stream_soak(a):
             nb = bps * pushes
             ch = pkg.synth_descriptors(nb, nch=nch, seed=int(rng.integers(1, 2 ** 31)))
             # Doppler: a slow drift per channel (what a real stream looks like) or independent per block
-            f0 = rng.uniform(-1.0, 1.0, size=nch) * fs / 2100.0 * 10.0 ** rng.uniform(-4, 0, size=nch)
+            f0 = rng.uniform(-1.0, 1.0, size=nch) * (min(fs / 2100.0, 2e4) if not low_rate else 6e3) * 10.0 ** rng.uniform(-4, 0, size=nch)
             if rng.random() < 0.6:
                 drift = rng.uniform(-1e-3, 1e-3, size=nch) * np.abs(f0)
                 f = f0[None, :] + drift[None, :] * np.arange(nb)[:, None]
@@ -56,6 +59,7 @@ def stream_soak(a):
             depth = int(rng.integers(2, 5))
             dev_only = bool(rng.integers(0, 2))
             synth.set_option(pkg.OPT_SEED_WHERE, 1 if rng.random() < 0.85 else 0)  # mostly: pre-pass and chain on the device
+            synth.set_option(pkg.OPT_SYNTH_KERNEL, 1 if rng.random() < 0.25 else 0)  # now and then the per-sample kernel where the other one would do
             st = synth.stream(nch, delt, nsamp, bps, depth=depth,
                               flags=pkg.CHAIN_CARRIER | (pkg.STREAM_DEVICE_ONLY if dev_only else 0))
             got = []

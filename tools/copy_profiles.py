@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""copy the summaries of a tools/gpu_round.sh run from gpurun_out/<tag> into the tracked profiles/ : python tools/copy_profiles.py <tag>"""
+import json, os, shutil, sqlite3, sys
+tag = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+c = sqlite3.connect(os.path.join(src, "prof", "trace_results.db"))
+cols = [r[1] for r in c.execute("pragma table_info(top_kernels)")]
+rows = c.execute("select * from top_kernels").fetchall()
+with open(os.path.join(dst, tag + "_stream_kernel_stats.txt"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu   (bench.py's defaults)\n")
+    f.write("# top_kernels view of the trace database; total_duration and average in microseconds\n")
+    f.write(" | ".join(cols) + "\n")
+    for r in rows:
+        f.write(" | ".join(("%.1f" % x if isinstance(x, float) else str(x)) for x in r) + "\n")
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_stream_bench.json"))
+shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(dst, tag + "_stream_pmc.json"))
+sq = os.path.join(ROOT, "gpurun_out", tag + "_sq.txt")
+if os.path.exists(sq):
+    shutil.copy(sq, os.path.join(dst, tag + "_sq_counters.txt"))
+s = json.load(open(os.path.join(src, "pmc_summary.json")))
+d = {k: s[k] for k in ("k_synth_hbm_write_bytes_per_launch", "k_synth_hbm_read_bytes_per_launch", "k_synth_hbm_bytes_per_launch")}
+d["kernel"] = "k_synth_ev"
+d["source"] = "profiles/%s_stream_pmc.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE in separate passes, KiB -> bytes, calibration factor 1.0 measured on k_fill_ceiling)" % tag
+json.dump(d, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
+b = json.load(open(os.path.join(src, "bench.json")))
+print("value %.4g  ms/step %.2f  seconds %s" % (b["value"], b["ms_per_step"], b["repeats"]["seconds"]))
+print("roofline", json.dumps(b["roofline"])[:700])
+for k in ("gather", "resident", "m1", "cpu_baseline", "prepass_ms_per_launch", "device_chain"):
+    print(k, json.dumps(b.get(k))[:420])
+for k, v in s["kernels"].items():
+    print(k, v.get("calls"), v.get("avg_us"), v.get("WRITE_SIZE_KiB_per_launch"), v.get("FETCH_SIZE_KiB_per_launch"))

@@ -316,28 +316,45 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
         const int prn = cb[i].prn;
         const bool down = kb[i].down != 0; /* falling carrier: the table back to front (see ev_first) */
         const double g = cb[i].gain;
-        for (int e = tid & 63; e < EV_AMP_STRIDE; e += 64) {
+        /* fully unrolled: all table loads of a wavefront are in flight at once (a workgroup that joins a block late
+         * idles its CU for as long as this staging takes) */
+        int32_t tc[(EV_AMP_STRIDE + 63) / 64], ts[(EV_AMP_STRIDE + 63) / 64];
+#pragma unroll
+        for (int j = 0; j < (EV_AMP_STRIDE + 63) / 64; j++) {
+            const int e = (tid & 63) + 64 * j;
             const int k = down ? 511 - (e & 511) : (e & 511);
+            tc[j] = p.tabs[k];
+            ts[j] = p.tabs[512 + k];
+        }
+        /* the PRN's 1023 chips are 32 words: one per lane, fetched once, handed round with ds_bpermute */
+        const uint32_t my_word = p.ca_bits[(prn > 0 ? prn : 0) * 32 + (tid & 31)];
+#pragma unroll
+        for (int j = 0; j < (EV_AMP_STRIDE + 63) / 64; j++) {
+            const int e = (tid & 63) + 64 * j;
             uint32_t v = 0;
             if (prn > 0) {
                 /* (int)(table * gain): one IEEE multiply, truncation toward zero (plutogpssim.c:2701-2702) */
-                const int ip = (int)mul_rn((double)p.tabs[k], g);
-                const int qp = (int)mul_rn((double)p.tabs[512 + k], g);
+                const int ip = (int)mul_rn((double)tc[j], g);
+                const int qp = (int)mul_rn((double)ts[j], g);
                 v = ((uint32_t)qp << 16) + (uint32_t)ip;
             }
-            L.amp[i][e] = v;
+            if (e < EV_AMP_STRIDE)
+                L.amp[i][e] = v;
         }
-        const uint32_t *__restrict__ bits = p.ca_bits + (prn > 0 ? prn : 0) * 32;
-        for (int c = tid & 63; c < EV_CHIP_LEN; c += 64) {
+#pragma unroll
+        for (int j = 0; j < (EV_CHIP_LEN + 63) / 64; j++) {
+            const int c = (tid & 63) + 64 * j;
             const int ca = c >= GPSBB_CA_LEN ? c - GPSBB_CA_LEN : c; /* c < 2 * 1023 */
             const int cb1 = c + 1 >= GPSBB_CA_LEN ? c + 1 - GPSBB_CA_LEN : c + 1;
+            const uint32_t w0 = (uint32_t)__shfl((int)my_word, (ca >> 5) & 31), w1 = (uint32_t)__shfl((int)my_word, (cb1 >> 5) & 31);
             uint32_t v = 0;
             if (prn > 0) {
-                const uint32_t b0 = (bits[ca >> 5] >> (ca & 31)) & 1u;
-                const uint32_t b1 = (bits[cb1 >> 5] >> (cb1 & 31)) & 1u;
+                const uint32_t b0 = (w0 >> (ca & 31)) & 1u;
+                const uint32_t b1 = (w1 >> (cb1 & 31)) & 1u;
                 v = (b0 ? 0x00u : 0xffu) | (b1 ? 0x0000u : 0xff00u);
             }
-            L.chip2[i][c] = (uint16_t)v;
+            if (c < EV_CHIP_LEN)
+                L.chip2[i][c] = (uint16_t)v;
         }
     }
     for (int e = tid; e < EV_WAVES * 16 * 64; e += EV_WG)

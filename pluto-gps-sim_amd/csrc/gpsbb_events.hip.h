@@ -306,6 +306,19 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
      * With the block as the slow dimension the launch proceeds in rounds of (CUs / workgroups per block)
      * blocks and the last round leaves part of the chip idle: 2.4 instead of 2.1 ms. */
     const int b = blockIdx.x;
+#ifdef GPSBB_EV_TIMING /* measurement build: when every workgroup started, finished staging and left (tools/wg_timing.py) */
+    const unsigned long long t_entry = wall_clock64();
+    unsigned long long *tlog = reinterpret_cast<unsigned long long *>(iq) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+    if (blockIdx.y > 0 && __hip_atomic_load(&p.tile_ctr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.ntiles) {
+        if (threadIdx.x == 0) {
+            tlog[0] = t_entry;
+            tlog[1] = t_entry;
+            tlog[2] = wall_clock64();
+            tlog[3] = 0;
+        }
+        return;
+    }
+#endif
     if (blockIdx.y > 0 && __hip_atomic_load(&p.tile_ctr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.ntiles)
         return;
     const gpsbb_chan_t *__restrict__ cb = p.ch + (size_t)b * p.nch;
@@ -360,6 +373,10 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
     for (int e = tid; e < EV_WAVES * 16 * 64; e += EV_WG)
         (&L.D[0][0][0])[e] = 0u;
     __syncthreads();
+#ifdef GPSBB_EV_TIMING
+    const unsigned long long t_staged = wall_clock64();
+    unsigned long long n_tiles_done = 0;
+#endif
 
     /* ---- from here on every wavefront works alone ---- */
     const int wave = tid >> 6, lane = tid & 63;
@@ -472,7 +489,19 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
         base = next_base;
         pos = next_pos;
         buf ^= 1;
+#ifdef GPSBB_EV_TIMING
+        n_tiles_done++;
+#endif
     }
+#ifdef GPSBB_EV_TIMING
+    __syncthreads(); /* the workgroup leaves when its last wavefront does */
+    if (threadIdx.x == 0) {
+        tlog[0] = t_entry;
+        tlog[1] = t_staged;
+        tlog[2] = wall_clock64();
+        tlog[3] = n_tiles_done; /* wavefront 0's */
+    }
+#endif
 }
 
 } /* namespace gpsbb_impl */

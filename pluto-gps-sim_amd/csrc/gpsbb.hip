@@ -1854,10 +1854,8 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     HIPCHK(h, hipSetDevice(h->device));
     auto &sl = s->slots[s->head % s->depth];
     gpsbb_batch *b = sl.batch;
-    /* Blocks consecutive in time with the IEEE carrier: the exact phase at the start of every block is
-     * computed here on host threads with the same jump-ahead the device uses (it depends on descriptors
-     * only), so the device sees independent blocks and the pre-pass stays fully parallel.  Chaining on the
-     * device (one lane per channel walking the slot's blocks in order) is ~12x slower for a 16-block slot. */
+    /* Blocks consecutive in time with the IEEE carrier: the carrier phase carries over from block to block and from
+     * push to push, exactly.  Where that is resolved is decided per push below (on the device: gpsbb_walk.hip.h). */
     unsigned run_flags = s->flags & (GPSBB_CHAIN_CARRIER | GPSBB_FIXED_CARRIER);
     const size_t nbc = (size_t)s->bps * s->nch;
     b->d_carry = nullptr;
@@ -1874,10 +1872,10 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
         for (size_t k = 0; k < nbc; k++)
             if (!chan_ok(ch[k], s->delt))
                 return GPSBB_E_BADCHAN;
-        /* Where the carrier is chained: on the device wherever the breakpoint kernel and the device pre-pass take
-         * the push (exactly, in parallel over the blocks, the phase carried from push to push in device memory),
-         * else on host threads (sequential per channel).  A stream may change sides between pushes: the carry
-         * then moves across, which costs a synchronisation. */
+        /* Where the carrier is chained: on the device wherever the pre-pass runs there (exactly, in parallel over the
+         * blocks, the phase carried from push to push in device memory; for either synthesis kernel), on host
+         * threads — sequential per channel — for pushes small enough to be seeded on the host.  A stream may
+         * change sides between pushes: the carry then moves across, which costs a synchronisation. */
         static const size_t host_lim = getenv("GPSBB_HOST_SEED_MAX") ? (size_t)atol(getenv("GPSBB_HOST_SEED_MAX")) : HOST_SEED_MAX_CHANNELS;
         static const bool dev_only = getenv("GPSBB_DEVICE_SEED_ONLY") != nullptr;
         const bool dev = h->opt_chain_where == 0 &&

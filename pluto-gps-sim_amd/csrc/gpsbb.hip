@@ -330,11 +330,10 @@ struct DevBuf {
 };
 
 /* Table sets of a batch.  Run k uses set k % nsets and its pre-pass may start as soon as the synthesis kernel
- * that last read that set has finished.  Per-sample kernel: two sets (the pre-pass of run k+1 overlaps the
- * synthesis of run k).  Breakpoint kernel: three, and consecutive runs seed on alternating streams: its
- * pre-pass (k_walk) is as long as its longest chain whatever the batch size — longer than the synthesis it
- * feeds — so two of them have to be in flight for the synthesis kernel to set the pace; four, three pre-passes in
- * flight on three streams, where the carrier is chained on the device (two walks and the fix-up per run). */
+ * that last read that set has finished.  Three sets, and consecutive runs seed on alternating streams: a
+ * pre-pass is as long as its longest chain whatever the batch size — longer than the synthesis it feeds — so
+ * two of them have to be in flight for the synthesis kernel to set the pace; four, three pre-passes in flight on
+ * three streams, where the carrier is chained on the device (two walks and the fix-up per run). */
 constexpr int NSETS = 4;
 
 struct gpsbb_batch {
@@ -752,7 +751,10 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     HIPCHK(h, (hipError_t)b->d_ch.reserve(nbc));
     HIPCHK(h, (hipError_t)b->d_row_off.reserve(2 * nbc + 1));
     HIPCHK(h, (hipError_t)b->d_tile_ctr.reserve((size_t)NSETS * (size_t)nblocks)); /* one set of counters per table set */
-    b->nsets = b->ev ? ((flags & GPSBB_CHAIN_CARRIER) && nblocks > 1 && h->opt_chain_where == 0 ? 4 : 3) : 2;
+    /* table sets = pre-passes in flight + 1: the pre-pass of either kernel takes longer than the synthesis it feeds
+     * (M1 geometry, per-sample kernel: two sets 6.6e10, three 7.7e10 samples/s), the chained ones longer still */
+    const bool chain_maybe_dev = (flags & GPSBB_CHAIN_CARRIER) && !fixed && nblocks > 1 && h->opt_chain_where == 0;
+    b->nsets = chain_maybe_dev ? 4 : 3;
     b->nsets = b->nsets > b->max_sets ? b->max_sets : b->nsets;
     for (int set = 0; set < b->nsets; set++) {
         HIPCHK(h, (hipError_t)b->d_end[set].reserve(nbc));

@@ -26,7 +26,7 @@ def run(pkg, synth, name, nav, motion, max_chan, fs, nsamp, nblocks, push_blocks
     ch = fe.generate(nblocks)
     fe.close()
     t_fe = time.perf_counter() - t0
-    depth = 4
+    depth = 6
     st = synth.stream(ch.shape[1], 1.0 / fs, nsamp, push_blocks, depth=depth, flags=pkg.CHAIN_CARRIER | pkg.STREAM_DEVICE_ONLY)
 
     def render():
@@ -59,11 +59,11 @@ def main():
     out = []
     with pkg.Synth(0) as s:
         out.append(run(pkg, s, "1/2 static, 2.6 MS/s, reference block (300000 samples)", "synth3540.14n", None, 12,
-                       2.6e6, 300000, 3000, 1000))
+                       2.6e6, 300000, 3000, 250))
         out.append(run(pkg, s, "4 user motion (10 Hz), 2.6 MS/s", "synth3540.14n", "circle_motion.csv", 12, 2.6e6,
-                       300000, 3000, 1000))
+                       300000, 3000, 250))
         out.append(run(pkg, s, "3 geometry through the front end: 16 ch, 25 MS/s, 2.5 M-sample blocks", "dense3540.14n",
-                       None, 16, 25e6, 2500000, 400, 200))
+                       None, 16, 25e6, 2500000, 400, 100))
     print(json.dumps(out, indent=1))
 
 

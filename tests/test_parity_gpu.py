@@ -669,6 +669,31 @@ def test_randomised_shapes_and_dopplers(pkg, synth, oracle):
     synth.hazards(reset=True)
 
 
+def test_headline_stream_chain_against_the_host_chain(pkg):
+    """The bench's own workload: eight pushes of 400 full-size blocks (16 ch, 25 MS/s, 2.5 M samples) of bench.py's
+    stream through the HBM-only ring, carrier chained on the device; the end-of-block carrier phases of all 3200
+    blocks equal, bit for bit, gpsbb_chain_carrier_host's exact walk of the same descriptors."""
+    sys.path.insert(0, ROOT)
+    import bench
+    PB, nch, delt, nsamp, npush = 400, 16, 1 / 25e6, 2500000, 8
+    ch = bench.stream_descriptors(pkg, PB * npush + 1, nch)
+    starts = pkg.chain_carrier_host(ch, delt, nsamp)
+    with pkg.Synth(0) as s:
+        st = s.stream(nch, delt, nsamp, PB, depth=4, flags=pkg.CHAIN_CARRIER | pkg.STREAM_DEVICE_ONLY)
+        ends = []
+        for k in range(npush):
+            if st.pending == 4:
+                ends.append(st.pop(copy=False)[1])
+            st.push(ch[k * PB:(k + 1) * PB])
+        while st.pending:
+            ends.append(st.pop(copy=False)[1])
+        st.close()
+        assert s.info(pkg.INFO_CHAIN_ON_DEVICE) == 1
+        assert s.info(pkg.INFO_LAST_KERNEL) == 2
+    ends = np.concatenate(ends)["carr_phase"]
+    assert ends.tobytes() == starts[1:PB * npush + 1].tobytes()
+
+
 def test_stream_soak_small(pkg):
     """A slice of the stream soak (tools/fuzz_parity.py --stream): 30 random chained streams — pushes of many short
     blocks through rings of random depth, Dopplers that drift or jump, exact binary steps, channels that change PRN

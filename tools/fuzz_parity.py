@@ -31,6 +31,8 @@ def stream_soak(a):
             low_rate = rng.random() < 0.25          # a rate only the per-sample kernel takes
             if low_rate:
                 fs = float(rng.choice([1e6, 2.6e6, 4.092e6, 10e6]))
+            if a.ties:                                 # f_carr * delt is then exact: the steps really have few bits
+                fs, low_rate = 2.0 ** 25, False
             nch = int(rng.integers(1, 17))
             bps = int(rng.choice([4, 16, 33, 64, 100] if a.nsamp_max <= 1000000 else [2, 3, 5]))
             pushes = int(rng.integers(2, 6 if a.nsamp_max <= 1000000 else 4))
@@ -46,6 +48,12 @@ def stream_soak(a):
                 f = f0[None, :] * rng.uniform(0.5, 1.0, size=(nb, nch)) * np.where(rng.random((nb, nch)) < 0.1, -1.0, 1.0)
             if rng.random() < 0.3:                     # exact binary steps: ties on coarse grids
                 f[:, 0] = np.sign(f[0, 0] if f[0, 0] != 0 else 1.0) * fs * 2.0 ** float(rng.integers(-20, -11))
+            if a.ties:                                 # every channel: steps with few mantissa bits (sums tie often), either sign
+                for i in range(nch):
+                    m = float(rng.integers(1, 1 << int(rng.integers(1, 12))) | 1)
+                    f[:, i] = (-1.0 if rng.random() < 0.5 else 1.0) * fs * m * 2.0 ** float(rng.integers(-24, -14))
+                    if not (abs(f[0, i]) < (fs / 2100.0 if not low_rate else 6e3)):
+                        f[:, i] = fs * 2.0 ** -15
             if rng.random() < 0.2:
                 f[:, -1] = 0.0
             ch["f_carr"] = f
@@ -107,6 +115,8 @@ def main():
                     help="chained streams instead of batches: several pushes of many short blocks through a ring, the carrier "
                          "chained on the device from push to push (PRN changes, idle channels, steps that tie), against the "
                          "oracle's sequential render of the whole stream")
+    ap.add_argument("--ties", action="store_true", help="--stream: every carrier step has only a few mantissa bits (exact ties at wraps and "
+                    "binade crossings are common instead of one in thousands)")
     ap.add_argument("--nsamp-max", type=int, default=200000, help="--stream: longest block")
     ap.add_argument("--budget", type=float, default=3e7, help="--stream: channel-samples per case (what the CPU oracle has to walk)")
     a = ap.parse_args()

@@ -157,7 +157,10 @@ bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vec
             amp_sum += 512.0 * std::fabs(c.gain) + 1.0;
             const volatile double sc = c.f_code * delt, sk = c.f_carr * delt;
             const double S = sk * 512.0, aS = std::fabs(S);
-            if (!(sc * reach < 1.0) || !(sc >= 0x1p-20))
+            /* more than one chip change per run: the channel is evaluated per sample (ev_dense), as long as the chip
+             * table reaches past what a tile covers (which also leaves at most one code roll-over per tile) */
+            const bool dense_code = !(sc * reach < 1.0);
+            if (!(sc >= 0x1p-20) || !(1023.0 + 1040.0 * sc + 2.0 <= (double)EV_CHIP_LEN))
                 return false;
             K.S = aS; /* a falling carrier is walked mirrored: phase -y, step |S| */
             K.sc = sc;
@@ -177,10 +180,10 @@ bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vec
                 const double w = EV_MODEL_ERR * K.rS + EV_T_EPS;
                 K.thrK = 0.5 - w;
                 const double kc = std::floor((reach + w) * aS) + 1.0;
-                if (kc > (double)EV_KC_MAX)
-                    return false;
-                K.kc = (int)kc;
+                K.kc = kc > (double)EV_KC_MAX ? EV_KC_DENSE : (int)kc; /* too many index changes per run: per sample */
             }
+            if (dense_code && K.kc > 0)
+                K.kc = EV_KC_DENSE;
         }
         if (!(amp_sum < 32768.0))
             return false;
@@ -375,6 +378,7 @@ struct gpsbb_batch {
     uint32_t *hs_tile_nav = nullptr;
     size_t hs_tx_cap = 0, hs_tn_cap = 0;
     /* GPSBB_CHAIN_CARRIER resolved on the device (gpsbb_walk.hip.h: k_chain_prefix / k_chain_fix) */
+    bool ev_dense = false; /* some channel is evaluated per sample: k_synth_ev<true> */
     bool chain_dev = false;
     bool chain_starts = false; /* ... with the per-sample kernel: the chain kernels only fix the blocks' start phases */
     DevBuf<int32_t> d_chain_order; /* chain_starts: the carrier chains, as k_walk's passes take them */
@@ -620,6 +624,8 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
                                  (int)sizeof(SynthLds))) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(EvLds))) != hipSuccess) return fail(e);
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev_dense), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(EvLds))) != hipSuccess) return fail(e);
     *out = h;
     return GPSBB_OK;
 }
@@ -726,6 +732,10 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     /* Which synthesis kernel: the breakpoint kernel (gpsbb_events.hip.h) where every run of SPT samples holds
      * at most one chip change and at most EV_KC_MAX table-index changes and the I sums stay below 2^15. */
     b->ev = !fixed && h->opt_synth_kernel != 1 && ev_plan(ch, nblocks, nch, delt, b->h_evc);
+    b->ev_dense = false;
+    if (b->ev)
+        for (size_t k = 0; k < nbc && !b->ev_dense; k++)
+            b->ev_dense = b->h_evc[k].kc == EV_KC_DENSE;
     PUSH_MARK("ev_plan");
 
     /* row pool plan: chain id = kind*nbc + block*nch + channel */
@@ -1459,7 +1469,10 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         long want = (wg_slots * oversub + b->nblocks - 1) / b->nblocks;
         want = want < min_wg ? min_wg : want;
         want = want > max_useful ? max_useful : want;
-        hipLaunchKernelGGL(k_synth_ev, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), sc, p, d_iq);
+        if (b->ev_dense)
+            hipLaunchKernelGGL(k_synth_ev_dense, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), sc, p, d_iq);
+        else
+            hipLaunchKernelGGL(k_synth_ev, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), sc, p, d_iq);
         h->last_kernel = 2;
         h->last_chain_dev = b->chain_dev ? 1 : 0;
     } else {

@@ -47,7 +47,9 @@ constexpr int EV_WAVES = EV_WG / 64;
 constexpr int EV_KC_MAX = 4;                       /* carrier breakpoints a run may hold */
 constexpr int EV_AMP_PAD = EV_KC_MAX;              /* table entries repeated after [511] */
 constexpr int EV_AMP_STRIDE = 512 + EV_AMP_PAD + 4;
-constexpr int EV_CHIP_LEN = 1024 + 80;             /* chips 0 .. 1023+79: a tile's model phase never passes 1023 + 1039*sc < 1023 + 68 */
+constexpr int EV_CHIP_LEN = 1024 + 544;            /* chips 0 .. 1567: a tile's model phase never passes 1023 + 1040*sc; the host admits
+                                                      sc up to (EV_CHIP_LEN - 1026) / 1040 = 0.52 chips per sample (1.96 MS/s) */
+constexpr int EV_KC_DENSE = EV_KC_MAX + 1;         /* EvConst::kc of a channel that is evaluated sample by sample (ev_dense) */
 #ifndef GPSBB_EV_CHUNK
 #define GPSBB_EV_CHUNK 2
 #endif
@@ -63,13 +65,13 @@ constexpr int EV_ROW_DISCARD = 15;                 /* D row of changes that fall
 struct EvLds {
     uint32_t amp[GPSBB_MAX_CHAN][EV_AMP_STRIDE]; /* P = Q*65536 + I of table index k mod 512 at [k], k = 0 .. 511+PAD;
                                                     channels with a falling carrier: of index 511 - k */
-    uint16_t chip2[GPSBB_MAX_CHAN][EV_CHIP_LEN]; /* low byte: 0 where codeCA of chip c mod 1023 is +1, 0xff where -1;
-                                                    high byte: the same for chip c+1 */
     uint32_t D[EV_WAVES][16][64];                /* difference arrays: row j-1 holds the change at sample j of the lane's
                                                     run (row 15 = discard), one column per lane */
     double tstate[EV_WAVES][2][2 * GPSBB_MAX_CHAN]; /* per wavefront, two tiles deep: the tile's exact states, column
                                                     2*channel = code phase, 2*channel+1 = carrier phase*512 (512 - that
                                                     for a falling carrier) */
+    uint16_t chip2[GPSBB_MAX_CHAN][EV_CHIP_LEN]; /* low byte: 0 where codeCA of chip c mod 1023 is +1, 0xff where -1;
+                                                    high byte: the same for chip c+1 */
 };
 
 /* (x ^ m) - m: x where m = 0, -x where m = -1 */
@@ -255,6 +257,50 @@ struct EvTile {
     uint32_t exact_mask;   /* bit i: channel i is always recomputed exactly */
 };
 
+/*
+ * A channel whose run holds more index or chip changes than the breakpoint path takes (low sample rates: at 2.6 MS/s
+ * the table index changes at almost every sample): the same linear in-tile model, evaluated at every sample of the
+ * lane's run — index and chip are floor(model), trusted wherever the model stays EV_MODEL_ERR away from an
+ * integer, else the lane's run is recomputed exactly as on the other path — and accumulated per sample in registers
+ * (accd), which the prefix sum of the difference arrays is added to at the end.  No rows, no NCO stepping.
+ */
+template <bool DF>
+__device__ __forceinline__ void ev_dense(EvLds &L, int wave, int lane, int i, const EvConst *kb, const EvTile &T, double off,
+                                         unsigned long long live_mask, uint32_t &acc0, uint32_t (&accd)[SPT],
+                                         unsigned long long *n_exact)
+{
+    const double S = scalar_load(&kb[i].S), sc = scalar_load(&kb[i].sc);
+    const double y0 = __fma_rn(off, S, T.ts[2 * i + 1]), x0 = __fma_rn(off, sc, T.ts[2 * i]);
+    const uint32_t db = 0u - ((T.dbits >> i) & 1u), dn = 0u - ((T.dnext >> i) & 1u);
+    const double thr = 0.5 - EV_MODEL_ERR;
+    unsigned long long um = 0ull;
+    uint32_t v[SPT];
+#pragma unroll
+    for (int j = 0; j < SPT; j++) {
+        const double yj = __fma_rn((double)j, S, y0), xj = __fma_rn((double)j, sc, x0);
+        um |= __builtin_amdgcn_fcmp(fabs(__builtin_amdgcn_fract(yj) - 0.5), thr, 2 /* ogt */);
+        um |= __builtin_amdgcn_fcmp(fabs(__builtin_amdgcn_fract(xj) - 0.5), thr, 2);
+        const int it = (int)yj & 511, ci = (int)xj;
+        uint32_t m = (uint32_t)(int32_t)(int8_t)(L.chip2[i][ci] & 0xffu);
+        m ^= DF ? (ci >= 1023 ? dn : db) : db;
+        v[j] = signed_by(L.amp[i][it], m);
+    }
+    um &= live_mask;
+    if (__builtin_expect(um != 0ull, 0)) {
+        if ((um >> lane) & 1ull) {
+#pragma unroll
+            for (int j = 0; j < SPT; j++)
+                v[j] = 0;
+            const uint32_t nb = ((T.dbits >> i) & 1u) | (((T.dnext >> i) & 1u) << 1);
+            acc0 += ev_exact_run(L, wave, lane, i, kb + i, T.tile_x, T.ntiles, nb, (int)off);
+            atomicAdd(n_exact, 1ull);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < SPT; j++)
+        accd[j] += v[j];
+}
+
 /* the channels of `mask` (bit i = channel i), all with KC breakpoints; two at a time, so that one channel's
  * arithmetic covers the other's LDS latency */
 template <int KC, bool DF>
@@ -294,7 +340,12 @@ __device__ __forceinline__ void ev_channels(EvLds &L, int wave, int lane, uint32
 #undef GPSBB_EV_OUT
 }
 
-__global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restrict__ iq)
+/* DENSE: the batch has channels that are evaluated per sample (ev_dense): a kernel of its own (k_synth_ev_dense), so
+ * that the common one keeps its register count: at <= 104 VGPRs four of its wavefronts leave room on a SIMD for a
+ * wavefront of the pre-pass of the next push; at 120 they do not, and a CU that hosts walk wavefronts cannot take a
+ * synthesis workgroup at all (measured: 2.2 -> 2.8 ms per launch beside the pre-passes). */
+template <bool DENSE>
+__device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__restrict__ iq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     EvLds &L = *reinterpret_cast<EvLds *>(smem_raw);
@@ -354,7 +405,7 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
             if (e < EV_AMP_STRIDE)
                 L.amp[i][e] = v;
         }
-#pragma unroll
+#pragma unroll 4
         for (int j = 0; j < (EV_CHIP_LEN + 63) / 64; j++) {
             const int c = (tid & 63) + 64 * j;
             const int ca = c >= GPSBB_CA_LEN ? c - GPSBB_CA_LEN : c; /* c < 2 * 1023 */
@@ -384,7 +435,7 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
     const int nch2 = 2 * p.nch;
     /* channels by the number of carrier breakpoints a run can hold (bit i = channel i) */
     uint32_t mk[EV_KC_MAX];
-    uint32_t exact_mask;
+    uint32_t exact_mask, mkd; /* always recomputed exactly; evaluated per sample */
     {
         const bool act = lane < p.nch && cb[lane < p.nch ? lane : 0].prn > 0;
         const int kc = act ? kb[lane].kc : 0;
@@ -392,6 +443,7 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
         for (int k = 0; k < EV_KC_MAX; k++)
             mk[k] = (uint32_t)__ballot(act && (kc == k + 1 || (k == 0 && kc < 1)));
         exact_mask = (uint32_t)__ballot(act && kc < 0);
+        mkd = DENSE ? (uint32_t)__ballot(act && kc == EV_KC_DENSE) : 0u;
     }
     /* lane c < 2*nch holds chain c = (channel c >> 1, kind c & 1) of the tile being staged */
     const bool chain_lane = lane < nch2;
@@ -467,12 +519,35 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
         /* ---- prefix sum over the run, back to int16 pairs, store (c:2754-2755) ---- */
         uint32_t o[SPT];
         uint32_t P = acc0;
+        if (DENSE && mkd != 0u) {
+            /* channels evaluated per sample: their sums per sample, on top of the prefix sums of the others */
+            uint32_t accd[SPT];
 #pragma unroll
-        for (int j = 0; j < SPT; j++) {
-            if (j)
-                P += __hip_atomic_exchange(&L.D[wave][j - 1][lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint32_t t = P + 0x8000u; /* undoes the borrow of a negative I in the high half */
-            o[j] = __builtin_amdgcn_perm(t, P, 0x07060100u); /* low half of P, high half of t (v_perm_b32) */
+            for (int j = 0; j < SPT; j++)
+                accd[j] = 0u;
+            for (uint32_t m = mkd; m; m &= m - 1) {
+                const int i = __builtin_ctz(m);
+                if ((dflip >> i) & 1u)
+                    ev_dense<true>(L, wave, lane, i, kb, T, off, live_mask, P, accd, n_exact);
+                else
+                    ev_dense<false>(L, wave, lane, i, kb, T, off, live_mask, P, accd, n_exact);
+            }
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                if (j)
+                    P += __hip_atomic_exchange(&L.D[wave][j - 1][lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t q = P + accd[j];
+                const uint32_t t = q + 0x8000u;
+                o[j] = __builtin_amdgcn_perm(t, q, 0x07060100u);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                if (j)
+                    P += __hip_atomic_exchange(&L.D[wave][j - 1][lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t t = P + 0x8000u; /* undoes the borrow of a negative I in the high half */
+                o[j] = __builtin_amdgcn_perm(t, P, 0x07060100u); /* low half of P, high half of t (v_perm_b32) */
+            }
         }
         uint32_t *out = reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + n0;
         if (nvalid == SPT && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) {
@@ -502,6 +577,17 @@ __global__ __launch_bounds__(EV_WG) void k_synth_ev(BatchDev p, int16_t *__restr
         tlog[3] = n_tiles_done; /* wavefront 0's */
     }
 #endif
+}
+
+/* The common kernel is held to the register budget of five wavefronts per SIMD (96 VGPRs; the allocator's count
+ * wanders between 97 and 117 with the size of the chip table): four of them then leave room for a walk wavefront. */
+__global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_synth_ev(BatchDev p, int16_t *__restrict__ iq)
+{
+    synth_ev_body<false>(p, iq);
+}
+__global__ __launch_bounds__(EV_WG) void k_synth_ev_dense(BatchDev p, int16_t *__restrict__ iq)
+{
+    synth_ev_body<true>(p, iq);
 }
 
 } /* namespace gpsbb_impl */

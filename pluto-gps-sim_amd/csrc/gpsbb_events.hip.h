@@ -270,17 +270,21 @@ __device__ __forceinline__ void ev_dense(EvLds &L, int wave, int lane, int i, co
                                          unsigned long long *n_exact)
 {
     const double S = scalar_load(&kb[i].S), sc = scalar_load(&kb[i].sc);
-    const double y0 = __fma_rn(off, S, T.ts[2 * i + 1]), x0 = __fma_rn(off, sc, T.ts[2 * i]);
+    /* Both models carry 2^20 on top, so that one unit in the last place is 2^-32: the low word of the double then IS the
+     * fraction in units of 2^-32 and the low bits of the high word are the integer part — index, chip and the test
+     * "within the error of an integer" are integer operations on the two words.  Adding 2^20 and the fma round by up
+     * to 2^-33 each: with the model's own 2^-33.9 the band is +-3 units of 2^-32. */
+    const double y0 = __fma_rn(off, S, T.ts[2 * i + 1]) + 0x1p+20, x0 = __fma_rn(off, sc, T.ts[2 * i]) + 0x1p+20;
     const uint32_t db = 0u - ((T.dbits >> i) & 1u), dn = 0u - ((T.dnext >> i) & 1u);
-    const double thr = 0.5 - EV_MODEL_ERR;
     unsigned long long um = 0ull;
     uint32_t v[SPT];
 #pragma unroll
     for (int j = 0; j < SPT; j++) {
         const double yj = __fma_rn((double)j, S, y0), xj = __fma_rn((double)j, sc, x0);
-        um |= __builtin_amdgcn_fcmp(fabs(__builtin_amdgcn_fract(yj) - 0.5), thr, 2 /* ogt */);
-        um |= __builtin_amdgcn_fcmp(fabs(__builtin_amdgcn_fract(xj) - 0.5), thr, 2);
-        const int it = (int)yj & 511, ci = (int)xj;
+        const uint32_t ylo = (uint32_t)__double2loint(yj), xlo = (uint32_t)__double2loint(xj);
+        um |= __builtin_amdgcn_uicmp(ylo + 3u, 7u, 36 /* ult */);
+        um |= __builtin_amdgcn_uicmp(xlo + 3u, 7u, 36);
+        const int it = __double2hiint(yj) & 511, ci = __double2hiint(xj) & 2047;
         uint32_t m = (uint32_t)(int32_t)(int8_t)(L.chip2[i][ci] & 0xffu);
         m ^= DF ? (ci >= 1023 ? dn : db) : db;
         v[j] = signed_by(L.amp[i][it], m);

@@ -366,8 +366,10 @@ def main():
         # the reference-faithful geometry (12 ch, 2.6 MS/s, 300 000-sample blocks)
         mch = pkg.synth_descriptors(1000, nch=12, seed=0xF00D)
         m1, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, 0, 10, 3, dev)
+        m1_kernel = {1: "k_synth", 2: "k_synth_ev_dense (every channel evaluated per sample on the in-tile model)"}.get(
+            synth.info(pkg.INFO_LAST_KERNEL), "?")
         res["m1"] = {"gpu": m1, "unit": "IQ samples/s",
-                     "workload": "12 ch, fs 2.6e6 S/s, 300000-sample blocks, 1000 independent blocks per step (per-sample kernel k_synth)"}
+                     "workload": "12 ch, fs 2.6e6 S/s, 300000-sample blocks, 1000 independent blocks per step; synthesis kernel " + m1_kernel}
         if not args.no_cpu:
             import oracle_binding as ob
             res["cpu_baseline"] = cpu_baseline(ob, mine, delt, nsamp)

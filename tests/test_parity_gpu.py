@@ -669,6 +669,26 @@ def test_randomised_shapes_and_dopplers(pkg, synth, oracle):
     synth.hazards(reset=True)
 
 
+def test_reference_geometry_runs_on_the_dense_model_kernel(pkg, synth, oracle, request):
+    """The reference's own geometry (12 channels, 2.6 MS/s, 300 000-sample blocks, plutogpssim.c:43-45): the table index
+    changes at almost every sample there, so every channel is evaluated per sample on the in-tile model
+    (k_synth_ev_dense) — chained on the device, bit-exact IQ and end states against the oracle."""
+    nb, nch, fs, nsamp = 6, 12, 2.6e6, 300000
+    ch = pkg.synth_descriptors(nb, nch=nch, seed=4242)
+    want_iq, want_st, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
+    b = synth.batch(ch, 1 / fs, nsamp, flags=pkg.CHAIN_CARRIER)
+    b.run()
+    synth.sync()
+    iq, st = b.read()
+    b.close()
+    where, kernel = request.node.callspec.params["seed_mode"].split("+")
+    if kernel == "auto":
+        assert synth.info(pkg.INFO_LAST_KERNEL) == 2
+    for k in range(nb):
+        assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
+    assert (iq == want_iq).all()
+
+
 def test_headline_stream_chain_against_the_host_chain(pkg):
     """The bench's own workload: eight pushes of 400 full-size blocks (16 ch, 25 MS/s, 2.5 M samples) of bench.py's
     stream through the HBM-only ring, carrier chained on the device; the end-of-block carrier phases of all 3200

@@ -8,14 +8,22 @@ Workload (config.workload = "synth16-S as one stream", BASELINE configs[2] in th
 time-continuous 16-channel stream at fs = 25 MS/s in 0.1 s blocks of 2.5 M samples — seeded descriptors
  with a slowly varying Doppler per channel, |f_carr| <= 5 kHz — whose carrier is chained
 exactly from block to block (GPSBB_CHAIN_CARRIER, c:2741-2746 never re-seeds carr_phase).  One "step" is one
-pass of the hot path over the next 3200 blocks of that stream (8e9 IQ samples, 32 GB of int16 IQ), every block
-rendered once, from descriptors the library has not seen before: per 400-block push the host validates and plans
-the descriptors and uploads them, the device chains the carrier exactly in parallel over the blocks (k_walk pass A,
-k_chain_prefix, k_walk pass B, k_chain_fix), expands the tile states (k_tiles) and synthesises (k_synth_ev); the
-IQ lands in the ring's HBM slots (GPSBB_STREAM_DEVICE_ONLY).  With N ranks the stream is cut into N contiguous
-time shards (rank r renders blocks [r*T/N, (r+1)*T/N) of the same T = K*3200 blocks: strong scaling, no data-path
-collective); a shard starts from the stream's exact carrier phase there (host chain, timed, reported as
-shard_seed_s); torch.distributed (RCCL) carries the barrier, the max-over-ranks time and the digests only.
+pass of the hot path over the next 3200 blocks of that stream (8e9 IQ samples, 32 GB of int16 IQ), from
+descriptors the library plans afresh: per 400-block push the host validates and plans the descriptors and uploads
+them, the device chains the carrier exactly in parallel over the blocks (k_walk pass A, k_chain_prefix, k_walk pass
+B, k_chain_fix_par), expands the tile states (k_tiles) and synthesises (k_synth_ev); the IQ lands in the ring's HBM
+slots (GPSBB_STREAM_DEVICE_ONLY).  The stream has T = K*3200 blocks; the warm-up and every one of the --repeats
+timed regions walk through its pushes cyclically (a region of K steps is one pass over a rank's whole shard).  With
+N ranks the stream is cut into N contiguous time shards (rank r renders blocks [r*T/N, (r+1)*T/N): strong scaling,
+no data-path collective); a shard starts from the stream's exact carrier phase there, which every rank computes for
+itself on its GPU (gpsbb_chain_carrier over the blocks before its shard: `shard_seed_s` = the slowest rank's,
+`value_incl_seed` charges it to one pass over the stream); torch.distributed (RCCL) carries the barrier, the
+max-over-ranks times and the digests only.
+
+After the timed regions the same kind of ring (GPSBB_STREAM_DEVICE_ONLY) renders the rank's shard once more in
+order and blocks of it are read back from HBM and compared with the CPU oracle, bit for bit (`parity`): the leading
+blocks of the shard (oracle chained from the shard's seed) and one block of its last push (oracle from the phase
+the stream itself reports there).  A mismatch on any rank makes the run exit non-zero.
 
 Prints ONE JSON line on rank 0.  `value` = IQ samples/s over all GPUs, from the MEDIAN of --repeats timed regions
 of K steps each, every region bracketed by barrier + synchronize on both sides with the ring drained (min / max
@@ -26,6 +34,7 @@ duration against the 8 TB/s HBM peak.  Beside it, measured in the same invocatio
   gather        the same shard through a ring with the pinned D2H gather (PCIe-inclusive; never `value`)
   m1            BASELINE.md section 3's other leg: 12 ch, 2.6 MS/s, 300 000-sample blocks (GPU, and the CPU port)
   cpu_baseline  the CPU restatement (oracle, 1 core) on a bounded sample of the same blocks
+With N > 1 these run on rank 0 (its GPU, its host cores) while the other ranks wait.
 """
 import argparse
 import json
@@ -62,6 +71,55 @@ def stream_descriptors(pkg, nblocks, nch, seed=0x5EED, max_doppler=5000.0):
     ch["f_carr"] = amp[None, :] * np.sin(ph[None, :] + 2.0 * np.pi * b / per[None, :])
     ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
     return ch
+
+
+def parity_check(pkg, ob, synth, mine, delt, nsamp, PB, nch, ncheck):
+    """Bytes of evidence on the mode the headline is timed in: the shard through a fresh GPSBB_STREAM_DEVICE_ONLY ring in
+    order; the first `ncheck` blocks and one block of the last push read back from the slots' HBM and compared with
+    the oracle (c:2690-2756 restated), IQ and end-of-block carrier phase, bit for bit (ob None: no oracle, only the
+    digests).  Also returns one 32-bit digest per block of its end-of-block NCO states: the concatenation over the
+    ranks must not depend on how many ranks the stream was cut into (every shard starts from its seed)."""
+    orc = ob.Oracle() if ob else None
+    npush = mine.shape[0] // PB
+    st = synth.stream(nch, delt, nsamp, PB, depth=3, flags=pkg.CHAIN_CARRIER | pkg.STREAM_DEVICE_ONLY)
+    checked, bad, digs = 0, [], []
+    pushed = 0
+    for k in range(npush):
+        while pushed < npush and st.pending < 3:
+            st.push(mine[pushed * PB:(pushed + 1) * PB])
+            pushed += 1
+        dptr, ends = st.pop(copy=False)
+        act = mine["prn"][k * PB:(k + 1) * PB] > 0
+        cp = np.where(act, ends["carr_phase"], 0.0)
+        xp = np.where(act, ends["code_phase"], 0.0)
+        digs.extend(zlib.crc32(xp[j].tobytes(), zlib.crc32(cp[j].tobytes())) for j in range(PB))
+        if orc is None:
+            continue
+        if k == 0:
+            want_iq, want_st, _ = orc.fill_blocks(mine[:ncheck], delt, nsamp, chain=True)
+            got = synth.device_read(dptr, (ncheck, nsamp, 2))
+            for j in range(ncheck):
+                ok_iq = bool((got[j] == want_iq[j]).all())
+                ok_ph = ends["carr_phase"][j].tobytes() == want_st["carr_phase"][j].tobytes()
+                checked += 1
+                if not (ok_iq and ok_ph):
+                    bad.append(j)
+                    sys.stderr.write("bench.py: block %d of the shard: IQ %s (%d samples differ), end-of-block carr_phase %s\n" %
+                                     (j, "equal" if ok_iq else "DIFFERS", int((got[j] != want_iq[j]).any(axis=1).sum()),
+                                      "equal" if ok_ph else "DIFFERS"))
+        if k == npush - 1 and npush > 1:
+            j = PB // 2
+            one = mine[k * PB + j:k * PB + j + 1].copy()
+            cont = (one["prn"][0] > 0) & (one["prn"][0] == mine["prn"][k * PB + j - 1])
+            one["carr_phase"][0] = np.where(cont, ends["carr_phase"][j - 1], one["carr_phase"][0])
+            want_iq, want_st, _ = orc.fill_blocks(one, delt, nsamp)
+            got = synth.device_read(dptr + j * nsamp * 4, (nsamp, 2))
+            ok = (got == want_iq[0]).all() and ends["carr_phase"][j].tobytes() == want_st["carr_phase"][0].tobytes()
+            checked += 1
+            if not ok:
+                bad.append(k * PB + j)
+    st.close()
+    return checked, bad, digs
 
 
 def cpu_baseline(ob, ch, delt, nsamp, budget_s=10.0):
@@ -164,7 +222,9 @@ def main():
     ap.add_argument("--nch", type=int, default=16)
     ap.add_argument("--fs", type=float, default=25e6)
     ap.add_argument("--nsamp", type=int, default=2500000)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (baselines and the parity check against the oracle)")
+    ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work per CPU baseline leg (the M1 leg gets half)")
+    ap.add_argument("--parity-blocks", type=int, default=4, help="leading blocks of the shard compared with the oracle (+1 in the last push)")
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling runs)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: sharding / seeds / digest exchange with the CPU oracle")
     args = ap.parse_args()
@@ -213,15 +273,16 @@ def main():
     ch_all = stream_descriptors(pkg, total, nch)
     t_gen = time.perf_counter() - t_gen
     b0, b1 = pkg.shard_blocks(total, rank, world)
+    synth = pkg.Synth(local)
+    synth.shard_seed(ch_all, min(b0, 64), delt, nsamp)   # first use: scratch allocation, kernels loaded (not part of the seed's cost)
+    synth.sync()
     t_seed = time.perf_counter()
-    seed0 = pkg.chain_carrier_host(ch_all[:b0 + 1], delt, nsamp)[b0] if b0 > 0 else ch_all["carr_phase"][0]
+    seed0 = synth.shard_seed(ch_all, b0, delt, nsamp)    # exact carrier phase at the shard's first block: the device chains the b0 blocks before it
     t_seed = time.perf_counter() - t_seed
     mine = ch_all[b0:b1].copy()
     mine["carr_phase"][0] = seed0              # the shard starts from the stream's exact phase
     npush = mine.shape[0] // PB                # = K * ppr
     del ch_all
-
-    synth = pkg.Synth(local)
 
     def barrier():
         synth.sync()
@@ -311,6 +372,35 @@ def main():
                   "digest_of_block_digests": zlib.crc32(np.asarray(digs, np.uint32).tobytes()),
                   "note": "IQ stored into pinned host memory by a copy kernel on the side stream, the first and last 64 KiB of every block digested on arrival; PCIe Gen5 x16 = 63 GB/s raw"}
 
+    # ---- the seed of the slowest rank; bytes of evidence on the timed mode's output ----
+    def over_ranks(x, op):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+    seed_max = over_ranks(t_seed, dist.ReduceOp.MAX)
+    parity = None
+    if not args.no_extras:
+        ob = None
+        if not args.no_cpu:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_binding as ob
+        n_ok, bad, digs = parity_check(pkg, ob, synth, mine, delt, nsamp, PB, nch, max(1, min(args.parity_blocks, PB)))
+        n_all = int(over_ranks(float(n_ok), dist.ReduceOp.SUM))
+        n_bad = int(over_ranks(float(len(bad)), dist.ReduceOp.SUM))
+        if world > 1:
+            allg = [None] * world
+            dist.all_gather_object(allg, digs)
+            digs = [d for part in allg for d in part]
+        parity = {"checked_blocks": n_all, "mismatching_blocks": n_bad, "per_rank": n_ok,
+                  "stream_end_state_digest": zlib.crc32(np.asarray(digs, np.uint32).tobytes()), "blocks_digested": len(digs),
+                  "what": "int16 IQ and end-of-block carr_phase of blocks read back from the HBM slots of a "
+                          "GPSBB_STREAM_DEVICE_ONLY ring (the timed mode) vs the CPU oracle, bit for bit: the first blocks of "
+                          "every rank's shard and one block of its last push"}
+        if n_bad:
+            sys.stderr.write("bench.py: rank %d: IQ differs from the oracle in blocks %s of its shard\n" % (rank, bad))
+
     res = None
     if rank == 0:
         res = {
@@ -339,17 +429,26 @@ def main():
                          "note": "VALU-issue-bound, not HBM-bound: see DESIGN.md"},
             "prepass_ms_per_launch": ms_seed,
             "device_chain": chain_info,
-            "shard_seed_s": t_seed, "descriptor_generation_s": t_gen,
+            "shard_seed_s": seed_max, "descriptor_generation_s": t_gen,
+            "shard_seed": {"seconds_max_over_ranks": seed_max, "seconds_rank0": t_seed,
+                           "blocks_before_the_last_shard": pkg.shard_blocks(total, world - 1, world)[0],
+                           "how": "gpsbb_chain_carrier on each rank's GPU over the blocks before its shard (exact, parallel over the blocks)"},
+            # one pass over the whole stream (K steps) with the slowest rank's seed charged to it
+            "value_incl_seed": samples_per_step * K / (elapsed + seed_max),
+            "parity": parity,
+            "parity_checked_blocks": parity["checked_blocks"] if parity else 0,
         }
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                res["roofline"]["traffic"] = json.load(open(pmc)).get("k_synth_hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                res["roofline"]["traffic"] = pj.get("k_synth_hbm_bytes_per_launch")
+                res["roofline"]["traffic_source"] = "PMC passes of an earlier run, %s" % pj.get("source", "profiles/pmc_latest.json")
             except Exception:
                 pass
         if gather:
             res["gather"] = gather
-    if world == 1 and not args.no_extras:
+    if rank == 0 and not args.no_extras:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         rch = pkg.synth_descriptors(PB, nch=nch, seed=0x5EED)
         r0, ceil_gbs = resident_leg(pkg, synth, torch, rch, delt, nsamp, 0, 20, 4, dev)
@@ -372,13 +471,17 @@ def main():
                      "workload": "12 ch, fs 2.6e6 S/s, 300000-sample blocks, 1000 independent blocks per step; synthesis kernel " + m1_kernel}
         if not args.no_cpu:
             import oracle_binding as ob
-            res["cpu_baseline"] = cpu_baseline(ob, mine, delt, nsamp)
-            res["m1"]["cpu"] = cpu_baseline(ob, mch, 1.0 / 2.6e6, 300000, budget_s=5.0)
+            res["cpu_baseline"] = cpu_baseline(ob, mine, delt, nsamp, budget_s=args.cpu_budget)
+            res["m1"]["cpu"] = cpu_baseline(ob, mch, 1.0 / 2.6e6, 300000, budget_s=args.cpu_budget / 2)
+    if world > 1:
+        dist.barrier()   # the other ranks wait for rank 0's legs
     if rank == 0:
         print(json.dumps(res))
     synth.close()
     if world > 1:
         dist.destroy_process_group()
+    if parity and parity["mismatching_blocks"]:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -47,9 +47,10 @@ API_SYMBOLS = [
     "gpsbb_create", "gpsbb_destroy", "gpsbb_strerror", "gpsbb_last_hip_error", "gpsbb_version",
     "gpsbb_fill_block", "gpsbb_fill_block_ex", "gpsbb_fill_block_ref", "gpsbb_batch_create", "gpsbb_batch_destroy",
     "gpsbb_batch_iq_bytes", "gpsbb_batch_run", "gpsbb_sync", "gpsbb_batch_read", "gpsbb_batch_device_iq",
-    "gpsbb_get_hazards", "gpsbb_batch_last_timing", "gpsbb_batch_timing_stats", "gpsbb_fill_ceiling", "gpsbb_stream_create",
+    "gpsbb_get_hazards", "gpsbb_device_read", "gpsbb_batch_last_timing", "gpsbb_batch_timing_stats", "gpsbb_fill_ceiling", "gpsbb_stream_create",
     "gpsbb_stream_destroy", "gpsbb_stream_push", "gpsbb_stream_pop", "gpsbb_stream_pending", "gpsbb_stream_timing_stats",
-    "gpsbb_codegen", "gpsbb_sincos_tables", "gpsbb_chain_carrier_host", "gpsbb_set_option", "gpsbb_get_info",
+    "gpsbb_codegen", "gpsbb_sincos_tables", "gpsbb_chain_carrier_host", "gpsbb_chain_carrier", "gpsbb_set_option",
+    "gpsbb_get_info",
 ]
 
 
@@ -101,6 +102,7 @@ def lib():
         L.gpsbb_batch_device_iq.argtypes = [vp]
         L.gpsbb_batch_device_iq.restype = vp
         L.gpsbb_get_hazards.argtypes = [vp, vp, i]
+        L.gpsbb_device_read.argtypes = [vp, vp, vp, C.c_size_t]
         L.gpsbb_batch_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.gpsbb_batch_timing_stats.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                                C.POINTER(C.c_float), i]
@@ -115,6 +117,7 @@ def lib():
         L.gpsbb_codegen.argtypes = [i, vp]
         L.gpsbb_sincos_tables.argtypes = [vp, vp]
         L.gpsbb_chain_carrier_host.argtypes = [vp, i, i, d, i, vp, i]
+        L.gpsbb_chain_carrier.argtypes = [vp, vp, i, i, d, i, vp, vp]
         # test hooks (csrc/gpsbb_testhooks.h)
         L.gpsbb_test_carr_jump.argtypes = [d, d, C.c_longlong]
         L.gpsbb_test_carr_jump.restype = d
@@ -209,6 +212,12 @@ class Synth:
     def sync(self):
         _chk(lib().gpsbb_sync(self._h), "gpsbb_sync")
 
+    def device_read(self, d_ptr, shape, dtype=np.int16):
+        """gpsbb_device_read: a numpy array filled from device memory the library handed out"""
+        out = np.empty(shape, dtype)
+        _chk(lib().gpsbb_device_read(self._h, out.ctypes.data, d_ptr, out.nbytes), "gpsbb_device_read")
+        return out
+
     def hazards(self, reset=False):
         v = np.zeros(2, np.uint64)
         _chk(lib().gpsbb_get_hazards(self._h, v.ctypes.data, int(reset)), "gpsbb_get_hazards")
@@ -223,6 +232,27 @@ class Synth:
         v = C.c_uint64()
         _chk(lib().gpsbb_get_info(self._h, what, C.byref(v)), "gpsbb_get_info")
         return int(v.value)
+
+    def chain_carrier(self, ch, delt, nsamp, want_seeds=True):
+        """gpsbb_chain_carrier: the exact carrier chain on the device, nothing rendered -> (start phase of every block
+        [nblocks, nch] or None, phase after the last block [nch])"""
+        ch = _as_chan(ch)
+        nb, nch = ch.shape
+        seed = np.zeros((nb, nch), np.float64) if want_seeds else None
+        end = np.zeros(nch, np.float64)
+        _chk(lib().gpsbb_chain_carrier(self._h, ch.ctypes.data, nb, nch, delt, nsamp,
+                                       seed.ctypes.data if want_seeds else None, end.ctypes.data), "gpsbb_chain_carrier")
+        return seed, end
+
+    def shard_seed(self, ch, b0, delt, nsamp):
+        """The exact carr_phase block b0 of the stream `ch` starts from (per channel): the end of the device-side chain
+        over the blocks before it for a channel that keeps its prn, the descriptor's own phase otherwise."""
+        ch = _as_chan(ch)
+        if b0 == 0:
+            return ch["carr_phase"][0].copy()
+        _, end = self.chain_carrier(ch[:b0], delt, nsamp, want_seeds=False)
+        cont = (ch["prn"][b0] > 0) & (ch["prn"][b0] == ch["prn"][b0 - 1])
+        return np.where(cont, end, ch["carr_phase"][b0])
 
     def fill_ceiling(self, d_ptr, nbytes, iters=10):
         ms = C.c_float()

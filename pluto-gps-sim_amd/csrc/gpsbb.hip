@@ -289,12 +289,14 @@ struct gpsbb {
     unsigned long long *d_hz = nullptr;
     int last_hip = 0;
     gpsbb_batch *scratch = nullptr;
+    struct ChainOnly *chain_only = nullptr; /* device scratch of gpsbb_chain_carrier, kept between calls */
     int sm_count = 0;
     /* per-handle options (gpsbb_set_option) */
     int opt_seed_where = 0;   /* 0 by size, 1 always k_seed, 2 always host threads */
     int opt_synth_kernel = 0; /* 0 automatic, 1 always the per-sample kernel */
     int opt_skip_seed = 0;    /* measurement: re-use the tables of the first two runs of a batch */
-    int opt_chain_where = 0;  /* GPSBB_CHAIN_CARRIER: 0 automatic (on the device where k_synth_ev runs), 1 host threads */
+    int opt_chain_where = 0;  /* GPSBB_CHAIN_CARRIER: 0 automatic (on the device wherever the pre-pass runs there), 1 host threads,
+                                 2 as 0 with the fix-up walking the blocks in order (k_chain_fix instead of k_chain_fix_par) */
     int last_kernel = 0;      /* synthesis kernel of the last launch: 1 per-sample, 2 breakpoint */
     int last_chain_dev = 0;   /* the last launch resolved GPSBB_CHAIN_CARRIER on the device */
 };
@@ -385,7 +387,13 @@ struct gpsbb_batch {
     int chain_lanes = 0;
     DevBuf<ChainAux> d_aux[NSETS];
     DevBuf<SynRow> d_prefix[NSETS];
-    std::vector<ChainAux> h_aux;
+    DevBuf<ChainDesc> d_cd;      /* what the chain kernels read of the descriptors (24 B per block-channel) */
+    DevBuf<double> d_start0;     /* rough start phases: where pass A walks from */
+    std::vector<ChainDesc> h_cd;
+    std::vector<double> h_start0;
+    bool chain_fix_seq = false;  /* k_chain_fix (blocks in order) instead of k_chain_fix_par: GPSBB_OPT_CHAIN_WHERE 2 */
+    bool host_seed = false;      /* the NCO tables of this batch are built on host threads: decided at set-up, like the
+                                    chain (a run never re-reads the handle's options) */
     int carr_lanes = 0; /* lanes of the seed plan that walk carrier chains (they come first) */
     /* a stream's slot: the carrier continues from the push before (set by gpsbb_stream_push around set-up / launch) */
     ChainCarryDev *d_carry = nullptr;
@@ -469,7 +477,7 @@ extern "C" int gpsbb_set_option(gpsbb_t *h, int option, long value)
         h->opt_skip_seed = value != 0;
         return GPSBB_OK;
     case GPSBB_OPT_CHAIN_WHERE:
-        if (value < 0 || value > 1)
+        if (value < 0 || value > 2)
             return GPSBB_E_BADARG;
         h->opt_chain_where = (int)value;
         return GPSBB_OK;
@@ -519,6 +527,8 @@ extern "C" int gpsbb_sincos_tables(int32_t sin512[512], int32_t cos512[512])
     return make_sincos(sin512, cos512) ? GPSBB_OK : GPSBB_E_INTERNAL;
 }
 
+static void chain_only_free(gpsbb *h);
+
 extern "C" void gpsbb_destroy(gpsbb_t *h)
 {
     if (!h)
@@ -526,6 +536,7 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
     (void)hipSetDevice(h->device);
     if (h->scratch)
         gpsbb_batch_destroy(h->scratch);
+    chain_only_free(h);
     if (h->s_seed)
         (void)hipStreamSynchronize(h->s_seed);
     for (hipStream_t st : h->s_more)
@@ -705,7 +716,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
 
     {
         /* everything a set-up uploads, with room to spare: descriptors, plans, per-channel constants, chain scratch */
-        const size_t need = nbc * (sizeof(gpsbb_chan_t) + sizeof(EvConst) + (size_t)NSETS * sizeof(ChainAux) + 2 * 8 + 2 * 4 + 5 * 4) +
+        const size_t need = nbc * (sizeof(gpsbb_chan_t) + sizeof(EvConst) + sizeof(ChainDesc) + 8 + 2 * 8 + 2 * 4 + 5 * 4) +
                             64 * 1024;
         if (b->upload_done) /* the previous set-up's copies out of the arena are long done; make sure */
             HIPCHK(h, hipEventSynchronize(b->upload_done));
@@ -763,7 +774,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     HIPCHK(h, (hipError_t)b->d_tile_ctr.reserve((size_t)NSETS * (size_t)nblocks)); /* one set of counters per table set */
     /* table sets = pre-passes in flight + 1: the pre-pass of either kernel takes longer than the synthesis it feeds
      * (M1 geometry, per-sample kernel: two sets 6.6e10, three 7.7e10 samples/s), the chained ones longer still */
-    const bool chain_maybe_dev = (flags & GPSBB_CHAIN_CARRIER) && !fixed && nblocks > 1 && h->opt_chain_where == 0;
+    const bool chain_maybe_dev = (flags & GPSBB_CHAIN_CARRIER) && !fixed && nblocks > 1 && h->opt_chain_where != 1;
     b->nsets = chain_maybe_dev ? 4 : 3;
     b->nsets = b->nsets > b->max_sets ? b->max_sets : b->nsets;
     for (int set = 0; set < b->nsets; set++) {
@@ -812,8 +823,10 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         HIPCHK(h, stage_upload(b, b->d_kstep.p, b->h_kstep.data(), nbc * 4, upload_stream));
     }
     b->h_ch.assign(ch, ch + nbc);
-    b->chain_dev = !fixed && (flags & GPSBB_CHAIN_CARRIER) && (nblocks > 1 || b->d_carry) && h->opt_chain_where == 0 &&
-                   !host_seeding_wanted(b);
+    b->host_seed = host_seeding_wanted(b);
+    b->chain_dev = !fixed && (flags & GPSBB_CHAIN_CARRIER) && (nblocks > 1 || b->d_carry) && h->opt_chain_where != 1 &&
+                   !b->host_seed;
+    b->chain_fix_seq = h->opt_chain_where == 2;
     b->chain_starts = b->chain_dev && !b->ev;
     b->cont0_mask = 0;
     if (b->chain_dev) {
@@ -821,35 +834,45 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
          * k_chain_prefix, k_walk pass B, k_chain_fix).  All the host contributes is a rough start phase per block:
          * the descriptor's phase carried forward by nsamp*step in plain double arithmetic (good to ~1e-7 cycles
          * after a few hundred blocks; pass A takes it from there). */
-        b->h_aux.assign(nbc, ChainAux());
+        b->h_cd.resize(nbc);
+        b->h_start0.resize(nbc);
         for (int i = 0; i < nch; i++) {
             double x = b->d_carry && b->carry_phase ? b->carry_phase[i] : 0.0;
             int prev_prn = b->d_carry && b->carry_prn ? b->carry_prn[i] : 0;
             for (int blk = 0; blk < nblocks; blk++) {
                 const gpsbb_chan_t &c = ch[(size_t)blk * nch + i];
-                ChainAux &a = b->h_aux[(size_t)blk * nch + i];
-                memset(&a, 0, sizeof a);
+                ChainDesc &cd = b->h_cd[(size_t)blk * nch + i];
+                cd.f_carr = c.f_carr;
+                cd.carr_phase = c.carr_phase;
+                cd.prn = c.prn;
+                cd._pad = 0;
+                double start0 = 0.0;
                 if (c.prn > 0) {
                     if (c.prn != prev_prn)
                         x = c.carr_phase;
                     else if (blk == 0)
                         b->cont0_mask |= 1u << i;
-                    a.start0 = x;
+                    start0 = x;
                     const volatile double sk = c.f_carr * delt;
                     x = x + (double)nsamp * sk;
                     x -= std::floor(x);
                 }
+                b->h_start0[(size_t)blk * nch + i] = start0;
                 prev_prn = c.prn > 0 ? c.prn : 0;
             }
             if (b->d_carry && b->carry_phase)
                 b->carry_phase[i] = x;
         }
+        /* the chain's scratch (ChainAux) needs no initial image: every field is written by the pass that owns it */
         for (int set = 0; set < b->nsets; set++) {
             HIPCHK(h, (hipError_t)b->d_aux[set].reserve(nbc));
             if (!b->chain_starts)
                 HIPCHK(h, (hipError_t)b->d_prefix[set].reserve(nbc * (size_t)CHAIN_PREFIX_CAP));
-            HIPCHK(h, stage_upload(b, b->d_aux[set].p, b->h_aux.data(), nbc * sizeof(ChainAux), upload_stream));
         }
+        HIPCHK(h, (hipError_t)b->d_cd.reserve(nbc));
+        HIPCHK(h, (hipError_t)b->d_start0.reserve(nbc));
+        HIPCHK(h, stage_upload(b, b->d_cd.p, b->h_cd.data(), nbc * sizeof(ChainDesc), upload_stream));
+        HIPCHK(h, stage_upload(b, b->d_start0.p, b->h_start0.data(), nbc * sizeof(double), upload_stream));
     }
     if ((flags & GPSBB_CHAIN_CARRIER) && !fixed && nblocks > 1 && !b->chain_dev) {
         /* blocks consecutive in time: resolve the carrier phase at the start of every block here, exactly
@@ -999,6 +1022,8 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         b->d_tile_x[k].release();
         b->d_tile_nav[k].release();
         b->d_aux[k].release();
+        b->d_cd.release();
+        b->d_start0.release();
         b->d_prefix[k].release();
         b->d_chain_order.release();
         b->d_evc.release();
@@ -1332,6 +1357,8 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.chain_dev = b->chain_dev ? 1 : 0;
     p.chain_starts = b->chain_starts ? 1 : 0;
     p.aux = b->chain_dev ? b->d_aux[set].p : nullptr;
+    p.cd = b->chain_dev ? b->d_cd.p : nullptr;
+    p.start0 = b->chain_dev ? b->d_start0.p : nullptr;
     p.prefix_rows = b->chain_dev && !b->chain_starts ? b->d_prefix[set].p : nullptr;
     p.carry = b->chain_dev ? b->d_carry : nullptr;
     p.cont0_mask = b->cont0_mask;
@@ -1379,7 +1406,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     bool ctr_reset_by_prepass = false;
     if (h->opt_skip_seed && b->run_count >= (unsigned)b->nsets) {
         /* measurement hook: time the synthesis kernel alone on tables already built */
-    } else if (host_seeding_wanted(b)) {
+    } else if (b->host_seed) {
         /* the previous user of the pinned images (this batch's last run) has been copied out: its upload was
          * followed by the synthesis kernel, which synth_done[] of that set covers */
         const int prev = (set + b->nsets - 1) % b->nsets;
@@ -1407,7 +1434,10 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
                 hipLaunchKernelGGL(k_walk<2>, wg_all, dim3(GPSBB_WALK_WG), 0, ss, p);
                 if (b->d_carry && b->ev_fix)
                     HIPCHK(h, hipStreamWaitEvent(ss, b->ev_fix, 0));
-                hipLaunchKernelGGL(k_chain_fix, dim3(1), dim3(64), 0, ss, p);
+                if (b->chain_fix_seq)
+                    hipLaunchKernelGGL(k_chain_fix, dim3(1), dim3(64), 0, ss, p);
+                else
+                    hipLaunchKernelGGL(k_chain_fix_par, dim3(b->nch), dim3(FIXP_WG), 0, ss, p);
                 if (b->d_carry && b->ev_fix)
                     HIPCHK(h, hipEventRecord(b->ev_fix, ss));
             } else {
@@ -1433,7 +1463,10 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
             hipLaunchKernelGGL(k_walk<3>, wg_c, dim3(GPSBB_WALK_WG), 0, ss, pc);
             if (b->d_carry && b->ev_fix)
                 HIPCHK(h, hipStreamWaitEvent(ss, b->ev_fix, 0));
-            hipLaunchKernelGGL(k_chain_fix, dim3(1), dim3(64), 0, ss, pc);
+            if (b->chain_fix_seq)
+                hipLaunchKernelGGL(k_chain_fix, dim3(1), dim3(64), 0, ss, pc);
+            else
+                hipLaunchKernelGGL(k_chain_fix_par, dim3(b->nch), dim3(FIXP_WG), 0, ss, pc);
             if (b->d_carry && b->ev_fix)
                 HIPCHK(h, hipEventRecord(b->ev_fix, ss));
         }
@@ -1559,6 +1592,15 @@ extern "C" int gpsbb_batch_read(gpsbb_batch_t *b, int16_t *iq_out, gpsbb_chan_st
     if (end_state)
         HIPCHK(h, hipMemcpy(end_state, b->d_end[b->last_set].p, (size_t)b->nblocks * b->nch * sizeof(gpsbb_chan_state_t),
                             hipMemcpyDeviceToHost));
+    return GPSBB_OK;
+}
+
+extern "C" int gpsbb_device_read(gpsbb_t *h, void *host_dst, const void *device_src, size_t bytes)
+{
+    if (!h || !host_dst || !device_src)
+        return GPSBB_E_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(host_dst, device_src, bytes, hipMemcpyDeviceToHost));
     return GPSBB_OK;
 }
 
@@ -1760,6 +1802,8 @@ struct gpsbb_stream {
     std::vector<double> seeds;
     int fx_prn[GPSBB_MAX_CHAN] = {0};          /* fixed-point carrier: channel state after the last push */
     uint32_t fx_phase[GPSBB_MAX_CHAN] = {0};
+    bool poisoned = false; /* a push failed after part of it had been enqueued: the chain's state on the device has
+                              moved on without the host's; nothing more can be pushed or popped */
 };
 
 extern "C" void gpsbb_stream_destroy(gpsbb_stream_t *s)
@@ -1862,7 +1906,7 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
 {
     if (!s || !ch)
         return GPSBB_E_BADARG;
-    if (s->head - s->tail >= (uint64_t)s->depth)
+    if (s->poisoned || s->head - s->tail >= (uint64_t)s->depth)
         return GPSBB_E_STATE; /* ring full: pop first */
     gpsbb *h = s->h;
     g_push_trace.start();
@@ -1874,11 +1918,10 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     unsigned run_flags = s->flags & (GPSBB_CHAIN_CARRIER | GPSBB_FIXED_CARRIER);
     const size_t nbc = (size_t)s->bps * s->nch;
     b->d_carry = nullptr;
-    /* the chaining state only moves on once every enqueue of this push has succeeded: a failed push can be retried */
+    /* the host's chaining state only moves on once every enqueue of this push has succeeded */
     ChainCarry carry_next;
     bool carry_host = false;
-    double rough_next[GPSBB_MAX_CHAN];
-    memcpy(rough_next, s->rough_phase, sizeof rough_next);
+    double rough_next[GPSBB_MAX_CHAN]; /* taken from s->rough_phase below, once the carry is where this push wants it */
     int fx_prn_next[GPSBB_MAX_CHAN];
     uint32_t fx_phase_next[GPSBB_MAX_CHAN];
     memcpy(fx_prn_next, s->fx_prn, sizeof fx_prn_next);
@@ -1893,7 +1936,7 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
          * change sides between pushes: the carry then moves across, which costs a synchronisation. */
         static const size_t host_lim = getenv("GPSBB_HOST_SEED_MAX") ? (size_t)atol(getenv("GPSBB_HOST_SEED_MAX")) : HOST_SEED_MAX_CHANNELS;
         static const bool dev_only = getenv("GPSBB_DEVICE_SEED_ONLY") != nullptr;
-        const bool dev = h->opt_chain_where == 0 &&
+        const bool dev = h->opt_chain_where != 1 &&
                          (h->opt_seed_where == 1 || (h->opt_seed_where == 0 && (dev_only || nbc > host_lim)));
         if (!s->carry) {
             s->carry = new (std::nothrow) ChainCarry();
@@ -1923,6 +1966,7 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
                 }
             }
             s->carry_on_device = true;
+            memcpy(rough_next, s->rough_phase, sizeof rough_next);
             b->d_carry = s->d_carry;
             b->carry_prn = s->last_prn;
             b->carry_phase = rough_next;
@@ -1954,6 +1998,8 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
             run_flags &= ~GPSBB_CHAIN_CARRIER;
         }
     }
+    if (!b->d_carry)
+        memcpy(rough_next, s->rough_phase, sizeof rough_next);
     /* the slot's previous D2H copy was waited for by the pop that freed it */
     const bool fx_chain = (s->flags & GPSBB_FIXED_CARRIER) && (s->flags & GPSBB_CHAIN_CARRIER) && s->head > 0;
     b->fixed_prev_prn = fx_chain ? s->fx_prn : nullptr;
@@ -1978,6 +2024,14 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
             fx_phase_next[i] = b->h_kph0[k] + (uint32_t)s->nsamp * (uint32_t)b->h_kstep[k];
         }
     b->last_iq = b->d_iq.p;
+    /* From here on kernels of this push may be in the queues (with the device-side chain they advance the carry in
+     * device memory): a failure leaves the host's and the device's view of the stream apart, so the stream is closed
+     * instead of letting a retry chain from the wrong phase. */
+    struct Poison {
+        gpsbb_stream *s;
+        bool armed = true;
+        ~Poison() { if (armed) s->poisoned = true; }
+    } poison{s};
     rc = batch_launch(b, b->d_iq.p);
     PUSH_MARK("launch");
     b->d_carry = nullptr;
@@ -2022,6 +2076,7 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     memcpy(s->fx_prn, fx_prn_next, sizeof fx_prn_next);
     memcpy(s->fx_phase, fx_phase_next, sizeof fx_phase_next);
     s->head++;
+    poison.armed = false;
     g_push_trace.end();
     return GPSBB_OK;
 }
@@ -2030,7 +2085,7 @@ extern "C" int gpsbb_stream_pop(gpsbb_stream_t *s, const int16_t **iq, gpsbb_cha
 {
     if (!s || !iq)
         return GPSBB_E_BADARG;
-    if (s->head == s->tail)
+    if (s->poisoned || s->head == s->tail)
         return GPSBB_E_STATE;
     gpsbb *h = s->h;
     HIPCHK(h, hipSetDevice(h->device));
@@ -2105,6 +2160,169 @@ extern "C" int gpsbb_chain_carrier_host(const gpsbb_chan_t *ch, int nblocks, int
         if (!chan_ok(ch[k], delt))
             return GPSBB_E_BADCHAN;
     chain_carrier_host(ch, nblocks, nch, delt, nsamp, seed, nthreads, nullptr);
+    return GPSBB_OK;
+}
+
+/* ---- the carrier chain alone, on the device ---------------------------------------------------------- */
+
+/* Device scratch of gpsbb_chain_carrier: 24-byte chain descriptors, rough start phases, the chain's per-block record
+ * and the carry from one sub-batch to the next.  Nothing of a synthesis batch (rows, tile states, IQ) exists here. */
+struct ChainOnly {
+    DevBuf<ChainDesc> d_cd;
+    DevBuf<double> d_start0;
+    DevBuf<ChainAux> d_aux;
+    ChainCarryDev *d_carry = nullptr;
+    std::vector<ChainDesc> h_cd;
+    std::vector<double> h_start0;
+};
+constexpr int CHAIN_ONLY_BLOCKS = 16384; /* blocks per sub-batch: 168 MB of ChainAux at 16 channels */
+
+static void chain_only_free(gpsbb *h)
+{
+    ChainOnly *c = h->chain_only;
+    if (!c)
+        return;
+    c->d_cd.release();
+    c->d_start0.release();
+    c->d_aux.release();
+    if (c->d_carry)
+        (void)hipFree(c->d_carry);
+    delete c;
+    h->chain_only = nullptr;
+}
+
+extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp,
+                                   double *carr_phase_seed, double *carr_phase_end)
+{
+    if (!h || !ch || nblocks < 1 || nch < 1 || nch > GPSBB_MAX_CHAN || nsamp < 1 || !(delt > 0.0) || !std::isfinite(delt))
+        return GPSBB_E_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->chain_only) {
+        h->chain_only = new (std::nothrow) ChainOnly;
+        if (!h->chain_only)
+            return GPSBB_E_NOMEM;
+    }
+    ChainOnly *c = h->chain_only;
+    if (!c->d_carry)
+        HIPCHK(h, hipMalloc((void **)&c->d_carry, sizeof(ChainCarryDev)));
+    HIPCHK(h, hipMemsetAsync(c->d_carry, 0, sizeof(ChainCarryDev), h->s_seed));
+    /* what the chain reads of a descriptor, and the rough start phases (plain double arithmetic; pass A takes it from
+     * there): one host thread per channel, the blocks in order */
+    const size_t nbc_all = (size_t)nblocks * nch;
+    c->h_cd.resize(nbc_all);
+    c->h_start0.resize(nbc_all);
+    std::vector<char> bad(nch, 0);
+    auto work = [&](int i0, int i1) {
+        for (int i = i0; i < i1; i++) {
+            double x = 0.0;
+            int prev_prn = 0;
+            for (int blk = 0; blk < nblocks; blk++) {
+                const size_t k = (size_t)blk * nch + i;
+                const gpsbb_chan_t &d = ch[k];
+                ChainDesc &cd = c->h_cd[k];
+                cd.f_carr = d.f_carr;
+                cd.carr_phase = d.carr_phase;
+                cd.prn = d.prn;
+                cd._pad = 0;
+                double start0 = 0.0;
+                if (d.prn != 0) {
+                    /* the part of the descriptor contract the carrier chain depends on */
+                    if (d.prn < 0 || d.prn > 32 || !std::isfinite(d.f_carr) || !std::isfinite(d.carr_phase) ||
+                        std::signbit(d.carr_phase) || d.carr_phase > 1.0 || !(std::fabs(d.f_carr * delt) <= 0.125)) {
+                        bad[i] = 1;
+                        cd.prn = 0;
+                    } else {
+                        if (d.prn != prev_prn)
+                            x = d.carr_phase;
+                        start0 = x;
+                        const volatile double sk = d.f_carr * delt;
+                        x = x + (double)nsamp * sk;
+                        x -= std::floor(x);
+                    }
+                }
+                c->h_start0[k] = start0;
+                prev_prn = cd.prn > 0 ? cd.prn : 0;
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int i = 0; i < nch; i++) {
+            try {
+                th.emplace_back(work, i, i + 1);
+            } catch (...) {
+                work(i, i + 1);
+            }
+        }
+        for (auto &t : th)
+            t.join();
+    }
+    for (int i = 0; i < nch; i++)
+        if (bad[i])
+            return GPSBB_E_BADCHAN;
+
+    hipStream_t ss = h->s_seed;
+    for (int b0 = 0; b0 < nblocks; b0 += CHAIN_ONLY_BLOCKS) {
+        const int nb = nblocks - b0 < CHAIN_ONLY_BLOCKS ? nblocks - b0 : CHAIN_ONLY_BLOCKS;
+        const size_t nbc = (size_t)nb * nch, k0 = (size_t)b0 * nch;
+        HIPCHK(h, (hipError_t)c->d_cd.reserve(nbc));
+        HIPCHK(h, (hipError_t)c->d_start0.reserve(nbc));
+        HIPCHK(h, (hipError_t)c->d_aux.reserve(nbc));
+        HIPCHK(h, hipMemcpyAsync(c->d_cd.p, c->h_cd.data() + k0, nbc * sizeof(ChainDesc), hipMemcpyHostToDevice, ss));
+        HIPCHK(h, hipMemcpyAsync(c->d_start0.p, c->h_start0.data() + k0, nbc * sizeof(double), hipMemcpyHostToDevice, ss));
+        BatchDev p;
+        memset(&p, 0, sizeof p);
+        p.nblocks = nb;
+        p.nch = nch;
+        p.nsamp = nsamp;
+        p.ntiles = (nsamp + TILE - 1) / TILE;
+        p.delt = delt;
+        p.flags = GPSBB_CHAIN_CARRIER;
+        p.status = h->d_status;
+        p.hazards = h->d_hz;
+        p.chain_dev = 1;
+        p.chain_starts = 1;
+        p.aux = c->d_aux.p;
+        p.cd = c->d_cd.p;
+        p.start0 = c->d_start0.p;
+        p.carry = c->d_carry;
+        p.cont0_mask = 0;
+        if (b0 > 0)
+            for (int i = 0; i < nch; i++) {
+                const int prn = c->h_cd[k0 + i].prn;
+                if (prn > 0 && prn == c->h_cd[k0 - nch + i].prn)
+                    p.cont0_mask |= 1u << i;
+            }
+        p.seed_order = nullptr; /* channel by channel, blocks in order (k_walk) */
+        p.seed_lanes = nch * ((nb + 63) & ~63);
+        const dim3 wg((p.seed_lanes + GPSBB_WALK_WG - 1) / GPSBB_WALK_WG);
+        hipLaunchKernelGGL(k_walk<1>, wg, dim3(GPSBB_WALK_WG), 0, ss, p);
+        hipLaunchKernelGGL(k_chain_prefix, dim3(nch), dim3(64), 0, ss, p);
+        hipLaunchKernelGGL(k_walk<3>, wg, dim3(GPSBB_WALK_WG), 0, ss, p);
+        hipLaunchKernelGGL(k_chain_fix_par, dim3(nch), dim3(FIXP_WG), 0, ss, p);
+        HIPCHK(h, hipGetLastError());
+        if (carr_phase_seed) {
+            /* the exact start phase of every block, as k_chain_fix_par left it in the chain descriptors */
+            HIPCHK(h, hipMemcpyAsync(c->h_cd.data() + k0, c->d_cd.p, nbc * sizeof(ChainDesc), hipMemcpyDeviceToHost, ss));
+        }
+        HIPCHK(h, hipStreamSynchronize(ss)); /* the host image of the next sub-batch's uploads is re-used scratch */
+    }
+    if (carr_phase_seed)
+        for (size_t k = 0; k < nbc_all; k++)
+            carr_phase_seed[k] = c->h_cd[k].prn > 0 ? c->h_cd[k].carr_phase : 0.0;
+    if (carr_phase_end) {
+        ChainCarryDev cc;
+        HIPCHK(h, hipMemcpy(&cc, c->d_carry, sizeof cc, hipMemcpyDeviceToHost));
+        for (int i = 0; i < nch; i++)
+            carr_phase_end[i] = c->h_cd[nbc_all - nch + i].prn > 0 ? cc.exact_end[i] : 0.0;
+    }
+    h->last_chain_dev = 1;
+    uint32_t st = 0;
+    HIPCHK(h, hipMemcpy(&st, h->d_status, 4, hipMemcpyDeviceToHost));
+    if (st) {
+        HIPCHK(h, hipMemset(h->d_status, 0, 4));
+        return GPSBB_E_INTERNAL;
+    }
     return GPSBB_OK;
 }
 

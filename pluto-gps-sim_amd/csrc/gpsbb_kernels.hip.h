@@ -102,9 +102,8 @@ static_assert(sizeof(EvConst) == 56, "EvConst layout");
 constexpr int CHAIN_MAX_CROSS = 20;
 constexpr int CHAIN_PREFIX_CAP = 64; /* rows of one lap walked by k_chain_fix on its own */
 struct ChainAux {
-    double start0; /* rough start phase (host: descriptor phase + sum of nsamp*step, in plain double arithmetic) */
     double start1; /* start phase pass B walks from: good to a few units in the last place                  */
-    double endA;   /* end phase of pass A's walk from start0                                               */
+    double endA;   /* end phase of pass A's walk from the rough start phase (BatchDev::start0)             */
     double margin; /* pass B: smallest distance of a row's first or last state to an edge of its binade    */
     /* pass B: the rows, up to and including the one after the first wrap, whose first state came out of a sum
      * rounded on a coarser grid than the states of the row before (a binade crossed upwards, or a wrap): only
@@ -125,6 +124,18 @@ struct ChainAux {
     double seg[CHAIN_MAX_CROSS + 1];
     double wrap_x; /* pass B's state at sample wrap_row */
 };
+
+/* What the chain kernels (k_walk passes A / B, k_chain_prefix, k_chain_fix*) read of a (block, channel): 24 bytes
+ * instead of the 296 of a descriptor, so that a chain over tens of thousands of blocks (the seed of a time shard,
+ * gpsbb_chain_carrier) uploads and reads little.  carr_phase: in: the descriptor's; out (chain_starts): the exact
+ * phase at the block's first sample. */
+struct ChainDesc {
+    double f_carr;
+    double carr_phase;
+    int32_t prn;
+    int32_t _pad;
+};
+static_assert(sizeof(ChainDesc) == 24, "ChainDesc layout");
 
 /* The carrier of a stream (gpsbb_stream_*) from one push to the next, on the device. */
 struct ChainCarryDev {
@@ -154,7 +165,8 @@ struct BatchDev {
     const int32_t *kstep;           /* ... and its per-sample step (int)round(2^25*f_carr*delt), c:2675 */
     int seed_lanes;                 /* entries of seed_order */
     const int32_t *seed_order;      /* the chain each lane of k_seed walks: kind*nblocks*nch + block*nch + channel,
-                                       -1 = idle lane.  Planned by the host: code and carrier chains never share
+                                       -1 = idle lane (NULL, chain-only runs: carrier chains channel by channel, blocks
+                                       in order, 64 consecutive blocks of one channel per wavefront).  Planned by the host: code and carrier chains never share
                                        a wavefront, carrier chains go by descending |f_carr| and the longest get
                                        wavefronts with few lanes (a wavefront runs as long as its longest chain
                                        and every extra lane adds turns of the loops its lanes do not share)   */
@@ -177,6 +189,10 @@ struct BatchDev {
     int chain_starts;               /* ... for the per-sample kernel: the chain kernels only put the exact start phase of every
                                        block into its descriptor (no rows, no offsets); k_seed then sees independent blocks */
     ChainAux *aux;                  /* [nblocks*nch]                                                  */
+    ChainDesc *cd;                  /* [nblocks*nch] what the chain kernels read of the descriptors (and, chain_starts, where
+                                       k_chain_fix* leaves the exact start phase of every block)        */
+    const double *start0;           /* [nblocks*nch] rough start phases (host: descriptor phase + sum of nsamp*step in plain
+                                       double arithmetic): where pass A walks from                     */
     SynRow *prefix_rows;            /* [nblocks*nch][CHAIN_PREFIX_CAP]: see ChainAux::prefix_cnt       */
     ChainCarryDev *carry;           /* stream: block 0 continues the previous push's last block; else NULL */
     uint32_t cont0_mask;            /* ... for the channels of this mask (same prn as in that block: the host knows) */

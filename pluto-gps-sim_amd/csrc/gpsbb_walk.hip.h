@@ -323,7 +323,7 @@ __device__ __forceinline__ void walk_both_signs(WalkLane<KIND> &w, int nsamp, un
 }
 
 /* a lane set up for chain k of its kind: block-channel k, rows region `chain` of the pool */
-template <int KIND>
+template <int KIND, bool STORE = true>
 __device__ __forceinline__ WalkLane<KIND> walk_lane(const BatchDev &p, int chain, double x0, double s, bool on)
 {
     WalkLane<KIND> w;
@@ -333,9 +333,13 @@ __device__ __forceinline__ WalkLane<KIND> walk_lane(const BatchDev &p, int chain
     w.nav = 0;
     w.bits = 0;
     w.dwrd = nullptr;
-    const uint64_t o0 = p.row_off[chain], o1 = p.row_off[chain + 1];
-    w.rows = reinterpret_cast<WalkRow *>(p.rows) + o0;
-    w.cap = (uint32_t)(o1 - o0);
+    w.rows = nullptr;
+    w.cap = 0;
+    if (STORE) { /* walks that keep no rows (pass A, the chain-only pass B) have no region of the pool */
+        const uint64_t o0 = p.row_off[chain], o1 = p.row_off[chain + 1];
+        w.rows = reinterpret_cast<WalkRow *>(p.rows) + o0;
+        w.cap = (uint32_t)(o1 - o0);
+    }
     w.cnt = 0;
     w.active = on;
     w.stuck = false;
@@ -365,8 +369,20 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
 {
     __builtin_amdgcn_s_setprio(GPSBB_SEED_PRIO);
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = gid < p.seed_lanes ? p.seed_order[gid] : -1;
     const int nbc = p.nblocks * p.nch;
+    int c = -1;
+    if (gid < p.seed_lanes) {
+        if (p.seed_order) {
+            c = p.seed_order[gid];
+        } else {
+            /* no plan (chain-only runs over very many blocks): the carrier chains channel by channel, blocks in order — 64
+             * consecutive blocks of one channel share a wavefront, and a stream continuous in time gives them the same
+             * direction and almost the same |f_carr|, which is all the plan's sort is for */
+            const int nbp = (p.nblocks + 63) & ~63;
+            const int i = gid / nbp, b = gid - i * nbp;
+            c = (i < p.nch && b < p.nblocks) ? nbc + b * p.nch + i : -1;
+        }
+    }
     const bool is_code = c >= 0 && c < nbc, is_carr = c >= nbc;
     if (PASS != 1 && PASS != 3 && __ballot(is_code)) {
         const int k = is_code ? c : 0;
@@ -398,10 +414,12 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
     }
     if (__ballot(is_carr)) {
         const int k = is_carr ? c - nbc : 0;
-        const gpsbb_chan_t &ch = p.ch[k];
-        const bool on = is_carr && ch.prn > 0;
-        const double x0 = PASS == 1 ? p.aux[k].start0 : (PASS >= 2 ? p.aux[k].start1 : ch.carr_phase);
-        WalkLane<NCO_CARR> w = walk_lane<NCO_CARR>(p, nbc + k, x0, mul_rn(ch.f_carr, p.delt) /* c:2741 */, on);
+        /* the passes of the device-side chain read the 24-byte chain descriptors, the others the descriptors themselves */
+        const int prn = PASS >= 1 ? p.cd[k].prn : p.ch[k].prn;
+        const double f_carr = PASS >= 1 ? p.cd[k].f_carr : p.ch[k].f_carr;
+        const bool on = is_carr && prn > 0;
+        const double x0 = PASS == 1 ? p.start0[k] : (PASS >= 2 ? p.aux[k].start1 : p.ch[k].carr_phase);
+        WalkLane<NCO_CARR> w = walk_lane<NCO_CARR, PASS == 0 || PASS == 2>(p, nbc + k, x0, mul_rn(f_carr, p.delt) /* c:2741 */, on);
         w.aux = PASS >= 2 ? &p.aux[k] : nullptr;
         if (PASS >= 2)
             walk_both_signs<NCO_CARR, true, PASS == 2>(w, p.nsamp, p.hazards, p.status);
@@ -436,10 +454,10 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
 /* does block b of channel i continue block b-1's carrier (GPSBB_CHAIN_CARRIER: same channel index, same prn)? */
 __device__ __forceinline__ bool chain_continues(const BatchDev &p, int b, int i)
 {
-    const int prn = p.ch[(size_t)b * p.nch + i].prn;
+    const int prn = p.cd[(size_t)b * p.nch + i].prn;
     if (b == 0) /* a stream's push continues the push before it */
         return p.carry && prn > 0 && ((p.cont0_mask >> i) & 1u);
-    return prn > 0 && prn == p.ch[(size_t)(b - 1) * p.nch + i].prn;
+    return prn > 0 && prn == p.cd[(size_t)(b - 1) * p.nch + i].prn;
 }
 
 /*
@@ -463,9 +481,10 @@ __global__ void k_chain_prefix(BatchDev p)
         const bool cont = in && chain_continues(p, b, i);
         /* the increment this block adds to the correction of the block before it: the phase lost between the end
          * of pass A's walk of block b-1 and the rough start of block b (a wrap of the unit interval apart at most) */
+        const double start0 = in ? p.start0[k] : 0.0;
         double c = 0.0;
         if (cont) {
-            c = (b == 0 ? p.carry->approx_end[i] : p.aux[k - p.nch].endA) - p.aux[k].start0;
+            c = (b == 0 ? p.carry->approx_end[i] : p.aux[k - p.nch].endA) - start0;
             c = c > 0.5 ? c - 1.0 : (c < -0.5 ? c + 1.0 : c);
         }
         /* segmented inclusive scan: (flag, value) pairs, flag = the sum restarts here */
@@ -483,12 +502,12 @@ __global__ void k_chain_prefix(BatchDev p)
         const double e = f ? v : v + carry;
         if (in) {
             ChainAux &a = p.aux[k];
-            double st = cont ? a.start0 + e : p.ch[k].carr_phase;
+            double st = cont ? start0 + e : p.cd[k].carr_phase;
             st = st >= 1.0 ? st - 1.0 : (st < 0.0 ? st + 1.0 : st);
             a.start1 = st;
             if (p.carry && b == p.nblocks - 1) {
                 /* where the stream's next push will start, as far as pass A can tell */
-                double en = a.endA + (st - a.start0);
+                double en = a.endA + (st - start0);
                 en = en >= 1.0 ? en - 1.0 : (en < 0.0 ? en + 1.0 : en);
                 p.carry->approx_end[i] = en;
             }
@@ -497,15 +516,9 @@ __global__ void k_chain_prefix(BatchDev p)
     }
 }
 
-/* an exact walk of which only the end state and the hazard count are wanted */
-struct FixNullSink {
-    uint32_t hz512;
-    __device__ __forceinline__ void row(int32_t, uint32_t, double, double, bool) {}
-    __device__ __forceinline__ void table_index_512() { hz512++; }
-    __device__ __forceinline__ void nav_fetch(uint32_t) {}
-};
-
-/* rows of one exact walk of a whole block, as k_walk writes them (build_rows_f64 drives it) */
+/* the rows of an exact walk as k_walk writes them (build_rows_f64 drives it); STORE = false: the walk is only wanted
+ * for its end state, its row count and its hazards (a trial evaluation, or a batch that keeps no rows) */
+template <bool STORE>
 struct FixRowSink {
     WalkRow *rows;
     uint32_t cap, cnt;
@@ -514,11 +527,13 @@ struct FixRowSink {
     __device__ __forceinline__ void row(int32_t n0, uint32_t, double x, double, bool)
     {
         if (cnt < cap) {
-            WalkRow r;
-            r.n0 = n0;
-            r.nav = 0;
-            r.x = x;
-            rows[cnt] = r;
+            if (STORE) {
+                WalkRow r;
+                r.n0 = n0;
+                r.nav = 0;
+                r.x = x;
+                rows[cnt] = r;
+            }
         } else {
             overflow = true;
         }
@@ -527,9 +542,16 @@ struct FixRowSink {
     __device__ __forceinline__ void table_index_512() { hz512++; }
     __device__ __forceinline__ void nav_fetch(uint32_t) {}
 };
+/* ... where not even the count matters */
+struct FixNullSink {
+    uint32_t hz512;
+    __device__ __forceinline__ void row(int32_t, uint32_t, double, double, bool) {}
+    __device__ __forceinline__ void table_index_512() { hz512++; }
+    __device__ __forceinline__ void nav_fetch(uint32_t) {}
+};
 
 /*
- * Device-side carrier chain, step 4 of 4: make it exact.  One lane per channel, blocks in order.
+ * Device-side carrier chain, step 4 of 4: make it exact.
  *
  * Pass B walked block b from start1, a few units in the last place away from the true start phase (the end of
  * block b-1, known exactly only now).  Inside one of pass B's rows all states lie in one binade, on one grid,
@@ -540,16 +562,20 @@ struct FixRowSink {
  * has been rounded on the coarsest grid there is (the one before a wrap: 2^-52 in [1,2) for a rising phase,
  * 2^-53 in [0.5,1) for a falling one) d is a multiple of every grid the phase will ever meet and stays put —
  * except at a later rounding on that coarsest grid that is an exact TIE while d is an odd number of its steps
- * (see below: a rising phase's step decides whether its wrap sums can tie at all; a falling phase's "+ 1.0"
- * ties or not depending on the state's low bits, so pass B tests every wrap and records the ties as well).  Pass B recorded those few rows; here, for each of them in turn: pass B's state
- * at the last sample of the row before, plus d, is the true state there; one genuine IEEE step (c:2741-2746)
- * gives the true first state of the row; minus pass B's, that is the new d.  k_tiles adds the offsets to the
- * rows' states, the end state gets the last one.  A block whose step can tie on the coarsest grid, is tiny,
- * has more crossings than the record holds, or whose margin is not larger than its offsets is walked exactly
- * by the lane on its own (rare, slow).
+ * (see below: a rising phase's step decides whether its wrap sums can tie at all; a falling phase's "+ 1.0" ties or
+ * not depending on the state's low bits, so pass B tests every wrap and records the ties as well).  Pass B recorded
+ * those few rows; fix_block, for each of them in turn: pass B's state at the last sample of the row before, plus d,
+ * is the true state there; one genuine IEEE step (c:2741-2746) gives the true first state of the row; minus pass
+ * B's, that is the new d.  k_tiles adds the offsets to the rows' states, the end state gets the last one.  A block
+ * whose step can tie on the coarsest grid, is tiny, has more crossings than the record holds, or whose margin is
+ * not larger than its offsets is walked exactly by the lane on its own (rare, slow).
+ *
+ * fix_block is that computation for ONE block given its true start phase x: a pure function of (pass B's record of
+ * the block, x).  Two kernels drive it: k_chain_fix (one lane per channel, the blocks in order — each block's x is
+ * the end the block before just returned) and k_chain_fix_par (one workgroup per channel, one lane per block — the
+ * x of all blocks guessed at once, then checked by the same function; see there).
  */
-/* what one turn of k_chain_fix's loop reads: fetched a block ahead, because the loop itself is one long chain of
- * dependent arithmetic (each block starts where the one before ended) and must not wait for memory as well */
+/* what fix_block reads of a block: fetched ahead of the arithmetic */
 constexpr int FIX_PREFETCH_CROSS = 6;
 struct FixIn {
     int prn, prn_prev, ncross, wrap_row;
@@ -560,11 +586,11 @@ struct FixIn {
 __device__ __forceinline__ FixIn fix_load(const BatchDev &p, int b, int i)
 {
     const size_t k = (size_t)b * p.nch + i;
-    const gpsbb_chan_t &ch = p.ch[k];
+    const ChainDesc &ch = p.cd[k];
     const ChainAux &a = p.aux[k];
     FixIn f;
     f.prn = ch.prn;
-    f.prn_prev = b > 0 ? p.ch[k - p.nch].prn : 0;
+    f.prn_prev = b > 0 ? p.cd[k - p.nch].prn : 0;
     f.carr_phase = ch.carr_phase;
     f.f_carr = ch.f_carr;
     f.start1 = a.start1;
@@ -582,17 +608,232 @@ __device__ __forceinline__ FixIn fix_load(const BatchDev &p, int b, int i)
     return f;
 }
 
+constexpr int FIX_OK = 0;   /* FixOut::end is the block's true end phase */
+constexpr int FIX_SLOW = 1; /* only a walk of the whole block tells (and the caller did not ask for one) */
+struct FixOut {
+    double end;
+    int kind;
+    uint32_t hz512;  /* samples of the block whose phase is exactly 1.0 */
+    bool walked;     /* the whole block was walked on its own (GPSBB_INFO_CHAIN_FALLBACKS) */
+};
+
+/*
+ * One block (k = block * nch + channel, `on`: the channel is active in it) from its true start phase x.
+ * COMMIT: leave what k_tiles needs (the offsets per stretch of rows, the rows of a lap or a block walked here) —
+ * without it nothing is written, so that a start phase that is only a guess can be tried.  run_slow: walk the whole
+ * block if nothing cheaper settles it (else FIX_SLOW comes back and the caller calls again once x is known to be true).
+ */
+template <bool COMMIT>
+__device__ __forceinline__ FixOut fix_block(const BatchDev &p, const FixIn &in, size_t k, bool on, double x, bool run_slow)
+{
+    FixOut out;
+    out.kind = FIX_OK;
+    out.walked = false;
+    ChainAux &a = p.aux[k];
+    const int nbc = p.nblocks * p.nch;
+    const double s = mul_rn(in.f_carr, p.delt);
+    const uint64_t sb = f64_bits(s);
+    const int es = (int)((sb >> 52) & 0x7ff);
+    const double margin = in.margin;
+    const int ncross = in.ncross;
+    double end = in.endB;
+    uint32_t hz512 = in.hz512; /* pass B's trajectory is the true one, or a translate that met no edge */
+    const double d0 = x - in.start1; /* exact: both in the same binade, or the margin test below fails */
+    /* Ties.  A sum exactly half-way between two grid points goes to the even one, so a tie commutes with the
+     * shift only if the shift is an even number of steps of that grid.  It always is on grids finer than the
+     * one the offset was last rounded on.  That leaves (1) the binades the phase visits before its offset has
+     * been through the coarsest grid — from its start binade upwards if it rises, its start binade only if it
+     * falls: if the step can tie there (walk_tiemask) the block's first lap is walked here;
+     * (2) the coarsest grid itself: pass B finds the first tie there after the first wrap (a wrap sum exactly
+     * half-way; for a falling phase whose step ties on the top binade's grid, the first step after the wrap) and
+     * records it as a crossing: both trajectories leave a tie with an even mantissa, so the offset is an even
+     * number of grid steps from there on and no later tie can change it. */
+    const bool fall = s < 0.0;
+    bool tie_top = true;
+    {
+        const int dt = (fall ? 1022 : 1023) - es; /* the step's last place is 2^dt times finer than that grid */
+        if (dt >= 1 && dt <= 52) {
+            const uint64_t low = ((sb & F64_MANT) | F64_HID) & ((1ull << dt) - 1);
+            tie_top = low == 0ull || low == (1ull << (dt - 1));
+        } else if (dt <= 0) {
+            tie_top = false; /* the step is a multiple of the grid: sums are never between grid points */
+        }
+    }
+    bool tie_asc = false;
+    if (on && d0 != 0.0 && es >= 123) {
+        const int dstart = (int)((f64_bits(x) >> 52) & 0x7ff) - es;
+        const int dtie = walk_tie_d(sb); /* the one binade (above the step's) in which the step ties */
+        tie_asc = dtie >= 2 && dtie <= 50 && (fall ? dtie == dstart : dtie >= dstart);
+    }
+    const bool base = on && es >= 123 && ncross >= 0 && fabs(d0) < margin - 0x1p-51;
+    bool ok = on && d0 == 0.0;
+    double d = d0;
+    if (COMMIT && on) {
+        a.seg[0] = d0;
+        if (ok) /* pass B walked the true trajectory: no offset anywhere (the record is not zeroed between runs) */
+            for (int j = 0; j < ncross; j++)
+                a.seg[j + 1] = 0.0;
+    }
+    if (base && !ok && !tie_asc) {
+        /* the usual way: one genuine step per recorded crossing */
+        ok = true;
+        for (int j = 0; ok && j < ncross; j++) {
+            /* pass B's state at the last sample before the crossing, the true one, one genuine step */
+            double pre_j = 0.0, post_j = 0.0;
+            if (j >= FIX_PREFETCH_CROSS) { /* rare: beyond what was fetched ahead */
+                pre_j = a.pre[j];
+                post_j = a.post[j];
+            } else {
+#pragma unroll
+                for (int q = 0; q < FIX_PREFETCH_CROSS; q++) {
+                    pre_j = j == q ? in.pre[q] : pre_j;
+                    post_j = j == q ? in.post[q] : post_j;
+                }
+            }
+            double xt = pre_j + d;
+            carr_step(xt, s);
+            d = xt - post_j;
+            ok = fabs(d) < margin - 0x1p-51;
+            if (COMMIT)
+                a.seg[j + 1] = d;
+        }
+    } else if (base && !ok && in.wrap_row >= 0) {
+        /* a tie-prone binade on the way up: the first lap exactly, on its own rows; after the wrap that ends it
+         * the offset is a multiple of every grid and the rest of the block is pass B's plus it */
+        const int nstar = in.wrap_row; /* a wrap always starts a row */
+        uint32_t nav = 0;
+        double xs;
+        bool overflow = false;
+        uint32_t lap_rows = 0, lap_hz = 0;
+        if (p.chain_starts) { /* only the state at the wrap is wanted */
+            FixNullSink ns;
+            ns.hz512 = 0;
+            xs = build_rows_f64<NCO_CARR>(x, s, nav, nstar, ns);
+            lap_hz = ns.hz512;
+        } else {
+            FixRowSink<COMMIT> sink;
+            sink.rows = reinterpret_cast<WalkRow *>(p.prefix_rows) + k * CHAIN_PREFIX_CAP;
+            sink.cap = CHAIN_PREFIX_CAP;
+            sink.cnt = 0;
+            sink.overflow = false;
+            sink.hz512 = 0;
+            xs = build_rows_f64<NCO_CARR>(x, s, nav, nstar, sink);
+            overflow = sink.overflow;
+            lap_rows = sink.cnt;
+            lap_hz = sink.hz512;
+        }
+        d = xs - in.wrap_x;
+        /* (a tie-prone coarsest grid and an odd offset there: pass B's recorded tie is not part of this path) */
+        ok = !overflow && lap_hz == 0 && fabs(d) < margin - 0x1p-51 &&
+             !(tie_top && fmod(fabs(d) * (fall ? 0x1p+53 : 0x1p+52), 2.0) != 0.0);
+        if (ok) {
+            /* pass B's rows from the wrap on: its offset there, then — as on the usual way — one genuine step
+             * through every crossing pass B recorded after it (ties at later wraps, the block's last step);
+             * the list is compacted in place (entry m is written after entry j >= m has been read) */
+            const double d_wrap = d;
+            int m = 1;
+            for (int j = 0; ok && j < ncross; j++) {
+                const int cj = a.cross[j];
+                if (cj <= nstar)
+                    continue;
+                double xt = a.pre[j] + d;
+                carr_step(xt, s);
+                d = xt - a.post[j];
+                ok = fabs(d) < margin - 0x1p-51;
+                if (COMMIT) {
+                    a.cross[m] = cj;
+                    a.seg[m + 1] = d;
+                }
+                m++;
+            }
+            if (ok && COMMIT) {
+                a.prefix_cnt = (int32_t)lap_rows;
+                a.prefix_end = nstar;
+                a.ncross = m;
+                a.cross[0] = nstar;
+                a.seg[0] = 0.0;
+                a.seg[1] = d_wrap;
+            }
+        }
+    }
+    if (on && ok && d0 != 0.0)
+        end = end + d; /* exact: the true end state is a double */
+#ifdef GPSBB_CHAIN_DEBUG
+    if (COMMIT && on && p.nch == 1) {
+        printf("fix k %d x %.17g start1 %.17g d0 %.3e margin %.3e ncross %d wrap_row %d tie_top %d tie_asc %d ok %d endB %.17g end %.17g s %.17g\n",
+               (int)k, x, in.start1, d0, margin, ncross, in.wrap_row, (int)tie_top, (int)tie_asc, (int)ok, in.endB, end, s);
+        for (int j = 0; j < ncross && j < CHAIN_MAX_CROSS; j++)
+            printf("    cross %d sample %d pre %.17g post %.17g seg %.3e\n", j, a.cross[j], a.pre[j], a.post[j], a.seg[j + 1]);
+    }
+#endif
+    if (on && !ok) {
+        if (!run_slow) {
+            out.kind = FIX_SLOW;
+            out.end = end;
+            out.hz512 = 0;
+            return out;
+        }
+        out.walked = true;
+        uint32_t nav = 0;
+        if (p.chain_starts) {
+            /* on its own: the whole block exactly; only its end state is wanted */
+            FixNullSink ns;
+            ns.hz512 = 0;
+            end = build_rows_f64<NCO_CARR>(x, s, nav, p.nsamp, ns);
+        } else {
+            /* on its own: the whole block exactly, rows in place of pass B's, no offsets */
+            FixRowSink<COMMIT> sink;
+            sink.rows = reinterpret_cast<WalkRow *>(p.rows) + p.row_off[nbc + k];
+            sink.cap = (uint32_t)(p.row_off[nbc + k + 1] - p.row_off[nbc + k]);
+            sink.cnt = 0;
+            sink.overflow = false;
+            sink.hz512 = 0;
+            end = build_rows_f64<NCO_CARR>(x, s, nav, p.nsamp, sink);
+            hz512 = sink.hz512;
+            if (COMMIT) {
+                if (sink.overflow)
+                    atomicOr(p.status, ST_ROW_OVERFLOW);
+                p.row_cnt[nbc + k] = (int32_t)(sink.cnt < sink.cap ? sink.cnt : sink.cap);
+                a.ncross = 0;
+                a.seg[0] = 0.0;
+                a.prefix_cnt = 0;
+            }
+        }
+    }
+    out.end = end;
+    out.hz512 = hz512;
+    return out;
+}
+
+/* what a block leaves behind once its true start phase x and end are known (after fix_block<true>) */
+__device__ __forceinline__ void fix_publish(const BatchDev &p, size_t k, bool on, bool cont, double x, const FixOut &r,
+                                            unsigned long long &n_hz)
+{
+    if (p.chain_starts) {
+        /* the per-sample kernel's pre-pass comes next (or nothing, gpsbb_chain_carrier): all that is wanted is where
+         * this block starts (k_seed counts the hazards and writes the end states itself) */
+        if (on && cont) {
+            p.cd[k].carr_phase = x;
+            if (p.ch)
+                const_cast<gpsbb_chan_t *>(p.ch)[k].carr_phase = x;
+        }
+    } else {
+        p.end[k].carr_phase = on ? r.end : 0.0;
+        if (on)
+            n_hz += r.hz512;
+    }
+}
+
+/* The blocks in order, one lane per channel: each block starts where the one before ended.  Kept beside
+ * k_chain_fix_par as the plain statement of the chain (GPSBB_OPT_CHAIN_WHERE 2; the tests run both). */
 __global__ __launch_bounds__(64) void k_chain_fix(BatchDev p)
 {
-#ifndef GPSBB_EXP_NOPRIO
     /* one wavefront on whose latency every later push of the stream waits: let it win the issue arbitration
      * against the synthesis wavefronts it shares its SIMD with */
     __builtin_amdgcn_s_setprio(3);
-#endif
     const int i = threadIdx.x;
     const bool lane_on = i < p.nch;
     const int il = lane_on ? i : 0;
-    const int nbc = p.nblocks * p.nch;
     double prev_end = p.carry ? p.carry->exact_end[il] : 0.0; /* a stream: where the push before this one ended */
     unsigned long long n_fallback = 0, n_hz = 0;
     /* two blocks ahead: a turn of this loop is a few hundred cycles of dependent arithmetic, a load from HBM beside
@@ -605,178 +846,238 @@ __global__ __launch_bounds__(64) void k_chain_fix(BatchDev p)
         nxt2 = fix_load(p, b + 2 < p.nblocks ? b + 2 : p.nblocks - 1, il);
         const size_t k = (size_t)b * p.nch + il;
         const bool on = lane_on && in.prn > 0;
-        ChainAux &a = p.aux[k];
-        const bool cont = lane_on && in.prn > 0 && (b > 0 ? in.prn == in.prn_prev : (p.carry && ((p.cont0_mask >> il) & 1u)));
+        const bool cont = on && (b > 0 ? in.prn == in.prn_prev : (p.carry && ((p.cont0_mask >> il) & 1u)));
         const double x = cont ? prev_end : in.carr_phase;
-        const double s = mul_rn(in.f_carr, p.delt);
-        const uint64_t sb = f64_bits(s);
-        const int es = (int)((sb >> 52) & 0x7ff);
-        const double margin = in.margin;
-        const int ncross = in.ncross;
-        double end = in.endB;
-        uint32_t hz512 = in.hz512; /* pass B's trajectory is the true one, or a translate that met no edge */
-        const double d0 = x - in.start1; /* exact: both in the same binade, or the margin test below fails */
-        /* Ties.  A sum exactly half-way between two grid points goes to the even one, so a tie commutes with the
-         * shift only if the shift is an even number of steps of that grid.  It always is on grids finer than the
-         * one the offset was last rounded on.  That leaves (1) the binades the phase visits before its offset has
-         * been through the coarsest grid — from its start binade upwards if it rises, its start binade only if it
-         * falls: if the step can tie there (walk_tiemask) the lane walks the block's first lap on its own;
-         * (2) the coarsest grid itself: pass B finds the first tie there after the first wrap (a wrap sum exactly
-         * half-way; for a falling phase whose step ties on the top binade's grid, the first step after the wrap) and
-         * records it as a crossing: both trajectories leave a tie with an even mantissa, so the offset is an even
-         * number of grid steps from there on and no later tie can change it. */
-        const bool fall = s < 0.0;
-        bool tie_top = true;
-        {
-            const int dt = (fall ? 1022 : 1023) - es; /* the step's last place is 2^dt times finer than that grid */
-            if (dt >= 1 && dt <= 52) {
-                const uint64_t low = ((sb & F64_MANT) | F64_HID) & ((1ull << dt) - 1);
-                tie_top = low == 0ull || low == (1ull << (dt - 1));
-            } else if (dt <= 0) {
-                tie_top = false; /* the step is a multiple of the grid: sums are never between grid points */
-            }
-        }
-        bool tie_asc = false;
-        if (on && d0 != 0.0 && es >= 123) {
-            const int dstart = (int)((f64_bits(x) >> 52) & 0x7ff) - es;
-            const int dtie = walk_tie_d(sb); /* the one binade (above the step's) in which the step ties */
-            tie_asc = dtie >= 2 && dtie <= 50 && (fall ? dtie == dstart : dtie >= dstart);
-        }
-        const double gtop = fall ? 0x1p-53 : 0x1p-52;
-        const bool base = on && es >= 123 && ncross >= 0 && fabs(d0) < margin - 0x1p-51;
-        bool ok = on && d0 == 0.0;
-        double d = d0;
-        if (on)
-            a.seg[0] = d0;
-        if (base && !ok && !tie_asc) {
-            /* the usual way: one genuine step per recorded crossing */
-            ok = true;
-            for (int j = 0; ok && j < ncross; j++) {
-                /* pass B's state at the last sample before the crossing, the true one, one genuine step */
-                double pre_j = 0.0, post_j = 0.0;
-                if (j >= FIX_PREFETCH_CROSS) { /* rare: beyond what was fetched ahead */
-                    pre_j = a.pre[j];
-                    post_j = a.post[j];
-                } else {
-#pragma unroll
-                    for (int q = 0; q < FIX_PREFETCH_CROSS; q++) {
-                        pre_j = j == q ? in.pre[q] : pre_j;
-                        post_j = j == q ? in.post[q] : post_j;
-                    }
-                }
-                double xt = pre_j + d;
-                carr_step(xt, s);
-                d = xt - post_j;
-                ok = fabs(d) < margin - 0x1p-51;
-                a.seg[j + 1] = d;
-            }
-        } else if (base && !ok && in.wrap_row >= 0) {
-            /* a tie-prone binade on the way up: the first lap exactly, on its own rows; after the wrap that ends it
-             * the offset is a multiple of every grid and the rest of the block is pass B's plus it */
-            const int nstar = in.wrap_row; /* a wrap always starts a row */
-            FixRowSink sink;
-            sink.rows = p.chain_starts ? nullptr : reinterpret_cast<WalkRow *>(p.prefix_rows) + k * CHAIN_PREFIX_CAP;
-            sink.cap = p.chain_starts ? 0 : CHAIN_PREFIX_CAP;
-            sink.cnt = 0;
-            sink.overflow = false;
-            sink.hz512 = 0;
-            uint32_t nav = 0;
-            double xs;
-            if (p.chain_starts) { /* only the state at the wrap is wanted */
-                FixNullSink ns;
-                ns.hz512 = 0;
-                xs = build_rows_f64<NCO_CARR>(x, s, nav, nstar, ns);
-                sink.hz512 = ns.hz512;
-            } else {
-                xs = build_rows_f64<NCO_CARR>(x, s, nav, nstar, sink);
-            }
-            d = xs - in.wrap_x;
-            /* (a tie-prone coarsest grid and an odd offset there: pass B's recorded tie is not part of this path) */
-            ok = !sink.overflow && sink.hz512 == 0 && fabs(d) < margin - 0x1p-51 &&
-                 !(tie_top && fmod(fabs(d) * (fall ? 0x1p+53 : 0x1p+52), 2.0) != 0.0);
-            if (ok) {
-                /* pass B's rows from the wrap on: its offset there, then — as on the usual way — one genuine step
-                 * through every crossing pass B recorded after it (ties at later wraps, the block's last step);
-                 * the list is compacted in place (entry m is written after entry j >= m has been read) */
-                const double d_wrap = d;
-                int m = 1;
-                for (int j = 0; ok && j < ncross; j++) {
-                    const int cj = a.cross[j];
-                    if (cj <= nstar)
-                        continue;
-                    double xt = a.pre[j] + d;
-                    carr_step(xt, s);
-                    d = xt - a.post[j];
-                    ok = fabs(d) < margin - 0x1p-51;
-                    a.cross[m] = cj;
-                    a.seg[m + 1] = d;
-                    m++;
-                }
-                if (ok) {
-                    a.prefix_cnt = (int32_t)sink.cnt;
-                    a.prefix_end = nstar;
-                    a.ncross = m;
-                    a.cross[0] = nstar;
-                    a.seg[0] = 0.0;
-                    a.seg[1] = d_wrap;
-                }
-            }
-        }
-        (void)gtop;
-        if (on && ok && d0 != 0.0)
-            end = end + d; /* exact: the true end state is a double */
-#ifdef GPSBB_CHAIN_DEBUG
-        if (on && p.nch == 1) {
-            printf("fix b %d x %.17g start1 %.17g d0 %.3e margin %.3e ncross %d wrap_row %d tie_top %d tie_asc %d ok %d endB %.17g end %.17g s %.17g\n", b, x,
-                   in.start1, d0, margin, ncross, in.wrap_row, (int)tie_top, (int)tie_asc, (int)ok, in.endB, end, s);
-            for (int j = 0; j < ncross && j < CHAIN_MAX_CROSS; j++)
-                printf("    cross %d sample %d pre %.17g post %.17g seg %.3e\n", j, a.cross[j], a.pre[j], a.post[j], a.seg[j + 1]);
-        }
-        if (on && !ok)
-            printf("chain fallback: block %d ch %d d0 %.3e d %.3e margin %.3e ncross %d es %d tie_top %d tie_asc %d wrap_row %d\n", b,
-                   i, d0, d, margin, ncross, es, (int)tie_top, (int)tie_asc, in.wrap_row);
-#endif
-        if (on && !ok && p.chain_starts) {
-            /* on its own: the whole block exactly; only its end state is wanted */
-            FixNullSink ns;
-            ns.hz512 = 0;
-            uint32_t nav = 0;
-            end = build_rows_f64<NCO_CARR>(x, s, nav, p.nsamp, ns);
-            n_fallback++;
-        } else if (on && !ok) {
-            /* on its own: the whole block exactly, rows in place of pass B's, no offsets */
-            FixRowSink sink;
-            sink.rows = reinterpret_cast<WalkRow *>(p.rows) + p.row_off[nbc + k];
-            sink.cap = (uint32_t)(p.row_off[nbc + k + 1] - p.row_off[nbc + k]);
-            sink.cnt = 0;
-            sink.overflow = false;
-            sink.hz512 = 0;
-            uint32_t nav = 0;
-            end = build_rows_f64<NCO_CARR>(x, s, nav, p.nsamp, sink);
-            hz512 = sink.hz512;
-            if (sink.overflow)
-                atomicOr(p.status, ST_ROW_OVERFLOW);
-            p.row_cnt[nbc + k] = (int32_t)(sink.cnt < sink.cap ? sink.cnt : sink.cap);
-            a.ncross = 0;
-            a.seg[0] = 0.0;
-            a.prefix_cnt = 0;
-            n_fallback++;
-        }
-        if (lane_on && p.chain_starts) {
-            /* the per-sample kernel's pre-pass comes next: all it needs is where this block starts (it counts the
-             * hazards and writes the end states itself) */
-            if (on && cont)
-                const_cast<gpsbb_chan_t *>(p.ch)[k].carr_phase = x;
-            prev_end = end;
-        } else if (lane_on) {
-            p.end[k].carr_phase = on ? end : 0.0;
-            prev_end = end;
-            if (on)
-                n_hz += hz512;
-        }
+        const FixOut r = fix_block<true>(p, in, k, on, x, true);
+        n_fallback += r.walked ? 1u : 0u;
+        if (lane_on)
+            fix_publish(p, k, on, cont, x, r, n_hz);
+        prev_end = r.end;
     }
     if (p.carry && lane_on)
         p.carry->exact_end[i] = prev_end;
+    if (n_hz)
+        atomicAdd(p.hazards, n_hz);
+    if (n_fallback)
+        atomicAdd(p.hazards + 4, n_fallback);
+}
+
+/*
+ * The same chain with the blocks in PARALLEL: one workgroup per channel, one lane per block (chunks of FIXP_WG blocks).
+ *
+ * The end of block b is fix_block(b, x_b) and x_(b+1) is that end: sequential as written.  But what a block does to
+ * a start phase is almost a translation.  With u = 2^-53 (every grid a phase meets after a wrap is a multiple of it)
+ * write the true end of block b as endB_b + o_b * u (endB: pass B's end).  For a block that wraps, shifting the start
+ * by 4u shifts the end by exactly 4u (all roundings, ties included, commute with a shift by an even number of steps
+ * of every grid — the coarsest is 2^-52), so
+ *     o_b = o_(b-1) + k_b[o_(b-1) mod 4],
+ * four small integers per block that every lane finds for its own block by running fix_block (no side effects) from the
+ * four start phases endB_(b-1) + j*u.  Maps of that form compose to maps of that form: an inclusive scan over the
+ * blocks gives every o_b at once.  A block that does not fit the form (no wrap, a start phase of its own, a lap or a
+ * whole block to be walked) enters the scan as a constant — a guess.
+ *
+ * Nothing rests on that argument.  The guessed start phases are CHECKED by induction: every lane runs fix_block from
+ * its guessed x_b and compares the end with the guess it handed to block b+1, bit for bit.  Up to the first block b*
+ * where that fails (or that needs a whole-block walk) every x is the true one, hence x_(b*) is, hence its end is
+ * (walked now if it has to be); that end enters the scan as a known constant and the blocks after b* are guessed and
+ * checked again.  When no block fails, every x_b is what k_chain_fix would have passed on, and every lane commits
+ * its block with fix_block<true>.  In a time-continuous stream a round fails for about one block-channel in 10^4.
+ */
+#ifndef GPSBB_FIXP_WG
+#define GPSBB_FIXP_WG 512
+#endif
+constexpr int FIXP_WG = GPSBB_FIXP_WG;
+
+struct FixMap {
+    int isconst; /* 1: o_b = v[0] whatever came before */
+    double v[4]; /* 0: o_b = o_(b-1) + v[o_(b-1) mod 4] */
+};
+/* the map "first B, then A" */
+__device__ __forceinline__ FixMap fix_compose(const FixMap &A, const FixMap &B)
+{
+    FixMap R;
+    if (A.isconst)
+        return A;
+    if (B.isconst) {
+        const double o = B.v[0];
+        const int cls = (int)fmax(fmin(o, 0x1p+30), -0x1p+30) & 3;
+        double add = A.v[0];
+        add = cls == 1 ? A.v[1] : add;
+        add = cls == 2 ? A.v[2] : add;
+        add = cls == 3 ? A.v[3] : add;
+        R.isconst = 1;
+        R.v[0] = o + add;
+        R.v[1] = R.v[2] = R.v[3] = 0.0;
+        return R;
+    }
+    R.isconst = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int cls = (r + (int)fmax(fmin(B.v[r], 0x1p+30), -0x1p+30)) & 3;
+        double add = A.v[0];
+        add = cls == 1 ? A.v[1] : add;
+        add = cls == 2 ? A.v[2] : add;
+        add = cls == 3 ? A.v[3] : add;
+        R.v[r] = B.v[r] + add;
+    }
+    return R;
+}
+
+struct FixParLds {
+    int mc[2][FIXP_WG];
+    double mv[2][4][FIXP_WG];
+    double eg[FIXP_WG + 1]; /* [b + 1]: the end of block b of the chunk as guessed (or known); [0]: of the block before it */
+    int first_bad;
+    int any_walk;
+};
+
+__global__ __launch_bounds__(FIXP_WG) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chain_fix_par(BatchDev p)
+{
+    __shared__ FixParLds L;
+    const int i = blockIdx.x; /* channel */
+    const int t = threadIdx.x;
+    if (i >= p.nch)
+        return;
+    unsigned long long n_fallback = 0, n_hz = 0;
+    if (t == 0)
+        L.eg[0] = p.carry ? p.carry->exact_end[i] : 0.0; /* a stream: where the push before this one ended */
+    for (int c0 = 0; c0 < p.nblocks; c0 += FIXP_WG) {
+        const int n = p.nblocks - c0 < FIXP_WG ? p.nblocks - c0 : FIXP_WG; /* blocks of this chunk */
+        const int b = c0 + t;
+        const bool mine = t < n;
+        const size_t k = (size_t)(mine ? b : c0) * p.nch + i;
+        const FixIn in = fix_load(p, mine ? b : c0, i);
+        const bool on = mine && in.prn > 0;
+        const bool cont = on && (b > 0 ? in.prn == in.prn_prev : (p.carry && ((p.cont0_mask >> i) & 1u)));
+        const double endB_prev = (mine && b > 0) ? p.aux[k - p.nch].endB : 0.0;
+        /* ---- this block as a map of the scan ---- */
+        FixMap my;
+        my.isconst = 0;
+        my.v[0] = my.v[1] = my.v[2] = my.v[3] = 0.0; /* lanes past the chunk: the identity */
+        if (mine && !on) {
+            my.isconst = 1; /* an idle channel ends at 0.0 = endB */
+        } else if (on && !cont) {
+            const FixOut r = fix_block<false>(p, in, k, on, in.carr_phase, false);
+            my.isconst = 1;
+            my.v[0] = r.kind == FIX_OK ? (r.end - in.endB) * 0x1p+53 : 0.0;
+        } else if (on) {
+            bool regular = b > 0 && t > 0; /* the chunk's first block is given its true start below */
+            double kk[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                kk[j] = 0.0;
+                if (regular) {
+                    const FixOut r = fix_block<false>(p, in, k, on, endB_prev + (double)j * 0x1p-53, false);
+                    const double o = (r.end - in.endB) * 0x1p+53;
+                    regular = r.kind == FIX_OK && fabs(o) < 0x1p+30 && o == __builtin_rint(o);
+                    kk[j] = o - (double)j;
+                }
+            }
+            if (regular) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    my.v[j] = kk[j];
+            } else {
+                my.isconst = 1; /* a guess: pass B's own end */
+            }
+        }
+        /* ---- guess, check, move the head: until every block's start phase is the true one ---- */
+        int lo = 0;
+        bool committed = false;
+        bool have = false; /* x_last / r_last hold an evaluation of this lane's block */
+        double x_last = 0.0;
+        FixOut r_last;
+        r_last.end = 0.0;
+        r_last.kind = FIX_OK;
+        r_last.hz512 = 0;
+        r_last.walked = false;
+        __syncthreads(); /* eg[0] */
+        for (;;) {
+            /* the head: its start phase is known to be true */
+            if (t == lo && mine) {
+                const double x = cont ? L.eg[lo] : in.carr_phase;
+                FixOut r = fix_block<false>(p, in, k, on, x, false);
+                if (r.kind == FIX_SLOW) {
+                    r = fix_block<true>(p, in, k, on, x, true); /* the whole block, now, for good */
+                    committed = true;
+                    n_fallback += r.walked ? 1u : 0u;
+                    fix_publish(p, k, on, cont, x, r, n_hz);
+                }
+                have = true;
+                x_last = x;
+                r_last = r;
+                my.isconst = 1;
+                my.v[0] = (r.end - in.endB) * 0x1p+53;
+                L.eg[lo + 1] = r.end;
+            }
+            /* inclusive scan of the maps over [lo, n): Hillis-Steele through LDS */
+            FixMap acc = my;
+            if (t < lo) {
+                acc.isconst = 0;
+                acc.v[0] = acc.v[1] = acc.v[2] = acc.v[3] = 0.0;
+            }
+            int cur = 0;
+            L.mc[0][t] = acc.isconst;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                L.mv[0][j][t] = acc.v[j];
+            __syncthreads();
+            for (int off = 1; off < FIXP_WG; off <<= 1) {
+                if (t >= off && t - off >= lo) {
+                    FixMap prev;
+                    prev.isconst = L.mc[cur][t - off];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        prev.v[j] = L.mv[cur][j][t - off];
+                    acc = fix_compose(acc, prev);
+                }
+                cur ^= 1;
+                L.mc[cur][t] = acc.isconst;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    L.mv[cur][j][t] = acc.v[j];
+                __syncthreads();
+                if ((off << 1) >= n)
+                    break;
+            }
+            /* every map from the head on is a constant now: the guessed ends */
+            if (mine && t > lo)
+                L.eg[t + 1] = in.endB + acc.v[0] * 0x1p-53;
+            if (t == 0)
+                L.first_bad = FIXP_WG;
+            __syncthreads();
+            /* check: from the guessed start, does this block end where the next one was told it would? */
+            if (mine && t > lo) {
+                const double x = cont ? L.eg[t] : in.carr_phase;
+                if (!have || f64_bits(x) != f64_bits(x_last)) {
+                    r_last = fix_block<false>(p, in, k, on, x, false);
+                    x_last = x;
+                    have = true;
+                }
+                if (r_last.kind != FIX_OK || f64_bits(r_last.end) != f64_bits(L.eg[t + 1]))
+                    atomicMin(&L.first_bad, t);
+            }
+            __syncthreads();
+            const int bad = L.first_bad;
+            __syncthreads();
+            if (bad >= FIXP_WG)
+                break;
+            lo = bad; /* every block before it is settled, so its start phase (eg[bad]) is the true one */
+        }
+        /* ---- commit ---- */
+        if (mine && !committed) {
+            const double x = cont ? L.eg[t] : in.carr_phase;
+            const FixOut r = fix_block<true>(p, in, k, on, x, true);
+            n_fallback += r.walked ? 1u : 0u;
+            fix_publish(p, k, on, cont, x, r, n_hz);
+        }
+        __syncthreads();
+        if (t == 0)
+            L.eg[0] = L.eg[n]; /* the next chunk continues here */
+        __syncthreads();
+    }
+    if (p.carry && t == 0)
+        p.carry->exact_end[i] = L.eg[0];
     if (n_hz)
         atomicAdd(p.hazards, n_hz);
     if (n_fallback)

@@ -5,7 +5,7 @@ carrier phase at its shard, digests exchanged, no data-path collective.
     sharding, the shard seeds (gpsbb_chain_carrier_host) and the digest exchange are the product's, the rendering is
     the CPU oracle's; the digest of the whole stream must not depend on the number of ranks;
   * on the GPU box (-m gpu): the real thing, two ranks sharing the one device (GPSBB_BENCH_BACKEND=gloo), through the
-    device-only ring and the pinned gather, small blocks."""
+    device-only ring and the pinned gather, small blocks; the second rank's seed comes from the device-side chain."""
 import json
 import os
 import socket
@@ -52,8 +52,14 @@ def test_dry_run_digest_does_not_depend_on_the_number_of_ranks(pkg):
 
 @pytest.mark.gpu
 def test_two_ranks_through_the_device_path(pkg):
-    args = ["--steps", "2", "--warmup", "1", "--repeats", "2", "--push-blocks", "8", "--nsamp", "200000", "--depth", "3", "--no-cpu"]
-    env = {"GPSBB_BENCH_BACKEND": "gloo", "GPSBB_DEVICE_SEED_ONLY": "1"}
+    """One rank and two ranks (sharing the one device, gloo) render the same stream: the second rank's shard starts from
+    the seed the device-side chain computes (gpsbb_chain_carrier over the first shard), and the digest of the
+    end-of-block states of all blocks, gathered over the ranks, is the 1-rank value; blocks read back from the HBM-only
+    ring equal the oracle's on every rank; the line carries the slowest rank's seed time, the seed-inclusive value and
+    the 2.6 MS/s and CPU legs at N = 2 as well."""
+    args = ["--steps", "2", "--warmup", "1", "--repeats", "2", "--push-blocks", "8", "--nsamp", "200000", "--depth", "3",
+            "--cpu-budget", "0.4", "--parity-blocks", "2"]
+    env = {"GPSBB_BENCH_BACKEND": "gloo"}
     one = _run(1, args, env)
     two = _run(2, args, env)
     for r, n in ((one, 1), (two, 2)):
@@ -61,4 +67,10 @@ def test_two_ranks_through_the_device_path(pkg):
         assert r["config"]["carrier_chain"] == "device" and r["config"]["synthesis_kernel"] == "k_synth_ev"
         assert r["value"] > 0 and r["roofline"]["frac"] > 0 and len(r["repeats"]["seconds"]) == 2
         assert len(r["gather"]["per_rank_GBps_to_host"]) == n
+        assert r["parity"]["mismatching_blocks"] == 0 and r["parity_checked_blocks"] == 3 * n
+        assert r["parity"]["blocks_digested"] == 2 * 8 * 8
+        assert r["shard_seed_s"] >= r["shard_seed"]["seconds_rank0"] and 0 < r["value_incl_seed"] <= r["value"]
+        assert r["m1"]["gpu"]["value"] > 0 and r["cpu_baseline"]["value"] > 0 and r["m1"]["cpu"]["value"] > 0
+    assert two["shard_seed"]["blocks_before_the_last_shard"] == 64
+    assert one["parity"]["stream_end_state_digest"] == two["parity"]["stream_end_state_digest"]
     assert one["config"]["global_samples_per_step"] == two["config"]["global_samples_per_step"]

@@ -23,18 +23,22 @@ def assert_state_equal(got, want, active):
         assert g.tobytes() == w.tobytes(), f
 
 
-@pytest.fixture(autouse=True, params=["k_seed+auto", "host+auto", "k_seed+per-sample", "host+per-sample"])
+@pytest.fixture(autouse=True, params=["k_seed+auto", "host+auto", "k_seed+per-sample", "host+per-sample",
+                                      "k_seed+auto+seqfix", "k_seed+per-sample+seqfix"])
 def seed_mode(pkg, synth, request):
-    """Every test below runs four ways.  The exact NCO pre-pass of a run is computed by k_seed on the device or,
-    for small batches, by host threads running the same code (by default the batch size decides); and the
-    synthesis kernel is chosen automatically (the breakpoint kernel k_synth_ev wherever it is eligible: sample
-    rates above ~16 MS/s) or forced to the per-sample kernel k_synth."""
-    where, kernel = request.param.split("+")
+    """Every test below runs six ways.  The exact NCO pre-pass of a run is computed by k_seed on the device or,
+    for small batches, by host threads running the same code (by default the batch size decides); the
+    synthesis kernel is chosen automatically (the model-based kernels k_synth_ev / k_synth_ev_dense wherever they are
+    eligible: sample rates above ~2 MS/s) or forced to the per-sample kernel k_synth; and the last step of the
+    device-side carrier chain takes the blocks in parallel (k_chain_fix_par, the default) or in order (k_chain_fix)."""
+    where, kernel = request.param.split("+")[:2]
     synth.set_option(pkg.OPT_SEED_WHERE, 1 if where == "k_seed" else 2)
     synth.set_option(pkg.OPT_SYNTH_KERNEL, 1 if kernel == "per-sample" else 0)
+    synth.set_option(pkg.OPT_CHAIN_WHERE, 2 if request.param.endswith("seqfix") else 0)
     yield
     synth.set_option(pkg.OPT_SEED_WHERE, 0)
     synth.set_option(pkg.OPT_SYNTH_KERNEL, 0)
+    synth.set_option(pkg.OPT_CHAIN_WHERE, 0)
 
 
 def test_native_library_is_what_runs(pkg, synth):
@@ -231,7 +235,7 @@ def test_carrier_chained_on_the_device(pkg, synth, oracle, request):
     synth.sync()
     iq, st = b.read()
     b.close()
-    where, kernel = request.node.callspec.params["seed_mode"].split("+")
+    where, kernel = request.node.callspec.params["seed_mode"].split("+")[:2]
     if where == "k_seed" and kernel == "auto":
         assert synth.info(pkg.INFO_LAST_KERNEL) == 2 and synth.info(pkg.INFO_CHAIN_ON_DEVICE) == 1
         # blocks the fix-up had to walk sequentially: at most those of the four special channels (often fewer:
@@ -299,7 +303,7 @@ def test_device_chain_through_wraps_that_tie(pkg, synth, oracle, request):
     synth.sync()
     iq, st = b.read()
     b.close()
-    where, kernel = request.node.callspec.params["seed_mode"].split("+")
+    where, kernel = request.node.callspec.params["seed_mode"].split("+")[:2]
     if where == "k_seed" and kernel == "auto":
         assert synth.info(pkg.INFO_CHAIN_ON_DEVICE) == 1
         # the first tie after a block's first wrap is recorded (later ones cannot matter): the case is really exercised,
@@ -388,7 +392,7 @@ def test_stream_carrier_carried_on_the_device(pkg, synth, oracle, request):
     ch["prn"][bps * 2:, 6] = 29            # re-allocated exactly at a push boundary
     ch["prn"][bps * 3 + 2:bps * 4 + 1, 11] = 0
     want_iq, want_st, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
-    where, kernel = request.node.callspec.params["seed_mode"].split("+")
+    where, kernel = request.node.callspec.params["seed_mode"].split("+")[:2]
     for flags in (pkg.CHAIN_CARRIER, pkg.CHAIN_CARRIER | pkg.STREAM_DEVICE_ONLY):
         st_ = synth.stream(nch, 1 / fs, nsamp, bps, depth=3, flags=flags)
         got, gst = [], []
@@ -681,12 +685,113 @@ def test_reference_geometry_runs_on_the_dense_model_kernel(pkg, synth, oracle, r
     synth.sync()
     iq, st = b.read()
     b.close()
-    where, kernel = request.node.callspec.params["seed_mode"].split("+")
+    where, kernel = request.node.callspec.params["seed_mode"].split("+")[:2]
     if kernel == "auto":
         assert synth.info(pkg.INFO_LAST_KERNEL) == 2
     for k in range(nb):
         assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
     assert (iq == want_iq).all()
+
+
+def _special_chain_descriptors(pkg, nb, nch, fs, seed):
+    """a chained batch with every kind of block the fix-up knows (see test_carrier_chained_on_the_device)"""
+    ch = pkg.synth_descriptors(nb, nch=nch, seed=seed)
+    rng = np.random.default_rng(seed)
+    f0 = rng.uniform(-5000, 5000, nch)
+    f0[0], f0[1], f0[2], f0[3] = 3.0, -40.0, 0.0, fs * 2.0 ** -14       # no wrap in a block / none ever / tie-prone step
+    ch["f_carr"] = f0[None, :] + rng.uniform(-0.5, 0.5, (nb, nch)) * (np.abs(f0[None, :]) > 100)
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    ch["prn"] = np.arange(1, nch + 1)[None, :]
+    ch["prn"][nb // 3:, 5] = 31
+    ch["prn"][nb // 2:nb // 2 + 3, 9] = 0
+    return ch
+
+
+def test_carrier_chain_alone_on_the_device(pkg, synth, request):
+    """gpsbb_chain_carrier: the exact carrier chain on the device with nothing rendered (what seeds a time shard) gives,
+    bit for bit, gpsbb_chain_carrier_host's sequential walk — start phase of every block and the phase after the last —
+    for special steps (no wrap, ties, idle and re-allocated channels), for the bench's own stream, and for more blocks
+    than one sub-batch of the device-side chain takes (the carry crosses sub-batches)."""
+    if not request.node.callspec.params["seed_mode"].startswith("k_seed+auto"):
+        pytest.skip("independent of the pre-pass mode")
+    sys.path.insert(0, ROOT)
+    import bench
+    cases = [(_special_chain_descriptors(pkg, 700, 16, 25e6, 17), 25e6, 120000),
+             (_special_chain_descriptors(pkg, 40, 12, 2.6e6, 18), 2.6e6, 300000),
+             (bench.stream_descriptors(pkg, 1500, 16), 25e6, 2500000),
+             (bench.stream_descriptors(pkg, 20000, 5, seed=0xC0FFEE), 25e6, 30000)]
+    k = np.array([1801439850948, 1801439850949, 3602879701896, 3602879701897, 901439850951, 1201439850950,
+                  2201439850947, 1501439850952], dtype=np.float64)
+    st = np.concatenate([k[:4] * 2.0 ** -53, k[4:] * 2.0 ** -52, -(2 * k[:4] + 1) * 2.0 ** -54, -k[4:] * 2.0 ** -53])
+    tie = pkg.synth_descriptors(600, nch=16, seed=99)
+    tie["f_carr"] = (st * 2.0 ** 25)[None, :]
+    cases.append((tie, 2.0 ** 25, 300000))
+    for ch, fs, nsamp in cases:
+        want = pkg.chain_carrier_host(ch, 1 / fs, nsamp)
+        got, end = synth.chain_carrier(ch, 1 / fs, nsamp)
+        assert got.tobytes() == want.tobytes(), (fs, nsamp, ch.shape)
+        # the phase after the last block = where one more block of the same channels would start
+        more = np.concatenate([ch, ch[-1:]])
+        want_end = pkg.chain_carrier_host(more, 1 / fs, nsamp)[-1]
+        assert end.tobytes() == np.where(ch["prn"][-1] > 0, want_end, 0.0).tobytes()
+        b0 = ch.shape[0] // 2 + 1
+        assert synth.shard_seed(ch, b0, 1 / fs, nsamp).tobytes() == np.where(ch["prn"][b0] > 0, want[b0], ch["carr_phase"][b0]).tobytes()
+    with pytest.raises(pkg.GpsbbError):
+        bad = cases[0][0][:4].copy()
+        bad["f_carr"][2, 1] = np.nan
+        synth.chain_carrier(bad, 1 / 25e6, 1000)
+
+
+def test_options_are_latched_when_a_batch_is_set_up(pkg, synth, oracle, request):
+    """A batch keeps the plan it was created with: flipping the handle's options between gpsbb_batch_create and
+    gpsbb_batch_run (where the pre-pass runs, where the chain is resolved, which kernel) changes nothing for it."""
+    nb, nch, fs, nsamp = 6, 8, 25e6, 60000
+    ch = pkg.synth_descriptors(nb, nch=nch, seed=31337)
+    ch["f_carr"] = np.linspace(-4000, 4000, nch)[None, :]
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    want_iq, want_st, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
+    b = synth.batch(ch, 1 / fs, nsamp, flags=pkg.CHAIN_CARRIER)
+    saved = []
+    try:
+        for opt, val in ((pkg.OPT_SEED_WHERE, 2), (pkg.OPT_SEED_WHERE, 1), (pkg.OPT_CHAIN_WHERE, 1), (pkg.OPT_SYNTH_KERNEL, 1)):
+            synth.set_option(opt, val)
+            b.run()
+            synth.sync()
+            iq, st = b.read()
+            assert (iq == want_iq).all(), (opt, val)
+            for k in range(nb):
+                assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
+    finally:
+        b.close()
+
+
+def test_stream_changes_sides_between_pushes(pkg, synth, oracle, request):
+    """A chained stream whose pushes are resolved now on the device, now on host threads (the handle's options change
+    between pushes): the carry moves across and the bytes stay the oracle's."""
+    nch, fs, nsamp, bps, npush = 8, 25e6, 50000, 4, 8
+    ch = pkg.synth_descriptors(bps * npush, nch=nch, seed=2024)
+    ch["f_carr"] = np.linspace(-4500, 4500, nch)[None, :] + np.linspace(0, 3, bps * npush)[:, None]
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    want_iq, want_st, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
+    st_ = synth.stream(nch, 1 / fs, nsamp, bps, depth=3, flags=pkg.CHAIN_CARRIER)
+    got, gst = [], []
+    plan = [(1, 0), (1, 0), (2, 0), (1, 2), (1, 1), (2, 0), (1, 0), (1, 2)]      # (OPT_SEED_WHERE, OPT_CHAIN_WHERE) per push
+    for k in range(npush):
+        if st_.pending == 3:
+            a, b = st_.pop()
+            got.append(a), gst.append(b)
+        synth.set_option(pkg.OPT_SEED_WHERE, plan[k][0])
+        synth.set_option(pkg.OPT_CHAIN_WHERE, plan[k][1])
+        st_.push(ch[k * bps:(k + 1) * bps])
+    while st_.pending:
+        a, b = st_.pop()
+        got.append(a), gst.append(b)
+    st_.close()
+    gst = np.concatenate(gst)
+    for k in range(bps * npush):
+        assert_state_equal(gst[k], want_st[k], ch["prn"][k] > 0)
+    assert (np.concatenate(got) == want_iq).all()
+
 
 
 def test_headline_stream_chain_against_the_host_chain(pkg):

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void k(double *out, double s, int n)
     const int raddr = (((threadIdx.x * 2654435761u) >> 8) & 1023) * 4; // random table lookups
     int x0 = threadIdx.x, x1 = blockIdx.x;
     for (int it = 0; it < n; it++) {
-        if (OP >= 19 && OP <= 23) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if ((OP >= 19 && OP <= 23) || OP == 71) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             if (OP == 0) a[i] = __dadd_rn(a[i], s);
@@ -60,6 +60,33 @@ __global__ __launch_bounds__(256) void k(double *out, double s, int n)
             if (OP == 43) { asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(b[i]) : "v"(b[(i + 1) & 7]) : "vcc"); }
             if (OP == 44) { asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7])); }
             if (OP == 45) { asm volatile("v_rndne_f64 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7])); }
+            if (OP == 46) { asm volatile("v_add_u32 %0, %1, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 47) { asm volatile("v_lshrrev_b32 %0, 27, %1" : "=v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 48) { asm volatile("v_bfe_u32 %0, %1, 27, 5" : "=v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 49) { asm volatile("v_min_u32 %0, %1, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 50) { asm volatile("v_min3_u32 %0, %1, %2, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7])); }
+            if (OP == 51) { asm volatile("v_add3_u32 %0, %1, %2, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7])); }
+            if (OP == 52) { asm volatile("v_xad_u32 %0, %1, %2, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7])); }
+            if (OP == 53) { asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7])); }
+            if (OP == 54) { float f = __int_as_float(b[i]); asm volatile("v_min3_f32 %0, |%1|, |%2|, %0" : "+v"(f) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7])); b[i] = __float_as_int(f); }
+            if (OP == 55) { asm volatile("v_alignbit_b32 %0, %1, %2, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7])); }
+            if (OP == 56) { asm volatile("v_perm_b32 %0, %1, %2, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7])); }
+            if (OP == 57) { asm volatile("v_and_b32 %0, 0x7fffff, %1" : "=v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 58) { asm volatile("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7])); }
+            if (OP == 59) { asm volatile("v_lshl_or_b32 %0, %1, 2, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 60) { asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(b[i]), "v"(b[(i + 1) & 7]) : "vcc"); }
+            if (OP == 61) { asm volatile("v_pk_min_u16 %0, %1, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 62) { asm volatile("v_mul_u32_u24 %0, %1, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 63) { asm volatile("v_or3_b32 %0, %1, %2, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7])); }
+            if (OP == 64) { asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 65) { asm volatile("v_add_co_u32 %0, vcc, %1, %0\n\tv_addc_co_u32 %2, vcc, %3, %2, vcc" : "+v"(b[i]), "+v"(b[(i + 4) & 7]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7]) : "vcc"); }
+            if (OP == 66) { asm volatile("v_add_f32 %0, %1, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 67) { asm volatile("v_min_f32 %0, |%1|, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 68) { asm volatile("v_bfe_u32 %0, %1, %2, 1" : "=v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7])); }
+            if (OP == 69) { asm volatile("v_lshl_add_u32 %0, %1, 11, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 70) { asm volatile("v_pk_add_u16 %0, %1, %0 op_sel_hi:[1,1]" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 71) { asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(b[i]) : "v"(raddr), "n"(i * 4)); }
+            if (OP == 72) { asm volatile("v_sad_u32 %0, %1, %2, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7])); }
             if (OP == 17) { scratch[(threadIdx.x & 63) * 17 + ((b[i] + it) & 15) + (threadIdx.x >> 6) * 1088] = (unsigned)i; }
             if (OP == 18) { b[i] += scratch[(threadIdx.x & 63) * 17 + ((b[(i+1)&7] + it) & 15) + (threadIdx.x >> 6) * 1088]; }
         }
@@ -134,5 +161,32 @@ int main()
     run<43>("v_cndmask_b32", 1);
     run<38>("v_sub_u32", 1);
     run<42>("v_and_or_b32", 1);
+    run<46>("v_add_u32", 1);
+    run<47>("v_lshrrev_b32 imm", 1);
+    run<64>("v_lshrrev_b32 vgpr shift", 1);
+    run<48>("v_bfe_u32 imm", 1);
+    run<68>("v_bfe_u32 vgpr offset", 1);
+    run<49>("v_min_u32", 1);
+    run<50>("v_min3_u32", 1);
+    run<51>("v_add3_u32", 1);
+    run<52>("v_xad_u32", 1);
+    run<53>("v_pk_add_f32", 1);
+    run<54>("v_min3_f32 |abs|", 1);
+    run<66>("v_add_f32", 1);
+    run<67>("v_min_f32 |abs| (VOP3)", 1);
+    run<55>("v_alignbit_b32", 1);
+    run<56>("v_perm_b32", 1);
+    run<57>("v_and_b32 literal", 1);
+    run<58>("v_mad_u32_u24", 1);
+    run<59>("v_lshl_or_b32", 1);
+    run<69>("v_lshl_add_u32 imm11", 1);
+    run<60>("v_cmp_lt_u32", 1);
+    run<61>("v_pk_min_u16", 1);
+    run<70>("v_pk_add_u16", 1);
+    run<62>("v_mul_u32_u24", 1);
+    run<63>("v_or3_b32", 1);
+    run<72>("v_sad_u32", 1);
+    run<65>("v_add_co + v_addc_co (64-bit add)", 2);
+    run<71>("ds_read_u16 (random)", 1);
     return 0;
 }

@@ -37,7 +37,7 @@ CHAIN_CARRIER = 1
 FIXED_CARRIER = 2
 STREAM_DEVICE_ONLY = 4
 OPT_SEED_WHERE, OPT_SYNTH_KERNEL, OPT_SKIP_SEED, OPT_CHAIN_WHERE = 1, 2, 3, 4
-INFO_LAST_KERNEL, INFO_EXACT_RUNS, INFO_CHAIN_ON_DEVICE, INFO_CHAIN_FALLBACKS, INFO_CHAIN_TIES = 1, 2, 3, 4, 5
+INFO_LAST_KERNEL, INFO_EXACT_RUNS, INFO_CHAIN_ON_DEVICE, INFO_CHAIN_FALLBACKS, INFO_CHAIN_TIES, INFO_CHAIN_REPAIRS = 1, 2, 3, 4, 5, 6
 
 ERRORS = {0: "GPSBB_OK", -1: "GPSBB_E_BADARG", -2: "GPSBB_E_BADCHAN", -3: "GPSBB_E_HIP", -4: "GPSBB_E_NOMEM",
           -5: "GPSBB_E_INTERNAL", -6: "GPSBB_E_NODEVICE", -7: "GPSBB_E_STATE"}

@@ -264,6 +264,8 @@ struct WorkPool {
 };
 
 constexpr int SEED_STREAMS_MAX = 8;
+constexpr int CHAIN_SEG_TILES = 600; /* tiles per segment of the device-side chain, about (see batch_setup) */
+constexpr int CHAIN_SEG_MAX = 8;     /* segments per block at most */
 constexpr unsigned STREAM_SEED_STREAMS = 6; /* pre-passes of a stream's pushes in flight (GPSBB_STREAM_SEED_STREAMS) */
 
 struct gpsbb {
@@ -391,6 +393,10 @@ struct gpsbb_batch {
     DevBuf<double> d_start0;     /* rough start phases: where pass A walks from */
     std::vector<ChainDesc> h_cd;
     std::vector<double> h_start0;
+    int nseg = 1, seg_tiles = 0; /* the device-side chain cuts every block into nseg segments (BatchDev::nseg) */
+    DevBuf<unsigned long long> d_fix_end; /* k_chain_fix_par: the hand-off between its chunks (BatchDev::fix_end) */
+    DevBuf<int> d_fix_flag;
+    int fix_epoch = 0, fix_chunks = 0;
     bool chain_fix_seq = false;  /* k_chain_fix (blocks in order) instead of k_chain_fix_par: GPSBB_OPT_CHAIN_WHERE 2 */
     bool host_seed = false;      /* the NCO tables of this batch are built on host threads: decided at set-up, like the
                                     chain (a run never re-reads the handle's options) */
@@ -496,10 +502,11 @@ extern "C" int gpsbb_get_info(gpsbb_t *h, int what, uint64_t *out)
         return GPSBB_OK;
     case GPSBB_INFO_EXACT_RUNS:
     case GPSBB_INFO_CHAIN_FALLBACKS:
-    case GPSBB_INFO_CHAIN_TIES: {
+    case GPSBB_INFO_CHAIN_TIES:
+    case GPSBB_INFO_CHAIN_REPAIRS: {
         HIPCHK(h, hipSetDevice(h->device));
         unsigned long long v = 0;
-        HIPCHK(h, hipMemcpy(&v, h->d_hz + (what == GPSBB_INFO_EXACT_RUNS ? 2 : (what == GPSBB_INFO_CHAIN_FALLBACKS ? 4 : 5)), 8,
+        HIPCHK(h, hipMemcpy(&v, h->d_hz + (what == GPSBB_INFO_EXACT_RUNS ? 2 : (what == GPSBB_INFO_CHAIN_FALLBACKS ? 4 : (what == GPSBB_INFO_CHAIN_TIES ? 5 : 6))), 8,
                             hipMemcpyDeviceToHost));
         *out = v;
         return GPSBB_OK;
@@ -716,8 +723,8 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
 
     {
         /* everything a set-up uploads, with room to spare: descriptors, plans, per-channel constants, chain scratch */
-        const size_t need = nbc * (sizeof(gpsbb_chan_t) + sizeof(EvConst) + sizeof(ChainDesc) + 8 + 2 * 8 + 2 * 4 + 5 * 4) +
-                            64 * 1024;
+        const size_t need = nbc * (sizeof(gpsbb_chan_t) + sizeof(EvConst) + 8 + 2 * 4 + 5 * 4 +
+                                   (size_t)CHAIN_SEG_MAX * (sizeof(ChainDesc) + 8 + 8 + 2 * 4)) + 64 * 1024;
         if (b->upload_done) /* the previous set-up's copies out of the arena are long done; make sure */
             HIPCHK(h, hipEventSynchronize(b->upload_done));
         PUSH_MARK("arena");
@@ -749,28 +756,73 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
             b->ev_dense = b->h_evc[k].kc == EV_KC_DENSE;
     PUSH_MARK("ev_plan");
 
-    /* row pool plan: chain id = kind*nbc + block*nch + channel */
-    b->row_off.assign(2 * nbc + 1, 0);
+    /* where the pre-pass runs and where the carrier chain is resolved: decided here, once, for all runs of the batch */
+    b->host_seed = host_seeding_wanted(b);
+    b->chain_dev = !fixed && (flags & GPSBB_CHAIN_CARRIER) && (nblocks > 1 || b->d_carry) && h->opt_chain_where != 1 &&
+                   !b->host_seed;
+    b->chain_fix_seq = h->opt_chain_where == 2;
+    b->chain_starts = b->chain_dev && !b->ev;
+    /* The device-side chain cuts blocks into segments of about CHAIN_SEG_TILES tiles that are chained like blocks: a
+     * walk takes as long as its chain whatever the batch (0.47 us per row: a 5 kHz carrier has 7 000 rows in a
+     * 2.5 M-sample block), so four segments per block make the two walks of a pre-pass four times shorter. */
+    b->nseg = 1;
+    if (b->chain_dev && !b->chain_starts) { /* (k_seed, the per-sample kernel's pre-pass, walks whole blocks) */
+        int n = (b->ntiles + CHAIN_SEG_TILES / 2) / CHAIN_SEG_TILES;
+        b->nseg = n < 1 ? 1 : (n > CHAIN_SEG_MAX ? CHAIN_SEG_MAX : n);
+    }
+    b->seg_tiles = (b->ntiles + b->nseg - 1) / b->nseg;
+    b->nseg = (b->ntiles + b->seg_tiles - 1) / b->seg_tiles; /* no empty last segment */
+    const size_t nvbc = nbc * (size_t)b->nseg; /* carrier chains: one per (segment, channel) */
+
+    /* row pool plan: the code chains (block*nch + channel), then the carrier chains ((block*nseg + segment)*nch + channel) */
+    b->row_off.assign(nbc + nvbc + 1, 0);
     uint64_t off = 0;
-    for (int kind = 0; kind < 2; kind++)
-        for (size_t k = 0; k < nbc; k++) {
-            b->row_off[kind * nbc + k] = off;
-            if (ch[k].prn > 0 && !(kind == 1 && fixed)) {
-                const double s = kind == 0 ? ch[k].f_code * delt : std::fabs(ch[k].f_carr * delt);
-                off += (kind == 0 ? row_bound(s, 1023.0, 9, nsamp) : row_bound(s, 1.0, -1, nsamp)) + 1;
-                if (b->ev)
-                    off += (uint64_t)nsamp / (uint64_t)WALK_ROW_MAX + 1; /* k_walk cuts long rows */
-            } else {
-                off += 1;
-            }
+    for (size_t k = 0; k < nbc; k++) {
+        b->row_off[k] = off;
+        if (ch[k].prn > 0) {
+            off += row_bound(ch[k].f_code * delt, 1023.0, 9, nsamp) + 1;
+            if (b->ev)
+                off += (uint64_t)nsamp / (uint64_t)WALK_ROW_MAX + 1; /* k_walk cuts long rows */
+        } else {
+            off += 1;
         }
-    b->row_off[2 * nbc] = off;
+    }
+    {
+        /* a segment's bound depends on the block-channel's step and the segment's length only: one evaluation per
+         * block-channel for the full segments, one for the (shorter) last */
+        const int full = b->seg_tiles * TILE, last = nsamp - (b->nseg - 1) * full;
+        const int ns_full = b->nseg == 1 ? nsamp : full, ns_last = b->nseg == 1 ? nsamp : last;
+        for (int blk = 0; blk < nblocks; blk++)
+            for (int sgi = 0; sgi < b->nseg; sgi++) {
+                uint64_t *ro = &b->row_off[nbc + ((size_t)blk * b->nseg + sgi) * nch];
+                const int ns = sgi == b->nseg - 1 ? ns_last : ns_full;
+                for (int i = 0; i < nch; i++) {
+                    const gpsbb_chan_t &c = ch[(size_t)blk * nch + i];
+                    ro[i] = 0; /* count first, offsets below */
+                    if (c.prn > 0 && !fixed) {
+                        if (sgi == 0 || sgi == b->nseg - 1)
+                            ro[i] = row_bound(std::fabs(c.f_carr * delt), 1.0, -1, ns) + 1 + (b->ev ? (uint64_t)ns / (uint64_t)WALK_ROW_MAX + 1 : 0);
+                        else
+                            ro[i] = b->row_off[nbc + ((size_t)blk * b->nseg) * nch + i]; /* as the block's first segment */
+                    } else {
+                        ro[i] = 1;
+                    }
+                }
+            }
+        /* (the first segments' entries are read above while later ones are filled: turn counts into offsets afterwards) */
+        for (size_t kv = 0; kv < nvbc; kv++) {
+            const uint64_t cnt = b->row_off[nbc + kv];
+            b->row_off[nbc + kv] = off;
+            off += cnt;
+        }
+    }
+    b->row_off[nbc + nvbc] = off;
     b->total_rows = off;
 
     /* device scratch of both table sets, sized here so that a launch never allocates (growing frees, and
      * a free synchronises the device) */
     HIPCHK(h, (hipError_t)b->d_ch.reserve(nbc));
-    HIPCHK(h, (hipError_t)b->d_row_off.reserve(2 * nbc + 1));
+    HIPCHK(h, (hipError_t)b->d_row_off.reserve(nbc + nvbc + 1));
     HIPCHK(h, (hipError_t)b->d_tile_ctr.reserve((size_t)NSETS * (size_t)nblocks)); /* one set of counters per table set */
     /* table sets = pre-passes in flight + 1: the pre-pass of either kernel takes longer than the synthesis it feeds
      * (M1 geometry, per-sample kernel: two sets 6.6e10, three 7.7e10 samples/s), the chained ones longer still */
@@ -783,7 +835,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
             HIPCHK(h, (hipError_t)b->d_tile_x[set].reserve(2 * nbc * (size_t)b->ntiles));
             HIPCHK(h, (hipError_t)b->d_tile_nav[set].reserve(nbc * (size_t)b->ntiles));
             HIPCHK(h, (hipError_t)b->d_rows[set].reserve(b->total_rows + 4, b->max_sets == 1 ? (size_t)(b->total_rows / 2) : 0));
-            HIPCHK(h, (hipError_t)b->d_row_cnt[set].reserve(2 * nbc));
+            HIPCHK(h, (hipError_t)b->d_row_cnt[set].reserve(nbc + nvbc));
         } else {
             HIPCHK(h, (hipError_t)b->d_rows[set].reserve(b->total_rows + 4)); /* + slack: k_synth prefetches one row past a chain */
             HIPCHK(h, (hipError_t)b->d_tile_row[set].reserve(2 * nbc * ((size_t)b->ntiles + 1)));
@@ -823,41 +875,40 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         HIPCHK(h, stage_upload(b, b->d_kstep.p, b->h_kstep.data(), nbc * 4, upload_stream));
     }
     b->h_ch.assign(ch, ch + nbc);
-    b->host_seed = host_seeding_wanted(b);
-    b->chain_dev = !fixed && (flags & GPSBB_CHAIN_CARRIER) && (nblocks > 1 || b->d_carry) && h->opt_chain_where != 1 &&
-                   !b->host_seed;
-    b->chain_fix_seq = h->opt_chain_where == 2;
-    b->chain_starts = b->chain_dev && !b->ev;
     b->cont0_mask = 0;
     if (b->chain_dev) {
         /* The carrier chain is resolved exactly on the device, in parallel over the blocks (k_walk pass A,
          * k_chain_prefix, k_walk pass B, k_chain_fix).  All the host contributes is a rough start phase per block:
          * the descriptor's phase carried forward by nsamp*step in plain double arithmetic (good to ~1e-7 cycles
          * after a few hundred blocks; pass A takes it from there). */
-        b->h_cd.resize(nbc);
-        b->h_start0.resize(nbc);
+        b->h_cd.resize(nvbc);
+        b->h_start0.resize(nvbc);
         for (int i = 0; i < nch; i++) {
             double x = b->d_carry && b->carry_phase ? b->carry_phase[i] : 0.0;
             int prev_prn = b->d_carry && b->carry_prn ? b->carry_prn[i] : 0;
             for (int blk = 0; blk < nblocks; blk++) {
                 const gpsbb_chan_t &c = ch[(size_t)blk * nch + i];
-                ChainDesc &cd = b->h_cd[(size_t)blk * nch + i];
-                cd.f_carr = c.f_carr;
-                cd.carr_phase = c.carr_phase;
-                cd.prn = c.prn;
-                cd._pad = 0;
-                double start0 = 0.0;
+                const volatile double sk = c.f_carr * delt;
                 if (c.prn > 0) {
                     if (c.prn != prev_prn)
                         x = c.carr_phase;
                     else if (blk == 0)
                         b->cont0_mask |= 1u << i;
-                    start0 = x;
-                    const volatile double sk = c.f_carr * delt;
-                    x = x + (double)nsamp * sk;
-                    x -= std::floor(x);
                 }
-                b->h_start0[(size_t)blk * nch + i] = start0;
+                for (int sgi = 0; sgi < b->nseg; sgi++) {
+                    const size_t kv = ((size_t)blk * b->nseg + sgi) * nch + i;
+                    ChainDesc &cd = b->h_cd[kv];
+                    cd.f_carr = c.f_carr;
+                    cd.carr_phase = c.carr_phase; /* read for a block's first segment only (one that starts a chain) */
+                    cd.prn = c.prn;
+                    cd._pad = 0;
+                    b->h_start0[kv] = c.prn > 0 ? x : 0.0;
+                    if (c.prn > 0) {
+                        const int left = nsamp - sgi * b->seg_tiles * TILE, full = b->seg_tiles * TILE;
+                        x = x + (double)(b->nseg == 1 ? nsamp : (left < full ? left : full)) * sk;
+                        x -= std::floor(x);
+                    }
+                }
                 prev_prn = c.prn > 0 ? c.prn : 0;
             }
             if (b->d_carry && b->carry_phase)
@@ -865,14 +916,26 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         }
         /* the chain's scratch (ChainAux) needs no initial image: every field is written by the pass that owns it */
         for (int set = 0; set < b->nsets; set++) {
-            HIPCHK(h, (hipError_t)b->d_aux[set].reserve(nbc));
+            HIPCHK(h, (hipError_t)b->d_aux[set].reserve(nvbc));
             if (!b->chain_starts)
-                HIPCHK(h, (hipError_t)b->d_prefix[set].reserve(nbc * (size_t)CHAIN_PREFIX_CAP));
+                HIPCHK(h, (hipError_t)b->d_prefix[set].reserve(nvbc * (size_t)CHAIN_PREFIX_CAP));
         }
-        HIPCHK(h, (hipError_t)b->d_cd.reserve(nbc));
-        HIPCHK(h, (hipError_t)b->d_start0.reserve(nbc));
-        HIPCHK(h, stage_upload(b, b->d_cd.p, b->h_cd.data(), nbc * sizeof(ChainDesc), upload_stream));
-        HIPCHK(h, stage_upload(b, b->d_start0.p, b->h_start0.data(), nbc * sizeof(double), upload_stream));
+        HIPCHK(h, (hipError_t)b->d_cd.reserve(nvbc));
+        HIPCHK(h, (hipError_t)b->d_start0.reserve(nvbc));
+        {
+            /* flags are compared with a launch number, never cleared: zeroed once, when the buffer is (re)allocated */
+            b->fix_chunks = (nblocks * b->nseg + FIXP_WG_BATCH - 1) / FIXP_WG_BATCH;
+            /* one set of flags per table set: runs of a resident batch overlap, each on its own table set */
+            const size_t nf = (size_t)NSETS * GPSBB_MAX_CHAN * b->fix_chunks;
+            if (nf > b->d_fix_flag.cap) {
+                HIPCHK(h, (hipError_t)b->d_fix_flag.reserve(nf));
+                HIPCHK(h, (hipError_t)b->d_fix_end.reserve(b->d_fix_flag.cap));
+                HIPCHK(h, hipMemsetAsync(b->d_fix_flag.p, 0, b->d_fix_flag.cap * sizeof(int), upload_stream));
+                b->fix_epoch = 0;
+            }
+        }
+        HIPCHK(h, stage_upload(b, b->d_cd.p, b->h_cd.data(), nvbc * sizeof(ChainDesc), upload_stream));
+        HIPCHK(h, stage_upload(b, b->d_start0.p, b->h_start0.data(), nvbc * sizeof(double), upload_stream));
     }
     if ((flags & GPSBB_CHAIN_CARRIER) && !fixed && nblocks > 1 && !b->chain_dev) {
         /* blocks consecutive in time: resolve the carrier phase at the start of every block here, exactly
@@ -887,7 +950,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     PUSH_MARK("aux");
     HIPCHK(h, stage_upload(b, b->d_ch.p, b->h_ch.data(), nbc * sizeof(gpsbb_chan_t), upload_stream));
     PUSH_MARK("up_ch");
-    HIPCHK(h, stage_upload(b, b->d_row_off.p, b->row_off.data(), (2 * nbc + 1) * 8, upload_stream));
+    HIPCHK(h, stage_upload(b, b->d_row_off.p, b->row_off.data(), (nbc + nvbc + 1) * 8, upload_stream));
     {
         /* which chain each lane of k_seed walks (BatchDev::seed_order).  k_seed takes as long as its slowest
          * wavefront: rows of its longest chain x the time of one turn of the loop, which grows with the
@@ -895,18 +958,41 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
          * 6.3 ms in block order, 6.1 ms with the carrier chains by descending |f_carr|, 5.3 ms with the
          * longest of them in wavefronts of few lanes.  (16 chains per wavefront throughout does not help
          * small batches: 16-block ring slots 6.0e9 vs 6.6e9 samples/s.) */
-        std::vector<int32_t> carr(nbc);
-        for (size_t k = 0; k < nbc; k++)
-            carr[k] = (int32_t)k;
+        /* carrier chains: one per (segment, channel), kv = (block*nseg + segment)*nch + channel (nseg = 1: per block) */
+        const size_t nvbc = nbc * (size_t)b->nseg;
+        const int nseg = b->nseg;
+        std::vector<int32_t> carr(nvbc);
         const gpsbb_chan_t *hc = b->h_ch.data();
         const bool by_sign = b->ev; /* k_walk runs the two directions in separate loops: keep them in separate wavefronts */
-        std::sort(carr.begin(), carr.end(), [hc, by_sign](int32_t x, int32_t y) {
-            const double fx = hc[x].prn > 0 ? std::fabs(hc[x].f_carr) : -1.0, fy = hc[y].prn > 0 ? std::fabs(hc[y].f_carr) : -1.0;
-            const bool nx = by_sign && hc[x].prn > 0 && std::signbit(hc[x].f_carr), ny = by_sign && hc[y].prn > 0 && std::signbit(hc[y].f_carr);
-            if (nx != ny)
-                return ny;
-            return fx > fy || (fx == fy && x < y);
-        });
+        {
+            /* By direction (rising first), then by descending |f_carr| — a wavefront runs as long as its longest chain —
+             * in CARR_BUCKETS classes of |f_carr| (a counting sort: the plan of a 400-block push with four segments per
+             * block orders 25 600 chains, and a comparison sort of them cost more than everything else in the push). */
+            constexpr int CARR_BUCKETS = 512;
+            double fmax = 0.0;
+            for (size_t k = 0; k < nbc; k++)
+                if (hc[k].prn > 0 && std::fabs(hc[k].f_carr) > fmax)
+                    fmax = std::fabs(hc[k].f_carr);
+            const double scale = fmax > 0.0 ? (CARR_BUCKETS - 1) / fmax : 0.0;
+            std::vector<uint16_t> key(nbc);
+            std::vector<uint32_t> head(2 * CARR_BUCKETS + 2, 0u);
+            for (size_t k = 0; k < nbc; k++) {
+                unsigned kk;
+                if (hc[k].prn <= 0) {
+                    kk = 2 * CARR_BUCKETS; /* idle channels last */
+                } else {
+                    const unsigned q = (unsigned)(CARR_BUCKETS - 1) - (unsigned)(std::fabs(hc[k].f_carr) * scale);
+                    kk = (by_sign && std::signbit(hc[k].f_carr) ? CARR_BUCKETS : 0) + (q < (unsigned)CARR_BUCKETS ? q : CARR_BUCKETS - 1);
+                }
+                key[k] = (uint16_t)kk;
+                head[kk + 1] += (uint32_t)nseg;
+            }
+            for (size_t j = 1; j < head.size(); j++)
+                head[j] += head[j - 1];
+            for (size_t vb = 0; vb < (size_t)nblocks * nseg; vb++)
+                for (int i = 0; i < nch; i++)
+                    carr[head[key[(vb / nseg) * nch + i]]++] = (int32_t)(vb * nch + i);
+        }
         std::vector<int32_t> &order = b->h_seed_order;
         order.clear();
         auto waves_of = [&](const int32_t *chains, size_t n, size_t per_wave, int32_t add) {
@@ -922,7 +1008,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
              * lanes take part, so wavefronts are full, the carrier chains by descending |f_carr| (a wavefront runs
              * as long as its longest chain) and the longest ones first */
             static const size_t lanes_per_wave = getenv("GPSBB_WALK_LANES") ? (size_t)atol(getenv("GPSBB_WALK_LANES")) : 64;
-            waves_of(carr.data(), nbc, lanes_per_wave, (int32_t)nbc);
+            waves_of(carr.data(), nvbc, lanes_per_wave, (int32_t)nbc);
             b->carr_lanes = (int)order.size();
             waves_of(code.data(), nbc, 64, 0);
         } else {
@@ -938,13 +1024,11 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         PUSH_MARK("order");
         HIPCHK(h, stage_upload(b, b->d_seed_order.p, order.data(), order.size() * 4, upload_stream));
         if (b->chain_starts) {
-            /* the chain's two walks take the carrier chains alone, in lockstep: by direction, then by |f_carr| */
-            std::sort(carr.begin(), carr.end(), [hc](int32_t x, int32_t y) {
-                const double fx = hc[x].prn > 0 ? std::fabs(hc[x].f_carr) : -1.0, fy = hc[y].prn > 0 ? std::fabs(hc[y].f_carr) : -1.0;
+            /* the chain's two walks take the carrier chains alone, in lockstep: by direction, then by |f_carr| (nseg = 1
+             * here: chains are blocks) */
+            std::stable_sort(carr.begin(), carr.end(), [hc](int32_t x, int32_t y) {
                 const bool nx = hc[x].prn > 0 && std::signbit(hc[x].f_carr), ny = hc[y].prn > 0 && std::signbit(hc[y].f_carr);
-                if (nx != ny)
-                    return ny;
-                return fx > fy || (fx == fy && x < y);
+                return nx != ny && ny;
             });
             std::vector<int32_t> co;
             for (size_t c = 0; c < nbc; c += 64)
@@ -1024,6 +1108,8 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         b->d_aux[k].release();
         b->d_cd.release();
         b->d_start0.release();
+        b->d_fix_end.release();
+        b->d_fix_flag.release();
         b->d_prefix[k].release();
         b->d_chain_order.release();
         b->d_evc.release();
@@ -1357,6 +1443,13 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.chain_dev = b->chain_dev ? 1 : 0;
     p.chain_starts = b->chain_starts ? 1 : 0;
     p.aux = b->chain_dev ? b->d_aux[set].p : nullptr;
+    p.nseg = b->nseg;
+    p.seg_tiles = b->seg_tiles;
+    p.nvb = b->nblocks * b->nseg;
+    p.fix_end = b->d_fix_end.p ? b->d_fix_end.p + (size_t)set * GPSBB_MAX_CHAN * b->fix_chunks : nullptr;
+    p.fix_flag = b->d_fix_flag.p ? b->d_fix_flag.p + (size_t)set * GPSBB_MAX_CHAN * b->fix_chunks : nullptr;
+    p.fix_epoch = b->fix_epoch;
+    p.fix_chunks = b->fix_chunks;
     p.cd = b->chain_dev ? b->d_cd.p : nullptr;
     p.start0 = b->chain_dev ? b->d_start0.p : nullptr;
     p.prefix_rows = b->chain_dev && !b->chain_starts ? b->d_prefix[set].p : nullptr;
@@ -1369,6 +1462,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
 {
     gpsbb *h = b->h;
     const int set = (int)(b->run_count % (unsigned)b->nsets);
+    b->fix_epoch++; /* a number no earlier launch of this batch handed to k_chain_fix_par */
     const BatchDev p = batch_dev(b, set);
     const int lanes = (int)b->h_seed_order.size();
     if (b->ev_used == b->evs.size()) {
@@ -1428,7 +1522,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
                 /* a stream: this push's prefix / fix-up follow the ones of the push before (other seeding stream) */
                 if (b->d_carry && b->ev_prefix)
                     HIPCHK(h, hipStreamWaitEvent(ss, b->ev_prefix, 0));
-                hipLaunchKernelGGL(k_chain_prefix, dim3(b->nch), dim3(64), 0, ss, p);
+                hipLaunchKernelGGL(k_chain_prefix, dim3(b->nch), dim3(PREFIX_WG), 0, ss, p);
                 if (b->d_carry && b->ev_prefix)
                     HIPCHK(h, hipEventRecord(b->ev_prefix, ss));
                 hipLaunchKernelGGL(k_walk<2>, wg_all, dim3(GPSBB_WALK_WG), 0, ss, p);
@@ -1437,13 +1531,13 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
                 if (b->chain_fix_seq)
                     hipLaunchKernelGGL(k_chain_fix, dim3(1), dim3(64), 0, ss, p);
                 else
-                    hipLaunchKernelGGL(k_chain_fix_par, dim3(b->nch), dim3(FIXP_WG), 0, ss, p);
+                    hipLaunchKernelGGL(k_chain_fix_par<FIXP_WG_BATCH>, dim3(b->nch, b->fix_chunks), dim3(FIXP_WG_BATCH), 0, ss, p);
                 if (b->d_carry && b->ev_fix)
                     HIPCHK(h, hipEventRecord(b->ev_fix, ss));
             } else {
                 hipLaunchKernelGGL(k_walk<0>, wg_all, dim3(GPSBB_WALK_WG), 0, ss, p);
             }
-            hipLaunchKernelGGL(k_tiles, dim3(2 * b->nblocks * b->nch), dim3(GPSBB_TILES_WG), 0, ss, p);
+            hipLaunchKernelGGL(k_tiles, dim3((1 + b->nseg) * b->nblocks * b->nch), dim3(GPSBB_TILES_WG), 0, ss, p);
             ctr_reset_by_prepass = true; /* k_tiles zeroes the set's tile counters */
         }
     } else {
@@ -1457,7 +1551,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
             hipLaunchKernelGGL(k_walk<1>, wg_c, dim3(GPSBB_WALK_WG), 0, ss, pc);
             if (b->d_carry && b->ev_prefix)
                 HIPCHK(h, hipStreamWaitEvent(ss, b->ev_prefix, 0));
-            hipLaunchKernelGGL(k_chain_prefix, dim3(b->nch), dim3(64), 0, ss, pc);
+            hipLaunchKernelGGL(k_chain_prefix, dim3(b->nch), dim3(PREFIX_WG), 0, ss, pc);
             if (b->d_carry && b->ev_prefix)
                 HIPCHK(h, hipEventRecord(b->ev_prefix, ss));
             hipLaunchKernelGGL(k_walk<3>, wg_c, dim3(GPSBB_WALK_WG), 0, ss, pc);
@@ -1466,7 +1560,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
             if (b->chain_fix_seq)
                 hipLaunchKernelGGL(k_chain_fix, dim3(1), dim3(64), 0, ss, pc);
             else
-                hipLaunchKernelGGL(k_chain_fix_par, dim3(b->nch), dim3(FIXP_WG), 0, ss, pc);
+                hipLaunchKernelGGL(k_chain_fix_par<FIXP_WG_BATCH>, dim3(b->nch, b->fix_chunks), dim3(FIXP_WG_BATCH), 0, ss, pc);
             if (b->d_carry && b->ev_fix)
                 HIPCHK(h, hipEventRecord(b->ev_fix, ss));
         }
@@ -2172,6 +2266,9 @@ struct ChainOnly {
     DevBuf<double> d_start0;
     DevBuf<ChainAux> d_aux;
     ChainCarryDev *d_carry = nullptr;
+    DevBuf<unsigned long long> d_fix_end;
+    DevBuf<int> d_fix_flag;
+    int fix_epoch = 0;
     std::vector<ChainDesc> h_cd;
     std::vector<double> h_start0;
 };
@@ -2185,6 +2282,8 @@ static void chain_only_free(gpsbb *h)
     c->d_cd.release();
     c->d_start0.release();
     c->d_aux.release();
+    c->d_fix_end.release();
+    c->d_fix_flag.release();
     if (c->d_carry)
         (void)hipFree(c->d_carry);
     delete c;
@@ -2268,6 +2367,16 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
         HIPCHK(h, (hipError_t)c->d_cd.reserve(nbc));
         HIPCHK(h, (hipError_t)c->d_start0.reserve(nbc));
         HIPCHK(h, (hipError_t)c->d_aux.reserve(nbc));
+        const int fix_chunks = (nb + FIXP_WG_ALONE - 1) / FIXP_WG_ALONE;
+        {
+            const size_t nf = (size_t)GPSBB_MAX_CHAN * ((CHAIN_ONLY_BLOCKS + FIXP_WG_ALONE - 1) / FIXP_WG_ALONE);
+            if (nf > c->d_fix_flag.cap) {
+                HIPCHK(h, (hipError_t)c->d_fix_flag.reserve(nf));
+                HIPCHK(h, (hipError_t)c->d_fix_end.reserve(c->d_fix_flag.cap));
+                HIPCHK(h, hipMemsetAsync(c->d_fix_flag.p, 0, c->d_fix_flag.cap * sizeof(int), ss));
+                c->fix_epoch = 0;
+            }
+        }
         HIPCHK(h, hipMemcpyAsync(c->d_cd.p, c->h_cd.data() + k0, nbc * sizeof(ChainDesc), hipMemcpyHostToDevice, ss));
         HIPCHK(h, hipMemcpyAsync(c->d_start0.p, c->h_start0.data() + k0, nbc * sizeof(double), hipMemcpyHostToDevice, ss));
         BatchDev p;
@@ -2282,10 +2391,17 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
         p.hazards = h->d_hz;
         p.chain_dev = 1;
         p.chain_starts = 1;
+        p.nseg = 1;
+        p.seg_tiles = p.ntiles;
+        p.nvb = nb;
         p.aux = c->d_aux.p;
         p.cd = c->d_cd.p;
         p.start0 = c->d_start0.p;
         p.carry = c->d_carry;
+        p.fix_end = c->d_fix_end.p;
+        p.fix_flag = c->d_fix_flag.p;
+        p.fix_epoch = ++c->fix_epoch;
+        p.fix_chunks = fix_chunks;
         p.cont0_mask = 0;
         if (b0 > 0)
             for (int i = 0; i < nch; i++) {
@@ -2297,9 +2413,9 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
         p.seed_lanes = nch * ((nb + 63) & ~63);
         const dim3 wg((p.seed_lanes + GPSBB_WALK_WG - 1) / GPSBB_WALK_WG);
         hipLaunchKernelGGL(k_walk<1>, wg, dim3(GPSBB_WALK_WG), 0, ss, p);
-        hipLaunchKernelGGL(k_chain_prefix, dim3(nch), dim3(64), 0, ss, p);
+        hipLaunchKernelGGL(k_chain_prefix, dim3(nch), dim3(PREFIX_WG), 0, ss, p);
         hipLaunchKernelGGL(k_walk<3>, wg, dim3(GPSBB_WALK_WG), 0, ss, p);
-        hipLaunchKernelGGL(k_chain_fix_par, dim3(nch), dim3(FIXP_WG), 0, ss, p);
+        hipLaunchKernelGGL(k_chain_fix_par<FIXP_WG_ALONE>, dim3(nch, fix_chunks), dim3(FIXP_WG_ALONE), 0, ss, p);
         HIPCHK(h, hipGetLastError());
         if (carr_phase_seed) {
             /* the exact start phase of every block, as k_chain_fix_par left it in the chain descriptors */

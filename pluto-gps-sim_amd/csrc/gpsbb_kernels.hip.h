@@ -153,11 +153,12 @@ struct BatchDev {
     const int32_t *tabs;            /* cos512[512] then sin512[512] (plutogpssim.c:93-161)           */
     const uint32_t *ca_bits;        /* [33][32] C/A chips per PRN, bit i of dword i>>5 = chip i      */
     SynRow *rows;                   /* row pool                                                      */
-    const uint64_t *row_off;        /* [2*nblocks*nch + 1] first row of each chain in the pool       */
+    const uint64_t *row_off;        /* [nblocks*nch + nvb*nch + 1] first row of each chain in the pool: the code chains
+                                       (block*nch + channel), then the carrier chains (vb*nch + channel)  */
     int32_t *tile_row;              /* [nblocks][ntiles+1][2*nch]: row (relative to its chain) holding each
                                        tile's first sample, column 2*channel + kind; the 2*nch entries of
                                        one tile share a cache line; entry [ntiles] = the chain's last row */
-    int32_t *row_cnt;               /* [2*nblocks*nch] rows each chain produced (0 = inactive)       */
+    int32_t *row_cnt;               /* [nblocks*nch + nvb*nch] rows each chain produced (0 = inactive) */
     gpsbb_chan_state_t *end;        /* [nblocks*nch] end-of-block state                              */
     int32_t *tile_ctr;              /* [nblocks] next tile to hand out (zeroed before every k_synth)  */
     const uint32_t *kph0;           /* fixed-point carrier variant (GPSBB_FIXED_CARRIER): [nblocks*nch] 32-bit
@@ -188,15 +189,35 @@ struct BatchDev {
     int chain_dev;                  /* 1: GPSBB_CHAIN_CARRIER is resolved on the device (k_chain_prefix / k_chain_fix) */
     int chain_starts;               /* ... for the per-sample kernel: the chain kernels only put the exact start phase of every
                                        block into its descriptor (no rows, no offsets); k_seed then sees independent blocks */
-    ChainAux *aux;                  /* [nblocks*nch]                                                  */
-    ChainDesc *cd;                  /* [nblocks*nch] what the chain kernels read of the descriptors (and, chain_starts, where
+    ChainAux *aux;                  /* [nvb*nch]                                                      */
+    /* The device-side chain works on SEGMENTS: every block is cut into nseg pieces of seg_tiles tiles (the last one
+     * shorter) that are chained like blocks, so that no walk is longer than a segment (a walk takes as long as its
+     * chain, whatever the batch).  Segment sgi of block b is "virtual block" vb = b*nseg + sgi; aux / cd / start0 and the
+     * carrier chains' regions of the row pool are indexed by vb*nch + channel.  nseg = 1: segments are blocks. */
+    int nseg, seg_tiles, nvb;       /* nvb = nblocks*nseg */
+    ChainDesc *cd;                  /* [nvb*nch] what the chain kernels read of the descriptors (and, chain_starts, where
                                        k_chain_fix* leaves the exact start phase of every block)        */
-    const double *start0;           /* [nblocks*nch] rough start phases (host: descriptor phase + sum of nsamp*step in plain
+    const double *start0;           /* [nvb*nch] rough start phases (host: descriptor phase + sum of nsamp*step in plain
                                        double arithmetic): where pass A walks from                     */
-    SynRow *prefix_rows;            /* [nblocks*nch][CHAIN_PREFIX_CAP]: see ChainAux::prefix_cnt       */
+    SynRow *prefix_rows;            /* [nvb*nch][CHAIN_PREFIX_CAP]: see ChainAux::prefix_cnt           */
     ChainCarryDev *carry;           /* stream: block 0 continues the previous push's last block; else NULL */
+    /* k_chain_fix_par: one workgroup per (channel, chunk of FIXP_WG segments); chunk c hands the true end phase of its
+     * last segment to chunk c + 1 through fix_end[channel * fix_chunks + c], published by fix_flag[...] = fix_epoch (a
+     * number no earlier launch on these buffers used: nothing is cleared between launches) */
+    unsigned long long *fix_end;
+    int *fix_flag;
+    int fix_epoch, fix_chunks;
     uint32_t cont0_mask;            /* ... for the channels of this mask (same prn as in that block: the host knows) */
 };
+
+/* samples of segment sgi of a block (see BatchDev::nseg) */
+__device__ __forceinline__ int seg_nsamp(const BatchDev &p, int sgi)
+{
+    const int n0 = sgi * p.seg_tiles * TILE;
+    const int left = p.nsamp - n0;
+    const int full = p.seg_tiles * TILE;
+    return p.nseg <= 1 ? p.nsamp : (left < full ? left : full);
+}
 
 __device__ __forceinline__ size_t tile_row_at(const BatchDev &p, int b, int t, int i, int kind)
 {

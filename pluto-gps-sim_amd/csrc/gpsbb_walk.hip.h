@@ -378,9 +378,9 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
             /* no plan (chain-only runs over very many blocks): the carrier chains channel by channel, blocks in order — 64
              * consecutive blocks of one channel share a wavefront, and a stream continuous in time gives them the same
              * direction and almost the same |f_carr|, which is all the plan's sort is for */
-            const int nbp = (p.nblocks + 63) & ~63;
+            const int nbp = (p.nvb + 63) & ~63;
             const int i = gid / nbp, b = gid - i * nbp;
-            c = (i < p.nch && b < p.nblocks) ? nbc + b * p.nch + i : -1;
+            c = (i < p.nch && b < p.nvb) ? nbc + b * p.nch + i : -1;
         }
     }
     const bool is_code = c >= 0 && c < nbc, is_carr = c >= nbc;
@@ -413,25 +413,29 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
         }
     }
     if (__ballot(is_carr)) {
+        /* k: the chain's segment (PASS >= 1: virtual block * nch + channel) or block (PASS 0: blocks are not cut) */
         const int k = is_carr ? c - nbc : 0;
         /* the passes of the device-side chain read the 24-byte chain descriptors, the others the descriptors themselves */
         const int prn = PASS >= 1 ? p.cd[k].prn : p.ch[k].prn;
         const double f_carr = PASS >= 1 ? p.cd[k].f_carr : p.ch[k].f_carr;
         const bool on = is_carr && prn > 0;
         const double x0 = PASS == 1 ? p.start0[k] : (PASS >= 2 ? p.aux[k].start1 : p.ch[k].carr_phase);
+        const int vb = k / p.nch, sgi = PASS >= 1 ? vb % p.nseg : 0;
+        const int ns = PASS >= 1 ? seg_nsamp(p, sgi) : p.nsamp; /* lanes of a wavefront may walk segments of different length */
         WalkLane<NCO_CARR> w = walk_lane<NCO_CARR, PASS == 0 || PASS == 2>(p, nbc + k, x0, mul_rn(f_carr, p.delt) /* c:2741 */, on);
         w.aux = PASS >= 2 ? &p.aux[k] : nullptr;
         if (PASS >= 2)
-            walk_both_signs<NCO_CARR, true, PASS == 2>(w, p.nsamp, p.hazards, p.status);
+            walk_both_signs<NCO_CARR, true, PASS == 2>(w, ns, p.hazards, p.status);
         else
-            walk_both_signs<NCO_CARR, false, PASS != 1>(w, p.nsamp, p.hazards, p.status);
+            walk_both_signs<NCO_CARR, false, PASS != 1>(w, ns, p.hazards, p.status);
         if (is_carr) {
             if (PASS == 1) {
                 p.aux[k].endA = on ? w.x : 0.0;
             } else {
                 if (PASS != 3) {
                     p.row_cnt[nbc + k] = on ? (int32_t)(w.cnt < w.cap ? w.cnt : w.cap) : 0;
-                    p.end[k].carr_phase = on ? w.x : 0.0;
+                    if (PASS == 0)
+                        p.end[k].carr_phase = on ? w.x : 0.0; /* (chained: the fix-up writes the blocks' true end phases) */
                 }
                 if (PASS >= 2) {
                     /* the trajectory walked here is not final: k_chain_fix decides what counts */
@@ -468,15 +472,20 @@ __device__ __forceinline__ bool chain_continues(const BatchDev &p, int b, int i)
  * restarting from 0 where a block does not continue the one before.  One wavefront per channel: a segmented
  * inclusive scan over the blocks, 64 at a time.
  */
-__global__ void k_chain_prefix(BatchDev p)
+constexpr int PREFIX_WG = 256;
+__global__ __launch_bounds__(PREFIX_WG) void k_chain_prefix(BatchDev p)
 {
-    const int i = blockIdx.x, lane = threadIdx.x;
+    __shared__ double wv[PREFIX_WG / 64];
+    __shared__ int wf[PREFIX_WG / 64];
+    __shared__ double carry_s;
+    __builtin_amdgcn_s_setprio(3); /* see k_chain_fix_par */
+    const int i = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (i >= p.nch)
         return;
     double carry = 0.0; /* e of the block before the chunk's first */
-    for (int b0 = 0; b0 < p.nblocks; b0 += 64) {
-        const int b = b0 + lane;
-        const bool in = b < p.nblocks;
+    for (int b0 = 0; b0 < p.nvb; b0 += PREFIX_WG) { /* b: a virtual block (segment) */
+        const int b = b0 + t;
+        const bool in = b < p.nvb;
         const size_t k = (size_t)(in ? b : 0) * p.nch + i;
         const bool cont = in && chain_continues(p, b, i);
         /* the increment this block adds to the correction of the block before it: the phase lost between the end
@@ -487,7 +496,7 @@ __global__ void k_chain_prefix(BatchDev p)
             c = (b == 0 ? p.carry->approx_end[i] : p.aux[k - p.nch].endA) - start0;
             c = c > 0.5 ? c - 1.0 : (c < -0.5 ? c + 1.0 : c);
         }
-        /* segmented inclusive scan: (flag, value) pairs, flag = the sum restarts here */
+        /* segmented inclusive scan: (flag, value) pairs, flag = the sum restarts here; inside the wavefront ... */
         double v = c;
         bool f = !cont;
 #pragma unroll
@@ -499,20 +508,34 @@ __global__ void k_chain_prefix(BatchDev p)
                 f = f || fu;
             }
         }
+        /* ... and across the wavefronts of the workgroup */
+        if (lane == 63) {
+            wv[wave] = v;
+            wf[wave] = f ? 1 : 0;
+        }
+        __syncthreads();
+        for (int w = wave - 1; w >= 0 && !f; w--) {
+            v += wv[w];
+            f = wf[w] != 0;
+        }
         const double e = f ? v : v + carry;
         if (in) {
             ChainAux &a = p.aux[k];
             double st = cont ? start0 + e : p.cd[k].carr_phase;
             st = st >= 1.0 ? st - 1.0 : (st < 0.0 ? st + 1.0 : st);
             a.start1 = st;
-            if (p.carry && b == p.nblocks - 1) {
+            if (p.carry && b == p.nvb - 1) {
                 /* where the stream's next push will start, as far as pass A can tell */
                 double en = a.endA + (st - start0);
                 en = en >= 1.0 ? en - 1.0 : (en < 0.0 ? en + 1.0 : en);
                 p.carry->approx_end[i] = en;
             }
         }
-        carry = __shfl(e, 63);
+        if (t == PREFIX_WG - 1)
+            carry_s = e;
+        __syncthreads();
+        carry = carry_s;
+        __syncthreads();
     }
 }
 
@@ -542,14 +565,6 @@ struct FixRowSink {
     __device__ __forceinline__ void table_index_512() { hz512++; }
     __device__ __forceinline__ void nav_fetch(uint32_t) {}
 };
-/* ... where not even the count matters */
-struct FixNullSink {
-    uint32_t hz512;
-    __device__ __forceinline__ void row(int32_t, uint32_t, double, double, bool) {}
-    __device__ __forceinline__ void table_index_512() { hz512++; }
-    __device__ __forceinline__ void nav_fetch(uint32_t) {}
-};
-
 /*
  * Device-side carrier chain, step 4 of 4: make it exact.
  *
@@ -608,6 +623,32 @@ __device__ __forceinline__ FixIn fix_load(const BatchDev &p, int b, int i)
     return f;
 }
 
+/* The exact walks of the rare paths, out of line: fix_block is instantiated many times over (k_chain_fix_par tries
+ * start phases with it) and must stay small.  STORE: rows are written (room for `cap` of them at `rows`), else only
+ * counted.  Returns the state after n steps. */
+struct FixWalkOut {
+    double x;
+    uint32_t cnt, hz512;
+    bool overflow;
+};
+template <bool STORE>
+__device__ __noinline__ FixWalkOut fix_walk(double x, double s, int n, WalkRow *rows, uint32_t cap)
+{
+    FixRowSink<STORE> sink;
+    sink.rows = rows;
+    sink.cap = cap;
+    sink.cnt = 0;
+    sink.overflow = false;
+    sink.hz512 = 0;
+    uint32_t nav = 0;
+    FixWalkOut o;
+    o.x = build_rows_f64<NCO_CARR>(x, s, nav, n, sink);
+    o.cnt = sink.cnt;
+    o.hz512 = sink.hz512;
+    o.overflow = sink.overflow;
+    return o;
+}
+
 constexpr int FIX_OK = 0;   /* FixOut::end is the block's true end phase */
 constexpr int FIX_SLOW = 1; /* only a walk of the whole block tells (and the caller did not ask for one) */
 struct FixOut {
@@ -626,6 +667,8 @@ struct FixOut {
 template <bool COMMIT>
 __device__ __forceinline__ FixOut fix_block(const BatchDev &p, const FixIn &in, size_t k, bool on, double x, bool run_slow)
 {
+    /* k = virtual block * nch + channel: a "block" here is a segment (BatchDev::nseg) */
+    const int nsamp_seg = seg_nsamp(p, (int)((k / (size_t)p.nch) % (size_t)p.nseg));
     FixOut out;
     out.kind = FIX_OK;
     out.walked = false;
@@ -701,28 +744,13 @@ __device__ __forceinline__ FixOut fix_block(const BatchDev &p, const FixIn &in, 
         /* a tie-prone binade on the way up: the first lap exactly, on its own rows; after the wrap that ends it
          * the offset is a multiple of every grid and the rest of the block is pass B's plus it */
         const int nstar = in.wrap_row; /* a wrap always starts a row */
-        uint32_t nav = 0;
-        double xs;
-        bool overflow = false;
-        uint32_t lap_rows = 0, lap_hz = 0;
-        if (p.chain_starts) { /* only the state at the wrap is wanted */
-            FixNullSink ns;
-            ns.hz512 = 0;
-            xs = build_rows_f64<NCO_CARR>(x, s, nav, nstar, ns);
-            lap_hz = ns.hz512;
-        } else {
-            FixRowSink<COMMIT> sink;
-            sink.rows = reinterpret_cast<WalkRow *>(p.prefix_rows) + k * CHAIN_PREFIX_CAP;
-            sink.cap = CHAIN_PREFIX_CAP;
-            sink.cnt = 0;
-            sink.overflow = false;
-            sink.hz512 = 0;
-            xs = build_rows_f64<NCO_CARR>(x, s, nav, nstar, sink);
-            overflow = sink.overflow;
-            lap_rows = sink.cnt;
-            lap_hz = sink.hz512;
-        }
-        d = xs - in.wrap_x;
+        /* (a batch that keeps no rows, chain_starts: only the state at the wrap is wanted) */
+        const FixWalkOut lap = (COMMIT && !p.chain_starts)
+                                   ? fix_walk<true>(x, s, nstar, reinterpret_cast<WalkRow *>(p.prefix_rows) + k * CHAIN_PREFIX_CAP, CHAIN_PREFIX_CAP)
+                                   : fix_walk<false>(x, s, nstar, nullptr, p.chain_starts ? 0x7fffffffu : (uint32_t)CHAIN_PREFIX_CAP);
+        const bool overflow = lap.overflow;
+        const uint32_t lap_rows = lap.cnt, lap_hz = lap.hz512;
+        d = lap.x - in.wrap_x;
         /* (a tie-prone coarsest grid and an odd offset there: pass B's recorded tie is not part of this path) */
         ok = !overflow && lap_hz == 0 && fabs(d) < margin - 0x1p-51 &&
              !(tie_top && fmod(fabs(d) * (fall ? 0x1p+53 : 0x1p+52), 2.0) != 0.0);
@@ -774,26 +802,20 @@ __device__ __forceinline__ FixOut fix_block(const BatchDev &p, const FixIn &in, 
             return out;
         }
         out.walked = true;
-        uint32_t nav = 0;
         if (p.chain_starts) {
             /* on its own: the whole block exactly; only its end state is wanted */
-            FixNullSink ns;
-            ns.hz512 = 0;
-            end = build_rows_f64<NCO_CARR>(x, s, nav, p.nsamp, ns);
+            end = fix_walk<false>(x, s, nsamp_seg, nullptr, 0x7fffffffu).x;
         } else {
             /* on its own: the whole block exactly, rows in place of pass B's, no offsets */
-            FixRowSink<COMMIT> sink;
-            sink.rows = reinterpret_cast<WalkRow *>(p.rows) + p.row_off[nbc + k];
-            sink.cap = (uint32_t)(p.row_off[nbc + k + 1] - p.row_off[nbc + k]);
-            sink.cnt = 0;
-            sink.overflow = false;
-            sink.hz512 = 0;
-            end = build_rows_f64<NCO_CARR>(x, s, nav, p.nsamp, sink);
-            hz512 = sink.hz512;
+            const uint32_t cap = (uint32_t)(p.row_off[nbc + k + 1] - p.row_off[nbc + k]);
+            WalkRow *rows = reinterpret_cast<WalkRow *>(p.rows) + p.row_off[nbc + k];
+            const FixWalkOut w = COMMIT ? fix_walk<true>(x, s, nsamp_seg, rows, cap) : fix_walk<false>(x, s, nsamp_seg, nullptr, cap);
+            end = w.x;
+            hz512 = w.hz512;
             if (COMMIT) {
-                if (sink.overflow)
+                if (w.overflow)
                     atomicOr(p.status, ST_ROW_OVERFLOW);
-                p.row_cnt[nbc + k] = (int32_t)(sink.cnt < sink.cap ? sink.cnt : sink.cap);
+                p.row_cnt[nbc + k] = (int32_t)(w.cnt < cap ? w.cnt : cap);
                 a.ncross = 0;
                 a.seg[0] = 0.0;
                 a.prefix_cnt = 0;
@@ -809,16 +831,20 @@ __device__ __forceinline__ FixOut fix_block(const BatchDev &p, const FixIn &in, 
 __device__ __forceinline__ void fix_publish(const BatchDev &p, size_t k, bool on, bool cont, double x, const FixOut &r,
                                             unsigned long long &n_hz)
 {
+    const size_t vb = k / (size_t)p.nch, i = k % (size_t)p.nch;
+    const size_t kb = (vb / (size_t)p.nseg) * (size_t)p.nch + i; /* the block the segment belongs to */
+    const int sgi = (int)(vb % (size_t)p.nseg);
     if (p.chain_starts) {
         /* the per-sample kernel's pre-pass comes next (or nothing, gpsbb_chain_carrier): all that is wanted is where
-         * this block starts (k_seed counts the hazards and writes the end states itself) */
+         * every block starts (k_seed counts the hazards and writes the end states itself) */
         if (on && cont) {
             p.cd[k].carr_phase = x;
-            if (p.ch)
-                const_cast<gpsbb_chan_t *>(p.ch)[k].carr_phase = x;
+            if (p.ch && sgi == 0)
+                const_cast<gpsbb_chan_t *>(p.ch)[kb].carr_phase = x;
         }
     } else {
-        p.end[k].carr_phase = on ? r.end : 0.0;
+        if (sgi == p.nseg - 1)
+            p.end[kb].carr_phase = on ? r.end : 0.0;
         if (on)
             n_hz += r.hz512;
     }
@@ -839,11 +865,11 @@ __global__ __launch_bounds__(64) void k_chain_fix(BatchDev p)
     /* two blocks ahead: a turn of this loop is a few hundred cycles of dependent arithmetic, a load from HBM beside
      * the other kernels takes longer than that */
     FixIn nxt = fix_load(p, 0, il);
-    FixIn nxt2 = fix_load(p, p.nblocks > 1 ? 1 : 0, il);
-    for (int b = 0; b < p.nblocks; b++) {
+    FixIn nxt2 = fix_load(p, p.nvb > 1 ? 1 : 0, il);
+    for (int b = 0; b < p.nvb; b++) { /* b: a virtual block (segment) */
         const FixIn in = nxt;
         nxt = nxt2;
-        nxt2 = fix_load(p, b + 2 < p.nblocks ? b + 2 : p.nblocks - 1, il);
+        nxt2 = fix_load(p, b + 2 < p.nvb ? b + 2 : p.nvb - 1, il);
         const size_t k = (size_t)b * p.nch + il;
         const bool on = lane_on && in.prn > 0;
         const bool cont = on && (b > 0 ? in.prn == in.prn_prev : (p.carry && ((p.cont0_mask >> il) & 1u)));
@@ -883,10 +909,10 @@ __global__ __launch_bounds__(64) void k_chain_fix(BatchDev p)
  * checked again.  When no block fails, every x_b is what k_chain_fix would have passed on, and every lane commits
  * its block with fix_block<true>.  In a time-continuous stream a round fails for about one block-channel in 10^4.
  */
-#ifndef GPSBB_FIXP_WG
-#define GPSBB_FIXP_WG 512
-#endif
-constexpr int FIXP_WG = GPSBB_FIXP_WG;
+/* lanes (= blocks) per workgroup: 128 for batches and pushes — its two wavefronts have to find room beside the synthesis
+ * kernel's (measured: 256 -> 1.03 ms per push beside the rest, 128 -> 0.57, 64 -> 1.08: more hand-offs) —, 256 for the
+ * chain alone (gpsbb_chain_carrier: nothing else runs, fewer hand-offs) */
+constexpr int FIXP_WG_BATCH = 128, FIXP_WG_ALONE = 256;
 
 struct FixMap {
     int isconst; /* 1: o_b = v[0] whatever came before */
@@ -923,161 +949,222 @@ __device__ __forceinline__ FixMap fix_compose(const FixMap &A, const FixMap &B)
     return R;
 }
 
+/* LDS of k_chain_fix_par: a few hundred bytes (the kernel must fit on a CU beside a workgroup of the synthesis kernel,
+ * which leaves 10 KB of LDS and 128 VGPRs per SIMD: anything bigger waits for a synthesis workgroup to leave) */
+template <int FIXP_WG>
 struct FixParLds {
-    int mc[2][FIXP_WG];
-    double mv[2][4][FIXP_WG];
-    double eg[FIXP_WG + 1]; /* [b + 1]: the end of block b of the chunk as guessed (or known); [0]: of the block before it */
+    static constexpr int FIXP_WAVES = FIXP_WG / 64;
+    int wc[FIXP_WAVES];        /* per wavefront: the composition of its lanes' maps */
+    double wv[FIXP_WAVES][4];
+    double wend[FIXP_WAVES];   /* per wavefront: its last lane's guessed end */
+    double head_end;           /* the true end of the block before the head (or before the chunk) */
     int first_bad;
-    int any_walk;
 };
 
-__global__ __launch_bounds__(FIXP_WG) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chain_fix_par(BatchDev p)
+__device__ __forceinline__ FixMap fix_map_shfl_up(const FixMap &m, int delta)
 {
-    __shared__ FixParLds L;
-    const int i = blockIdx.x; /* channel */
-    const int t = threadIdx.x;
-    if (i >= p.nch)
+    FixMap r;
+    r.isconst = __shfl_up(m.isconst, delta);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        r.v[j] = __shfl_up(m.v[j], delta);
+    return r;
+}
+
+template <int FIXP_WG>
+__global__ __launch_bounds__(FIXP_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_chain_fix_par(BatchDev p)
+{
+    __shared__ FixParLds<FIXP_WG> L;
+    /* a few wavefronts on whose latency the rest of the pre-pass (and every later push of a stream) waits, on SIMDs
+     * they share with four older, VALU-bound wavefronts of the synthesis kernel: let them win the issue arbitration */
+    __builtin_amdgcn_s_setprio(3);
+    const int i = blockIdx.x;     /* channel */
+    const int chunk = blockIdx.y; /* FIXP_WG consecutive "blocks" — virtual blocks (segments) from here on */
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int c0 = chunk * FIXP_WG;
+    if (i >= p.nch || c0 >= p.nvb)
         return;
-    unsigned long long n_fallback = 0, n_hz = 0;
-    if (t == 0)
-        L.eg[0] = p.carry ? p.carry->exact_end[i] : 0.0; /* a stream: where the push before this one ended */
-    for (int c0 = 0; c0 < p.nblocks; c0 += FIXP_WG) {
-        const int n = p.nblocks - c0 < FIXP_WG ? p.nblocks - c0 : FIXP_WG; /* blocks of this chunk */
-        const int b = c0 + t;
-        const bool mine = t < n;
-        const size_t k = (size_t)(mine ? b : c0) * p.nch + i;
-        const FixIn in = fix_load(p, mine ? b : c0, i);
-        const bool on = mine && in.prn > 0;
-        const bool cont = on && (b > 0 ? in.prn == in.prn_prev : (p.carry && ((p.cont0_mask >> i) & 1u)));
-        const double endB_prev = (mine && b > 0) ? p.aux[k - p.nch].endB : 0.0;
-        /* ---- this block as a map of the scan ---- */
-        FixMap my;
-        my.isconst = 0;
-        my.v[0] = my.v[1] = my.v[2] = my.v[3] = 0.0; /* lanes past the chunk: the identity */
-        if (mine && !on) {
-            my.isconst = 1; /* an idle channel ends at 0.0 = endB */
-        } else if (on && !cont) {
-            const FixOut r = fix_block<false>(p, in, k, on, in.carr_phase, false);
-            my.isconst = 1;
-            my.v[0] = r.kind == FIX_OK ? (r.end - in.endB) * 0x1p+53 : 0.0;
-        } else if (on) {
-            bool regular = b > 0 && t > 0; /* the chunk's first block is given its true start below */
-            double kk[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                kk[j] = 0.0;
-                if (regular) {
-                    const FixOut r = fix_block<false>(p, in, k, on, endB_prev + (double)j * 0x1p-53, false);
-                    const double o = (r.end - in.endB) * 0x1p+53;
-                    regular = r.kind == FIX_OK && fabs(o) < 0x1p+30 && o == __builtin_rint(o);
-                    kk[j] = o - (double)j;
-                }
-            }
-            if (regular) {
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    my.v[j] = kk[j];
+    unsigned long long n_fallback = 0, n_hz = 0, n_rounds = 0;
+    const int n = p.nvb - c0 < FIXP_WG ? p.nvb - c0 : FIXP_WG; /* blocks of this chunk */
+    const int b = c0 + t;
+    const bool mine = t < n;
+    const size_t k = (size_t)(mine ? b : c0) * p.nch + i;
+    const FixIn in = fix_load(p, mine ? b : c0, i);
+    const bool on = mine && in.prn > 0;
+    const bool cont = on && (b > 0 ? in.prn == in.prn_prev : (p.carry && ((p.cont0_mask >> i) & 1u)));
+    const double endB_prev = (mine && b > 0) ? p.aux[k - p.nch].endB : 0.0;
+    /* ---- this block as a map of the scan (nothing here depends on the chunks before this one) ---- */
+    FixMap my;
+    my.isconst = 0;
+    my.v[0] = my.v[1] = my.v[2] = my.v[3] = 0.0; /* lanes past the chunk: the identity */
+    bool have = false; /* x_last / r_last hold an evaluation of this lane's block */
+    double x_last = 0.0, my_end = 0.0;
+    FixOut r_last;
+    r_last.end = 0.0;
+    r_last.kind = FIX_OK;
+    r_last.hz512 = 0;
+    r_last.walked = false;
+    if (mine && !on) {
+        my.isconst = 1; /* an idle channel ends at 0.0 = endB */
+    } else if (on && !(cont && t == 0)) { /* (the chunk's first block, if it continues the chunk before: the first head) */
+        /* a block that starts a chain of its own is a constant from the start; any other is tried from the four start
+         * phases endB_(b-1) + j*u */
+        const bool known = !cont;
+        bool regular = true;
+        double kk[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+        for (int j = 0; j < (known ? 1 : 4) && regular; j++) {
+            const double xj = known ? in.carr_phase : endB_prev + (double)j * 0x1p-53;
+            const FixOut r = fix_block<false>(p, in, k, on, xj, false);
+            const double o = (r.end - in.endB) * 0x1p+53;
+            if (known) {
+                have = true;
+                x_last = xj;
+                r_last = r;
+                kk[0] = r.kind == FIX_OK ? o : 0.0; /* (a whole-block walk to come: a guess until then) */
             } else {
-                my.isconst = 1; /* a guess: pass B's own end */
+                regular = r.kind == FIX_OK && fabs(o) < 0x1p+30 && o == __builtin_rint(o);
+                const double kj = o - (double)j;
+                kk[0] = j == 0 ? kj : kk[0];
+                kk[1] = j == 1 ? kj : kk[1];
+                kk[2] = j == 2 ? kj : kk[2];
+                kk[3] = j == 3 ? kj : kk[3];
             }
         }
-        /* ---- guess, check, move the head: until every block's start phase is the true one ---- */
-        int lo = 0;
-        bool committed = false;
-        bool have = false; /* x_last / r_last hold an evaluation of this lane's block */
-        double x_last = 0.0;
-        FixOut r_last;
-        r_last.end = 0.0;
-        r_last.kind = FIX_OK;
-        r_last.hz512 = 0;
-        r_last.walked = false;
-        __syncthreads(); /* eg[0] */
-        for (;;) {
-            /* the head: its start phase is known to be true */
-            if (t == lo && mine) {
-                const double x = cont ? L.eg[lo] : in.carr_phase;
-                FixOut r = fix_block<false>(p, in, k, on, x, false);
-                if (r.kind == FIX_SLOW) {
-                    r = fix_block<true>(p, in, k, on, x, true); /* the whole block, now, for good */
-                    committed = true;
-                    n_fallback += r.walked ? 1u : 0u;
-                    fix_publish(p, k, on, cont, x, r, n_hz);
-                }
-                have = true;
-                x_last = x;
-                r_last = r;
-                my.isconst = 1;
-                my.v[0] = (r.end - in.endB) * 0x1p+53;
-                L.eg[lo + 1] = r.end;
-            }
-            /* inclusive scan of the maps over [lo, n): Hillis-Steele through LDS */
-            FixMap acc = my;
-            if (t < lo) {
-                acc.isconst = 0;
-                acc.v[0] = acc.v[1] = acc.v[2] = acc.v[3] = 0.0;
-            }
-            int cur = 0;
-            L.mc[0][t] = acc.isconst;
+        if (known || !regular) {
+            my.isconst = 1; /* not regular: a guess, pass B's own end */
+            my.v[0] = known ? kk[0] : 0.0;
+        } else {
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                L.mv[0][j][t] = acc.v[j];
-            __syncthreads();
-            for (int off = 1; off < FIXP_WG; off <<= 1) {
-                if (t >= off && t - off >= lo) {
-                    FixMap prev;
-                    prev.isconst = L.mc[cur][t - off];
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        prev.v[j] = L.mv[cur][j][t - off];
-                    acc = fix_compose(acc, prev);
-                }
-                cur ^= 1;
-                L.mc[cur][t] = acc.isconst;
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    L.mv[cur][j][t] = acc.v[j];
-                __syncthreads();
-                if ((off << 1) >= n)
-                    break;
-            }
-            /* every map from the head on is a constant now: the guessed ends */
-            if (mine && t > lo)
-                L.eg[t + 1] = in.endB + acc.v[0] * 0x1p-53;
-            if (t == 0)
-                L.first_bad = FIXP_WG;
-            __syncthreads();
-            /* check: from the guessed start, does this block end where the next one was told it would? */
-            if (mine && t > lo) {
-                const double x = cont ? L.eg[t] : in.carr_phase;
-                if (!have || f64_bits(x) != f64_bits(x_last)) {
-                    r_last = fix_block<false>(p, in, k, on, x, false);
-                    x_last = x;
-                    have = true;
-                }
-                if (r_last.kind != FIX_OK || f64_bits(r_last.end) != f64_bits(L.eg[t + 1]))
-                    atomicMin(&L.first_bad, t);
-            }
-            __syncthreads();
-            const int bad = L.first_bad;
-            __syncthreads();
-            if (bad >= FIXP_WG)
-                break;
-            lo = bad; /* every block before it is settled, so its start phase (eg[bad]) is the true one */
+                my.v[j] = kk[j];
         }
-        /* ---- commit ---- */
-        if (mine && !committed) {
-            const double x = cont ? L.eg[t] : in.carr_phase;
+    }
+    /* ---- where the chunk before this one ended: the only thing chunks wait for each other for ---- */
+    if (t == 0) {
+        double cs = p.carry ? p.carry->exact_end[i] : 0.0; /* a stream: where the push before this one ended */
+        if (chunk > 0) {
+            const size_t at = (size_t)i * p.fix_chunks + (chunk - 1);
+            __builtin_amdgcn_s_setprio(0); /* waiting must not cost the wavefronts it shares the SIMD with anything */
+            while (__hip_atomic_load(&p.fix_flag[at], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.fix_epoch)
+                __builtin_amdgcn_s_sleep(32);
+            __builtin_amdgcn_s_setprio(3);
+            cs = bits_f64(__hip_atomic_load(&p.fix_end[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        L.head_end = cs;
+    }
+    __syncthreads();
+    const double chunk_start = L.head_end;
+    __syncthreads();
+    /* ---- guess, check, move the head: until every block's start phase is the true one, then commit ---- */
+    int lo = 0;
+    double lo_start = chunk_start; /* the true end of block lo - 1 (wave-uniform) */
+    bool committed = false, final = false;
+    double prev_end = 0.0;
+    for (;;) {
+        const bool head = t == lo && mine && !final;
+        if (head) { /* from its true start phase (a block that became the head in the round before has just been there) */
+            const double x = cont ? lo_start : in.carr_phase;
+            if (!have || f64_bits(x) != f64_bits(x_last)) {
+                r_last = fix_block<false>(p, in, k, on, x, false);
+                x_last = x;
+                have = true;
+            }
+        }
+        /* Whoever has to leave its results now: the head if only a walk of the whole block tells where it ends, and —
+         * last round — every block. */
+        const bool commit_now = mine && !committed && (final || (head && r_last.kind == FIX_SLOW));
+        if (commit_now) {
+            const double x = cont ? (final ? prev_end : lo_start) : in.carr_phase;
             const FixOut r = fix_block<true>(p, in, k, on, x, true);
+            committed = true;
             n_fallback += r.walked ? 1u : 0u;
             fix_publish(p, k, on, cont, x, r, n_hz);
+            x_last = x;
+            r_last = r;
+            have = true;
+        }
+        if (final)
+            break;
+        if (head) {
+            my.isconst = 1;
+            my.v[0] = (r_last.end - in.endB) * 0x1p+53;
+        }
+        /* inclusive scan of the maps over [lo, n): inside the wavefront by shuffles ... */
+        FixMap acc = my;
+        if (t < lo) {
+            acc.isconst = 0;
+            acc.v[0] = acc.v[1] = acc.v[2] = acc.v[3] = 0.0;
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const FixMap prev = fix_map_shfl_up(acc, off);
+            if (lane >= off)
+                acc = fix_compose(acc, prev);
+        }
+        /* ... across the wavefronts through LDS */
+        if (lane == 63) {
+            L.wc[wave] = acc.isconst;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                L.wv[wave][j] = acc.v[j];
+        }
+        if (t == 0)
+            L.first_bad = FIXP_WG;
+        __syncthreads();
+        for (int w = wave - 1; w >= 0 && !acc.isconst; w--) { /* (a constant absorbs everything before it) */
+            FixMap pw;
+            pw.isconst = L.wc[w];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                pw.v[j] = L.wv[w][j];
+            acc = fix_compose(acc, pw);
+        }
+        /* every map from the head on is a constant now: the guessed ends */
+        if (mine && t >= lo)
+            my_end = t == lo ? r_last.end : in.endB + acc.v[0] * 0x1p-53;
+        if (lane == 63)
+            L.wend[wave] = my_end;
+        __syncthreads();
+        prev_end = __shfl_up(my_end, 1);
+        if (lane == 0)
+            prev_end = wave > 0 ? L.wend[wave - 1] : chunk_start;
+        /* check: from the guessed start, does this block end where the next one was told it would? */
+        if (mine && t > lo) {
+            const double x = cont ? prev_end : in.carr_phase;
+            if (!have || f64_bits(x) != f64_bits(x_last)) {
+                r_last = fix_block<false>(p, in, k, on, x, false);
+                x_last = x;
+                have = true;
+            }
+            if (r_last.kind != FIX_OK || f64_bits(r_last.end) != f64_bits(my_end))
+                atomicMin(&L.first_bad, t);
         }
         __syncthreads();
-        if (t == 0)
-            L.eg[0] = L.eg[n]; /* the next chunk continues here */
+        const int bad = L.first_bad;
+        if (bad >= FIXP_WG) {
+            /* every x is the true one.  The next chunk can go on (it waits for nothing else); then everybody commits. */
+            if (t == n - 1) {
+                const size_t at = (size_t)i * p.fix_chunks + chunk;
+                __hip_atomic_store(&p.fix_end[at], f64_bits(my_end), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&p.fix_flag[at], p.fix_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (p.carry && c0 + n >= p.nvb)
+                    p.carry->exact_end[i] = my_end;
+            }
+            final = true;
+            continue;
+        }
+        /* every block before `bad` is settled, so the guess handed to it is its true start phase (and the evaluation
+         * it has just made from it stands) */
+        if (t == bad)
+            L.head_end = prev_end;
         __syncthreads();
+        lo_start = L.head_end;
+        lo = bad;
+        n_rounds++;
     }
-    if (p.carry && t == 0)
-        p.carry->exact_end[i] = L.eg[0];
+    if (t == 0 && n_rounds)
+        atomicAdd(p.hazards + 6, n_rounds); /* rounds of guess-and-check beyond the first (GPSBB_INFO_CHAIN_REPAIRS) */
     if (n_hz)
         atomicAdd(p.hazards, n_hz);
     if (n_fallback)
@@ -1094,9 +1181,17 @@ __global__ __launch_bounds__(FIXP_WG) __attribute__((amdgpu_waves_per_eu(1, 2)))
 #endif
 __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
 {
+    __builtin_amdgcn_s_setprio(GPSBB_SEED_PRIO); /* latency-bound and short, like the walks it follows */
     const int chain = blockIdx.x;
     const int nbc = p.nblocks * p.nch;
-    const int kind = chain >= nbc ? 1 : 0, bi = chain - kind * nbc;
+    /* code chains: one per (block, channel); carrier chains: one per (segment, channel) where the carrier is chained on
+     * the device (BatchDev::nseg), else per (block, channel) */
+    const int kind = chain >= nbc ? 1 : 0, kv = chain - kind * nbc;
+    const int nseg = (kind && p.chain_dev) ? p.nseg : 1;
+    const int vb = kv / p.nch, sgi = vb % nseg;
+    const int bi = (vb / nseg) * p.nch + kv % p.nch;                   /* block * nch + channel */
+    const int t0 = sgi * p.seg_tiles;                                   /* the segment's first tile ... */
+    const int ntl = nseg > 1 ? ((p.ntiles - t0 < p.seg_tiles) ? p.ntiles - t0 : p.seg_tiles) : p.ntiles; /* ... and how many it has */
     /* the tile counters of this table set, for the synthesis kernel that follows (the one that last used them has
      * finished: the pre-pass waited for it): saves a memset and its launch gap on the synthesis stream */
     if (chain < p.nblocks && threadIdx.x == 0)
@@ -1108,25 +1203,25 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
     const int b = bi / p.nch, i = bi % p.nch;
     /* the chain's step (c:2709 / c:2741), from which every row's increment follows (walk_row_step) */
     const double s = kind ? mul_rn(p.ch[bi].f_carr, p.delt) : mul_rn(p.ch[bi].f_code, p.delt);
-    double *__restrict__ tx = p.tile_x + ((size_t)b * (2 * (size_t)p.nch) + 2 * i + kind) * (size_t)p.ntiles;
+    double *__restrict__ tx = p.tile_x + ((size_t)b * (2 * (size_t)p.nch) + 2 * i + kind) * (size_t)p.ntiles + t0;
     uint32_t *__restrict__ tn = p.tile_nav + ((size_t)b * (size_t)p.nch + i) * (size_t)p.ntiles;
     /* carrier chained on the device: the true states are pass B's plus an offset per stretch of rows (k_chain_fix) */
     const bool shifted = kind && p.aux && p.chain_dev;
-    const ChainAux *aux = shifted ? &p.aux[bi] : nullptr;
+    const ChainAux *aux = shifted ? &p.aux[kv] : nullptr;
     const int ncross = shifted ? (aux->ncross > 0 ? aux->ncross : 0) : 0;
     /* k_chain_fix walked the first lap on its own: those rows (in the chain's prefix region) hold the samples
      * before prefix_end, pass B's rows before wrap_row are void */
     const int prefix_cnt = shifted ? aux->prefix_cnt : 0;
     const int void_before = prefix_cnt > 0 ? aux->prefix_end : 0; /* pass B's rows before this sample are void */
     if (prefix_cnt > 0) {
-        const WalkRow *pr = reinterpret_cast<const WalkRow *>(p.prefix_rows) + (size_t)bi * CHAIN_PREFIX_CAP;
+        const WalkRow *pr = reinterpret_cast<const WalkRow *>(p.prefix_rows) + (size_t)kv * CHAIN_PREFIX_CAP;
         const int pend = aux->prefix_end;
         for (int r = threadIdx.x; r < prefix_cnt; r += blockDim.x) {
             const WalkRow row = pr[r];
             const int n_next = r + 1 < prefix_cnt ? pr[r + 1].n0 : pend;
             int t = (int)(((uint32_t)row.n0 + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
             int t_end = (int)(((uint32_t)n_next + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
-            t_end = t_end < p.ntiles ? t_end : p.ntiles;
+            t_end = t_end < ntl ? t_end : ntl;
             for (; t < t_end; t++)
                 tx[t] = mul_rn(__fma_rn((double)(t * TILE - row.n0), walk_row_step(row.x, s), row.x), 512.0);
         }
@@ -1161,7 +1256,7 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
         for (int j = 0; j < U; j++) {
             int t = (int)(((uint32_t)row[j].n0 + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
             int t_end = (int)(((uint32_t)n_next[j] + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
-            t_end = t_end < p.ntiles ? t_end : p.ntiles;
+            t_end = t_end < ntl ? t_end : ntl;
             const double S = walk_row_step(row[j].x, s);
             for (; t < t_end; t++) {
                 double v = __fma_rn((double)(t * TILE - row[j].n0), S, row[j].x);

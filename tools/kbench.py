@@ -62,7 +62,9 @@ def main():
     print(json.dumps({"value": n * a.steps / dt, "ms_per_step": dt / a.steps * 1e3,
                       "roofline": {"ms_per_launch": st["ms_synth_sum"] / max(st["runs"], 1)},
                       "seed_kernel_ms_per_launch": st["ms_seed_sum"] / max(st["runs"], 1),
-                      "kernel": synth.info(pkg.INFO_LAST_KERNEL), "chain_on_device": synth.info(pkg.INFO_CHAIN_ON_DEVICE)}))
+                      "kernel": synth.info(pkg.INFO_LAST_KERNEL), "chain_on_device": synth.info(pkg.INFO_CHAIN_ON_DEVICE),
+                      "chain_fallbacks": synth.info(pkg.INFO_CHAIN_FALLBACKS), "chain_repairs": synth.info(pkg.INFO_CHAIN_REPAIRS),
+                      "launches": a.steps + a.warmup}))
     synth.set_option(pkg.OPT_SKIP_SEED, 0)
     batch.close()
     synth.close()

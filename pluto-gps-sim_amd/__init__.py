@@ -19,7 +19,12 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgpsbb.so")
+# The product is libgpsbb.so: it reads no environment variable and exports include/gpsbb.h, nothing else.  The experiments
+# build of the same sources (libgpsbb_exp.so: measurement knobs from the environment, gpsbb_test_* hooks) is what the
+# tuning scripts under tools/ use when they say so (GPSBB_PY_LIB=exp, read HERE, in the Python veneer) and what
+# exp_lib() hands to the NCO unit tests.
+LIB_PATH = os.path.join(HERE, "libgpsbb_exp.so" if os.environ.get("GPSBB_PY_LIB") == "exp" else "libgpsbb.so")
+EXP_LIB_PATH = os.path.join(HERE, "libgpsbb_exp.so")
 
 MAX_CHAN = 16
 N_DWRD = 60
@@ -62,8 +67,8 @@ class GpsbbError(RuntimeError):
 
 def build(force=False):
     """Compile csrc/ for gfx950 with hipcc into libgpsbb.so next to this file (in-tree, so it travels)."""
-    if force or not os.path.exists(LIB_PATH) or any(
-            os.path.getmtime(os.path.join(HERE, "csrc", f)) > os.path.getmtime(LIB_PATH)
+    if force or not os.path.exists(LIB_PATH) or not os.path.exists(EXP_LIB_PATH) or any(
+            os.path.getmtime(os.path.join(HERE, "csrc", f)) > min(os.path.getmtime(LIB_PATH), os.path.getmtime(EXP_LIB_PATH))
             for f in os.listdir(os.path.join(HERE, "csrc"))):
         subprocess.check_call(["make", "-C", os.path.join(HERE, "csrc")])
     return LIB_PATH
@@ -118,7 +123,22 @@ def lib():
         L.gpsbb_sincos_tables.argtypes = [vp, vp]
         L.gpsbb_chain_carrier_host.argtypes = [vp, i, i, d, i, vp, i]
         L.gpsbb_chain_carrier.argtypes = [vp, vp, i, i, d, i, vp, vp]
-        # test hooks (csrc/gpsbb_testhooks.h)
+        _lib = L
+    return _lib
+
+
+_exp_lib = None
+
+
+def exp_lib():
+    """The experiments build (libgpsbb_exp.so) with the gpsbb_test_* hooks of csrc/gpsbb_testhooks.h: the shared NCO code
+    (gpsbb_nco.h) compiled for the host, which tests/test_nco_host.py checks against brute-force stepping without a GPU."""
+    global _exp_lib
+    if _exp_lib is None:
+        if not os.path.exists(EXP_LIB_PATH):
+            raise RuntimeError("libgpsbb_exp.so is not built (make -C %s/csrc)" % HERE)
+        L = C.CDLL(EXP_LIB_PATH)
+        i, d, u, vp = C.c_int, C.c_double, C.c_uint, C.c_void_p
         L.gpsbb_test_carr_jump.argtypes = [d, d, C.c_longlong]
         L.gpsbb_test_carr_jump.restype = d
         L.gpsbb_test_code_jump.argtypes = [d, d, C.c_longlong, C.POINTER(C.c_longlong)]
@@ -126,8 +146,8 @@ def lib():
         L.gpsbb_test_build_rows.argtypes = [i, d, d, u, i, vp, i, C.POINTER(d), C.POINTER(u)]
         L.gpsbb_test_row_bound.argtypes = [i, d, i]
         L.gpsbb_test_row_bound.restype = C.c_ulonglong
-        _lib = L
-    return _lib
+        _exp_lib = L
+    return _exp_lib
 
 
 def _chk(rc, what):

@@ -24,11 +24,24 @@
 #include "gpsbb.h"
 #include "gpsbb_kernels.hip.h"
 #include "gpsbb_events.hip.h"
+#include "gpsbb_dense.hip.h"
 #include "gpsbb_walk.hip.h"
 #include "gpsbb_nco.h"
 #include "gpsbb_testhooks.h"
 
 using namespace gpsbb_impl;
+
+/* Measurement knobs.  The library as shipped reads NO environment variable: a drop-in must not change its behaviour with
+ * what happens to be in its host's environment.  The experiments build (make exp: -DGPSBB_EXPERIMENTS ->
+ * libgpsbb_exp.so, which the tuning scripts under tools/ and the NCO unit tests load) turns the constants below into
+ * getenv look-ups and exports the gpsbb_test_* hooks. */
+#ifdef GPSBB_EXPERIMENTS
+#define GPSBB_KNOB_LONG(name, dflt) ([](long d) -> long { static const char *const e = getenv(name); return e ? atol(e) : d; }((long)(dflt)))
+#define GPSBB_KNOB_SET(name) ([]() -> bool { static const bool v = getenv(name) != nullptr; return v; }())
+#else
+#define GPSBB_KNOB_LONG(name, dflt) ((long)(dflt))
+#define GPSBB_KNOB_SET(name) (false)
+#endif
 
 /* ================================================================================================== */
 /* host-side tables                                                                                   */
@@ -264,8 +277,9 @@ struct WorkPool {
 };
 
 constexpr int SEED_STREAMS_MAX = 8;
-constexpr int CHAIN_SEG_TILES = 600; /* tiles per segment of the device-side chain, about (see batch_setup) */
-constexpr int CHAIN_SEG_MAX = 8;     /* segments per block at most */
+constexpr int CHAIN_SEG_ROWS = 1750;    /* rows of a carrier chain per segment of the device-side chain, about (see batch_setup) */
+constexpr int CHAIN_SEG_MIN_TILES = 16; /* ... but no segment shorter than this many tiles */
+constexpr int CHAIN_SEG_MAX = 8;        /* segments per block at most */
 constexpr unsigned STREAM_SEED_STREAMS = 6; /* pre-passes of a stream's pushes in flight (GPSBB_STREAM_SEED_STREAMS) */
 
 struct gpsbb {
@@ -341,7 +355,7 @@ struct DevBuf {
  * pre-pass is as long as its longest chain whatever the batch size — longer than the synthesis it feeds — so
  * two of them have to be in flight for the synthesis kernel to set the pace; four, three pre-passes in flight on
  * three streams, where the carrier is chained on the device (two walks and the fix-up per run). */
-constexpr int NSETS = 4;
+constexpr int NSETS = 6;
 
 struct gpsbb_batch {
     gpsbb *h = nullptr;
@@ -383,6 +397,7 @@ struct gpsbb_batch {
     size_t hs_tx_cap = 0, hs_tn_cap = 0;
     /* GPSBB_CHAIN_CARRIER resolved on the device (gpsbb_walk.hip.h: k_chain_prefix / k_chain_fix) */
     bool ev_dense = false; /* some channel is evaluated per sample: k_synth_ev<true> */
+    bool ev_all_dense = false; /* every active channel is: k_synth_pd */
     bool chain_dev = false;
     bool chain_starts = false; /* ... with the per-sample kernel: the chain kernels only fix the blocks' start phases */
     DevBuf<int32_t> d_chain_order; /* chain_starts: the carrier chains, as k_walk's passes take them */
@@ -413,9 +428,9 @@ struct gpsbb_batch {
     char *stage = nullptr;
     size_t stage_cap = 0, stage_used = 0;
     unsigned stream_turn = 0; /* the stream's push count */
-    hipEvent_t synth_done_ref[NSETS] = {nullptr, nullptr, nullptr, nullptr}; /* not owned: the run's ev[3] */
+    hipEvent_t synth_done_ref[NSETS] = {}; /* not owned: the run's ev[3] */
     hipEvent_t last_done = nullptr;
-    bool synth_pending[NSETS] = {false, false, false, false};
+    bool synth_pending[NSETS] = {};
     hipEvent_t upload_done = nullptr; /* descriptors and plans of the last set-up are on the device */
     int nsets = 2;                    /* table sets in use: run k works on set k % nsets */
     unsigned run_count = 0;
@@ -588,11 +603,10 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     if (!out)
         return GPSBB_E_BADARG;
     *out = nullptr;
-    /* Up to seven streams carry work at the same time (three pre-pass streams, upload, compute, gather, the null
-     * stream).  The runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share one
-     * run one after the other: ask for twelve, unless the host has said otherwise.  Only takes effect if this is the
-     * process's first HIP call; a host that initialises HIP earlier (e.g. through torch) sets it itself. */
-    setenv("GPU_MAX_HW_QUEUES", "12", 0);
+    /* Up to nine streams carry work at the same time (six pre-pass streams, upload, compute, gather).  The HIP runtime
+     * maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share one run one after the
+     * other: a host that wants the stream rates of DESIGN.md exports GPU_MAX_HW_QUEUES=12 before its first HIP call
+     * (gpsbb-sim and bench.py do).  The library itself neither reads nor writes the environment. */
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
         return GPSBB_E_NODEVICE;
@@ -644,6 +658,8 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
                                  (int)sizeof(EvLds))) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev_dense), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(EvLds))) != hipSuccess) return fail(e);
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_pd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(PdLds))) != hipSuccess) return fail(e);
     *out = h;
     return GPSBB_OK;
 }
@@ -667,9 +683,11 @@ struct PushTrace {
     std::chrono::steady_clock::time_point t[32];
     PushTrace()
     {
+#ifdef GPSBB_EXPERIMENTS
         const char *e = getenv("GPSBB_PUSH_TRACE");
         if (e)
             limit_ms = atof(e);
+#endif
     }
     void start() { n = 0; mark("start"); }
     void mark(const char *w)
@@ -751,24 +769,41 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
      * at most one chip change and at most EV_KC_MAX table-index changes and the I sums stay below 2^15. */
     b->ev = !fixed && h->opt_synth_kernel != 1 && ev_plan(ch, nblocks, nch, delt, b->h_evc);
     b->ev_dense = false;
+    b->ev_all_dense = b->ev;
     if (b->ev)
-        for (size_t k = 0; k < nbc && !b->ev_dense; k++)
-            b->ev_dense = b->h_evc[k].kc == EV_KC_DENSE;
+        for (size_t k = 0; k < nbc; k++) {
+            b->ev_dense = b->ev_dense || b->h_evc[k].kc == EV_KC_DENSE;
+            b->ev_all_dense = b->ev_all_dense && (ch[k].prn <= 0 || b->h_evc[k].kc == EV_KC_DENSE);
+        }
+    b->ev_all_dense = b->ev_all_dense && b->ev_dense;
     PUSH_MARK("ev_plan");
 
     /* where the pre-pass runs and where the carrier chain is resolved: decided here, once, for all runs of the batch */
     b->host_seed = host_seeding_wanted(b);
-    b->chain_dev = !fixed && (flags & GPSBB_CHAIN_CARRIER) && (nblocks > 1 || b->d_carry) && h->opt_chain_where != 1 &&
-                   !b->host_seed;
+    const bool chained = !fixed && (flags & GPSBB_CHAIN_CARRIER) && (nblocks > 1 || b->d_carry);
+    b->chain_dev = chained && h->opt_chain_where != 1 && !b->host_seed;
     b->chain_fix_seq = h->opt_chain_where == 2;
     b->chain_starts = b->chain_dev && !b->ev;
-    /* The device-side chain cuts blocks into segments of about CHAIN_SEG_TILES tiles that are chained like blocks: a
-     * walk takes as long as its chain whatever the batch (0.47 us per row: a 5 kHz carrier has 7 000 rows in a
-     * 2.5 M-sample block), so four segments per block make the two walks of a pre-pass four times shorter. */
+    /* The device-side chain cuts blocks into SEGMENTS that are chained like blocks: a walk takes as long as its chain
+     * whatever the batch (0.47 us per row; a 5 kHz carrier has 7 000 rows per 0.1 s of signal, at any sample rate), so
+     * segments of about CHAIN_SEG_ROWS rows make the two walks of a pre-pass that many times shorter.  (Tried for batches
+     * of independent blocks as well, every block's first segment starting a chain: the five dependent kernels of the
+     * chain cost more than the shorter walks save — M1 geometry 1.77e11 -> 1.45e11 samples/s — so those keep k_walk<0>.) */
     b->nseg = 1;
     if (b->chain_dev && !b->chain_starts) { /* (k_seed, the per-sample kernel's pre-pass, walks whole blocks) */
-        int n = (b->ntiles + CHAIN_SEG_TILES / 2) / CHAIN_SEG_TILES;
-        b->nseg = n < 1 ? 1 : (n > CHAIN_SEG_MAX ? CHAIN_SEG_MAX : n);
+        double rows_max = 0.0;
+        for (size_t k = 0; k < nbc; k++)
+            if (ch[k].prn > 0) {
+                const double sa = std::fabs(ch[k].f_carr * delt);
+                const double r = sa > 0.0 ? ((double)nsamp * sa + 1.0) * (2.0 - std::log2(sa)) : 1.0;
+                rows_max = r > rows_max ? r : rows_max;
+            }
+        int n = (int)(rows_max / (double)CHAIN_SEG_ROWS + 0.5);
+        const int n_cap = b->ntiles / CHAIN_SEG_MIN_TILES;
+        n = n > CHAIN_SEG_MAX ? CHAIN_SEG_MAX : n;
+        n = n > n_cap ? n_cap : n;
+        n = n < 1 ? 1 : n;
+        b->nseg = n;
     }
     b->seg_tiles = (b->ntiles + b->nseg - 1) / b->nseg;
     b->nseg = (b->ntiles + b->seg_tiles - 1) / b->seg_tiles; /* no empty last segment */
@@ -826,8 +861,8 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     HIPCHK(h, (hipError_t)b->d_tile_ctr.reserve((size_t)NSETS * (size_t)nblocks)); /* one set of counters per table set */
     /* table sets = pre-passes in flight + 1: the pre-pass of either kernel takes longer than the synthesis it feeds
      * (M1 geometry, per-sample kernel: two sets 6.6e10, three 7.7e10 samples/s), the chained ones longer still */
-    const bool chain_maybe_dev = (flags & GPSBB_CHAIN_CARRIER) && !fixed && nblocks > 1 && h->opt_chain_where != 1;
-    b->nsets = chain_maybe_dev ? 4 : 3;
+    b->nsets = (int)GPSBB_KNOB_LONG("GPSBB_NSETS", b->chain_dev ? 4 : 3);
+    b->nsets = b->nsets < 2 ? 2 : (b->nsets > NSETS ? NSETS : b->nsets);
     b->nsets = b->nsets > b->max_sets ? b->max_sets : b->nsets;
     for (int set = 0; set < b->nsets; set++) {
         HIPCHK(h, (hipError_t)b->d_end[set].reserve(nbc));
@@ -1007,7 +1042,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
             /* k_walk keeps the lanes of a wavefront in lockstep: a turn of its loop costs the same however many
              * lanes take part, so wavefronts are full, the carrier chains by descending |f_carr| (a wavefront runs
              * as long as its longest chain) and the longest ones first */
-            static const size_t lanes_per_wave = getenv("GPSBB_WALK_LANES") ? (size_t)atol(getenv("GPSBB_WALK_LANES")) : 64;
+            const size_t lanes_per_wave = (size_t)GPSBB_KNOB_LONG("GPSBB_WALK_LANES", 64);
             waves_of(carr.data(), nvbc, lanes_per_wave, (int32_t)nbc);
             b->carr_lanes = (int)order.size();
             waves_of(code.data(), nbc, 64, 0);
@@ -1353,8 +1388,8 @@ int host_pinned_reserve(void **p, size_t *cap, size_t bytes)
 /* where the NCO tables of a run are built: by size (default), or as GPSBB_OPT_SEED_WHERE says (tests run both ways) */
 static bool host_seeding_wanted(const gpsbb_batch *b)
 {
-    static const bool off = getenv("GPSBB_DEVICE_SEED_ONLY") != nullptr;
-    static const size_t lim = getenv("GPSBB_HOST_SEED_MAX") ? (size_t)atol(getenv("GPSBB_HOST_SEED_MAX")) : HOST_SEED_MAX_CHANNELS;
+    const bool off = GPSBB_KNOB_SET("GPSBB_DEVICE_SEED_ONLY");
+    const size_t lim = (size_t)GPSBB_KNOB_LONG("GPSBB_HOST_SEED_MAX", HOST_SEED_MAX_CHANNELS);
     if (b->h->opt_seed_where)
         return b->h->opt_seed_where == 2;
     return !off && (size_t)b->nblocks * b->nch <= lim;
@@ -1435,7 +1470,7 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.seed_order = b->d_seed_order.p;
     p.seed_lanes = (int)b->h_seed_order.size();
     p.ev = b->ev ? 1 : 0;
-    static const int ev_chunk = getenv("GPSBB_EV_CHUNK") ? atoi(getenv("GPSBB_EV_CHUNK")) : EV_CHUNK;
+    const int ev_chunk = (int)GPSBB_KNOB_LONG("GPSBB_EV_CHUNK", EV_CHUNK);
     p.ev_chunk = ev_chunk < 1 ? 1 : ev_chunk;
     p.tile_x = b->d_tile_x[set].p;
     p.tile_nav = b->d_tile_nav[set].p;
@@ -1489,7 +1524,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         /* a stream's slot (one table set): consecutive pushes take the seeding streams in turn, so that as many
          * pre-passes are in flight (a pre-pass is a chain of latency-bound kernels: ~12 ms whatever the size of the
          * push, and the ring delivers one push per (that / streams)) */
-        static const unsigned nseed = getenv("GPSBB_STREAM_SEED_STREAMS") ? (unsigned)atoi(getenv("GPSBB_STREAM_SEED_STREAMS")) : STREAM_SEED_STREAMS;
+        const unsigned nseed = (unsigned)GPSBB_KNOB_LONG("GPSBB_STREAM_SEED_STREAMS", STREAM_SEED_STREAMS);
         HIPCHK(h, seed_stream_at(h, b->stream_turn % (nseed >= 1 && nseed <= (unsigned)SEED_STREAMS_MAX ? nseed : STREAM_SEED_STREAMS), &ss));
     }
     if (b->upload_done)
@@ -1510,7 +1545,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         if (rc != GPSBB_OK)
             return rc;
     } else if (b->ev) {
-        static const bool old_seed = getenv("GPSBB_EV_KSEED") != nullptr; /* experiment: the one-kernel pre-pass */
+        const bool old_seed = GPSBB_KNOB_SET("GPSBB_EV_KSEED"); /* experiment: the one-kernel pre-pass */
         if (old_seed) {
             hipLaunchKernelGGL(k_seed<true>, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, ss, p);
         } else {
@@ -1572,7 +1607,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
 
     /* off by default: +2 % on a stream of pushes, but overlapping kernels make the per-launch time (the roofline figure)
      * meaningless and re-runs of a resident batch get slower */
-    static const bool one_cs = getenv("GPSBB_TWO_COMPUTE_STREAMS") == nullptr;
+    const bool one_cs = !GPSBB_KNOB_SET("GPSBB_TWO_COMPUTE_STREAMS");
     /* consecutive launches take the two synthesis streams in turn — they work on different table sets (or, slots of
      * a ring, different batches) — except re-runs of a batch that has a single table set */
     hipStream_t sc = h->s_compute;
@@ -1591,12 +1626,14 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         const long wg_slots = (long)(h->sm_count > 0 ? h->sm_count : 256);
         const long chunks = ((long)b->ntiles + p.ev_chunk - 1) / p.ev_chunk;
         const long max_useful = (chunks + EV_WAVES - 1) / EV_WAVES;
-        static const long oversub = getenv("GPSBB_EV_OVERSUB") ? atol(getenv("GPSBB_EV_OVERSUB")) : 3;
-        static const long min_wg = getenv("GPSBB_EV_MIN_WG") ? atol(getenv("GPSBB_EV_MIN_WG")) : 3;
+        const long oversub = GPSBB_KNOB_LONG("GPSBB_EV_OVERSUB", 3);
+        const long min_wg = GPSBB_KNOB_LONG("GPSBB_EV_MIN_WG", 3);
         long want = (wg_slots * oversub + b->nblocks - 1) / b->nblocks;
         want = want < min_wg ? min_wg : want;
         want = want > max_useful ? max_useful : want;
-        if (b->ev_dense)
+        if (b->ev_all_dense)
+            hipLaunchKernelGGL(k_synth_pd, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(PdLds), sc, p, d_iq);
+        else if (b->ev_dense)
             hipLaunchKernelGGL(k_synth_ev_dense, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), sc, p, d_iq);
         else
             hipLaunchKernelGGL(k_synth_ev, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), sc, p, d_iq);
@@ -1611,7 +1648,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         const long wg_slots = (long)(h->sm_count > 0 ? h->sm_count : 256) * 2;
         const long chunks = ((long)b->ntiles + TILE_CHUNK - 1) / TILE_CHUNK;
         const long max_useful = (chunks + WAVES_PER_WG - 1) / WAVES_PER_WG;
-        static const long oversub = getenv("GPSBB_OVERSUB") ? atol(getenv("GPSBB_OVERSUB")) : 12;
+        const long oversub = GPSBB_KNOB_LONG("GPSBB_OVERSUB", 12);
         long want = (wg_slots * oversub + b->nblocks - 1) / b->nblocks;
         want = want < 1 ? 1 : (want > max_useful ? max_useful : want);
         const int gx = (int)want;
@@ -2028,8 +2065,8 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
          * blocks, the phase carried from push to push in device memory; for either synthesis kernel), on host
          * threads — sequential per channel — for pushes small enough to be seeded on the host.  A stream may
          * change sides between pushes: the carry then moves across, which costs a synchronisation. */
-        static const size_t host_lim = getenv("GPSBB_HOST_SEED_MAX") ? (size_t)atol(getenv("GPSBB_HOST_SEED_MAX")) : HOST_SEED_MAX_CHANNELS;
-        static const bool dev_only = getenv("GPSBB_DEVICE_SEED_ONLY") != nullptr;
+        const size_t host_lim = (size_t)GPSBB_KNOB_LONG("GPSBB_HOST_SEED_MAX", HOST_SEED_MAX_CHANNELS);
+        const bool dev_only = GPSBB_KNOB_SET("GPSBB_DEVICE_SEED_ONLY");
         const bool dev = h->opt_chain_where != 1 &&
                          (h->opt_seed_where == 1 || (h->opt_seed_where == 0 && (dev_only || nbc > host_lim)));
         if (!s->carry) {
@@ -2137,8 +2174,8 @@ extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
     HIPCHK(h, hipStreamWaitEvent(cs, b->last_done, 0));
     PUSH_MARK("wait");
     if (sl.h_iq) {
-        static const bool sdma = getenv("GPSBB_GATHER_SDMA") != nullptr; /* experiment: the runtime's copy instead */
-        static const int gwg = getenv("GPSBB_GATHER_WGS") ? atoi(getenv("GPSBB_GATHER_WGS")) : 32;
+        const bool sdma = GPSBB_KNOB_SET("GPSBB_GATHER_SDMA"); /* experiment: the runtime's copy instead */
+        const int gwg = (int)GPSBB_KNOB_LONG("GPSBB_GATHER_WGS", 32);
         if (sdma) {
             HIPCHK(h, hipMemcpyAsync(sl.h_iq, b->d_iq.p, (size_t)s->bps * s->nsamp * 4, hipMemcpyDeviceToHost, cs));
         } else {
@@ -2442,6 +2479,7 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
     return GPSBB_OK;
 }
 
+#ifdef GPSBB_EXPERIMENTS
 /* ---- test hooks (gpsbb_testhooks.h): the shared NCO code, compiled for the host -------------------- */
 
 extern "C" double gpsbb_test_carr_jump(double x, double s, long long n) { return carr_jump(x, s, n); }
@@ -2526,3 +2564,4 @@ extern "C" unsigned long long gpsbb_test_row_bound(int kind, double s_abs, int n
 {
     return kind == NCO_CODE ? row_bound(s_abs, 1023.0, 9, nsamp) : row_bound(s_abs, 1.0, -1, nsamp);
 }
+#endif /* GPSBB_EXPERIMENTS */

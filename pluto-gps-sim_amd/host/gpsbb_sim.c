@@ -31,6 +31,9 @@ static void usage(void)
 
 int main(int argc, char **argv)
 {
+    /* libgpsbb keeps up to nine HIP streams busy; the runtime's default of four hardware queues would make unrelated
+     * streams share one.  This is the host's call (before its first HIP call); the library does not touch the environment. */
+    setenv("GPU_MAX_HW_QUEUES", "12", 0);
     gpsfe_config_t cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.pos[0] = 35.681298; /* default static location: Tokyo (c:2266-2268) */

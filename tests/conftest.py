@@ -4,6 +4,10 @@ import sys
 
 import pytest
 
+# The library keeps up to nine HIP streams busy; the runtime's default of four hardware queues would make unrelated
+# streams share a queue.  A host sets this before its first HIP call; the library reads no environment.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+
 try:  # torch bundles its own libamdhip64: import it BEFORE libgpsbb.so is loaded so both share one HIP runtime
     import torch  # noqa: F401
 except Exception:  # pragma: no cover

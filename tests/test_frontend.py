@@ -169,7 +169,7 @@ def test_feed_back_keeps_a_newly_allocated_channels_own_phase(fe_pkg):
     want = z["desc"].view(pkg.CHAN_DTYPE).reshape(len(blocks), -1)
     assert want["prn"][1][10] == 11 and want["prn"][2][10] == 18
     fe = pkg.FrontEnd(os.path.join(GOLDEN, "dense3540.14n"), llh=SITE, max_chan=16, start=(2014, 12, 20, 1, 20, 0.0))
-    lib = pkg.lib()
+    lib = pkg.exp_lib()
     for b in range(max(blocks) + 1):
         ch = fe.next_block()
         if b in blocks:

@@ -58,7 +58,7 @@ def carr_cases(rng, n):
 
 
 def test_carr_jump_random(pkg):
-    L = pkg.lib()
+    L = pkg.exp_lib()
     rng = random.Random(1234)
     for x0, s in carr_cases(rng, 60):
         n = rng.choice([1, 7, 1000, 30000, 300000])
@@ -68,7 +68,7 @@ def test_carr_jump_random(pkg):
 
 
 def test_carr_jump_edge_cases(pkg):
-    L = pkg.lib()
+    L = pkg.exp_lib()
     cases = [
         (0.0, 1e-4), (0.0, -1e-4), (1.0, 1e-4), (1.0, -1e-4), (1.0, 0.0), (0.5, 0.0), (0.25, -0.0),
         (0.5, 2.0 ** -10), (0.5, -(2.0 ** -10)),              # step with a 1-bit mantissa: ties everywhere
@@ -86,7 +86,7 @@ def test_carr_jump_edge_cases(pkg):
 
 
 def test_code_jump_random(pkg):
-    L = pkg.lib()
+    L = pkg.exp_lib()
     rng = random.Random(99)
     for _ in range(40):
         fs = rng.choice(FS)
@@ -101,7 +101,7 @@ def test_code_jump_random(pkg):
 
 
 def test_code_jump_edges(pkg):
-    L = pkg.lib()
+    L = pkg.exp_lib()
     for x0, s in [(0.0, 1.023), (1022.999999, 1.5), (1022.5, 0.5), (512.0, 0.25), (0.0, 0.04092), (1023.0 - 2.0 ** -43, 0.3)]:
         for n in (1, 2, 100, 4000, 100000):
             want, w = brute_code(x0, s, n)
@@ -111,7 +111,7 @@ def test_code_jump_edges(pkg):
 
 
 def rows_for(pkg, kind, x0, s, nav0, nsamp):
-    L = pkg.lib()
+    L = pkg.exp_lib()
     cap = int(L.gpsbb_test_row_bound(kind, abs(s), nsamp))
     rows = np.zeros(cap, pkg.ROW_DTYPE)
     xe, ne = C.c_double(), C.c_uint()
@@ -170,7 +170,7 @@ def test_rows_code_and_nav(pkg):
 
 
 def rows_f64_for(pkg, kind, x0, s, nav0, nsamp):
-    L = pkg.lib()
+    L = pkg.exp_lib()
     cap = int(L.gpsbb_test_row_bound(kind, abs(s), nsamp))
     rows = np.zeros(cap, pkg.ROW_DTYPE)
     xe, ne = C.c_double(), C.c_uint()

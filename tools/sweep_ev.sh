@@ -1,4 +1,5 @@
 #!/bin/bash
+export GPSBB_PY_LIB=exp   # the environment knobs below exist in the experiments build only (libgpsbb_exp.so)
 # sweep launch parameters of k_synth_ev (synth-only timing)
 P='import json,sys
 for l in sys.stdin:

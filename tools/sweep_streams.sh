@@ -1,3 +1,4 @@
+export GPSBB_PY_LIB=exp   # the environment knobs below exist in the experiments build only (libgpsbb_exp.so)
 # sweep of the stream ring's depth and the number of pre-pass streams (bench.py's headline leg only)
 # usage: bash tools/sweep_streams.sh "8 16 8" "4 8 6" ...   (seed streams, hardware queues, ring depth)
 if [ $# -eq 0 ]; then set -- "8 16 8" "8 16 12" "6 12 8" "4 8 6"; fi

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GPSBB_PY_LIB=exp   # the environment knobs below exist in the experiments build only (libgpsbb_exp.so)
 for m in "" "-DGPSBB_EXP_NOROWSTORE"; do
   make -C pluto-gps-sim_amd/csrc EXTRA="$m" -B >/dev/null 2>&1
   for l in 64 32 16 8; do

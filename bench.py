@@ -218,7 +218,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median is reported")
     ap.add_argument("--push-blocks", type=int, default=PUSH_BLOCKS, help="0.1 s blocks per push")
-    ap.add_argument("--depth", type=int, default=8, help="ring slots")
+    ap.add_argument("--depth", type=int, default=6, help="ring slots")
     ap.add_argument("--nch", type=int, default=16)
     ap.add_argument("--fs", type=float, default=25e6)
     ap.add_argument("--nsamp", type=int, default=2500000)
@@ -450,11 +450,11 @@ def main():
             res["gather"] = gather
     if rank == 0 and not args.no_extras:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        rch = pkg.synth_descriptors(PB, nch=nch, seed=0x5EED)
+        rch = mine[:PB]  # the shard's first push: the headline's own descriptors, resident
         r0, ceil_gbs = resident_leg(pkg, synth, torch, rch, delt, nsamp, 0, 20, 4, dev)
         r1, _ = resident_leg(pkg, synth, torch, rch, delt, nsamp, pkg.CHAIN_CARRIER, 20, 5, dev)
         res["resident"] = {"independent_blocks": r0, "chained": r1, "unit": "IQ samples/s",
-                           "note": "one 400-block batch re-run 20 times, descriptors and plans resident in HBM (round 1's value)"}
+                           "note": "the stream's first push (%d blocks) as one batch re-run 20 times, descriptors and plans resident in HBM (round 1's kind of value)" % PB}
         res["roofline"]["write_ceiling_measured_GBs"] = ceil_gbs
         res["roofline"]["frac_of_measured_ceiling"] = achieved / ceil_gbs
         # the same kernel with the GPU to itself (tables already built): what the pre-passes running beside it cost
@@ -465,9 +465,18 @@ def main():
         # the reference-faithful geometry (12 ch, 2.6 MS/s, 300 000-sample blocks)
         mch = pkg.synth_descriptors(1000, nch=12, seed=0xF00D)
         m1, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, 0, 10, 3, dev)
-        m1_kernel = {1: "k_synth", 2: "k_synth_ev_dense (every channel evaluated per sample on the in-tile model)"}.get(
+        m1_kernel = {1: "k_synth", 2: "k_synth_pd (every channel evaluated per sample on the in-tile model)"}.get(
             synth.info(pkg.INFO_LAST_KERNEL), "?")
-        res["m1"] = {"gpu": m1, "unit": "IQ samples/s",
+        m1s, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, 0, 10, 5, dev, synth_only=True)
+        m1c, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, pkg.CHAIN_CARRIER, 10, 4, dev)
+        m1_alg = 4.0 * mch.shape[0] * 300000
+        res["m1"] = {"gpu": m1, "gpu_chained_on_the_device": m1c, "unit": "IQ samples/s",
+                     "roofline": {"bound": "hbm", "kernel": "k_synth_pd", "ms_per_launch": m1["synth_kernel_ms"],
+                                  "achieved": m1_alg / (m1["synth_kernel_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": m1_alg / (m1["synth_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "alone": {"ms_per_launch": m1s["synth_kernel_ms"],
+                                            "frac": m1_alg / (m1s["synth_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                  "note": "VALU-issue-bound (about 31 issue cycles per channel-sample), not HBM-bound: DESIGN.md"},
                      "workload": "12 ch, fs 2.6e6 S/s, 300000-sample blocks, 1000 independent blocks per step; synthesis kernel " + m1_kernel}
         if not args.no_cpu:
             import oracle_binding as ob

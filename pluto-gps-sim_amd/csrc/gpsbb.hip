@@ -178,23 +178,29 @@ bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vec
             K.S = aS; /* a falling carrier is walked mirrored: phase -y, step |S| */
             K.sc = sc;
             K.rsc = 1.0 / sc;
-            K.thrC = 0.5 - (EV_MODEL_ERR * K.rsc + EV_T_EPS);
             K.down = S < 0.0;
+            /* how far an estimated change position may be off (in samples): the model's error over the step, plus the
+             * roundings of the guard format (one unit in the last place is 2^-32 there) */
+            const double wC = EV_MODEL_ERR * K.rsc + EV_T_EPS;
+            double wK = 0.0;
             if (aS == 0.0) {
                 K.rS = 0x1p+1000; /* the index never changes */
-                K.thrK = 0.25;
                 K.kc = 1;
             } else if (aS < 0x1p-28) {
                 K.rS = 0x1p+1000; /* the model error exceeds a quarter of a step: every run is recomputed exactly */
-                K.thrK = 0.25;
                 K.kc = -1;
             } else {
                 K.rS = 1.0 / aS;
-                const double w = EV_MODEL_ERR * K.rS + EV_T_EPS;
-                K.thrK = 0.5 - w;
-                const double kc = std::floor((reach + w) * aS) + 1.0;
+                wK = EV_MODEL_ERR * K.rS + EV_T_EPS;
+                const double kc = std::floor((reach + wK) * aS) + 1.0;
                 K.kc = kc > (double)EV_KC_MAX ? EV_KC_DENSE : (int)kc; /* too many index changes per run: per sample */
             }
+            /* one bias W for everything tested in the channel (first-sample fractions: W >= the model error in index units /
+             * chips; change positions: W >= wK, wC): the tests are then all "low word of the biased quantity < 2W" */
+            K.W = std::max(std::max(wK, wC), EV_T_EPS);
+            K.danger = K.W >= 0.25 ? 0x80000000u : (uint32_t)std::ceil(2.0 * K.W * 4294967296.0) + 1u;
+            K.tK0 = K.rS * (1.0 + K.W) + 0x1p+20 + K.W;
+            K.tC0 = K.rsc * (1.0 + K.W) + 0x1p+20 + K.W;
             if (dense_code && K.kc > 0)
                 K.kc = EV_KC_DENSE;
         }
@@ -280,7 +286,8 @@ constexpr int SEED_STREAMS_MAX = 8;
 constexpr int CHAIN_SEG_ROWS = 1750;    /* rows of a carrier chain per segment of the device-side chain, about (see batch_setup) */
 constexpr int CHAIN_SEG_MIN_TILES = 16; /* ... but no segment shorter than this many tiles */
 constexpr int CHAIN_SEG_MAX = 8;        /* segments per block at most */
-constexpr unsigned STREAM_SEED_STREAMS = 6; /* pre-passes of a stream's pushes in flight (GPSBB_STREAM_SEED_STREAMS) */
+constexpr unsigned STREAM_SEED_STREAMS = 4; /* pre-passes of a stream's pushes in flight (measured with 2 .. 6 and rings of 4 .. 8 slots: 4.1 .. 4.3e11
+                                               samples/s, all within 5 %: the pre-pass is 4 ms now, the synthesis 2.2) */
 
 struct gpsbb {
     int device = 0;

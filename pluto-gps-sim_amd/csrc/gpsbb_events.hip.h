@@ -58,8 +58,15 @@ constexpr int EV_ROW_DISCARD = 15;                 /* D row of changes that fall
 
 /* bound used for |model - truth| (table-index units / chips); the derivation above gives < 2^-33.9 */
 #define EV_MODEL_ERR 0x1p-32
-/* a breakpoint estimate t = g * (1/|step|) carries a few roundings on top of the model error */
-#define EV_T_EPS 0x1p-44
+/* The quantities a lane tests travel in GUARD FORMAT: 2^20 + value, so that one unit in the last place is 2^-32, the
+ * double's low word IS the fraction (in units of 2^-32) and the low bits of its high word ARE the integer part — index,
+ * chip and row come out with one v_and, and "within the error of an integer" is a comparison of low words.  Every
+ * tested quantity also carries the channel's bias +W (EvConst::W >= its error bound): floor(value + W) = floor(truth)
+ * unless the low word of the biased value is below 2W (EvConst::danger), and the minimum of the low words of everything
+ * a lane tests for a channel is compared once.  EV_T_EPS: the roundings of that format (a handful of operations at half
+ * a unit each) on top of the model error. */
+#define EV_T_EPS 0x1p-30
+#define EV_GUARD 0x1p+20
 
 /* LDS image of one workgroup */
 struct EvLds {
@@ -67,9 +74,9 @@ struct EvLds {
                                                     channels with a falling carrier: of index 511 - k */
     uint32_t D[EV_WAVES][16][64];                /* difference arrays: row j-1 holds the change at sample j of the lane's
                                                     run (row 15 = discard), one column per lane */
-    double tstate[EV_WAVES][2][2 * GPSBB_MAX_CHAN]; /* per wavefront, two tiles deep: the tile's exact states, column
-                                                    2*channel = code phase, 2*channel+1 = carrier phase*512 (512 - that
-                                                    for a falling carrier) */
+    double tstate[EV_WAVES][2][2 * GPSBB_MAX_CHAN]; /* per wavefront, two tiles deep: the tile's exact states in guard format
+                                                    with the channel's bias (2^20 + W + state), column 2*channel = code
+                                                    phase, 2*channel+1 = carrier phase*512 (512 - that for a falling carrier) */
     uint16_t chip2[GPSBB_MAX_CHAN][EV_CHIP_LEN]; /* low byte: 0 where codeCA of chip c mod 1023 is +1, 0xff where -1;
                                                     high byte: the same for chip c+1 */
 };
@@ -128,17 +135,19 @@ __device__ __noinline__ uint32_t ev_exact_run(EvLds &L, int wave, int lane, int 
 
 /* per-channel constants of the fast path (scalar registers) */
 struct EvK {
-    double S, rS, thrK, sc, rsc, thrC;
+    double S, rS, tK0, sc, rsc, tC0;
+    uint32_t danger;
 };
 __device__ __forceinline__ EvK ev_load_k(const EvConst *kb, int i)
 {
     EvK k;
     k.S = scalar_load(&kb[i].S);
     k.rS = scalar_load(&kb[i].rS);
-    k.thrK = scalar_load(&kb[i].thrK);
+    k.tK0 = scalar_load(&kb[i].tK0);
     k.sc = scalar_load(&kb[i].sc);
     k.rsc = scalar_load(&kb[i].rsc);
-    k.thrC = scalar_load(&kb[i].thrC);
+    k.tC0 = scalar_load(&kb[i].tC0);
+    k.danger = scalar_load(&kb[i].danger);
     return k;
 }
 
@@ -165,18 +174,18 @@ template <int KC>
 __device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK &K, double xt, double yt, double off)
 {
     EvHalf<KC> h;
-    const double b = EV_MODEL_ERR;
+    const double sat = 15.5 + EV_GUARD; /* a change past the run's last sample: row 15, fraction one half */
     /* ---- carrier: table index of the first sample and the samples at which it changes ---- */
-    const double y0 = __fma_rn(off, K.S, yt); /* >= 0 */
+    const double y0 = __fma_rn(off, K.S, yt); /* guard format, biased: 2^20 + W + phase */
     const double fr = __builtin_amdgcn_fract(y0);
-    const int it0 = (int)y0 & 511;
-    h.um = __builtin_amdgcn_fcmp(fr, b, 4 /* olt */); /* the previous change lies within the model error of sample 0 */
-    double t = __fma_rn(-fr, K.rS, K.rS); /* (1 - fr) / |step|: samples until the next index change */
+    const int it0 = __double2hiint(y0) & 511;
+    uint32_t m = (uint32_t)__double2loint(y0); /* the previous change lies within the model error of sample 0: low word below 2W */
+    double t = __fma_rn(-fr, K.rS, K.tK0);     /* 2^20 + W + (1 - fraction) / |step|: samples until the next index change */
 #pragma unroll
     for (int k = 0; k < KC; k++) {
-        const double tq = fmin(t, 15.5);
-        h.um |= __builtin_amdgcn_fcmp(fabs(__builtin_amdgcn_fract(tq) - 0.5), K.thrK, 2 /* ogt */);
-        h.jk[k] = (int)tq; /* the change shows at sample (int)tq + 1: rows 0..14, or 15 */
+        const double tq = fmin(t, sat);
+        m = min(m, (uint32_t)__double2loint(tq));
+        h.jk[k] = __double2hiint(tq) & 15; /* the change shows at sample floor + 1: rows 0..14, or 15 */
         t += K.rS;
     }
     const uint32_t *ampi = &L.amp[i][it0];
@@ -186,12 +195,13 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK 
     /* ---- code: chip of the first sample and the sample at which it changes ---- */
     const double x0 = __fma_rn(off, K.sc, xt);
     const double frc = __builtin_amdgcn_fract(x0);
-    h.c0 = (int)x0;
-    h.um |= __builtin_amdgcn_fcmp(frc, b, 4);
-    const double tc = fmin(__fma_rn(-frc, K.rsc, K.rsc), 15.5);
-    h.um |= __builtin_amdgcn_fcmp(fabs(__builtin_amdgcn_fract(tc) - 0.5), K.thrC, 2);
-    h.jc = (int)tc;
+    h.c0 = __double2hiint(x0) & 2047;
+    const double tc = fmin(__fma_rn(-frc, K.rsc, K.tC0), sat);
+    m = min(m, min((uint32_t)__double2loint(x0), (uint32_t)__double2loint(tc)));
+    h.jc = __double2hiint(tc) & 15;
     h.ch2 = L.chip2[i][h.c0];
+    /* lanes that cannot rule out a disagreement between the model and the reference: one comparison for everything tested */
+    h.um = __builtin_amdgcn_uicmp(m, K.danger, 36 /* ult */);
     return h;
 }
 
@@ -270,11 +280,10 @@ __device__ __forceinline__ void ev_dense(EvLds &L, int wave, int lane, int i, co
                                          unsigned long long *n_exact)
 {
     const double S = scalar_load(&kb[i].S), sc = scalar_load(&kb[i].sc);
-    /* Both models carry 2^20 on top, so that one unit in the last place is 2^-32: the low word of the double then IS the
-     * fraction in units of 2^-32 and the low bits of the high word are the integer part — index, chip and the test
-     * "within the error of an integer" are integer operations on the two words.  Adding 2^20 and the fma round by up
-     * to 2^-33 each: with the model's own 2^-33.9 the band is +-3 units of 2^-32. */
-    const double y0 = __fma_rn(off, S, T.ts[2 * i + 1]) + 0x1p+20, x0 = __fma_rn(off, sc, T.ts[2 * i]) + 0x1p+20;
+    const uint32_t danger = scalar_load(&kb[i].danger);
+    /* Both models in guard format with the channel's bias (see EV_T_EPS): index, chip and the test "within the error of an
+     * integer" are integer operations on the two words. */
+    const double y0 = __fma_rn(off, S, T.ts[2 * i + 1]), x0 = __fma_rn(off, sc, T.ts[2 * i]);
     const uint32_t db = 0u - ((T.dbits >> i) & 1u), dn = 0u - ((T.dnext >> i) & 1u);
     unsigned long long um = 0ull;
     uint32_t v[SPT];
@@ -282,8 +291,7 @@ __device__ __forceinline__ void ev_dense(EvLds &L, int wave, int lane, int i, co
     for (int j = 0; j < SPT; j++) {
         const double yj = __fma_rn((double)j, S, y0), xj = __fma_rn((double)j, sc, x0);
         const uint32_t ylo = (uint32_t)__double2loint(yj), xlo = (uint32_t)__double2loint(xj);
-        um |= __builtin_amdgcn_uicmp(ylo + 3u, 7u, 36 /* ult */);
-        um |= __builtin_amdgcn_uicmp(xlo + 3u, 7u, 36);
+        um |= __builtin_amdgcn_uicmp(min(ylo, xlo), danger, 36 /* ult */);
         const int it = __double2hiint(yj) & 511, ci = __double2hiint(xj) & 2047;
         uint32_t m = (uint32_t)(int32_t)(int8_t)(L.chip2[i][ci] & 0xffu);
         m ^= DF ? (ci >= 1023 ? dn : db) : db;
@@ -457,6 +465,7 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
     const double *__restrict__ tx = txb + (size_t)(chain_lane ? lane : 0) * ntw;
     const uint32_t *__restrict__ tn = p.tile_nav + ((size_t)b * p.nch + (lane < p.nch ? lane : 0)) * ntw;
     const double off = (double)(lane * SPT);
+    const double guard_w = EV_GUARD + (chain_lane ? kb[lane >> 1].W : 0.0); /* this lane's chain in guard format, biased */
     unsigned long long *n_exact = p.hazards + 2;
 
     /* chunks of EV_CHUNK consecutive tiles from a per-block counter; the next chunk is asked for while the
@@ -477,7 +486,7 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         const int wt = base + pos;
         /* the tile's states -> this wavefront's LDS slot, its data bits -> scalar masks */
         if (chain_lane)
-            L.tstate[wave][buf][lane] = mirror ? 512.0 - ts_v : ts_v;
+            L.tstate[wave][buf][lane] = (mirror ? 512.0 - ts_v : ts_v) + guard_w; /* one rounding, half a unit of 2^-32 */
         EvTile T;
         T.ts = L.tstate[wave][buf];
         T.tile_x = txb + wt;
@@ -553,6 +562,10 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
                 o[j] = __builtin_amdgcn_perm(t, P, 0x07060100u); /* low half of P, high half of t (v_perm_b32) */
             }
         }
+#ifdef GPSBB_SABOTAGE /* a deliberately wrong build (make broken): bench.py's parity check must refuse it (tests/test_bench_shards.py) */
+        if (b == 1 && wt == 3 && lane == 5)
+            o[7] ^= 1u;
+#endif
         uint32_t *out = reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + n0;
         if (nvalid == SPT && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) {
             uint4 *o4 = reinterpret_cast<uint4 *>(out);

@@ -89,14 +89,18 @@ static_assert(sizeof(SynRow) == sizeof(NcoRow), "row pool is sized for NcoRow");
 struct EvConst {
     double S;     /* |carrier step| per sample in table-index units: 512 * |fl(f_carr*delt)|, exact        */
     double rS;    /* 1/|S| (2^1000 where S == 0: no index change is ever in reach)                        */
-    double thrK;  /* a carrier breakpoint estimate t is trusted when |fract(t) - 0.5| <= thrK             */
+    double tK0;   /* rS*(1 + W) + 2^20 + W: what turns the fraction of the (biased) first-sample model into the position
+                     of the next index change, in guard format (gpsbb_events.hip.h)                         */
     double sc;    /* code step per sample in chips: fl(f_code*delt)                                       */
     double rsc;   /* 1/sc                                                                                  */
-    double thrC;  /* as thrK, for the chip change                                                          */
+    double tC0;   /* as tK0, for the chip change                                                           */
+    double W;     /* the channel's bias: every tested quantity carries +W, W >= its model error             */
     int32_t kc;   /* carrier breakpoints a run of SPT samples can hold (1..4); -1: always recompute exactly */
     int32_t down; /* the carrier step is negative                                                         */
+    uint32_t danger; /* a low word (fraction in units of 2^-32) below this: the model cannot be trusted (= 2W)  */
+    uint32_t _pad;
 };
-static_assert(sizeof(EvConst) == 56, "EvConst layout");
+static_assert(sizeof(EvConst) == 72, "EvConst layout");
 
 /* Per (block, channel) scratch of the device-side carrier chain (gpsbb_walk.hip.h, k_chain_fix). */
 constexpr int CHAIN_MAX_CROSS = 20;

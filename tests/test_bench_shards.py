@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _run(world, extra, env_extra=None, timeout=600):
+def _run(world, extra, env_extra=None, timeout=600, expect_rc=0):
     env = dict(os.environ)
     env.update(env_extra or {})
     if world == 1:
@@ -35,7 +35,7 @@ def _run(world, extra, env_extra=None, timeout=600):
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + extra
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
-    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.returncode == expect_rc, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]      # ONE JSON line, from rank 0
     return json.loads(lines[0])
@@ -74,3 +74,16 @@ def test_two_ranks_through_the_device_path(pkg):
     assert two["shard_seed"]["blocks_before_the_last_shard"] == 64
     assert one["parity"]["stream_end_state_digest"] == two["parity"]["stream_end_state_digest"]
     assert one["config"]["global_samples_per_step"] == two["config"]["global_samples_per_step"]
+
+
+@pytest.mark.gpu
+def test_a_wrong_kernel_fails_the_bench(pkg):
+    """bench.py's parity check reads blocks of the timed mode's ring back and compares them with the oracle: a build of
+    the library whose synthesis kernel flips ONE bit of ONE sample (make broken) makes the run exit non-zero, with the
+    mismatch in the line."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "pluto-gps-sim_amd", "csrc"), "broken"])
+    args = ["--steps", "1", "--warmup", "1", "--repeats", "1", "--push-blocks", "8", "--nsamp", "200000", "--depth", "3",
+            "--cpu-budget", "0.2", "--parity-blocks", "2"]
+    r = _run(1, args, {"GPSBB_PY_LIB": "broken"}, expect_rc=3)
+    assert r["parity"]["mismatching_blocks"] == 1 and r["parity_checked_blocks"] == 3

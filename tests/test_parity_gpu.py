@@ -907,6 +907,76 @@ def test_config5_at_full_block_size_in_1_2_and_4_time_shards(pkg, synth, oracle,
         assert xxhash.xxh3_64_intdigest(memoryview(np.ascontiguousarray(want[0])).cast("B")) == one[b], b
 
 
+def test_config5_at_its_stated_length(pkg, synth, oracle, request):
+    """BASELINE configs[4] at its STATED length: 3600 s of the 16-channel 25 MS/s stream — 36 000 blocks of 2.5 M samples,
+    9e10 samples, 360 GB of int16 IQ — chained on the device and gathered into pinned host memory through the ring on one
+    GPU, every block digested (xxh3) as it lands.  The carrier phase at the end of every one of the 36 000 blocks equals
+    gpsbb_chain_carrier_host's sequential walk bit for bit; the digests of the first 3600 blocks equal those of the same
+    descriptors rendered as a stream of their own; two blocks from the stream's far end equal the CPU oracle's render from
+    the phase the stream reports there; no hazard.  The sustained gather rate goes to gpurun_out/ (copied to profiles/)."""
+    if request.node.callspec.params["seed_mode"] != "k_seed+auto":
+        pytest.skip("full-length run: once")
+    import json
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    import xxhash
+    import bench
+    nch, fs, nsamp, nb, bps, depth = 16, 25e6, 2500000, 36000, 36, 6
+    delt = 1.0 / fs
+    ch = bench.stream_descriptors(pkg, nb, nch)
+    synth.hazards(reset=True)
+    pool = ThreadPoolExecutor(8)
+
+    def render(nblocks):
+        digs, ends, pend = [None] * nblocks, [], {}
+        st = synth.stream(nch, delt, nsamp, bps, depth=depth, flags=pkg.CHAIN_CARRIER)
+        nslots = nblocks // bps
+        pushed = popped = 0
+        t0 = time.perf_counter()
+        while popped < nslots:
+            while pushed < nslots and st.pending < depth:
+                for f in pend.pop(pushed % depth, []):     # the slot's previous blocks have been digested
+                    f.result()
+                st.push(ch[pushed * bps:(pushed + 1) * bps])
+                pushed += 1
+            iq, e = st.pop(copy=False)
+            ends.append(e["carr_phase"].copy())
+
+            def job(k, v):
+                digs[k] = xxhash.xxh3_64_intdigest(v)
+            pend[popped % depth] = [pool.submit(job, popped * bps + k, memoryview(iq[k]).cast("B")) for k in range(bps)]
+            popped += 1
+        for fs_ in pend.values():
+            for f in fs_:
+                f.result()
+        dt = time.perf_counter() - t0
+        st.close()
+        return digs, np.concatenate(ends), dt
+
+    digs, ends, dt = render(nb)
+    assert synth.info(pkg.INFO_CHAIN_ON_DEVICE) == 1 and synth.info(pkg.INFO_LAST_KERNEL) == 2
+    assert synth.hazards(reset=True) == {"itable_512": 0, "dwrd_oob": 0}
+    starts = pkg.chain_carrier_host(np.concatenate([ch, ch[-1:]]), delt, nsamp)
+    assert ends.tobytes() == starts[1:].tobytes()                      # all 36 000 end-of-block carrier phases
+    first, _, _ = render(3600)
+    assert first == digs[:3600]
+    # the far end against the oracle: blocks nb-2, nb-1 from the phase the stream reports at the end of block nb-3
+    tail = ch[nb - 2:].copy()
+    tail["carr_phase"][0] = ends[nb - 3]
+    want_iq, want_st, _ = oracle.fill_blocks(tail, delt, nsamp, chain=True)
+    assert [xxhash.xxh3_64_intdigest(want_iq[k].tobytes()) for k in range(2)] == digs[nb - 2:]
+    assert want_st["carr_phase"].tobytes() == ends[nb - 2:].tobytes()
+    rec = {"blocks": nb, "samples": nb * nsamp, "iq_bytes": nb * nsamp * 4, "seconds": dt, "GB_per_s_to_pinned_host": nb * nsamp * 4 / dt / 1e9,
+           "samples_per_s": nb * nsamp / dt, "ring": {"slot_blocks": bps, "depth": depth},
+           "digest_of_block_digests": "%016x" % xxhash.xxh3_64_intdigest(np.asarray(digs, np.uint64).tobytes()),
+           "checks": "36000 end-of-block carrier phases == gpsbb_chain_carrier_host; first 3600 block digests == the same descriptors as a "
+                     "stream of their own; last two blocks == CPU oracle; hazards zero"}
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(rec, open(os.path.join(out, "config5_full.json"), "w"), indent=1)
+    print(json.dumps(rec))
+
+
 def test_handle_and_batch_lifecycle(pkg, oracle):
     """Create/destroy churn, one handle reused across shapes, many small blocks in one batch, API misuse."""
     import ctypes as C

@@ -9,6 +9,8 @@ print("roofline achieved %.0f GB/s frac %.4f  ms/launch %.3f  alone %s" % (r["ac
 print("prepass ms %.2f  chain %s" % (d["prepass_ms_per_launch"], json.dumps(d["device_chain"])))
 if d.get("parity"):
     print("parity checked %d mismatching %d digest %s" % (d["parity"]["checked_blocks"], d["parity"]["mismatching_blocks"], d["parity"]["stream_end_state_digest"]))
+if "m1" in d and "roofline" in d["m1"]:
+    print("m1 roofline", json.dumps(d["m1"]["roofline"])[:300])
 for k in ("resident", "m1", "gather", "cpu_baseline"):
     if k in d:
         print(k, json.dumps(d[k])[:420])

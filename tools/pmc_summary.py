@@ -25,12 +25,15 @@ def q(db, sql):
         c.close()
 
 
+KERNELS = ("k_synth_ev", "k_synth_ev_dense", "k_synth_pd", "k_synth", "k_walk<0>", "k_walk<1>", "k_walk<2>", "k_walk<3>", "k_tiles",
+           "k_chain_fix", "k_chain_fix_par<128>", "k_chain_fix_par<256>", "k_chain_prefix", "k_seed<true>", "k_seed<false>", "k_fill_ceiling",
+           "k_gather_to_host", "k_end_states_to_host")
+
+
 def short(name):
-    for k in ("k_synth_ev", "k_synth", "k_walk<1>", "k_walk<2>", "k_walk<0>", "k_tiles", "k_chain_fix", "k_chain_prefix", "k_seed",
-              "k_fill_ceiling"):
-        if k in name:
-            return k
-    return None
+    """the kernel's own name, exactly (rocprofv3 prints "[void ]gpsbb_impl::<name>(<args>)"): k_synth_ev_dense is not k_synth_ev"""
+    n = name.split("(")[0].split("::")[-1].strip()
+    return n if n in KERNELS else None
 
 
 def main():

@@ -418,7 +418,7 @@ struct gpsbb_batch {
     int nseg = 1, seg_tiles = 0; /* the device-side chain cuts every block into nseg segments (BatchDev::nseg) */
     DevBuf<unsigned long long> d_fix_end; /* k_chain_fix_par: the hand-off between its chunks (BatchDev::fix_end) */
     DevBuf<int> d_fix_flag;
-    int fix_epoch = 0, fix_chunks = 0;
+    int fix_epoch = 0, fix_chunks = 0, fix_wg = FIXP_WG_BATCH;
     bool chain_fix_seq = false;  /* k_chain_fix (blocks in order) instead of k_chain_fix_par: GPSBB_OPT_CHAIN_WHERE 2 */
     bool host_seed = false;      /* the NCO tables of this batch are built on host threads: decided at set-up, like the
                                     chain (a run never re-reads the handle's options) */
@@ -966,7 +966,9 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         HIPCHK(h, (hipError_t)b->d_start0.reserve(nvbc));
         {
             /* flags are compared with a launch number, never cleared: zeroed once, when the buffer is (re)allocated */
-            b->fix_chunks = (nblocks * b->nseg + FIXP_WG_BATCH - 1) / FIXP_WG_BATCH;
+            /* long chains (thousands of segments per channel): fewer, larger chunks — fewer hand-offs */
+            b->fix_wg = nblocks * b->nseg >= 2048 ? FIXP_WG_ALONE : FIXP_WG_BATCH;
+            b->fix_chunks = (nblocks * b->nseg + b->fix_wg - 1) / b->fix_wg;
             /* one set of flags per table set: runs of a resident batch overlap, each on its own table set */
             const size_t nf = (size_t)NSETS * GPSBB_MAX_CHAN * b->fix_chunks;
             if (nf > b->d_fix_flag.cap) {
@@ -1573,7 +1575,10 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
                 if (b->chain_fix_seq)
                     hipLaunchKernelGGL(k_chain_fix, dim3(1), dim3(64), 0, ss, p);
                 else
-                    hipLaunchKernelGGL(k_chain_fix_par<FIXP_WG_BATCH>, dim3(b->nch, b->fix_chunks), dim3(FIXP_WG_BATCH), 0, ss, p);
+                    if (b->fix_wg == FIXP_WG_ALONE)
+                        hipLaunchKernelGGL(k_chain_fix_par<FIXP_WG_ALONE>, dim3(b->nch, b->fix_chunks), dim3(FIXP_WG_ALONE), 0, ss, p);
+                    else
+                        hipLaunchKernelGGL(k_chain_fix_par<FIXP_WG_BATCH>, dim3(b->nch, b->fix_chunks), dim3(FIXP_WG_BATCH), 0, ss, p);
                 if (b->d_carry && b->ev_fix)
                     HIPCHK(h, hipEventRecord(b->ev_fix, ss));
             } else {
@@ -1602,7 +1607,10 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
             if (b->chain_fix_seq)
                 hipLaunchKernelGGL(k_chain_fix, dim3(1), dim3(64), 0, ss, pc);
             else
-                hipLaunchKernelGGL(k_chain_fix_par<FIXP_WG_BATCH>, dim3(b->nch, b->fix_chunks), dim3(FIXP_WG_BATCH), 0, ss, pc);
+                if (b->fix_wg == FIXP_WG_ALONE)
+                    hipLaunchKernelGGL(k_chain_fix_par<FIXP_WG_ALONE>, dim3(b->nch, b->fix_chunks), dim3(FIXP_WG_ALONE), 0, ss, pc);
+                else
+                    hipLaunchKernelGGL(k_chain_fix_par<FIXP_WG_BATCH>, dim3(b->nch, b->fix_chunks), dim3(FIXP_WG_BATCH), 0, ss, pc);
             if (b->d_carry && b->ev_fix)
                 HIPCHK(h, hipEventRecord(b->ev_fix, ss));
         }

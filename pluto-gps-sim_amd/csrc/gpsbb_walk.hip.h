@@ -1006,15 +1006,17 @@ __global__ __launch_bounds__(FIXP_WG) __attribute__((amdgpu_waves_per_eu(4, 4)))
     r_last.walked = false;
     if (mine && !on) {
         my.isconst = 1; /* an idle channel ends at 0.0 = endB */
-    } else if (on && !(cont && t == 0)) { /* (the chunk's first block, if it continues the chunk before: the first head) */
-        /* a block that starts a chain of its own is a constant from the start; any other is tried from the four start
+    } else if (on) {
+        /* a block whose start phase is known — one that starts a chain of its own, and the very first one (a stream: it
+         * starts where the push before ended) — is a constant from the start; any other is tried from the four start
          * phases endB_(b-1) + j*u */
-        const bool known = !cont;
+        const bool known = !cont || b == 0;
+        const double xk = (cont && b == 0) ? p.carry->exact_end[i] : in.carr_phase; /* (b == 0 continues only in a stream) */
         bool regular = true;
         double kk[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
         for (int j = 0; j < (known ? 1 : 4) && regular; j++) {
-            const double xj = known ? in.carr_phase : endB_prev + (double)j * 0x1p-53;
+            const double xj = known ? xk : endB_prev + (double)j * 0x1p-53;
             const FixOut r = fix_block<false>(p, in, k, on, xj, false);
             const double o = (r.end - in.endB) * 0x1p+53;
             if (known) {
@@ -1040,6 +1042,35 @@ __global__ __launch_bounds__(FIXP_WG) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 my.v[j] = kk[j];
         }
     }
+    /* ---- the maps of the chunk composed, lane t: blocks c0 .. c0 + t (still nothing that depends on other chunks) ---- */
+    FixMap acc = my;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const FixMap prev = fix_map_shfl_up(acc, off);
+        if (lane >= off)
+            acc = fix_compose(acc, prev);
+    }
+    if (lane == 63) {
+        L.wc[wave] = acc.isconst;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            L.wv[wave][j] = acc.v[j];
+    }
+    if (t == 0) {
+        L.first_bad = FIXP_WG;
+        L.head_end = endB_prev; /* pass B's end of the block before the chunk: what the incoming offset is counted from */
+    }
+    __syncthreads();
+    for (int w = wave - 1; w >= 0 && !acc.isconst; w--) { /* (a constant absorbs everything before it) */
+        FixMap pw;
+        pw.isconst = L.wc[w];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            pw.v[j] = L.wv[w][j];
+        acc = fix_compose(acc, pw);
+    }
+    const double endB_before = L.head_end;
+    __syncthreads();
     /* ---- where the chunk before this one ended: the only thing chunks wait for each other for ---- */
     if (t == 0) {
         double cs = p.carry ? p.carry->exact_end[i] : 0.0; /* a stream: where the push before this one ended */
@@ -1056,10 +1087,18 @@ __global__ __launch_bounds__(FIXP_WG) __attribute__((amdgpu_waves_per_eu(4, 4)))
     __syncthreads();
     const double chunk_start = L.head_end;
     __syncthreads();
+    if (chunk > 0) {
+        /* everything before the chunk as one constant: the offset its first block starts with */
+        FixMap inc;
+        inc.isconst = 1;
+        inc.v[0] = (chunk_start - endB_before) * 0x1p+53;
+        inc.v[1] = inc.v[2] = inc.v[3] = 0.0;
+        acc = fix_compose(acc, inc);
+    }
     /* ---- guess, check, move the head: until every block's start phase is the true one, then commit ---- */
-    int lo = 0;
+    int lo = -1; /* the head: the last block whose end is known to be true (-1: the block before the chunk) */
     double lo_start = chunk_start; /* the true end of block lo - 1 (wave-uniform) */
-    bool committed = false, final = false;
+    bool committed = false, final = false, pre = true; /* pre: first round, the maps are composed already */
     double prev_end = 0.0;
     for (;;) {
         const bool head = t == lo && mine && !final;
@@ -1086,40 +1125,43 @@ __global__ __launch_bounds__(FIXP_WG) __attribute__((amdgpu_waves_per_eu(4, 4)))
         }
         if (final)
             break;
-        if (head) {
-            my.isconst = 1;
-            my.v[0] = (r_last.end - in.endB) * 0x1p+53;
-        }
-        /* inclusive scan of the maps over [lo, n): inside the wavefront by shuffles ... */
-        FixMap acc = my;
-        if (t < lo) {
-            acc.isconst = 0;
-            acc.v[0] = acc.v[1] = acc.v[2] = acc.v[3] = 0.0;
-        }
+        if (!pre) {
+            if (head) {
+                my.isconst = 1;
+                my.v[0] = (r_last.end - in.endB) * 0x1p+53;
+            }
+            /* inclusive scan of the maps over [lo, n): inside the wavefront by shuffles ... */
+            acc = my;
+            if (t < lo) {
+                acc.isconst = 0;
+                acc.v[0] = acc.v[1] = acc.v[2] = acc.v[3] = 0.0;
+            }
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const FixMap prev = fix_map_shfl_up(acc, off);
-            if (lane >= off)
-                acc = fix_compose(acc, prev);
-        }
-        /* ... across the wavefronts through LDS */
-        if (lane == 63) {
-            L.wc[wave] = acc.isconst;
+            for (int off = 1; off < 64; off <<= 1) {
+                const FixMap prev = fix_map_shfl_up(acc, off);
+                if (lane >= off)
+                    acc = fix_compose(acc, prev);
+            }
+            /* ... across the wavefronts through LDS */
+            if (lane == 63) {
+                L.wc[wave] = acc.isconst;
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                L.wv[wave][j] = acc.v[j];
-        }
-        if (t == 0)
-            L.first_bad = FIXP_WG;
-        __syncthreads();
-        for (int w = wave - 1; w >= 0 && !acc.isconst; w--) { /* (a constant absorbs everything before it) */
-            FixMap pw;
-            pw.isconst = L.wc[w];
+                for (int j = 0; j < 4; j++)
+                    L.wv[wave][j] = acc.v[j];
+            }
+            if (t == 0)
+                L.first_bad = FIXP_WG;
+            __syncthreads();
+            for (int w = wave - 1; w >= 0 && !acc.isconst; w--) { /* (a constant absorbs everything before it) */
+                FixMap pw;
+                pw.isconst = L.wc[w];
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                pw.v[j] = L.wv[w][j];
-            acc = fix_compose(acc, pw);
+                for (int j = 0; j < 4; j++)
+                    pw.v[j] = L.wv[w][j];
+                acc = fix_compose(acc, pw);
+            }
         }
+        pre = false;
         /* every map from the head on is a constant now: the guessed ends */
         if (mine && t >= lo)
             my_end = t == lo ? r_last.end : in.endB + acc.v[0] * 0x1p-53;

@@ -19,6 +19,19 @@ shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(dst, tag + "_str
 sq = os.path.join(ROOT, "gpurun_out", tag + "_sq.txt")
 if os.path.exists(sq):
     shutil.copy(sq, os.path.join(dst, tag + "_sq_counters.txt"))
+sq = os.path.join(ROOT, "gpurun_out", tag + "_m1_sq.txt")
+if os.path.exists(sq):
+    shutil.copy(sq, os.path.join(dst, tag + "_m1_sq_counters.txt"))
+if os.path.exists(os.path.join(src, "seed_rate.txt")):
+    shutil.copy(os.path.join(src, "seed_rate.txt"), os.path.join(dst, tag + "_shard_seed_rate.txt"))
+m1db = os.path.join(src, "prof_m1", "trace_results.db")
+if os.path.exists(m1db):
+    c1 = sqlite3.connect(m1db)
+    with open(os.path.join(dst, tag + "_m1_kernel_stats.txt"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python tools/m1_rate.py   (12 ch, 2.6 MS/s, 300 000-sample blocks, 1000 blocks per run)\n")
+        f.write(" | ".join(cols) + "\n")
+        for r in c1.execute("select * from top_kernels").fetchall():
+            f.write(" | ".join(("%.1f" % x if isinstance(x, float) else str(x)) for x in r) + "\n")
 s = json.load(open(os.path.join(src, "pmc_summary.json")))
 d = {k: s[k] for k in ("k_synth_hbm_write_bytes_per_launch", "k_synth_hbm_read_bytes_per_launch", "k_synth_hbm_bytes_per_launch")}
 d["kernel"] = "k_synth_ev"

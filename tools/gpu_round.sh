@@ -8,7 +8,7 @@ OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 ROOT=$PWD
-timeout 1500 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
+timeout 1500 python -m pytest tests -m gpu -x -q --timeout 900 > "$OUT/pytest_gpu.log" 2>&1
 echo "pytest rc=$?" >> "$OUT/pytest_gpu.log"
 tail -4 "$OUT/pytest_gpu.log"
 timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
@@ -21,3 +21,8 @@ tail -c 2500 "$OUT/bench.json"
 # WRITE_SIZE calibration on a kernel that writes a known byte count (k_fill_ceiling runs in the resident leg of the full bench)
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$ROOT/$OUT/pmc_w" -o pmc_cal -- python "$ROOT/tools/kbench.py" --steps 2 --warmup 4 --fill-ceiling > "$ROOT/$OUT/pmc_cal_stdout.log" 2>&1 )
 python tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.json" 2> "$OUT/pmc_summary.err"; head -c 3000 "$OUT/pmc_summary.json"
+# the reference's own geometry (M1: 12 ch, 2.6 MS/s, 300 000-sample blocks, k_synth_pd): kernel stats and SQ counters
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/prof_m1" -o trace -- python "$ROOT/tools/m1_rate.py" > "$ROOT/$OUT/prof_m1_stdout.log" 2>&1 )
+timeout 600 bash tools/pmc_sq.sh ${TAG}_m1_sq --fs 2.6e6 --nsamp 300000 --nch 12 --blocks 333 > gpurun_out/${TAG}_m1_sq.txt 2>&1
+timeout 600 bash tools/pmc_sq.sh ${TAG}_sq > gpurun_out/${TAG}_sq.txt 2>&1
+timeout 200 python tools/seed_rate.py --host > "$OUT/seed_rate.txt" 2>&1

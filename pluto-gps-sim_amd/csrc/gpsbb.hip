@@ -665,8 +665,10 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
                                  (int)sizeof(EvLds))) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev_dense), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(EvLds))) != hipSuccess) return fail(e);
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_pd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)sizeof(PdLds))) != hipSuccess) return fail(e);
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_pd<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(PdLds<true>))) != hipSuccess) return fail(e);
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_pd<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(PdLds<false>))) != hipSuccess) return fail(e);
     *out = h;
     return GPSBB_OK;
 }
@@ -1646,8 +1648,10 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         long want = (wg_slots * oversub + b->nblocks - 1) / b->nblocks;
         want = want < min_wg ? min_wg : want;
         want = want > max_useful ? max_useful : want;
-        if (b->ev_all_dense)
-            hipLaunchKernelGGL(k_synth_pd, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(PdLds), sc, p, d_iq);
+        if (b->ev_all_dense && b->nch <= PD_WIDE_CHAN)
+            hipLaunchKernelGGL(k_synth_pd<true>, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(PdLds<true>), sc, p, d_iq);
+        else if (b->ev_all_dense)
+            hipLaunchKernelGGL(k_synth_pd<false>, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(PdLds<false>), sc, p, d_iq);
         else if (b->ev_dense)
             hipLaunchKernelGGL(k_synth_ev_dense, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), sc, p, d_iq);
         else

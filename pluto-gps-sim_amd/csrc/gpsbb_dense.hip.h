@@ -24,6 +24,8 @@
 #ifndef GPSBB_DENSE_HIP_H
 #define GPSBB_DENSE_HIP_H
 
+#include <type_traits>
+
 #include "gpsbb_events.hip.h"
 
 namespace gpsbb_impl {
@@ -31,15 +33,21 @@ namespace gpsbb_impl {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr uint32_t PD_BAND = 4; /* |model - truth| in units of 2^-32 of the scaled models, roundings of the guard format included:
-                                   carrier 8 * 2^-33.9 * 2^32 = 2.2 + 1.5, code 2 * 0.27 + 1.5 */
+                                   carrier 8 * 2^-33.9 * 2^32 = 2.2 + 1.5, code (4 or 2) * 0.27 + 1.5 */
 
+/* WIDE: up to PD_WIDE_CHAN channels (the reference's MAX_CHAN, h:21): the chips as whole binary32 +-1.0 (no shift per
+ * channel-sample); else up to GPSBB_MAX_CHAN with the chips as the upper halves (160 KB of LDS do not hold 16 wide tables) */
+constexpr int PD_WIDE_CHAN = 12;
+template <bool WIDE>
 struct PdLds {
-    v2f amp[GPSBB_MAX_CHAN][512];              /* ((float)(int)(cos*gain), (float)(int)(sin*gain)) of table index k (a falling
-                                                  carrier: of 511 - k, see ev_first) */
-    uint16_t chipf[GPSBB_MAX_CHAN][EV_CHIP_LEN]; /* the upper half of the binary32 +1.0 / -1.0: codeCA of chip c mod 1023 */
+    static constexpr int NCH = WIDE ? PD_WIDE_CHAN : GPSBB_MAX_CHAN;
+    typedef typename std::conditional<WIDE, uint32_t, uint16_t>::type chip_t;
+    v2f amp[NCH][512];               /* ((float)(int)(cos*gain), (float)(int)(sin*gain)) of table index k (a falling
+                                        carrier: of 511 - k, see ev_first) */
+    chip_t chipf[NCH][EV_CHIP_LEN];  /* binary32 +1.0 / -1.0 (its upper half): codeCA of chip c mod 1023 */
     double tstate[EV_WAVES][2][2 * GPSBB_MAX_CHAN]; /* per wavefront, two tiles deep: the tile's models at sample 0 in guard
-                                                  format: column 2*channel = 2^20 + band + address of chipf[channel] + 2 * code
-                                                  phase, 2*channel + 1 = 2^20 + band + 8 * carrier phase (mirrored) */
+                                        format: column 2*channel = 2^20 + band + address of chipf[channel] + sizeof(chip_t) *
+                                        code phase, 2*channel + 1 = 2^20 + band + 8 * carrier phase (mirrored) */
 };
 
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
@@ -59,7 +67,8 @@ __device__ __forceinline__ T lds_read_at(uint32_t a)
  * (gpsbb_nco.h), then index, chip and data bit as the reference has them there (c:2697-2737).  Out of line, and with
  * nothing but scalars in and out, so that the accumulators of the fast path stay in registers.
  */
-__device__ __noinline__ v2f pd_exact_sample(const PdLds &L, int i, const EvConst *kbi, const double *tile_x, int ntiles, uint32_t dbits_i,
+template <bool WIDE>
+__device__ __noinline__ v2f pd_exact_sample(const PdLds<WIDE> &L, int i, const EvConst *kbi, const double *tile_x, int ntiles, uint32_t dbits_i,
                                             uint32_t dnext_i, int n)
 {
     const bool down = kbi->down != 0;
@@ -71,7 +80,7 @@ __device__ __noinline__ v2f pd_exact_sample(const PdLds &L, int i, const EvConst
     const double cp = carr_jump(yt * (1.0 / 512.0), S * (1.0 / 512.0), (int64_t)n);
     const int it = (int)(cp * 512.0) & 511; /* c:2697; carr_phase == 1.0: index 512 defined as 0 */
     const int ci = (int)x;                  /* c:2737 */
-    const float sg = __uint_as_float(((uint32_t)L.chipf[i][ci] << 16) ^ (neg ? 0x80000000u : 0u));
+    const float sg = __uint_as_float(((uint32_t)L.chipf[i][ci] << (WIDE ? 0 : 16)) ^ (neg ? 0x80000000u : 0u));
     const v2f a = L.amp[i][down ? 511 - it : it];
     v2f t;
     t.x = sg * a.x;
@@ -81,8 +90,8 @@ __device__ __noinline__ v2f pd_exact_sample(const PdLds &L, int i, const EvConst
 
 /* one channel of one tile on the fast path: SPT samples per lane, 64 apart.  NEG: the data bit in force is -1; DF: it
  * changes inside the tile (samples past the code's roll-over, chip index >= 1023, take the other one) */
-template <bool NEG, bool DF, bool UNDO>
-__device__ __forceinline__ uint32_t pd_channel(const PdLds &L, int lane, uint32_t amp_base, double S8, double sc2, double ytg, double xtg,
+template <bool WIDE, bool NEG, bool DF, bool UNDO>
+__device__ __forceinline__ uint32_t pd_channel(const PdLds<WIDE> &L, int lane, uint32_t amp_base, double S8, double sc2, double ytg, double xtg,
                                                uint32_t roll_addr, v2f (&acc)[SPT])
 {
     const double lf = (double)lane;
@@ -94,12 +103,12 @@ __device__ __forceinline__ uint32_t pd_channel(const PdLds &L, int lane, uint32_
         const double yj = j ? __fma_rn((double)j, dy, y0) : y0, xj = j ? __fma_rn((double)j, dx, x0) : x0;
         const uint32_t ylo = (uint32_t)__double2loint(yj), xlo = (uint32_t)__double2loint(xj);
         const uint32_t ia = ((uint32_t)__double2hiint(yj) & 0xff8u) | amp_base; /* 8 bytes per table entry, index modulo 512 */
-        const uint32_t ic = (uint32_t)__double2hiint(xj) & 0xffffeu;             /* 2 bytes per chip, the table's address included */
+        const uint32_t ic = (uint32_t)__double2hiint(xj) & (WIDE ? 0xffffcu : 0xffffeu); /* 4 / 2 bytes per chip, the table's address included */
         /* both fractions stay PD_BAND units away from an integer (the models carry +PD_BAND: safe iff low word >= 2*PD_BAND);
          * the low word of the carrier model misses its top three bits (the model is scaled by 8): a conservative test */
         m = min(m, min(ylo, xlo));
         const v2f a = lds_read_at<v2f>(ia);
-        uint32_t sgb = (uint32_t)lds_read_at<uint16_t>(ic) << 16;
+        uint32_t sgb = WIDE ? lds_read_at<uint32_t>(ic) : (uint32_t)lds_read_at<uint16_t>(ic) << 16;
         if (DF)
             sgb ^= (ic >= roll_addr) != NEG ? 0x80000000u : 0u; /* NEG here: the data bit BEFORE the roll-over is -1; after it, the other */
         const float sg = __uint_as_float(sgb);
@@ -111,10 +120,11 @@ __device__ __forceinline__ uint32_t pd_channel(const PdLds &L, int lane, uint32_
     return m;
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_synth_pd(BatchDev p, int16_t *__restrict__ iq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    PdLds &L = *reinterpret_cast<PdLds *>(smem_raw);
+    PdLds<WIDE> &L = *reinterpret_cast<PdLds<WIDE> *>(smem_raw);
     const int tid = threadIdx.x;
     const int b = blockIdx.x; /* the block is the fast grid dimension, helpers join blocks still in flight (see k_synth_ev) */
     if (blockIdx.y > 0 && __hip_atomic_load(&p.tile_ctr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.ntiles)
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             const uint32_t w0 = (uint32_t)__shfl((int)my_word, (ca >> 5) & 31);
             const uint32_t bit = (w0 >> (ca & 31)) & 1u;
             if (c < EV_CHIP_LEN)
-                L.chipf[i][c] = prn > 0 ? (bit ? 0x3f80u : 0xbf80u) : 0u; /* codeCA = chip * 2 - 1 (c:2737); idle: 0.0 */
+                L.chipf[i][c] = (typename PdLds<WIDE>::chip_t)((prn > 0 ? (bit ? 0x3f800000u : 0xbf800000u) : 0u) >> (WIDE ? 0 : 16)); /* codeCA = chip * 2 - 1 (c:2737); idle: 0.0 */
         }
     }
     __syncthreads();
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     const uint32_t *__restrict__ tn = p.tile_nav + ((size_t)b * p.nch + (lane < p.nch ? lane : 0)) * ntw;
     /* what turns a tile state into its model in guard format (see PdLds::tstate) */
     const double guard = 0x1p+20 + (double)PD_BAND * 0x1p-32;
-    const double g_scale = (lane & 1) ? 8.0 : 2.0;
+    const double g_scale = (lane & 1) ? 8.0 : (WIDE ? 4.0 : 2.0);
     const double g_add = guard + ((lane & 1) ? 0.0 : (double)lds_addr_of(&L.chipf[chain_lane ? lane >> 1 : 0][0]));
     unsigned long long *n_exact = p.hazards + 2;
 
@@ -213,18 +223,18 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             acc[j].x = acc[j].y = 0.0f;
         for (uint32_t mk = act_mask; mk; mk &= mk - 1) {
             const int i = __builtin_ctz(mk);
-            const double S8 = scalar_load(&kb[i].S) * 8.0, sc2 = scalar_load(&kb[i].sc) * 2.0;
+            const double S8 = scalar_load(&kb[i].S) * 8.0, sc2 = scalar_load(&kb[i].sc) * (WIDE ? 4.0 : 2.0);
             const double xtg = ts[2 * i], ytg = ts[2 * i + 1];
             const uint32_t amp_base = lds_addr_of(&L.amp[i][0]);
             const uint32_t roll_addr = lds_addr_of(&L.chipf[i][GPSBB_CA_LEN]);
             const bool neg = (dbits >> i) & 1u, df = (dflip >> i) & 1u;
             uint32_t m;
             if (__builtin_expect(df, 0)) {
-                m = neg ? pd_channel<true, true, false>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc)
-                        : pd_channel<false, true, false>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
+                m = neg ? pd_channel<WIDE, true, true, false>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc)
+                        : pd_channel<WIDE, false, true, false>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
             } else {
-                m = neg ? pd_channel<true, false, false>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc)
-                        : pd_channel<false, false, false>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
+                m = neg ? pd_channel<WIDE, true, false, false>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc)
+                        : pd_channel<WIDE, false, false, false>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
             }
             const unsigned long long um = ((exact_mask >> i) & 1u) ? ~0ull : __builtin_amdgcn_uicmp(m, 2u * PD_BAND, 36 /* ult */);
             if (__builtin_expect(um != 0ull, 0)) {
@@ -232,14 +242,14 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
                     /* take the model's contributions back, put the exact ones in their place */
                     if (df) {
                         if (neg)
-                            (void)pd_channel<true, true, true>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
+                            (void)pd_channel<WIDE, true, true, true>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
                         else
-                            (void)pd_channel<false, true, true>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
+                            (void)pd_channel<WIDE, false, true, true>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
                     } else {
                         if (neg)
-                            (void)pd_channel<true, false, true>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
+                            (void)pd_channel<WIDE, true, false, true>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
                         else
-                            (void)pd_channel<false, false, true>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
+                            (void)pd_channel<WIDE, false, false, true>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
                     }
 #pragma unroll 1
                     for (int j = 0; j < SPT; j++) {

@@ -87,6 +87,15 @@ __global__ __launch_bounds__(256) void k(double *out, double s, int n)
             if (OP == 70) { asm volatile("v_pk_add_u16 %0, %1, %0 op_sel_hi:[1,1]" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); }
             if (OP == 71) { asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(b[i]) : "v"(raddr), "n"(i * 4)); }
             if (OP == 72) { asm volatile("v_sad_u32 %0, %1, %2, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7])); }
+            if (OP == 73) { asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7])); }
+            if (OP == 74) { asm volatile("v_or_b32 %0, %1, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 75) { asm volatile("v_mul_f32 %0, %1, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 76) { asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 77) { asm volatile("v_min_f32 %0, %1, %0" : "+v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 78) { asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7])); }
+            if (OP == 79) { asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(b[i]) : "v"(b[(i + 1) & 7])); }
+            if (OP == 80) { asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(b[i]) : "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7])); }
+            if (OP == 81) { asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(b[i]) : "v"(b[(i + 1) & 7])); }
             if (OP == 17) { scratch[(threadIdx.x & 63) * 17 + ((b[i] + it) & 15) + (threadIdx.x >> 6) * 1088] = (unsigned)i; }
             if (OP == 18) { b[i] += scratch[(threadIdx.x & 63) * 17 + ((b[(i+1)&7] + it) & 15) + (threadIdx.x >> 6) * 1088]; }
         }
@@ -188,5 +197,13 @@ int main()
     run<72>("v_sad_u32", 1);
     run<65>("v_add_co + v_addc_co (64-bit add)", 2);
     run<71>("ds_read_u16 (random)", 1);
+    run<73>("v_fma_mix_f32 (f16 src0)", 1);
+    run<74>("v_or_b32", 1);
+    run<75>("v_mul_f32", 1);
+    run<76>("v_cvt_f32_f16", 1);
+    run<77>("v_min_f32 (VOP2)", 1);
+    run<78>("v_pk_mul_f32", 1);
+    run<80>("v_fmac_f32", 1);
+    run<81>("v_lshlrev_b32 16", 1);
     return 0;
 }

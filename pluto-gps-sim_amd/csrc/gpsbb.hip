@@ -148,6 +148,66 @@ uint64_t row_bound(double s_abs, double range, int top_e, int nsamp)
 }
 
 /*
+ * Where a carrier will be n steps on, to ~1e-14 cycles, WITHOUT walking it: the phase pass B of the device-side chain
+ * starts a segment from.  The reference's recurrence x = fl(x + s) does not advance by s per step but,
+ * while x is in binade e, by s rounded to a multiple of that binade's last place (gpsbb_nco.h): a drift of
+ * delta_e = RN(s / ulp_e) * ulp_e - s per step, i.e. of delta_e / |s| per unit of phase travelled there.  R(x) is that
+ * density integrated from 0 to x (piecewise linear, one piece per binade from s's own up to [0.5, 1)); a path of
+ * n steps from x0 covers whole laps R(1) each plus the two ends.  What is left out — the roundings of the steps that
+ * cross a binade edge or wrap, and that a binade holds a whole number of steps — averages out: 6e-15 rms per 625 000
+ * samples at 25 MS/s against 1e-11 for x0 + n*s (measured against the exact jump-ahead).  The chain's exactness does
+ * not rest on this: fix_block takes any start phase within pass B's margin of the truth; a poor prediction only costs a
+ * walk of the segment.
+ */
+struct CarrDrift {
+    int e_lo = 0, n = 0;
+    double sa = 0.0, R1 = 0.0;
+    bool neg = false;
+    double dens[64], cum[65];
+    explicit CarrDrift(double s)
+    {
+        sa = std::fabs(s);
+        neg = s < 0.0;
+        if (!(sa >= 0x1p-60) || !(sa < 0.25))
+            return; /* no model: plain arithmetic */
+        int es;
+        std::frexp(sa, &es);
+        es -= 1; /* sa in [2^es, 2^(es+1)) */
+        e_lo = es - 1 < -1 ? es - 1 : -1;
+        cum[0] = 0.0;
+        for (int e = e_lo; e <= -1; e++) {
+            const double ulp = std::ldexp(1.0, e - 52);
+            const double q = s / ulp; /* exact: a power of two */
+            const double delta = (std::nearbyint(q) - q) * ulp;
+            dens[n] = delta / sa;
+            cum[n + 1] = cum[n] + dens[n] * std::ldexp(1.0, e); /* the binade is 2^e wide */
+            n++;
+        }
+        R1 = cum[n];
+    }
+    double R(double x) const
+    {
+        if (n == 0 || !(x > std::ldexp(1.0, e_lo)))
+            return 0.0;
+        if (x >= 1.0)
+            return R1;
+        const int e = std::ilogb(x);
+        const int k = e - e_lo;
+        return cum[k] + dens[k] * (x - std::ldexp(1.0, e));
+    }
+    /* the phase n steps after x0 (both in [0, 1)) */
+    double advance(double x0, int nsteps, double s) const
+    {
+        const double u = x0 + (double)nsteps * s;
+        const double fl = std::floor(u), end = u - fl;
+        const double drift = neg ? -fl * R1 + R(x0) - R(end) : fl * R1 + R(end) - R(x0);
+        double v = end + drift;
+        v -= std::floor(v);
+        return v;
+    }
+};
+
+/*
  * Can the breakpoint kernel render these blocks, and with which per-channel constants (EvConst)?  Eligible
  * when, for every active channel, a run of SPT samples holds at most one chip change (sc*15.5 < 1) and at
  * most EV_KC_MAX table-index changes, and, per block, the I sums cannot reach 2^15 (sum of 512*|gain|+1: the
@@ -286,6 +346,7 @@ constexpr int SEED_STREAMS_MAX = 8;
 constexpr int CHAIN_SEG_ROWS = 1750;    /* rows of a carrier chain per segment of the device-side chain, about (see batch_setup) */
 constexpr int CHAIN_SEG_MIN_TILES = 16; /* ... but no segment shorter than this many tiles */
 constexpr int CHAIN_SEG_MAX = 8;        /* segments per block at most */
+constexpr long CHAIN_MODEL_MAX_SEGS = 4096; /* segments per channel up to which pass B starts from the host's drift model */
 constexpr unsigned STREAM_SEED_STREAMS = 4; /* pre-passes of a stream's pushes in flight (measured with 2 .. 6 and rings of 4 .. 8 slots: 4.1 .. 4.3e11
                                                samples/s, all within 5 %: the pre-pass is 4 ms now, the synthesis 2.2) */
 
@@ -419,6 +480,7 @@ struct gpsbb_batch {
     DevBuf<unsigned long long> d_fix_end; /* k_chain_fix_par: the hand-off between its chunks (BatchDev::fix_end) */
     DevBuf<int> d_fix_flag;
     int fix_epoch = 0, fix_chunks = 0, fix_wg = FIXP_WG_BATCH;
+    bool chain_model = false;    /* pass B starts from the host's drift model of the carrier (no pass A, no k_chain_prefix) */
     bool chain_fix_seq = false;  /* k_chain_fix (blocks in order) instead of k_chain_fix_par: GPSBB_OPT_CHAIN_WHERE 2 */
     bool host_seed = false;      /* the NCO tables of this batch are built on host threads: decided at set-up, like the
                                     chain (a run never re-reads the handle's options) */
@@ -505,7 +567,7 @@ extern "C" int gpsbb_set_option(gpsbb_t *h, int option, long value)
         h->opt_skip_seed = value != 0;
         return GPSBB_OK;
     case GPSBB_OPT_CHAIN_WHERE:
-        if (value < 0 || value > 2)
+        if (value < 0 || value > 3)
             return GPSBB_E_BADARG;
         h->opt_chain_where = (int)value;
         return GPSBB_OK;
@@ -793,6 +855,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     b->chain_dev = chained && h->opt_chain_where != 1 && !b->host_seed;
     b->chain_fix_seq = h->opt_chain_where == 2;
     b->chain_starts = b->chain_dev && !b->ev;
+    b->chain_model = false; /* decided below, once the number of segments is known */
     /* The device-side chain cuts blocks into SEGMENTS that are chained like blocks: a walk takes as long as its chain
      * whatever the batch (0.47 us per row; a 5 kHz carrier has 7 000 rows per 0.1 s of signal, at any sample rate), so
      * segments of about CHAIN_SEG_ROWS rows make the two walks of a pre-pass that many times shorter.  (Tried for batches
@@ -816,6 +879,14 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     }
     b->seg_tiles = (b->ntiles + b->nseg - 1) / b->nseg;
     b->nseg = (b->ntiles + b->seg_tiles - 1) / b->seg_tiles; /* no empty last segment */
+    /* Pass B's start phases from the host's drift model of the carrier (CarrDrift) instead of a first walk — where the
+     * model's error cannot pile up: it is ~6e-15 cycles per segment (partly systematic), and a start phase further than
+     * pass B's margin from the truth costs a walk of the segment (about one segment-channel in 10^5 per 1e-12 of error).  So:
+     * batches of up to CHAIN_MODEL_MAX_SEGS segments.  Not the pushes of a stream — the belief can only be re-anchored on
+     * end states that are a ring's depth of pushes old (measured: 3.3 segment walks per 400-block push, stream 4.48e11 ->
+     * 4.26e11 samples/s), and not chains over tens of thousands of blocks (gpsbb_chain_carrier): those keep pass A. */
+    b->chain_model = b->chain_dev && !b->chain_starts && !b->d_carry && h->opt_chain_where != 3 &&
+                     (long)nblocks * b->nseg <= CHAIN_MODEL_MAX_SEGS;
     const size_t nvbc = nbc * (size_t)b->nseg; /* carrier chains: one per (segment, channel) */
 
     /* row pool plan: the code chains (block*nch + channel), then the carrier chains ((block*nseg + segment)*nch + channel) */
@@ -933,6 +1004,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
             for (int blk = 0; blk < nblocks; blk++) {
                 const gpsbb_chan_t &c = ch[(size_t)blk * nch + i];
                 const volatile double sk = c.f_carr * delt;
+                const CarrDrift drift(b->chain_model && c.prn > 0 ? (double)sk : 0.0);
                 if (c.prn > 0) {
                     if (c.prn != prev_prn)
                         x = c.carr_phase;
@@ -949,8 +1021,13 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
                     b->h_start0[kv] = c.prn > 0 ? x : 0.0;
                     if (c.prn > 0) {
                         const int left = nsamp - sgi * b->seg_tiles * TILE, full = b->seg_tiles * TILE;
-                        x = x + (double)(b->nseg == 1 ? nsamp : (left < full ? left : full)) * sk;
-                        x -= std::floor(x);
+                        const int ns = b->nseg == 1 ? nsamp : (left < full ? left : full);
+                        if (b->chain_model && x < 1.0) {
+                            x = drift.advance(x, ns, sk);
+                        } else {
+                            x = x + (double)ns * sk;
+                            x -= std::floor(x);
+                        }
                     }
                 }
                 prev_prn = c.prn > 0 ? c.prn : 0;
@@ -1496,6 +1573,7 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.fix_flag = b->d_fix_flag.p ? b->d_fix_flag.p + (size_t)set * GPSBB_MAX_CHAN * b->fix_chunks : nullptr;
     p.fix_epoch = b->fix_epoch;
     p.fix_chunks = b->fix_chunks;
+    p.model_start = b->chain_model ? 1 : 0;
     p.cd = b->chain_dev ? b->d_cd.p : nullptr;
     p.start0 = b->chain_dev ? b->d_start0.p : nullptr;
     p.prefix_rows = b->chain_dev && !b->chain_starts ? b->d_prefix[set].p : nullptr;
@@ -1562,15 +1640,17 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         } else {
             const dim3 wg_all((lanes + GPSBB_WALK_WG - 1) / GPSBB_WALK_WG);
             if (b->chain_dev) {
-                BatchDev pa = p; /* pass A: the carrier chains only (they come first in the plan) */
-                pa.seed_lanes = b->carr_lanes;
-                hipLaunchKernelGGL(k_walk<1>, dim3((b->carr_lanes + GPSBB_WALK_WG - 1) / GPSBB_WALK_WG), dim3(GPSBB_WALK_WG), 0, ss, pa);
-                /* a stream: this push's prefix / fix-up follow the ones of the push before (other seeding stream) */
-                if (b->d_carry && b->ev_prefix)
-                    HIPCHK(h, hipStreamWaitEvent(ss, b->ev_prefix, 0));
-                hipLaunchKernelGGL(k_chain_prefix, dim3(b->nch), dim3(PREFIX_WG), 0, ss, p);
-                if (b->d_carry && b->ev_prefix)
-                    HIPCHK(h, hipEventRecord(b->ev_prefix, ss));
+                if (!b->chain_model) {
+                    BatchDev pa = p; /* pass A: the carrier chains only (they come first in the plan) */
+                    pa.seed_lanes = b->carr_lanes;
+                    hipLaunchKernelGGL(k_walk<1>, dim3((b->carr_lanes + GPSBB_WALK_WG - 1) / GPSBB_WALK_WG), dim3(GPSBB_WALK_WG), 0, ss, pa);
+                    /* a stream: this push's prefix / fix-up follow the ones of the push before (other seeding stream) */
+                    if (b->d_carry && b->ev_prefix)
+                        HIPCHK(h, hipStreamWaitEvent(ss, b->ev_prefix, 0));
+                    hipLaunchKernelGGL(k_chain_prefix, dim3(b->nch), dim3(PREFIX_WG), 0, ss, p);
+                    if (b->d_carry && b->ev_prefix)
+                        HIPCHK(h, hipEventRecord(b->ev_prefix, ss));
+                } /* else: pass B walks from the host's drift model of every segment's start (batch_setup) */
                 hipLaunchKernelGGL(k_walk<2>, wg_all, dim3(GPSBB_WALK_WG), 0, ss, p);
                 if (b->d_carry && b->ev_fix)
                     HIPCHK(h, hipStreamWaitEvent(ss, b->ev_fix, 0));
@@ -2447,6 +2527,7 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
         p.hazards = h->d_hz;
         p.chain_dev = 1;
         p.chain_starts = 1;
+        p.model_start = 0; /* over tens of thousands of blocks a prediction drifts too far: pass A and the prefix stay */
         p.nseg = 1;
         p.seg_tiles = p.ntiles;
         p.nvb = nb;

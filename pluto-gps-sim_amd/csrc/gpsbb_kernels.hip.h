@@ -199,6 +199,8 @@ struct BatchDev {
      * chain, whatever the batch).  Segment sgi of block b is "virtual block" vb = b*nseg + sgi; aux / cd / start0 and the
      * carrier chains' regions of the row pool are indexed by vb*nch + channel.  nseg = 1: segments are blocks. */
     int nseg, seg_tiles, nvb;       /* nvb = nblocks*nseg */
+    int model_start;                /* 1: pass B walks every segment from start0 (the host's drift model of the carrier): no
+                                       pass A, no k_chain_prefix; 0: from ChainAux::start1                 */
     ChainDesc *cd;                  /* [nvb*nch] what the chain kernels read of the descriptors (and, chain_starts, where
                                        k_chain_fix* leaves the exact start phase of every block)        */
     const double *start0;           /* [nvb*nch] rough start phases (host: descriptor phase + sum of nsamp*step in plain

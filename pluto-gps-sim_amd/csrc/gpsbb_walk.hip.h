@@ -419,7 +419,7 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
         const int prn = PASS >= 1 ? p.cd[k].prn : p.ch[k].prn;
         const double f_carr = PASS >= 1 ? p.cd[k].f_carr : p.ch[k].f_carr;
         const bool on = is_carr && prn > 0;
-        const double x0 = PASS == 1 ? p.start0[k] : (PASS >= 2 ? p.aux[k].start1 : p.ch[k].carr_phase);
+        const double x0 = PASS == 1 ? p.start0[k] : (PASS >= 2 ? (p.model_start ? p.start0[k] : p.aux[k].start1) : p.ch[k].carr_phase);
         const int vb = k / p.nch, sgi = PASS >= 1 ? vb % p.nseg : 0;
         const int ns = PASS >= 1 ? seg_nsamp(p, sgi) : p.nsamp; /* lanes of a wavefront may walk segments of different length */
         WalkLane<NCO_CARR> w = walk_lane<NCO_CARR, PASS == 0 || PASS == 2>(p, nbc + k, x0, mul_rn(f_carr, p.delt) /* c:2741 */, on);
@@ -608,7 +608,7 @@ __device__ __forceinline__ FixIn fix_load(const BatchDev &p, int b, int i)
     f.prn_prev = b > 0 ? p.cd[k - p.nch].prn : 0;
     f.carr_phase = ch.carr_phase;
     f.f_carr = ch.f_carr;
-    f.start1 = a.start1;
+    f.start1 = p.model_start ? p.start0[k] : a.start1; /* what pass B walked from */
     f.margin = a.margin;
     f.endB = a.endB;
     f.ncross = a.ncross;

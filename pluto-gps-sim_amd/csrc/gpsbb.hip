@@ -346,6 +346,7 @@ constexpr int SEED_STREAMS_MAX = 8;
 constexpr int CHAIN_SEG_ROWS = 1750;    /* rows of a carrier chain per segment of the device-side chain, about (see batch_setup) */
 constexpr int CHAIN_SEG_MIN_TILES = 16; /* ... but no segment shorter than this many tiles */
 constexpr int CHAIN_SEG_MAX = 8;        /* segments per block at most */
+constexpr int CHAIN_INDEP_MIN_TILES = 1024; /* independent blocks of at least this many tiles are cut into segments as well */
 constexpr long CHAIN_MODEL_MAX_SEGS = 4096; /* segments per channel up to which pass B starts from the host's drift model */
 constexpr unsigned STREAM_SEED_STREAMS = 4; /* pre-passes of a stream's pushes in flight (measured with 2 .. 6 and rings of 4 .. 8 slots: 4.1 .. 4.3e11
                                                samples/s, all within 5 %: the pre-pass is 4 ms now, the synthesis 2.2) */
@@ -480,6 +481,7 @@ struct gpsbb_batch {
     DevBuf<unsigned long long> d_fix_end; /* k_chain_fix_par: the hand-off between its chunks (BatchDev::fix_end) */
     DevBuf<int> d_fix_flag;
     int fix_epoch = 0, fix_chunks = 0, fix_wg = FIXP_WG_BATCH;
+    bool chain_indep = false;    /* the chain machinery runs on a batch whose blocks are independent: only the segments of a block are chained */
     bool chain_model = false;    /* pass B starts from the host's drift model of the carrier (no pass A, no k_chain_prefix) */
     bool chain_fix_seq = false;  /* k_chain_fix (blocks in order) instead of k_chain_fix_par: GPSBB_OPT_CHAIN_WHERE 2 */
     bool host_seed = false;      /* the NCO tables of this batch are built on host threads: decided at set-up, like the
@@ -856,13 +858,21 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     b->chain_fix_seq = h->opt_chain_where == 2;
     b->chain_starts = b->chain_dev && !b->ev;
     b->chain_model = false; /* decided below, once the number of segments is known */
+    b->chain_indep = false;
     /* The device-side chain cuts blocks into SEGMENTS that are chained like blocks: a walk takes as long as its chain
      * whatever the batch (0.47 us per row; a 5 kHz carrier has 7 000 rows per 0.1 s of signal, at any sample rate), so
      * segments of about CHAIN_SEG_ROWS rows make the two walks of a pre-pass that many times shorter.  (Tried for batches
      * of independent blocks as well, every block's first segment starting a chain: the five dependent kernels of the
      * chain cost more than the shorter walks save — M1 geometry 1.77e11 -> 1.45e11 samples/s — so those keep k_walk<0>.) */
     b->nseg = 1;
-    if (b->chain_dev && !b->chain_starts) { /* (k_seed, the per-sample kernel's pre-pass, walks whole blocks) */
+    /* Batches of INDEPENDENT blocks go through the same machinery where the model of the carrier serves (no pass A): every
+     * block's first segment starts a chain from its descriptor's phase, the walks are as many times shorter, and the three
+     * kernels that follow cost less than a walk of whole blocks — for long blocks (25 MS/s, 2.5 M samples: 4.08e11 ->
+     * 4.26e11 samples/s on a resident batch); for the reference's 300 000-sample blocks the fix-up over four thousand short
+     * segments costs more than the walks save (1.72e11 -> 1.61e11): those keep k_walk<0>. */
+    const bool indep_ok = !chained && !b->d_carry && b->ev && !fixed && !b->host_seed && h->opt_chain_where == 0 &&
+                          b->ntiles >= CHAIN_INDEP_MIN_TILES;
+    if ((b->chain_dev && !b->chain_starts) || indep_ok) { /* (k_seed, the per-sample kernel's pre-pass, walks whole blocks) */
         double rows_max = 0.0;
         for (size_t k = 0; k < nbc; k++)
             if (ch[k].prn > 0) {
@@ -875,7 +885,13 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
         n = n > CHAIN_SEG_MAX ? CHAIN_SEG_MAX : n;
         n = n > n_cap ? n_cap : n;
         n = n < 1 ? 1 : n;
-        b->nseg = n;
+        if (b->chain_dev) {
+            b->nseg = n;
+        } else if (n > 1 && (long)nblocks * n <= CHAIN_MODEL_MAX_SEGS) {
+            b->chain_dev = true;
+            b->chain_indep = true;
+            b->nseg = n;
+        }
     }
     b->seg_tiles = (b->ntiles + b->nseg - 1) / b->nseg;
     b->nseg = (b->ntiles + b->seg_tiles - 1) / b->seg_tiles; /* no empty last segment */
@@ -1006,7 +1022,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
                 const volatile double sk = c.f_carr * delt;
                 const CarrDrift drift(b->chain_model && c.prn > 0 ? (double)sk : 0.0);
                 if (c.prn > 0) {
-                    if (c.prn != prev_prn)
+                    if (c.prn != prev_prn || b->chain_indep)
                         x = c.carr_phase;
                     else if (blk == 0)
                         b->cont0_mask |= 1u << i;
@@ -1017,7 +1033,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
                     cd.f_carr = c.f_carr;
                     cd.carr_phase = c.carr_phase; /* read for a block's first segment only (one that starts a chain) */
                     cd.prn = c.prn;
-                    cd._pad = 0;
+                    cd.start = (b->chain_indep && sgi == 0) ? 1 : 0;
                     b->h_start0[kv] = c.prn > 0 ? x : 0.0;
                     if (c.prn > 0) {
                         const int left = nsamp - sgi * b->seg_tiles * TILE, full = b->seg_tiles * TILE;
@@ -1737,10 +1753,10 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         else
             hipLaunchKernelGGL(k_synth_ev, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), sc, p, d_iq);
         h->last_kernel = 2;
-        h->last_chain_dev = b->chain_dev ? 1 : 0;
+        h->last_chain_dev = b->chain_dev && !b->chain_indep ? 1 : 0;
     } else {
         h->last_kernel = 1;
-        h->last_chain_dev = b->chain_dev ? 1 : 0;
+        h->last_chain_dev = b->chain_dev && !b->chain_indep ? 1 : 0;
         /* Workgroups per block: enough of them to oversubscribe the chip ~3x (tiles are handed out
          * dynamically in chunks, so the tail is short), never more than there are chunks; the per-block
          * LDS tables (amplitude LUT, chips, nav words) are then built few times per block. */
@@ -2458,7 +2474,7 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
                 cd.f_carr = d.f_carr;
                 cd.carr_phase = d.carr_phase;
                 cd.prn = d.prn;
-                cd._pad = 0;
+                cd.start = 0;
                 double start0 = 0.0;
                 if (d.prn != 0) {
                     /* the part of the descriptor contract the carrier chain depends on */

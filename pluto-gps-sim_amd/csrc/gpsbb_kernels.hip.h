@@ -137,7 +137,9 @@ struct ChainDesc {
     double f_carr;
     double carr_phase;
     int32_t prn;
-    int32_t _pad;
+    int32_t start; /* 1: this segment starts a chain from its own carr_phase whatever came before (the first segment of a
+                      block of a batch whose blocks are independent); 0: it continues the segment before it if the prn is
+                      the same */
 };
 static_assert(sizeof(ChainDesc) == 24, "ChainDesc layout");
 

@@ -458,10 +458,10 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
 /* does block b of channel i continue block b-1's carrier (GPSBB_CHAIN_CARRIER: same channel index, same prn)? */
 __device__ __forceinline__ bool chain_continues(const BatchDev &p, int b, int i)
 {
-    const int prn = p.cd[(size_t)b * p.nch + i].prn;
+    const ChainDesc &d = p.cd[(size_t)b * p.nch + i];
     if (b == 0) /* a stream's push continues the push before it */
-        return p.carry && prn > 0 && ((p.cont0_mask >> i) & 1u);
-    return prn > 0 && prn == p.cd[(size_t)(b - 1) * p.nch + i].prn;
+        return p.carry && d.prn > 0 && ((p.cont0_mask >> i) & 1u);
+    return d.prn > 0 && !d.start && d.prn == p.cd[(size_t)(b - 1) * p.nch + i].prn;
 }
 
 /*
@@ -593,7 +593,7 @@ struct FixRowSink {
 /* what fix_block reads of a block: fetched ahead of the arithmetic */
 constexpr int FIX_PREFETCH_CROSS = 6;
 struct FixIn {
-    int prn, prn_prev, ncross, wrap_row;
+    int prn, prn_prev, ncross, wrap_row; /* prn_prev: 0 where the block starts a chain of its own (ChainDesc::start) */
     uint32_t hz512;
     double carr_phase, f_carr, start1, margin, endB, wrap_x;
     double pre[FIX_PREFETCH_CROSS], post[FIX_PREFETCH_CROSS]; /* the first crossings (a block has about five) */
@@ -605,7 +605,7 @@ __device__ __forceinline__ FixIn fix_load(const BatchDev &p, int b, int i)
     const ChainAux &a = p.aux[k];
     FixIn f;
     f.prn = ch.prn;
-    f.prn_prev = b > 0 ? p.cd[k - p.nch].prn : 0;
+    f.prn_prev = (b > 0 && !ch.start) ? p.cd[k - p.nch].prn : 0;
     f.carr_phase = ch.carr_phase;
     f.f_carr = ch.f_carr;
     f.start1 = p.model_start ? p.start0[k] : a.start1; /* what pass B walked from */

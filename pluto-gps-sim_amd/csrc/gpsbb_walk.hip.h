@@ -706,7 +706,10 @@ __device__ __forceinline__ FixOut fix_block(const BatchDev &p, const FixIn &in, 
     if (on && d0 != 0.0 && es >= 123) {
         const int dstart = (int)((f64_bits(x) >> 52) & 0x7ff) - es;
         const int dtie = walk_tie_d(sb); /* the one binade (above the step's) in which the step ties */
-        tie_asc = dtie >= 2 && dtie <= 50 && (fall ? dtie == dstart : dtie >= dstart);
+        /* (dtie == 1 included: one binade above the step's every sum is a tie — the walk takes those steps one by one, but
+         * an offset that is an odd number of that binade's last places still flips them: found by the parity soak once the
+         * start phases came from the drift model, tests/golden/chain_model_big_step_desc.npy) */
+        tie_asc = dtie >= 1 && dtie <= 50 && (fall ? dtie == dstart : dtie >= dstart);
     }
     const bool base = on && es >= 123 && ncross >= 0 && fabs(d0) < margin - 0x1p-51;
     bool ok = on && d0 == 0.0;

@@ -340,6 +340,25 @@ def test_device_chain_with_steps_that_tie_on_the_coarsest_grid(pkg, synth, oracl
     assert (iq == want_iq).all()
 
 
+def test_device_chain_step_that_ties_one_binade_up(pkg, synth, oracle):
+    """Found by the batch soak (tools/fuzz_parity.py --seed 401, case 138) once pass B's start phases came from the drift
+    model: a rising carrier with a large step (0.063 cycles per sample) whose mantissa is odd starts a block ONE binade
+    above the step — there every sum x + s is an exact tie, and a start phase an odd number of last places away from the
+    true one rounds every one of them the other way.  The fix-up has to walk that first lap (it used to look for tie-prone
+    binades from two above the step only).  Two chained blocks of nine channels at 3 MS/s, bit-exact."""
+    ch = np.load(os.path.join(GOLDEN, "chain_model_big_step_desc.npy"))
+    fs, nsamp = 3e6, 10240
+    want_iq, want_st, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
+    b = synth.batch(ch, 1 / fs, nsamp, flags=pkg.CHAIN_CARRIER)
+    b.run()
+    synth.sync()
+    iq, st = b.read()
+    b.close()
+    for k in range(ch.shape[0]):
+        assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
+    assert (iq == want_iq).all()
+
+
 @pytest.mark.parametrize("fixture,fs,nsamp,bps", [("chain_first_wrap_tie_desc.npy", 30e6, 24607, 33),
                                                   ("chain_prefix_then_tie_desc.npy", 50e6, 3507, 100)])
 def test_device_chain_cases_found_by_the_stream_soak(pkg, synth, oracle, request, fixture, fs, nsamp, bps):

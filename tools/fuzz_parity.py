@@ -81,6 +81,22 @@ def stream_soak(a):
                 popped += 1
             st.close()
             what = dict(case=case, fs=fs, nsamp=nsamp, nch=nch, bps=bps, pushes=pushes, depth=depth, dev_only=dev_only)
+            if a.also_batch:
+                # the same blocks as ONE chained batch (no stream to continue: pass B starts from the host's drift model of the
+                # carrier, long blocks are cut into segments) and as a batch of independent blocks seeded with the oracle's phases
+                bt = synth.batch(ch, delt, nsamp, flags=pkg.CHAIN_CARRIER)
+                bt.run(); synth.sync(); biq, bst = bt.read(); bt.close()
+                act_all = ch["prn"] > 0
+                if not (biq == want_iq).all() or bst["carr_phase"][act_all].tobytes() != want_st["carr_phase"][act_all].tobytes():
+                    np.save("gpurun_out/fuzz_stream_fail_ch.npy", ch)
+                    raise SystemExit("BATCH (chained) MISMATCH %r" % what)
+                ind = ch.copy()
+                ind["carr_phase"][1:] = np.where((ch["prn"][1:] > 0) & (ch["prn"][1:] == ch["prn"][:-1]), want_st["carr_phase"][:-1], ch["carr_phase"][1:])
+                bt = synth.batch(ind, delt, nsamp)
+                bt.run(); synth.sync(); biq, bst = bt.read(); bt.close()
+                if not (biq == want_iq).all() or bst["carr_phase"][act_all].tobytes() != want_st["carr_phase"][act_all].tobytes():
+                    np.save("gpurun_out/fuzz_stream_fail_ch.npy", ind)
+                    raise SystemExit("BATCH (independent blocks) MISMATCH %r" % what)
             for j, (iq, es) in enumerate(got):
                 w = want_iq[j * bps:(j + 1) * bps].reshape(bps, -1)
                 if iq is not None and not (iq == w).all():
@@ -117,6 +133,7 @@ def main():
                          "oracle's sequential render of the whole stream")
     ap.add_argument("--ties", action="store_true", help="--stream: every carrier step has only a few mantissa bits (exact ties at wraps and "
                     "binade crossings are common instead of one in thousands)")
+    ap.add_argument("--also-batch", action="store_true", help="--stream: every case also as one chained batch and as a batch of independent blocks")
     ap.add_argument("--nsamp-max", type=int, default=200000, help="--stream: longest block")
     ap.add_argument("--budget", type=float, default=3e7, help="--stream: channel-samples per case (what the CPU oracle has to walk)")
     a = ap.parse_args()

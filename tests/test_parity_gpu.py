@@ -843,11 +843,12 @@ def test_headline_stream_chain_against_the_host_chain(pkg):
 def test_stream_soak_small(pkg):
     """A slice of the stream soak (tools/fuzz_parity.py --stream): 30 random chained streams — pushes of many short
     blocks through rings of random depth, Dopplers that drift or jump, exact binary steps, channels that change PRN
-    or go idle, pre-pass and chain on the device — every one bit-exact against the oracle's sequential render."""
+    or go idle, pre-pass and chain on the device — every one bit-exact against the oracle's sequential render; each also as
+    one chained batch and as a batch of independent blocks."""
     import types
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_parity
-    fuzz_parity.stream_soak(types.SimpleNamespace(cases=30, seed=3, nsamp_max=200000, budget=3e7, ties=False))
+    fuzz_parity.stream_soak(types.SimpleNamespace(cases=30, seed=3, nsamp_max=200000, budget=3e7, ties=False, also_batch=True))
 
 
 def test_time_shards_through_the_ring_give_one_digest(pkg, synth, oracle):

@@ -81,7 +81,7 @@ def stream_soak(a):
                 popped += 1
             st.close()
             what = dict(case=case, fs=fs, nsamp=nsamp, nch=nch, bps=bps, pushes=pushes, depth=depth, dev_only=dev_only)
-            if a.also_batch:
+            if getattr(a, "also_batch", False):
                 # the same blocks as ONE chained batch (no stream to continue: pass B starts from the host's drift model of the
                 # carrier, long blocks are cut into segments) and as a batch of independent blocks seeded with the oracle's phases
                 bt = synth.batch(ch, delt, nsamp, flags=pkg.CHAIN_CARRIER)

@@ -146,6 +146,8 @@ def exp_lib():
         L.gpsbb_test_build_rows.argtypes = [i, d, d, u, i, vp, i, C.POINTER(d), C.POINTER(u)]
         L.gpsbb_test_row_bound.argtypes = [i, d, i]
         L.gpsbb_test_row_bound.restype = C.c_ulonglong
+        L.gpsbb_test_carr_predict.argtypes = [d, d, i]
+        L.gpsbb_test_carr_predict.restype = d
         _exp_lib = L
     return _exp_lib
 

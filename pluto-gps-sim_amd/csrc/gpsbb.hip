@@ -2676,6 +2676,13 @@ extern "C" int gpsbb_test_build_rows_f64(int kind, double x0, double s, unsigned
     return sink.cnt;
 }
 
+/* the host's prediction of a carrier n steps on (CarrDrift: where pass B of the device-side chain starts a segment) */
+extern "C" double gpsbb_test_carr_predict(double x0, double s, int n)
+{
+    const CarrDrift d(s);
+    return d.advance(x0, n, s);
+}
+
 extern "C" unsigned long long gpsbb_test_row_bound(int kind, double s_abs, int nsamp)
 {
     return kind == NCO_CODE ? row_bound(s_abs, 1023.0, 9, nsamp) : row_bound(s_abs, 1.0, -1, nsamp);

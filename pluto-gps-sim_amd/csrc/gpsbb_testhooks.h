@@ -27,6 +27,8 @@ int gpsbb_test_build_rows(int kind, double x0, double s, unsigned nav0, int nsam
 int gpsbb_test_build_rows_f64(int kind, double x0, double s, unsigned nav0, int nsamp, gpsbb_test_row_t *rows,
                               int cap, double *x_end, unsigned *nav_end);
 unsigned long long gpsbb_test_row_bound(int kind, double s_abs, int nsamp);
+/* the host's drift model of the carrier recurrence: the predicted phase n steps after x0 (not exact: ~1e-14) */
+double gpsbb_test_carr_predict(double x0, double s, int n);
 
 #ifdef __cplusplus
 }

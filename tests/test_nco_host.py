@@ -265,3 +265,29 @@ def test_chain_carrier_host_matches_oracle(pkg, oracle):
             else:
                 assert bits(seeds[b, i]) == bits(ch["carr_phase"][b, i])
     assert (seeds[0, :4] == ch["carr_phase"][0, :4]).all()
+
+
+def test_drift_model_predicts_the_carrier_to_1e13(pkg):
+    """The host's drift model of the recurrence (CarrDrift: where pass B of the device-side chain starts a segment when
+    no walk predicts it) against the exact jump-ahead: within 2e-13 cycles over a segment's length for Dopplers of either
+    sign at both sample rates, and an order of magnitude closer than x0 + n*s.  Only a prediction — the chain's
+    exactness never rests on it — but a prediction this good is what keeps the fix-up from walking segments."""
+    L = pkg.exp_lib()
+    rng = np.random.default_rng(7)
+    for fs, n in ((25e6, 625000), (2.6e6, 75000), (3e6, 300000)):
+        err, naive = [], []
+        for _ in range(200):
+            s = float(rng.uniform(-5000.0, 5000.0)) / fs
+            x0 = float(rng.random())
+            want = L.gpsbb_test_carr_jump(x0, s, n)
+            d = L.gpsbb_test_carr_predict(x0, s, n) - want
+            err.append(d - round(d))
+            v = x0 + n * s
+            d = (v - np.floor(v)) - want
+            naive.append(d - round(d))
+        assert np.abs(err).max() < 2e-13, (fs, np.abs(err).max())
+        assert np.std(err) * 10 < np.std(naive), (fs, np.std(err), np.std(naive))
+    # steps the model does not cover fall back to plain arithmetic: still a number in [0, 1)
+    for s in (0.0, 1e-30, 0.3, -0.3):
+        v = L.gpsbb_test_carr_predict(0.25, s, 1000)
+        assert 0.0 <= v < 1.0

@@ -58,6 +58,8 @@ def main():
     pkg.build_frontend()
     out = []
     with pkg.Synth(0) as s:
+        if len(sys.argv) > 1:  # e.g. 3: stream pushes keep pass A (gpsbb.h, GPSBB_OPT_CHAIN_WHERE)
+            s.set_option(pkg.OPT_CHAIN_WHERE, int(sys.argv[1]))
         out.append(run(pkg, s, "1/2 static, 2.6 MS/s, reference block (300000 samples)", "synth3540.14n", None, 12,
                        2.6e6, 300000, 3000, 250))
         out.append(run(pkg, s, "4 user motion (10 Hz), 2.6 MS/s", "synth3540.14n", "circle_motion.csv", 12, 2.6e6,

@@ -261,6 +261,10 @@ bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vec
             K.danger = K.W >= 0.25 ? 0x80000000u : (uint32_t)std::ceil(2.0 * K.W * 4294967296.0) + 1u;
             K.tK0 = K.rS * (1.0 + K.W) + 0x1p+20 + K.W;
             K.tC0 = K.rsc * (1.0 + K.W) + 0x1p+20 + K.W;
+            K.pd_S8 = aS * 8.0;
+            K.pd_dy = aS * 512.0;
+            K.pd_sc2 = sc * 2.0;
+            K.pd_dx = sc * 128.0;
             if (dense_code && K.kc > 0)
                 K.kc = EV_KC_DENSE;
         }

@@ -13,13 +13,21 @@
  *       The stores are 16 dword stores of 256 contiguous bytes per wavefront.
  *   the model in "guard format": 2^20 + (8 * table index | 2 * chip + table address).  One unit in the last place is
  *       2^-32, so the double's low word IS the fraction and the low bits of its high word ARE the byte address of the
- *       entry: one v_and per lookup, and the test "did the model come within its error of an integer" is the minimum of
- *       the low words over the run (v_min3_u32, one per channel-sample for both NCOs), compared once.
+ *       entry: one v_and(_or) per lookup, and the test "did the model come within its error of an integer" is the minimum
+ *       of the low words over the run (v_min3_u32, one per channel-sample for both NCOs), compared once.  From one
+ *       sample of a lane to its next the models advance by one v_add_f64 each (the sums' roundings, half a unit of 2^-32
+ *       apiece, are part of PD_BAND).
  *   amplitudes as float pairs, chips as +-1.0: a channel-sample's contribution is ONE packed FMA (I and Q together);
- *       sums of at most 16 integers below 2^15 are exact in binary32.  No sign extraction, no xor / sub / add chain.
+ *       sums of at most 16 integers below 2^15 are exact in binary32.  No sign extraction, no xor / sub / add chain: the
+ *       chips are the upper halves of binary32 +-1.0, read with ds_read_u16_d16_hi into registers whose lower halves
+ *       stay zero, and the data bit picks one of two chip tables (the second one negated) through the model's address.
+ *   the 16 samples of a channel in ONE block of assembly (pd_channel_fast): six VALU instructions per channel-sample
+ *       (2 v_add_f64, v_and_or, v_and, v_min3, v_pk_fma) and the LDS reads of four samples in flight behind counted
+ *       waits — the compiler's own schedule of the same source waited for every pair of reads on the spot, copied the
+ *       32 accumulators once per channel and moved both models through a register pair per sample: 12 instructions.
  *
- * Per channel-sample: 2 v_fma_f64, 2 v_and (+1 or), 1 v_min3_u32, 1 shift, 1 v_pk_fma_f32, 2 conflict-free LDS reads —
- * about 31 issue cycles against the 58 of ev_dense (tools/ubench/valu_rates.hip).
+ * About 27 issue cycles per channel-sample against the 58 of ev_dense (tools/ubench/valu_rates.hip); the two LDS reads
+ * (12 bytes per lane) cost the CU about as much, so the kernel sits where VALU and LDS meet.
  */
 #ifndef GPSBB_DENSE_HIP_H
 #define GPSBB_DENSE_HIP_H
@@ -32,22 +40,24 @@ namespace gpsbb_impl {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-constexpr uint32_t PD_BAND = 4; /* |model - truth| in units of 2^-32 of the scaled models, roundings of the guard format included:
-                                   carrier 8 * 2^-33.9 * 2^32 = 2.2 + 1.5, code (4 or 2) * 0.27 + 1.5 */
+constexpr uint32_t PD_BAND = 12; /* |model - truth| in units of 2^-32 of the scaled models, roundings of the guard format included:
+                                    carrier 8 * 2^-33.9 * 2^32 = 2.2, code 2 * 0.27; the tile state's and the first sample's
+                                    fma half a unit each, the 15 additions after it 7.5 */
 
-/* WIDE: up to PD_WIDE_CHAN channels (the reference's MAX_CHAN, h:21): the chips as whole binary32 +-1.0 (no shift per
- * channel-sample); else up to GPSBB_MAX_CHAN with the chips as the upper halves (160 KB of LDS do not hold 16 wide tables) */
+/* WIDE: up to PD_WIDE_CHAN channels (the reference's MAX_CHAN, h:21): two chip tables, the second one negated, so that
+ * the data bit in force is an address offset; else up to GPSBB_MAX_CHAN with one table and the data bit as a sign
+ * modifier of the packed FMA (160 KB of LDS do not hold 16 channels' tables twice) */
 constexpr int PD_WIDE_CHAN = 12;
 template <bool WIDE>
 struct PdLds {
     static constexpr int NCH = WIDE ? PD_WIDE_CHAN : GPSBB_MAX_CHAN;
-    typedef typename std::conditional<WIDE, uint32_t, uint16_t>::type chip_t;
-    v2f amp[NCH][512];               /* ((float)(int)(cos*gain), (float)(int)(sin*gain)) of table index k (a falling
-                                        carrier: of 511 - k, see ev_first) */
-    chip_t chipf[NCH][EV_CHIP_LEN];  /* binary32 +1.0 / -1.0 (its upper half): codeCA of chip c mod 1023 */
+    static constexpr int NTAB = WIDE ? 2 : 1;
+    v2f amp[NCH][512];                     /* ((float)(int)(cos*gain), (float)(int)(sin*gain)) of table index k (a falling
+                                              carrier: of 511 - k, see ev_first) */
+    uint16_t chipf[NTAB][NCH][EV_CHIP_LEN]; /* upper half of binary32 +1.0 / -1.0: codeCA of chip c mod 1023; [1]: negated */
     double tstate[EV_WAVES][2][2 * GPSBB_MAX_CHAN]; /* per wavefront, two tiles deep: the tile's models at sample 0 in guard
-                                        format: column 2*channel = 2^20 + band + address of chipf[channel] + sizeof(chip_t) *
-                                        code phase, 2*channel + 1 = 2^20 + band + 8 * carrier phase (mirrored) */
+                                              format: column 2*channel = 2^20 + band + address of chipf[0][channel] + 2 * code
+                                              phase, 2*channel + 1 = 2^20 + band + 8 * carrier phase (mirrored) */
 };
 
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
@@ -60,64 +70,216 @@ __device__ __forceinline__ T lds_read_at(uint32_t a)
     return *(__attribute__((address_space(3))) const T *)(uintptr_t)a;
 }
 
-/*
- * Rare: a lane cannot rule out that the model and the reference disagree somewhere in its 16 samples of channel i.
- * It takes back what it added for the channel (the fast path run again with the sign turned) and takes the true
- * contributions instead, one sample at a time: from the tile's exact state to sample n with the exact jump-ahead
- * (gpsbb_nco.h), then index, chip and data bit as the reference has them there (c:2697-2737).  Out of line, and with
- * nothing but scalars in and out, so that the accumulators of the fast path stay in registers.
- */
-template <bool WIDE>
-__device__ __noinline__ v2f pd_exact_sample(const PdLds<WIDE> &L, int i, const EvConst *kbi, const double *tile_x, int ntiles, uint32_t dbits_i,
-                                            uint32_t dnext_i, int n)
+/* what the fast path added for sample j*64 + lane of a channel: the models exactly as pd_channel_fast advances them (one
+ * fma, then j additions), index and chip as floor(model), the data bit before / after the code's roll-over */
+struct PdModel {
+    double ytg, xtg, S8, sc2, dy, dx; /* the tile's models (xtg: the plain chip table's) and their steps */
+    uint32_t amp_base, roll_addr;
+    uint32_t neg, neg_next;           /* the data bit in force at the tile start / after the roll-over is -1 */
+};
+__device__ __forceinline__ v2f pd_model_sample(const PdModel &M, int lane, int j)
 {
-    const bool down = kbi->down != 0;
-    const double S = down ? -kbi->S : kbi->S, sc = kbi->sc;
-    const double xt = tile_x[(size_t)(2 * i) * ntiles], yt = tile_x[(size_t)(2 * i + 1) * ntiles];
-    int64_t wraps = 0;
-    const double x = code_jump(xt, sc, (int64_t)n, &wraps);
-    const bool neg = wraps > 0 ? dnext_i != 0 : dbits_i != 0; /* at most one roll-over per tile (checked by the host) */
-    const double cp = carr_jump(yt * (1.0 / 512.0), S * (1.0 / 512.0), (int64_t)n);
-    const int it = (int)(cp * 512.0) & 511; /* c:2697; carr_phase == 1.0: index 512 defined as 0 */
-    const int ci = (int)x;                  /* c:2737 */
-    const float sg = __uint_as_float(((uint32_t)L.chipf[i][ci] << (WIDE ? 0 : 16)) ^ (neg ? 0x80000000u : 0u));
-    const v2f a = L.amp[i][down ? 511 - it : it];
+    double y = __fma_rn((double)lane, M.S8, M.ytg), x = __fma_rn((double)lane, M.sc2, M.xtg);
+#pragma unroll 1
+    for (int q = 0; q < j; q++) {
+        y = __dadd_rn(y, M.dy);
+        x = __dadd_rn(x, M.dx);
+    }
+    const uint32_t ia = ((uint32_t)__double2hiint(y) & 0xff8u) | M.amp_base;
+    const uint32_t ic = (uint32_t)__double2hiint(x) & 0xffffeu;
+    const uint32_t ng = ic >= M.roll_addr ? M.neg_next : M.neg;
+    const float sg = __uint_as_float(((uint32_t)lds_read_at<uint16_t>(ic) << 16) ^ (ng ? 0x80000000u : 0u));
+    const v2f a = lds_read_at<v2f>(ia);
     v2f t;
     t.x = sg * a.x;
     t.y = sg * a.y;
     return t;
 }
 
-/* one channel of one tile on the fast path: SPT samples per lane, 64 apart.  NEG: the data bit in force is -1; DF: it
- * changes inside the tile (samples past the code's roll-over, chip index >= 1023, take the other one) */
-template <bool WIDE, bool NEG, bool DF, bool UNDO>
-__device__ __forceinline__ uint32_t pd_channel(const PdLds<WIDE> &L, int lane, uint32_t amp_base, double S8, double sc2, double ytg, double xtg,
-                                               uint32_t roll_addr, v2f (&acc)[SPT])
+/*
+ * Rare: a lane cannot rule out that the model and the reference disagree somewhere in its 16 samples of channel i.
+ * For each of them it takes back what the model added and takes the true contribution instead: from the tile's exact
+ * state to sample n with the exact jump-ahead (gpsbb_nco.h), then index, chip and data bit as the reference has them
+ * there (c:2697-2737).  Out of line, and with nothing but scalars in and out, so that the accumulators of the fast path
+ * stay in registers.  Returns (true contribution) - (the model's).
+ */
+template <bool WIDE>
+__device__ __noinline__ v2f pd_fix_sample(const PdLds<WIDE> &L, int i, const EvConst *kbi, const double *tile_x, int ntiles, double ytg,
+                                          double xtg, uint32_t amp_base, uint32_t roll_addr, uint32_t negs, int lane, int j)
 {
-    const double lf = (double)lane;
-    const double y0 = __fma_rn(lf, S8, ytg), x0 = __fma_rn(lf, sc2, xtg);
-    const double dy = S8 * 64.0, dx = sc2 * 64.0; /* exact */
+    PdModel M;
+    M.ytg = ytg;
+    M.xtg = xtg;
+    M.S8 = kbi->pd_S8;
+    M.sc2 = kbi->pd_sc2;
+    M.dy = kbi->pd_dy;
+    M.dx = kbi->pd_dx;
+    M.amp_base = amp_base;
+    M.roll_addr = roll_addr;
+    M.neg = negs & 1u;
+    M.neg_next = (negs >> 1) & 1u;
+    const int n = j * 64 + lane;
+    const bool down = kbi->down != 0;
+    const double S = down ? -kbi->S : kbi->S, sc = kbi->sc;
+    const double xt = tile_x[(size_t)(2 * i) * ntiles], yt = tile_x[(size_t)(2 * i + 1) * ntiles];
+    int64_t wraps = 0;
+    const double x = code_jump(xt, sc, (int64_t)n, &wraps);
+    const bool neg = wraps > 0 ? M.neg_next != 0 : M.neg != 0; /* at most one roll-over per tile (checked by the host) */
+    const double cp = carr_jump(yt * (1.0 / 512.0), S * (1.0 / 512.0), (int64_t)n);
+    const int it = (int)(cp * 512.0) & 511; /* c:2697; carr_phase == 1.0: index 512 defined as 0 */
+    const int ci = (int)x;                  /* c:2737 */
+    const float sg = __uint_as_float(((uint32_t)L.chipf[0][i][ci] << 16) ^ (neg ? 0x80000000u : 0u));
+    const v2f a = L.amp[i][down ? 511 - it : it];
+    const v2f mdl = pd_model_sample(M, lane, j);
+    v2f t;
+    t.x = sg * a.x - mdl.x; /* exact: integers below 2^15 */
+    t.y = sg * a.y - mdl.y;
+    return t;
+}
+
+/* One channel of one tile, in C++: SPT samples per lane, 64 apart — the tiles in which the data bit changes (samples past
+ * the code's roll-over, chip address >= roll_addr, take the other one: one channel-tile in a hundred).  The same
+ * arithmetic as pd_channel_fast. */
+__device__ __forceinline__ uint32_t pd_channel_slow(const PdModel &M, int lane, v2f (&acc)[SPT])
+{
+    double yj = __fma_rn((double)lane, M.S8, M.ytg), xj = __fma_rn((double)lane, M.sc2, M.xtg);
     uint32_t m = 0xffffffffu;
 #pragma unroll
     for (int j = 0; j < SPT; j++) {
-        const double yj = j ? __fma_rn((double)j, dy, y0) : y0, xj = j ? __fma_rn((double)j, dx, x0) : x0;
         const uint32_t ylo = (uint32_t)__double2loint(yj), xlo = (uint32_t)__double2loint(xj);
-        const uint32_t ia = ((uint32_t)__double2hiint(yj) & 0xff8u) | amp_base; /* 8 bytes per table entry, index modulo 512 */
-        const uint32_t ic = (uint32_t)__double2hiint(xj) & (WIDE ? 0xffffcu : 0xffffeu); /* 4 / 2 bytes per chip, the table's address included */
+        const uint32_t ia = ((uint32_t)__double2hiint(yj) & 0xff8u) | M.amp_base; /* 8 bytes per table entry, index modulo 512 */
+        const uint32_t ic = (uint32_t)__double2hiint(xj) & 0xffffeu;              /* 2 bytes per chip, the table's address included */
         /* both fractions stay PD_BAND units away from an integer (the models carry +PD_BAND: safe iff low word >= 2*PD_BAND);
          * the low word of the carrier model misses its top three bits (the model is scaled by 8): a conservative test */
         m = min(m, min(ylo, xlo));
         const v2f a = lds_read_at<v2f>(ia);
-        uint32_t sgb = WIDE ? lds_read_at<uint32_t>(ic) : (uint32_t)lds_read_at<uint16_t>(ic) << 16;
-        if (DF)
-            sgb ^= (ic >= roll_addr) != NEG ? 0x80000000u : 0u; /* NEG here: the data bit BEFORE the roll-over is -1; after it, the other */
-        const float sg = __uint_as_float(sgb);
+        const uint32_t ng = ic >= M.roll_addr ? M.neg_next : M.neg;
+        const float sg = __uint_as_float(((uint32_t)lds_read_at<uint16_t>(ic) << 16) ^ (ng ? 0x80000000u : 0u));
         v2f sv;
-        sv.x = (NEG && !DF) != UNDO ? -sg : sg;
-        sv.y = sv.x;
+        sv.x = sg;
+        sv.y = sg;
         acc[j] = __builtin_elementwise_fma(sv, a, acc[j]);
+        yj = __dadd_rn(yj, M.dy);
+        xj = __dadd_rn(xj, M.dx);
     }
     return m;
+}
+
+/*
+ * One channel of one tile on the fast path (WIDE): ONE statement of assembly, so that the 16 accumulators have one
+ * producer per channel and stay where they are (two producers — this block and a C++ path for the tiles in which the data
+ * bit changes — cost 64 register copies per channel-tile at the join).  y = v[72:73], x = v[74:75]: the models; four
+ * samples' LDS reads in flight: amplitude pairs in v[76:83], chips (d16_hi, lower halves zero) in v84 / v86 / v88 / v90;
+ * v92, v93: addresses.  LDS returns in order, so "lgkmcnt(6)" = all but the last three samples' reads have landed
+ * (whatever else may be outstanding from before the block only makes the waits longer).  The data bit in force at the
+ * tile start is in xtg's table address; where it changes inside the tile (df) the second body moves the addresses past the
+ * code's roll-over (>= roll) by delta, into the other table.
+ */
+#define GPSBB_PD_ADDR                                                                                                  \
+    "v_and_or_b32 v92, v73, %[msk], %[ab]\n"                                                                           \
+    "v_and_b32 v93, 0xffffe, v75\n"                                                                                    \
+    "v_min3_u32 %[m], %[m], v72, v74\n"
+#define GPSBB_PD_ISSUE(A0, A1, C)                                                                                      \
+    GPSBB_PD_ADDR                                                                                                      \
+    "ds_read_b64 v[" #A0 ":" #A1 "], v92\n"                                                                            \
+    "ds_read_u16_d16_hi v" #C ", v93\n"
+#define GPSBB_PD_ISSUE_DF(A0, A1, C)                                                                                   \
+    GPSBB_PD_ADDR                                                                                                      \
+    "ds_read_b64 v[" #A0 ":" #A1 "], v92\n"                                                                            \
+    "v_cmp_le_u32 vcc, %[roll], v93\n"                                                                                 \
+    "v_cndmask_b32 v92, 0, %[delta], vcc\n"                                                                            \
+    "v_add_u32 v93, v93, v92\n"                                                                                        \
+    "ds_read_u16_d16_hi v" #C ", v93\n"
+#define GPSBB_PD_STEP                                                                                                  \
+    "v_add_f64 v[72:73], v[72:73], %[dy]\n"                                                                            \
+    "v_add_f64 v[74:75], v[74:75], %[dx]\n"
+#define GPSBB_PD_FMA(ACC, A0, A1, C0, C1, CNT)                                                                         \
+    "s_waitcnt lgkmcnt(" #CNT ")\n"                                                                                    \
+    "v_pk_fma_f32 %[" #ACC "], v[" #C0 ":" #C1 "], v[" #A0 ":" #A1 "], %[" #ACC "] op_sel_hi:[0,1,1]\n"
+#define GPSBB_PD_BODY(ISSUE)                                                                                           \
+    ISSUE(76, 77, 84) GPSBB_PD_STEP                                                                                    \
+    ISSUE(78, 79, 86) GPSBB_PD_STEP                                                                                    \
+    ISSUE(80, 81, 88) GPSBB_PD_STEP                                                                                    \
+    ISSUE(82, 83, 90) GPSBB_PD_STEP                                                                                    \
+    GPSBB_PD_FMA(a0, 76, 77, 84, 85, 6) ISSUE(76, 77, 84) GPSBB_PD_STEP                                                \
+    GPSBB_PD_FMA(a1, 78, 79, 86, 87, 6) ISSUE(78, 79, 86) GPSBB_PD_STEP                                                \
+    GPSBB_PD_FMA(a2, 80, 81, 88, 89, 6) ISSUE(80, 81, 88) GPSBB_PD_STEP                                                \
+    GPSBB_PD_FMA(a3, 82, 83, 90, 91, 6) ISSUE(82, 83, 90) GPSBB_PD_STEP                                                \
+    GPSBB_PD_FMA(a4, 76, 77, 84, 85, 6) ISSUE(76, 77, 84) GPSBB_PD_STEP                                                \
+    GPSBB_PD_FMA(a5, 78, 79, 86, 87, 6) ISSUE(78, 79, 86) GPSBB_PD_STEP                                                \
+    GPSBB_PD_FMA(a6, 80, 81, 88, 89, 6) ISSUE(80, 81, 88) GPSBB_PD_STEP                                                \
+    GPSBB_PD_FMA(a7, 82, 83, 90, 91, 6) ISSUE(82, 83, 90) GPSBB_PD_STEP                                                \
+    GPSBB_PD_FMA(a8, 76, 77, 84, 85, 6) ISSUE(76, 77, 84) GPSBB_PD_STEP                                                \
+    GPSBB_PD_FMA(a9, 78, 79, 86, 87, 6) ISSUE(78, 79, 86) GPSBB_PD_STEP                                                \
+    GPSBB_PD_FMA(a10, 80, 81, 88, 89, 6) ISSUE(80, 81, 88) GPSBB_PD_STEP                                               \
+    GPSBB_PD_FMA(a11, 82, 83, 90, 91, 6) ISSUE(82, 83, 90)                                                             \
+    GPSBB_PD_FMA(a12, 76, 77, 84, 85, 6)                                                                               \
+    GPSBB_PD_FMA(a13, 78, 79, 86, 87, 4)                                                                               \
+    GPSBB_PD_FMA(a14, 80, 81, 88, 89, 2)                                                                               \
+    GPSBB_PD_FMA(a15, 82, 83, 90, 91, 0)
+__device__ __forceinline__ uint32_t pd_channel_fast(const PdModel &M, double xtg, double lf, uint32_t df, uint32_t roll, int32_t delta,
+                                                    v2f (&acc)[SPT])
+{
+    static_assert(SPT == 16, "the block below is written for 16 samples per lane");
+    uint32_t m = 0xffffffffu;
+    asm volatile("v_fma_f64 v[72:73], %[lf], %[s8], %[ytg]\n"
+                 "v_fma_f64 v[74:75], %[lf], %[sc2], %[xtg]\n"
+                 "v_mov_b32 v84, 0\n"
+                 "v_mov_b32 v86, 0\n"
+                 "v_mov_b32 v88, 0\n"
+                 "v_mov_b32 v90, 0\n"
+                 "s_cmp_lg_u32 %[df], 0\n"
+                 "s_cbranch_scc1 1f\n"
+                 GPSBB_PD_BODY(GPSBB_PD_ISSUE)
+                 "s_branch 2f\n"
+                 "1:\n"
+                 GPSBB_PD_BODY(GPSBB_PD_ISSUE_DF)
+                 "2:\n"
+                 : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]), [a5] "+v"(acc[5]),
+                   [a6] "+v"(acc[6]), [a7] "+v"(acc[7]), [a8] "+v"(acc[8]), [a9] "+v"(acc[9]), [a10] "+v"(acc[10]), [a11] "+v"(acc[11]),
+                   [a12] "+v"(acc[12]), [a13] "+v"(acc[13]), [a14] "+v"(acc[14]), [a15] "+v"(acc[15]), [m] "+v"(m)
+                 : [lf] "v"(lf), [ytg] "v"(M.ytg), [xtg] "v"(xtg), [s8] "s"(M.S8), [sc2] "s"(M.sc2), [dy] "s"(M.dy), [dx] "s"(M.dx),
+                   [ab] "v"(M.amp_base), [msk] "s"(0xff8u), [df] "s"(df), [roll] "s"(roll), [delta] "v"(delta)
+                 : "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87",
+                   "v88", "v89", "v90", "v91", "v92", "v93", "vcc", "scc");
+    return m;
+}
+#undef GPSBB_PD_ADDR
+#undef GPSBB_PD_ISSUE
+#undef GPSBB_PD_ISSUE_DF
+#undef GPSBB_PD_STEP
+#undef GPSBB_PD_FMA
+#undef GPSBB_PD_BODY
+
+/* the smallest low word of a lane's models over its 16 samples of a channel, as the fast path sees it (for the lanes that
+ * have to be looked at again) */
+__device__ __forceinline__ uint32_t pd_model_min(const PdModel &M, int lane)
+{
+    double y = __fma_rn((double)lane, M.S8, M.ytg), x = __fma_rn((double)lane, M.sc2, M.xtg);
+    uint32_t m = 0xffffffffu;
+#pragma unroll 1
+    for (int j = 0; j < SPT; j++) {
+        m = min(m, min((uint32_t)__double2loint(y), (uint32_t)__double2loint(x)));
+        y = __dadd_rn(y, M.dy);
+        x = __dadd_rn(x, M.dx);
+    }
+    return m;
+}
+
+/* channel i's models for the tile whose states are at ts */
+template <bool WIDE>
+__device__ __forceinline__ void pd_model_of(const PdLds<WIDE> &L, const EvConst *kb, const double *ts, int i, uint32_t dbits, uint32_t dnext, PdModel &M)
+{
+    M.S8 = scalar_load(&kb[i].pd_S8);
+    M.dy = scalar_load(&kb[i].pd_dy);
+    M.sc2 = scalar_load(&kb[i].pd_sc2);
+    M.dx = scalar_load(&kb[i].pd_dx);
+    M.xtg = ts[2 * i];
+    M.ytg = ts[2 * i + 1];
+    M.amp_base = lds_addr_of(&L.amp[i][0]);
+    M.roll_addr = lds_addr_of(&L.chipf[0][i][GPSBB_CA_LEN]);
+    M.neg = (dbits >> i) & 1u;
+    M.neg_next = (dnext >> i) & 1u;
 }
 
 template <bool WIDE>
@@ -156,8 +318,12 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             const int ca = c >= GPSBB_CA_LEN ? c - GPSBB_CA_LEN : c; /* c < 2 * 1023 */
             const uint32_t w0 = (uint32_t)__shfl((int)my_word, (ca >> 5) & 31);
             const uint32_t bit = (w0 >> (ca & 31)) & 1u;
-            if (c < EV_CHIP_LEN)
-                L.chipf[i][c] = (typename PdLds<WIDE>::chip_t)((prn > 0 ? (bit ? 0x3f800000u : 0xbf800000u) : 0u) >> (WIDE ? 0 : 16)); /* codeCA = chip * 2 - 1 (c:2737); idle: 0.0 */
+            if (c < EV_CHIP_LEN) {
+                /* codeCA = chip * 2 - 1 (c:2737) as the upper half of a binary32; idle: 0.0 */
+                L.chipf[0][i][c] = (uint16_t)(prn > 0 ? (bit ? 0x3f80u : 0xbf80u) : 0u);
+                if (WIDE)
+                    L.chipf[PdLds<WIDE>::NTAB - 1][i][c] = (uint16_t)(prn > 0 ? (bit ? 0xbf80u : 0x3f80u) : 0u);
+            }
         }
     }
     __syncthreads();
@@ -179,8 +345,11 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     const uint32_t *__restrict__ tn = p.tile_nav + ((size_t)b * p.nch + (lane < p.nch ? lane : 0)) * ntw;
     /* what turns a tile state into its model in guard format (see PdLds::tstate) */
     const double guard = 0x1p+20 + (double)PD_BAND * 0x1p-32;
-    const double g_scale = (lane & 1) ? 8.0 : (WIDE ? 4.0 : 2.0);
-    const double g_add = guard + ((lane & 1) ? 0.0 : (double)lds_addr_of(&L.chipf[chain_lane ? lane >> 1 : 0][0]));
+    const double g_scale = (lane & 1) ? 8.0 : 2.0;
+    const double g_add = guard + ((lane & 1) ? 0.0 : (double)lds_addr_of(&L.chipf[0][chain_lane ? lane >> 1 : 0][0]));
+    constexpr uint32_t neg_table_bytes = (uint32_t)(sizeof(uint16_t) * PdLds<WIDE>::NCH * EV_CHIP_LEN); /* from chipf[0] to the negated table */
+    const double neg_table = (double)neg_table_bytes;
+    const double lf = (double)lane;
     unsigned long long *n_exact = p.hazards + 2;
 
     int base = 0;
@@ -221,39 +390,36 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
 #pragma unroll
         for (int j = 0; j < SPT; j++)
             acc[j].x = acc[j].y = 0.0f;
+        uint32_t fixmask = 0u; /* channels in which some lane has to look again */
         for (uint32_t mk = act_mask; mk; mk &= mk - 1) {
             const int i = __builtin_ctz(mk);
-            const double S8 = scalar_load(&kb[i].S) * 8.0, sc2 = scalar_load(&kb[i].sc) * (WIDE ? 4.0 : 2.0);
-            const double xtg = ts[2 * i], ytg = ts[2 * i + 1];
-            const uint32_t amp_base = lds_addr_of(&L.amp[i][0]);
-            const uint32_t roll_addr = lds_addr_of(&L.chipf[i][GPSBB_CA_LEN]);
-            const bool neg = (dbits >> i) & 1u, df = (dflip >> i) & 1u;
+            PdModel M;
+            pd_model_of(L, kb, ts, i, dbits, dnext, M);
             uint32_t m;
-            if (__builtin_expect(df, 0)) {
-                m = neg ? pd_channel<WIDE, true, true, false>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc)
-                        : pd_channel<WIDE, false, true, false>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
+            if (WIDE) {
+                /* the table of the data bit in force at the tile start; past the roll-over, the other bit's */
+                const double xtg = M.neg ? M.xtg + neg_table : M.xtg;
+                const uint32_t roll = M.roll_addr + (M.neg ? neg_table_bytes : 0u);
+                const int32_t delta = ((int32_t)M.neg_next - (int32_t)M.neg) * (int32_t)neg_table_bytes;
+                m = pd_channel_fast(M, xtg, lf, M.neg ^ M.neg_next, roll, delta, acc);
             } else {
-                m = neg ? pd_channel<WIDE, true, false, false>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc)
-                        : pd_channel<WIDE, false, false, false>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
+                m = pd_channel_slow(M, lane, acc);
             }
-            const unsigned long long um = ((exact_mask >> i) & 1u) ? ~0ull : __builtin_amdgcn_uicmp(m, 2u * PD_BAND, 36 /* ult */);
-            if (__builtin_expect(um != 0ull, 0)) {
-                if ((um >> lane) & 1ull) {
-                    /* take the model's contributions back, put the exact ones in their place */
-                    if (df) {
-                        if (neg)
-                            (void)pd_channel<WIDE, true, true, true>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
-                        else
-                            (void)pd_channel<WIDE, false, true, true>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
-                    } else {
-                        if (neg)
-                            (void)pd_channel<WIDE, true, false, true>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
-                        else
-                            (void)pd_channel<WIDE, false, false, true>(L, lane, amp_base, S8, sc2, ytg, xtg, roll_addr, acc);
-                    }
+            const unsigned long long um = __builtin_amdgcn_uicmp(m, 2u * PD_BAND, 36 /* ult */);
+            fixmask |= (um != 0ull || ((exact_mask >> i) & 1u)) ? 1u << i : 0u;
+        }
+        /* ---- rare: lanes that cannot rule out that the model and the reference disagree somewhere in their 16 samples of a
+         * channel take the model's contributions out and put the exact ones in (after the channel loop: a second producer
+         * of the accumulators inside it would cost register copies on every pass) ---- */
+        if (__builtin_expect(fixmask != 0u, 0)) {
+            for (uint32_t mk = fixmask; mk; mk &= mk - 1) {
+                const int i = __builtin_ctz(mk);
+                PdModel M;
+                pd_model_of(L, kb, ts, i, dbits, dnext, M);
+                if (((exact_mask >> i) & 1u) || pd_model_min(M, lane) < 2u * PD_BAND) {
 #pragma unroll 1
                     for (int j = 0; j < SPT; j++) {
-                        const v2f t = pd_exact_sample(L, i, kb + i, txb + wt, ntw, (dbits >> i) & 1u, (dnext >> i) & 1u, j * 64 + lane);
+                        const v2f t = pd_fix_sample(L, i, kb + i, txb + wt, ntw, M.ytg, M.xtg, M.amp_base, M.roll_addr, M.neg | (M.neg_next << 1), lane, j);
 #pragma unroll
                         for (int q = 0; q < SPT; q++) {
                             acc[q].x += q == j ? t.x : 0.0f;

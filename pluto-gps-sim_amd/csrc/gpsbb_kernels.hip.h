@@ -99,8 +99,13 @@ struct EvConst {
     int32_t down; /* the carrier step is negative                                                         */
     uint32_t danger; /* a low word (fraction in units of 2^-32) below this: the model cannot be trusted (= 2W)  */
     uint32_t _pad;
+    /* k_synth_pd's steps, scaled to LDS byte addresses (exact: powers of two): per sample and per 64 samples */
+    double pd_S8;   /* 8 * S: the amplitude table has 8 bytes per entry   */
+    double pd_dy;   /* 64 * pd_S8                                          */
+    double pd_sc2;  /* 2 * sc: the chip tables have 2 bytes per chip      */
+    double pd_dx;   /* 64 * pd_sc2                                         */
 };
-static_assert(sizeof(EvConst) == 72, "EvConst layout");
+static_assert(sizeof(EvConst) == 104, "EvConst layout");
 
 /* Per (block, channel) scratch of the device-side carrier chain (gpsbb_walk.hip.h, k_chain_fix). */
 constexpr int CHAIN_MAX_CROSS = 20;

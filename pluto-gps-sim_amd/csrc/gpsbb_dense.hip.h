@@ -137,36 +137,8 @@ __device__ __noinline__ v2f pd_fix_sample(const PdLds<WIDE> &L, int i, const EvC
     return t;
 }
 
-/* One channel of one tile, in C++: SPT samples per lane, 64 apart — the tiles in which the data bit changes (samples past
- * the code's roll-over, chip address >= roll_addr, take the other one: one channel-tile in a hundred).  The same
- * arithmetic as pd_channel_fast. */
-__device__ __forceinline__ uint32_t pd_channel_slow(const PdModel &M, int lane, v2f (&acc)[SPT])
-{
-    double yj = __fma_rn((double)lane, M.S8, M.ytg), xj = __fma_rn((double)lane, M.sc2, M.xtg);
-    uint32_t m = 0xffffffffu;
-#pragma unroll
-    for (int j = 0; j < SPT; j++) {
-        const uint32_t ylo = (uint32_t)__double2loint(yj), xlo = (uint32_t)__double2loint(xj);
-        const uint32_t ia = ((uint32_t)__double2hiint(yj) & 0xff8u) | M.amp_base; /* 8 bytes per table entry, index modulo 512 */
-        const uint32_t ic = (uint32_t)__double2hiint(xj) & 0xffffeu;              /* 2 bytes per chip, the table's address included */
-        /* both fractions stay PD_BAND units away from an integer (the models carry +PD_BAND: safe iff low word >= 2*PD_BAND);
-         * the low word of the carrier model misses its top three bits (the model is scaled by 8): a conservative test */
-        m = min(m, min(ylo, xlo));
-        const v2f a = lds_read_at<v2f>(ia);
-        const uint32_t ng = ic >= M.roll_addr ? M.neg_next : M.neg;
-        const float sg = __uint_as_float(((uint32_t)lds_read_at<uint16_t>(ic) << 16) ^ (ng ? 0x80000000u : 0u));
-        v2f sv;
-        sv.x = sg;
-        sv.y = sg;
-        acc[j] = __builtin_elementwise_fma(sv, a, acc[j]);
-        yj = __dadd_rn(yj, M.dy);
-        xj = __dadd_rn(xj, M.dx);
-    }
-    return m;
-}
-
 /*
- * One channel of one tile on the fast path (WIDE): ONE statement of assembly, so that the 16 accumulators have one
+ * One channel of one tile, SPT samples per lane, 64 apart: ONE statement of assembly, so that the 16 accumulators have one
  * producer per channel and stay where they are (two producers — this block and a C++ path for the tiles in which the data
  * bit changes — cost 64 register copies per channel-tile at the join).  y = v[72:73], x = v[74:75]: the models; four
  * samples' LDS reads in flight: amplitude pairs in v[76:83], chips (d16_hi, lower halves zero) in v84 / v86 / v88 / v90;
@@ -179,16 +151,24 @@ __device__ __forceinline__ uint32_t pd_channel_slow(const PdModel &M, int lane, 
     "v_and_or_b32 v92, v73, %[msk], %[ab]\n"                                                                           \
     "v_and_b32 v93, 0xffffe, v75\n"                                                                                    \
     "v_min3_u32 %[m], %[m], v72, v74\n"
-#define GPSBB_PD_ISSUE(A0, A1, C)                                                                                      \
+#define GPSBB_PD_ISSUE(A0, A1, C, C1)                                                                                  \
     GPSBB_PD_ADDR                                                                                                      \
     "ds_read_b64 v[" #A0 ":" #A1 "], v92\n"                                                                            \
     "ds_read_u16_d16_hi v" #C ", v93\n"
-#define GPSBB_PD_ISSUE_DF(A0, A1, C)                                                                                   \
+/* WIDE, the data bit changes: past the roll-over the other table */
+#define GPSBB_PD_ISSUE_DFW(A0, A1, C, C1)                                                                              \
     GPSBB_PD_ADDR                                                                                                      \
     "ds_read_b64 v[" #A0 ":" #A1 "], v92\n"                                                                            \
     "v_cmp_le_u32 vcc, %[roll], v93\n"                                                                                 \
     "v_cndmask_b32 v92, 0, %[delta], vcc\n"                                                                            \
     "v_add_u32 v93, v93, v92\n"                                                                                        \
+    "ds_read_u16_d16_hi v" #C ", v93\n"
+/* one table, the data bit changes: the sample's sign bit next to its chip (the upper register of the chip's pair) */
+#define GPSBB_PD_ISSUE_DFN(A0, A1, C, C1)                                                                              \
+    GPSBB_PD_ADDR                                                                                                      \
+    "ds_read_b64 v[" #A0 ":" #A1 "], v92\n"                                                                            \
+    "v_cmp_le_u32 vcc, %[roll], v93\n"                                                                                 \
+    "v_cndmask_b32 v" #C1 ", %[sgn0], %[sgn1], vcc\n"                                                                  \
     "ds_read_u16_d16_hi v" #C ", v93\n"
 #define GPSBB_PD_STEP                                                                                                  \
     "v_add_f64 v[72:73], v[72:73], %[dy]\n"                                                                            \
@@ -196,60 +176,108 @@ __device__ __forceinline__ uint32_t pd_channel_slow(const PdModel &M, int lane, 
 #define GPSBB_PD_FMA(ACC, A0, A1, C0, C1, CNT)                                                                         \
     "s_waitcnt lgkmcnt(" #CNT ")\n"                                                                                    \
     "v_pk_fma_f32 %[" #ACC "], v[" #C0 ":" #C1 "], v[" #A0 ":" #A1 "], %[" #ACC "] op_sel_hi:[0,1,1]\n"
-#define GPSBB_PD_BODY(ISSUE)                                                                                           \
-    ISSUE(76, 77, 84) GPSBB_PD_STEP                                                                                    \
-    ISSUE(78, 79, 86) GPSBB_PD_STEP                                                                                    \
-    ISSUE(80, 81, 88) GPSBB_PD_STEP                                                                                    \
-    ISSUE(82, 83, 90) GPSBB_PD_STEP                                                                                    \
-    GPSBB_PD_FMA(a0, 76, 77, 84, 85, 6) ISSUE(76, 77, 84) GPSBB_PD_STEP                                                \
-    GPSBB_PD_FMA(a1, 78, 79, 86, 87, 6) ISSUE(78, 79, 86) GPSBB_PD_STEP                                                \
-    GPSBB_PD_FMA(a2, 80, 81, 88, 89, 6) ISSUE(80, 81, 88) GPSBB_PD_STEP                                                \
-    GPSBB_PD_FMA(a3, 82, 83, 90, 91, 6) ISSUE(82, 83, 90) GPSBB_PD_STEP                                                \
-    GPSBB_PD_FMA(a4, 76, 77, 84, 85, 6) ISSUE(76, 77, 84) GPSBB_PD_STEP                                                \
-    GPSBB_PD_FMA(a5, 78, 79, 86, 87, 6) ISSUE(78, 79, 86) GPSBB_PD_STEP                                                \
-    GPSBB_PD_FMA(a6, 80, 81, 88, 89, 6) ISSUE(80, 81, 88) GPSBB_PD_STEP                                                \
-    GPSBB_PD_FMA(a7, 82, 83, 90, 91, 6) ISSUE(82, 83, 90) GPSBB_PD_STEP                                                \
-    GPSBB_PD_FMA(a8, 76, 77, 84, 85, 6) ISSUE(76, 77, 84) GPSBB_PD_STEP                                                \
-    GPSBB_PD_FMA(a9, 78, 79, 86, 87, 6) ISSUE(78, 79, 86) GPSBB_PD_STEP                                                \
-    GPSBB_PD_FMA(a10, 80, 81, 88, 89, 6) ISSUE(80, 81, 88) GPSBB_PD_STEP                                               \
-    GPSBB_PD_FMA(a11, 82, 83, 90, 91, 6) ISSUE(82, 83, 90)                                                             \
-    GPSBB_PD_FMA(a12, 76, 77, 84, 85, 6)                                                                               \
-    GPSBB_PD_FMA(a13, 78, 79, 86, 87, 4)                                                                               \
-    GPSBB_PD_FMA(a14, 80, 81, 88, 89, 2)                                                                               \
-    GPSBB_PD_FMA(a15, 82, 83, 90, 91, 0)
-__device__ __forceinline__ uint32_t pd_channel_fast(const PdModel &M, double xtg, double lf, uint32_t df, uint32_t roll, int32_t delta,
-                                                    v2f (&acc)[SPT])
+#define GPSBB_PD_FMA_NEG(ACC, A0, A1, C0, C1, CNT)                                                                     \
+    "s_waitcnt lgkmcnt(" #CNT ")\n"                                                                                    \
+    "v_pk_fma_f32 %[" #ACC "], v[" #C0 ":" #C1 "], v[" #A0 ":" #A1 "], %[" #ACC "] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+#define GPSBB_PD_FMA_SGN(ACC, A0, A1, C0, C1, CNT)                                                                     \
+    "s_waitcnt lgkmcnt(" #CNT ")\n"                                                                                    \
+    "v_xor_b32 v" #C0 ", v" #C0 ", v" #C1 "\n"                                                                         \
+    "v_pk_fma_f32 %[" #ACC "], v[" #C0 ":" #C1 "], v[" #A0 ":" #A1 "], %[" #ACC "] op_sel_hi:[0,1,1]\n"
+#define GPSBB_PD_BODY(ISSUE, FMA)                                                                                      \
+    ISSUE(76, 77, 84, 85) GPSBB_PD_STEP                                                                                \
+    ISSUE(78, 79, 86, 87) GPSBB_PD_STEP                                                                                \
+    ISSUE(80, 81, 88, 89) GPSBB_PD_STEP                                                                                \
+    ISSUE(82, 83, 90, 91) GPSBB_PD_STEP                                                                                \
+    FMA(a0, 76, 77, 84, 85, 6) ISSUE(76, 77, 84, 85) GPSBB_PD_STEP                                                     \
+    FMA(a1, 78, 79, 86, 87, 6) ISSUE(78, 79, 86, 87) GPSBB_PD_STEP                                                     \
+    FMA(a2, 80, 81, 88, 89, 6) ISSUE(80, 81, 88, 89) GPSBB_PD_STEP                                                     \
+    FMA(a3, 82, 83, 90, 91, 6) ISSUE(82, 83, 90, 91) GPSBB_PD_STEP                                                     \
+    FMA(a4, 76, 77, 84, 85, 6) ISSUE(76, 77, 84, 85) GPSBB_PD_STEP                                                     \
+    FMA(a5, 78, 79, 86, 87, 6) ISSUE(78, 79, 86, 87) GPSBB_PD_STEP                                                     \
+    FMA(a6, 80, 81, 88, 89, 6) ISSUE(80, 81, 88, 89) GPSBB_PD_STEP                                                     \
+    FMA(a7, 82, 83, 90, 91, 6) ISSUE(82, 83, 90, 91) GPSBB_PD_STEP                                                     \
+    FMA(a8, 76, 77, 84, 85, 6) ISSUE(76, 77, 84, 85) GPSBB_PD_STEP                                                     \
+    FMA(a9, 78, 79, 86, 87, 6) ISSUE(78, 79, 86, 87) GPSBB_PD_STEP                                                     \
+    FMA(a10, 80, 81, 88, 89, 6) ISSUE(80, 81, 88, 89) GPSBB_PD_STEP                                                    \
+    FMA(a11, 82, 83, 90, 91, 6) ISSUE(82, 83, 90, 91)                                                                  \
+    FMA(a12, 76, 77, 84, 85, 6)                                                                                        \
+    FMA(a13, 78, 79, 86, 87, 4)                                                                                        \
+    FMA(a14, 80, 81, 88, 89, 2)                                                                                        \
+    FMA(a15, 82, 83, 90, 91, 0)
+#define GPSBB_PD_HEAD                                                                                                  \
+    "v_fma_f64 v[72:73], %[lf], %[s8], %[ytg]\n"                                                                       \
+    "v_fma_f64 v[74:75], %[lf], %[sc2], %[xtg]\n"                                                                      \
+    "v_mov_b32 v84, 0\n"                                                                                               \
+    "v_mov_b32 v86, 0\n"                                                                                               \
+    "v_mov_b32 v88, 0\n"                                                                                               \
+    "v_mov_b32 v90, 0\n"
+#define GPSBB_PD_ACCS                                                                                                  \
+    [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]), [a5] "+v"(acc[5]),   \
+        [a6] "+v"(acc[6]), [a7] "+v"(acc[7]), [a8] "+v"(acc[8]), [a9] "+v"(acc[9]), [a10] "+v"(acc[10]),               \
+        [a11] "+v"(acc[11]), [a12] "+v"(acc[12]), [a13] "+v"(acc[13]), [a14] "+v"(acc[14]), [a15] "+v"(acc[15]),       \
+        [m] "+v"(m)
+#define GPSBB_PD_CLOBBERS                                                                                              \
+    "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87",     \
+        "v88", "v89", "v90", "v91", "v92", "v93", "vcc", "scc"
+/* WIDE: two chip tables.  The data bit in force at the tile start is in xtg's table address; where it changes inside the
+ * tile (df) the second body moves the addresses past the code's roll-over (>= roll) by delta, into the other table. */
+__device__ __forceinline__ uint32_t pd_channel_fast_wide(const PdModel &M, double xtg, double lf, uint32_t df, uint32_t roll, int32_t delta,
+                                                         v2f (&acc)[SPT])
 {
     static_assert(SPT == 16, "the block below is written for 16 samples per lane");
     uint32_t m = 0xffffffffu;
-    asm volatile("v_fma_f64 v[72:73], %[lf], %[s8], %[ytg]\n"
-                 "v_fma_f64 v[74:75], %[lf], %[sc2], %[xtg]\n"
-                 "v_mov_b32 v84, 0\n"
-                 "v_mov_b32 v86, 0\n"
-                 "v_mov_b32 v88, 0\n"
-                 "v_mov_b32 v90, 0\n"
+    asm volatile(GPSBB_PD_HEAD
                  "s_cmp_lg_u32 %[df], 0\n"
                  "s_cbranch_scc1 1f\n"
-                 GPSBB_PD_BODY(GPSBB_PD_ISSUE)
+                 GPSBB_PD_BODY(GPSBB_PD_ISSUE, GPSBB_PD_FMA)
                  "s_branch 2f\n"
                  "1:\n"
-                 GPSBB_PD_BODY(GPSBB_PD_ISSUE_DF)
+                 GPSBB_PD_BODY(GPSBB_PD_ISSUE_DFW, GPSBB_PD_FMA)
                  "2:\n"
-                 : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]), [a5] "+v"(acc[5]),
-                   [a6] "+v"(acc[6]), [a7] "+v"(acc[7]), [a8] "+v"(acc[8]), [a9] "+v"(acc[9]), [a10] "+v"(acc[10]), [a11] "+v"(acc[11]),
-                   [a12] "+v"(acc[12]), [a13] "+v"(acc[13]), [a14] "+v"(acc[14]), [a15] "+v"(acc[15]), [m] "+v"(m)
+                 : GPSBB_PD_ACCS
                  : [lf] "v"(lf), [ytg] "v"(M.ytg), [xtg] "v"(xtg), [s8] "s"(M.S8), [sc2] "s"(M.sc2), [dy] "s"(M.dy), [dx] "s"(M.dx),
                    [ab] "v"(M.amp_base), [msk] "s"(0xff8u), [df] "s"(df), [roll] "s"(roll), [delta] "v"(delta)
-                 : "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87",
-                   "v88", "v89", "v90", "v91", "v92", "v93", "vcc", "scc");
+                 : GPSBB_PD_CLOBBERS);
+    return m;
+}
+/* One chip table (13 to 16 channels): the data bit as a sign modifier of the packed FMA; where it changes inside the tile
+ * every sample carries its own sign bit (sgn0 before the roll-over, sgn1 past it). */
+__device__ __forceinline__ uint32_t pd_channel_fast_narrow(const PdModel &M, double lf, v2f (&acc)[SPT])
+{
+    uint32_t m = 0xffffffffu;
+    const uint32_t sgn0 = M.neg ? 0x80000000u : 0u, sgn1 = M.neg_next ? 0x80000000u : 0u;
+    asm volatile(GPSBB_PD_HEAD
+                 "s_cmp_lg_u32 %[df], 0\n"
+                 "s_cbranch_scc1 1f\n"
+                 "s_cmp_lg_u32 %[neg], 0\n"
+                 "s_cbranch_scc1 3f\n"
+                 GPSBB_PD_BODY(GPSBB_PD_ISSUE, GPSBB_PD_FMA)
+                 "s_branch 2f\n"
+                 "3:\n"
+                 GPSBB_PD_BODY(GPSBB_PD_ISSUE, GPSBB_PD_FMA_NEG)
+                 "s_branch 2f\n"
+                 "1:\n"
+                 GPSBB_PD_BODY(GPSBB_PD_ISSUE_DFN, GPSBB_PD_FMA_SGN)
+                 "2:\n"
+                 : GPSBB_PD_ACCS
+                 : [lf] "v"(lf), [ytg] "v"(M.ytg), [xtg] "v"(M.xtg), [s8] "s"(M.S8), [sc2] "s"(M.sc2), [dy] "s"(M.dy), [dx] "s"(M.dx),
+                   [ab] "v"(M.amp_base), [msk] "s"(0xff8u), [df] "s"(M.neg ^ M.neg_next), [neg] "s"(M.neg), [roll] "s"(M.roll_addr),
+                   [sgn0] "v"(sgn0), [sgn1] "v"(sgn1)
+                 : GPSBB_PD_CLOBBERS);
     return m;
 }
 #undef GPSBB_PD_ADDR
 #undef GPSBB_PD_ISSUE
-#undef GPSBB_PD_ISSUE_DF
+#undef GPSBB_PD_ISSUE_DFW
+#undef GPSBB_PD_ISSUE_DFN
 #undef GPSBB_PD_STEP
 #undef GPSBB_PD_FMA
+#undef GPSBB_PD_FMA_NEG
+#undef GPSBB_PD_FMA_SGN
 #undef GPSBB_PD_BODY
+#undef GPSBB_PD_HEAD
+#undef GPSBB_PD_ACCS
+#undef GPSBB_PD_CLOBBERS
 
 /* the smallest low word of a lane's models over its 16 samples of a channel, as the fast path sees it (for the lanes that
  * have to be looked at again) */
@@ -401,9 +429,9 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
                 const double xtg = M.neg ? M.xtg + neg_table : M.xtg;
                 const uint32_t roll = M.roll_addr + (M.neg ? neg_table_bytes : 0u);
                 const int32_t delta = ((int32_t)M.neg_next - (int32_t)M.neg) * (int32_t)neg_table_bytes;
-                m = pd_channel_fast(M, xtg, lf, M.neg ^ M.neg_next, roll, delta, acc);
+                m = pd_channel_fast_wide(M, xtg, lf, M.neg ^ M.neg_next, roll, delta, acc);
             } else {
-                m = pd_channel_slow(M, lane, acc);
+                m = pd_channel_fast_narrow(M, lf, acc);
             }
             const unsigned long long um = __builtin_amdgcn_uicmp(m, 2u * PD_BAND, 36 /* ult */);
             fixmask |= (um != 0ull || ((exact_mask >> i) & 1u)) ? 1u << i : 0u;

@@ -28,7 +28,7 @@ def stream_soak(a):
     with pkg.Synth(0) as synth:
         for case in range(a.cases):
             fs = float(rng.choice([16.368e6, 20e6, 25e6, 30e6, 2.0 ** 25, 50e6]))
-            low_rate = rng.random() < 0.25          # a rate only the per-sample kernel takes
+            low_rate = rng.random() < (1.0 if getattr(a, "low_rate", False) else 0.25)  # a rate below the breakpoint kernel's: k_synth_pd
             if low_rate:
                 fs = float(rng.choice([1e6, 2.6e6, 4.092e6, 10e6]))
             if a.ties:                                 # f_carr * delt is then exact: the steps really have few bits
@@ -133,6 +133,7 @@ def main():
                          "oracle's sequential render of the whole stream")
     ap.add_argument("--ties", action="store_true", help="--stream: every carrier step has only a few mantissa bits (exact ties at wraps and "
                     "binade crossings are common instead of one in thousands)")
+    ap.add_argument("--low-rate", action="store_true", help="--stream: every case at 1 .. 10 MS/s (k_synth_pd / the per-sample kernels)")
     ap.add_argument("--also-batch", action="store_true", help="--stream: every case also as one chained batch and as a batch of independent blocks")
     ap.add_argument("--nsamp-max", type=int, default=200000, help="--stream: longest block")
     ap.add_argument("--budget", type=float, default=3e7, help="--stream: channel-samples per case (what the CPU oracle has to walk)")

@@ -48,6 +48,7 @@ constexpr uint32_t PD_BAND = 12; /* |model - truth| in units of 2^-32 of the sca
  * the data bit in force is an address offset; else up to GPSBB_MAX_CHAN with one table and the data bit as a sign
  * modifier of the packed FMA (160 KB of LDS do not hold 16 channels' tables twice) */
 constexpr int PD_WIDE_CHAN = 12;
+constexpr float PD_ACC0 = 12582912.0f; /* 1.5 * 2^23: where the accumulators start (see k_synth_pd) */
 template <bool WIDE>
 struct PdLds {
     static constexpr int NCH = WIDE ? PD_WIDE_CHAN : GPSBB_MAX_CHAN;
@@ -398,7 +399,6 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             L.tstate[wave][buf][lane] = __fma_rn(mirror ? 512.0 - ts_v : ts_v, g_scale, g_add);
         const double *ts = L.tstate[wave][buf];
         const uint32_t dbits = (uint32_t)__ballot(nav_v & 1u), dnext = (uint32_t)__ballot(nav_v & 2u);
-        const uint32_t dflip = dbits ^ dnext;
         if (pos == 0 && lane == 0)
             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(pending) : "v"(p.tile_ctr + b), "v"(p.ev_chunk) : "memory");
         const bool last_of_chunk = pos + 1 >= p.ev_chunk || wt + 1 >= ntw;
@@ -414,10 +414,12 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             nav_v = lane < p.nch ? tn[wt_next] : 0u;
         }
 
+        /* the sums start at 1.5 * 2^23: every partial sum is then an integer below 2^24 in magnitude (exact in binary32) whose
+         * low 16 bits ARE the int16 the reference's (short) cast keeps (c:2754-2755) */
         v2f acc[SPT];
 #pragma unroll
         for (int j = 0; j < SPT; j++)
-            acc[j].x = acc[j].y = 0.0f;
+            acc[j].x = acc[j].y = PD_ACC0;
         uint32_t fixmask = 0u; /* channels in which some lane has to look again */
         for (uint32_t mk = act_mask; mk; mk &= mk - 1) {
             const int i = __builtin_ctz(mk);
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             uint32_t m;
             if (WIDE) {
                 /* the table of the data bit in force at the tile start; past the roll-over, the other bit's */
-                const double xtg = M.neg ? M.xtg + neg_table : M.xtg;
+                const double xtg = M.xtg + (M.neg ? neg_table : 0.0); /* exact: an integer number of bytes */
                 const uint32_t roll = M.roll_addr + (M.neg ? neg_table_bytes : 0u);
                 const int32_t delta = ((int32_t)M.neg_next - (int32_t)M.neg) * (int32_t)neg_table_bytes;
                 m = pd_channel_fast_wide(M, xtg, lf, M.neg ^ M.neg_next, roll, delta, acc);
@@ -458,16 +460,18 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
                 }
             }
         }
-        /* ---- back to int16 pairs, store (c:2754-2755): sample wt*TILE + j*64 + lane ---- */
+        /* ---- the low halves of the two sums side by side, store (c:2754-2755): sample wt*TILE + j*64 + lane ---- */
         uint32_t *out = reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + (size_t)wt * TILE + lane;
         const int left = p.nsamp - wt * TILE - lane; /* samples j*64 < left exist */
+        if (__builtin_expect(p.nsamp - wt * TILE >= TILE, 1)) {
 #pragma unroll
-        for (int j = 0; j < SPT; j++) {
-            const int ii = (int)acc[j].x, qq = (int)acc[j].y; /* exact: sums of integers below 2^15 */
-            uint32_t o;
-            asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(o) : "v"(ii), "v"(qq));
-            if (j * 64 < left)
-                out[j * 64] = o;
+            for (int j = 0; j < SPT; j++)
+                out[j * 64] = __builtin_amdgcn_perm(__float_as_uint(acc[j].y), __float_as_uint(acc[j].x), 0x05040100u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < SPT; j++)
+                if (j * 64 < left)
+                    out[j * 64] = __builtin_amdgcn_perm(__float_as_uint(acc[j].y), __float_as_uint(acc[j].x), 0x05040100u);
         }
         base = next_base;
         pos = next_pos;

@@ -259,6 +259,12 @@ bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vec
              * chips; change positions: W >= wK, wC): the tests are then all "low word of the biased quantity < 2W" */
             K.W = std::max(std::max(wK, wC), EV_T_EPS);
             K.danger = K.W >= 0.25 ? 0x80000000u : (uint32_t)std::ceil(2.0 * K.W * 4294967296.0) + 1u;
+            {
+                /* (test aid, experiments build: a larger threshold sends more lane-runs to the exact path; never a smaller one) */
+                const long floor_ = GPSBB_KNOB_LONG("GPSBB_EV_DANGER", 0);
+                if (floor_ > 0 && (uint32_t)floor_ > K.danger)
+                    K.danger = (uint32_t)floor_;
+            }
             K.tK0 = K.rS * (1.0 + K.W) + 0x1p+20 + K.W;
             K.tC0 = K.rsc * (1.0 + K.W) + 0x1p+20 + K.W;
             K.pd_S8 = aS * 8.0;
@@ -875,7 +881,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
      * 4.26e11 samples/s on a resident batch); for the reference's 300 000-sample blocks the fix-up over four thousand short
      * segments costs more than the walks save (1.72e11 -> 1.61e11): those keep k_walk<0>. */
     const bool indep_ok = !chained && !b->d_carry && b->ev && !fixed && !b->host_seed && h->opt_chain_where == 0 &&
-                          b->ntiles >= CHAIN_INDEP_MIN_TILES;
+                          b->ntiles >= (int)GPSBB_KNOB_LONG("GPSBB_INDEP_MIN_TILES", CHAIN_INDEP_MIN_TILES);
     if ((b->chain_dev && !b->chain_starts) || indep_ok) { /* (k_seed, the per-sample kernel's pre-pass, walks whole blocks) */
         double rows_max = 0.0;
         for (size_t k = 0; k < nbc; k++)
@@ -884,7 +890,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
                 const double r = sa > 0.0 ? ((double)nsamp * sa + 1.0) * (2.0 - std::log2(sa)) : 1.0;
                 rows_max = r > rows_max ? r : rows_max;
             }
-        int n = (int)(rows_max / (double)CHAIN_SEG_ROWS + 0.5);
+        int n = (int)(rows_max / (double)GPSBB_KNOB_LONG("GPSBB_SEG_ROWS", CHAIN_SEG_ROWS) + 0.5);
         const int n_cap = b->ntiles / CHAIN_SEG_MIN_TILES;
         n = n > CHAIN_SEG_MAX ? CHAIN_SEG_MAX : n;
         n = n > n_cap ? n_cap : n;
@@ -1580,6 +1586,7 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.ev = b->ev ? 1 : 0;
     const int ev_chunk = (int)GPSBB_KNOB_LONG("GPSBB_EV_CHUNK", EV_CHUNK);
     p.ev_chunk = ev_chunk < 1 ? 1 : ev_chunk;
+    p.pd_danger = (uint32_t)GPSBB_KNOB_LONG("GPSBB_PD_DANGER", 2u * PD_BAND); /* (larger: more lanes take the exact path; a test aid) */
     p.tile_x = b->d_tile_x[set].p;
     p.tile_nav = b->d_tile_nav[set].p;
     p.evc = b->d_evc.p;

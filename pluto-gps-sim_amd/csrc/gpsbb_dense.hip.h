@@ -435,18 +435,19 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             } else {
                 m = pd_channel_fast_narrow(M, lf, acc);
             }
-            const unsigned long long um = __builtin_amdgcn_uicmp(m, 2u * PD_BAND, 36 /* ult */);
+            const unsigned long long um = __builtin_amdgcn_uicmp(m, p.pd_danger, 36 /* ult */);
             fixmask |= (um != 0ull || ((exact_mask >> i) & 1u)) ? 1u << i : 0u;
         }
         /* ---- rare: lanes that cannot rule out that the model and the reference disagree somewhere in their 16 samples of a
          * channel take the model's contributions out and put the exact ones in (after the channel loop: a second producer
          * of the accumulators inside it would cost register copies on every pass) ---- */
         if (__builtin_expect(fixmask != 0u, 0)) {
+            GPSBB_EV_SETTLE_CLAIM(); /* the calls below make the compiler save registers: the chunk claim must have landed */
             for (uint32_t mk = fixmask; mk; mk &= mk - 1) {
                 const int i = __builtin_ctz(mk);
                 PdModel M;
                 pd_model_of(L, kb, ts, i, dbits, dnext, M);
-                if (((exact_mask >> i) & 1u) || pd_model_min(M, lane) < 2u * PD_BAND) {
+                if (((exact_mask >> i) & 1u) || pd_model_min(M, lane) < p.pd_danger) {
 #pragma unroll 1
                     for (int j = 0; j < SPT; j++) {
                         const v2f t = pd_fix_sample(L, i, kb + i, txb + wt, ntw, M.ytg, M.xtg, M.amp_base, M.roll_addr, M.neg | (M.neg_next << 1), lane, j);

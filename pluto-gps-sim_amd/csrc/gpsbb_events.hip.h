@@ -28,7 +28,8 @@
  *
  * I and Q travel as one 32-bit integer P = Q*65536 + I: sums of such integers are exact modulo 2^32, the
  * low half is the I sum modulo 2^16 (what the reference's (short) cast keeps) and the high half is the Q
- * sum plus the borrow of the low half, which one add of 0x8000 undoes as long as |I sum| < 2^15.  The
+ * sum plus the borrow of the low half.  The sum starts at 2^15, so that as long as |I sum| < 2^15 the low half
+ * is I + 2^15 >= 0 and never borrows: one v_xor with 0x8000 per sample gives the int16 pair.  The
  * host only selects this kernel when the gains guarantee that (sum of |gain| < 63); other batches, low
  * sample rates and the fixed-point carrier run on k_synth.
  */
@@ -67,6 +68,13 @@ constexpr int EV_ROW_DISCARD = 15;                 /* D row of changes that fall
  * a unit each) on top of the model error. */
 #define EV_T_EPS 0x1p-30
 #define EV_GUARD 0x1p+20
+
+/* A wavefront claims its next chunk of tiles with a returning atomic that it does not wait for (inline assembly: the
+ * compiler does not know that the destination register is still in flight).  Before anything that can make the compiler
+ * save or move registers — the out-of-line exact paths — the claim has to have landed: a register saved while the atomic is
+ * under way is restored with what it held BEFORE, and the chunk is lost (seen with one channel per block and the exact
+ * path forced on every tile: the call then comes a few hundred cycles after the claim). */
+#define GPSBB_EV_SETTLE_CLAIM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 /* LDS image of one workgroup */
 struct EvLds {
@@ -229,6 +237,7 @@ __device__ __forceinline__ void ev_second(EvLds &L, int wave, int lane, int i, E
     /* ---- rare: this lane cannot rule out that the model and the reference disagree ---- */
     const unsigned long long um = (always_exact ? ~0ull : h.um) & live_mask;
     if (__builtin_expect(um != 0ull, 0)) {
+        GPSBB_EV_SETTLE_CLAIM();
         if ((um >> lane) & 1ull) {
             /* its fast-path contribution becomes nothing ... */
 #pragma unroll
@@ -299,6 +308,7 @@ __device__ __forceinline__ void ev_dense(EvLds &L, int wave, int lane, int i, co
     }
     um &= live_mask;
     if (__builtin_expect(um != 0ull, 0)) {
+        GPSBB_EV_SETTLE_CLAIM();
         if ((um >> lane) & 1ull) {
 #pragma unroll
             for (int j = 0; j < SPT; j++)
@@ -518,7 +528,7 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         const int nvalid = p.nsamp - n0 < SPT ? p.nsamp - n0 : SPT;
         const bool lane_live = nvalid > 0;
         const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(lane_live);
-        uint32_t acc0 = 0;
+        uint32_t acc0 = 0x8000u; /* the I sum travels biased by 2^15: never negative, so the low half never borrows from the Q sum */
         ev_channels<1, false>(L, wave, lane, mk[0] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
         ev_channels<2, false>(L, wave, lane, mk[1] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
         if (__builtin_expect((mk[2] | mk[3] | dflip) != 0u, 0)) {
@@ -549,17 +559,14 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
             for (int j = 0; j < SPT; j++) {
                 if (j)
                     P += __hip_atomic_exchange(&L.D[wave][j - 1][lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const uint32_t q = P + accd[j];
-                const uint32_t t = q + 0x8000u;
-                o[j] = __builtin_amdgcn_perm(t, q, 0x07060100u);
+                o[j] = (P + accd[j]) ^ 0x8000u;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < SPT; j++) {
                 if (j)
                     P += __hip_atomic_exchange(&L.D[wave][j - 1][lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const uint32_t t = P + 0x8000u; /* undoes the borrow of a negative I in the high half */
-                o[j] = __builtin_amdgcn_perm(t, P, 0x07060100u); /* low half of P, high half of t (v_perm_b32) */
+                o[j] = P ^ 0x8000u; /* the bias off again: the low half is I + 2^15 in [0, 2^16), the high half Q */
             }
         }
 #ifdef GPSBB_SABOTAGE /* a deliberately wrong build (make broken): bench.py's parity check must refuse it (tests/test_bench_shards.py) */

@@ -191,6 +191,7 @@ struct BatchDev {
      * chain at the first sample of every tile */
     int ev;                         /* 1: this batch runs on k_synth_ev                               */
     int ev_chunk;                   /* consecutive tiles a wavefront of k_synth_ev takes at a time     */
+    uint32_t pd_danger;             /* k_synth_pd: a model's low word below this sends the lane to the exact path (2 * PD_BAND) */
     double *tile_x;                 /* [nblocks][2*nch][ntiles]: row 2*channel = code phase (chips), 2*channel+1 =
                                        carrier phase * 512, at sample tile*TILE (tile-contiguous per chain: the
                                        pre-pass writes it coalesced, k_synth_ev reads it through the L2)  */

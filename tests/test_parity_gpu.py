@@ -851,6 +851,35 @@ def test_stream_soak_small(pkg):
     fuzz_parity.stream_soak(types.SimpleNamespace(cases=30, seed=3, nsamp_max=200000, budget=3e7, ties=False, also_batch=True))
 
 
+def test_low_rate_soak_with_the_exact_path_forced_often(pkg, request):
+    """k_synth_pd's rare path made common: the experiments build with the danger threshold of its models raised from 24 to
+    2^22 units of 2^-32 (one test in a thousand instead of one in 10^8 sends a lane to pd_fix_sample: most wavefronts
+    then hold lanes that take the model's 16 contributions of a channel out and put exact ones in), over random chained
+    streams at 1 .. 10 MS/s with 1 to 16 channels (both chip-table layouts, data bits that change inside tiles)."""
+    if request.node.callspec.params["seed_mode"] != "k_seed+auto":
+        pytest.skip("a process of its own with its own options: once")
+    import subprocess
+    env = dict(os.environ, GPSBB_PY_LIB="exp", GPSBB_PD_DANGER=str(1 << 22))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--stream", "--low-rate", "--cases", "24",
+                        "--seed", "77", "--budget", "1.5e7"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "bit-exact" in r.stdout
+
+
+def test_high_rate_soak_with_the_exact_path_forced_often(pkg, request):
+    """The same for k_synth_ev: the danger threshold of every channel raised to 2^22 units of 2^-32, so that about one
+    lane-run in two hundred is recomputed by ev_exact_run (out of line) — with one or two channels per block the call
+    then comes right after the wavefront has claimed its next chunk of tiles, which must not get lost."""
+    if request.node.callspec.params["seed_mode"] != "k_seed+auto":
+        pytest.skip("a process of its own with its own options: once")
+    import subprocess
+    env = dict(os.environ, GPSBB_PY_LIB="exp", GPSBB_EV_DANGER=str(1 << 22))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--stream", "--cases", "30", "--seed", "78",
+                        "--budget", "1.5e7"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "bit-exact" in r.stdout
+
+
 def test_time_shards_through_the_ring_give_one_digest(pkg, synth, oracle):
     """BASELINE configs[4] in small: a stream continuous in time (drifting Dopplers, carrier carried from block
     to block) cut into 1, 2 and 3 contiguous time shards; each shard is rendered on its own through the

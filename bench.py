@@ -464,11 +464,11 @@ def main():
                                     "note": "k_synth_ev on resident tables, no pre-pass running beside it"}
         # the reference-faithful geometry (12 ch, 2.6 MS/s, 300 000-sample blocks)
         mch = pkg.synth_descriptors(1000, nch=12, seed=0xF00D)
-        m1, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, 0, 10, 3, dev)
+        m1, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, 0, 30, 4, dev)
         m1_kernel = {1: "k_synth", 2: "k_synth_pd (every channel evaluated per sample on the in-tile model)"}.get(
             synth.info(pkg.INFO_LAST_KERNEL), "?")
-        m1s, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, 0, 10, 5, dev, synth_only=True)
-        m1c, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, pkg.CHAIN_CARRIER, 10, 4, dev)
+        m1s, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, 0, 30, 5, dev, synth_only=True)
+        m1c, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, pkg.CHAIN_CARRIER, 30, 4, dev)
         m1_alg = 4.0 * mch.shape[0] * 300000
         res["m1"] = {"gpu": m1, "gpu_chained_on_the_device": m1c, "unit": "IQ samples/s",
                      "roofline": {"bound": "hbm", "kernel": "k_synth_pd", "ms_per_launch": m1["synth_kernel_ms"],
@@ -476,7 +476,7 @@ def main():
                                   "frac": m1_alg / (m1["synth_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "alone": {"ms_per_launch": m1s["synth_kernel_ms"],
                                             "frac": m1_alg / (m1s["synth_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                                  "note": "VALU-issue-bound (about 31 issue cycles per channel-sample), not HBM-bound: DESIGN.md"},
+                                  "note": "VALU- and LDS-issue-bound (about 27 VALU issue cycles and 12 bytes of LDS reads per channel-sample), not HBM-bound: DESIGN.md 2.7"},
                      "workload": "12 ch, fs 2.6e6 S/s, 300000-sample blocks, 1000 independent blocks per step; synthesis kernel " + m1_kernel}
         if not args.no_cpu:
             import oracle_binding as ob

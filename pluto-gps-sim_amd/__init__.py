@@ -23,7 +23,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # build of the same sources (libgpsbb_exp.so: measurement knobs from the environment, gpsbb_test_* hooks) is what the
 # tuning scripts under tools/ use when they say so (GPSBB_PY_LIB=exp, read HERE, in the Python veneer) and what
 # exp_lib() hands to the NCO unit tests.
-LIB_PATH = os.path.join(HERE, {"exp": "libgpsbb_exp.so", "broken": "libgpsbb_broken.so"}.get(os.environ.get("GPSBB_PY_LIB"), "libgpsbb.so"))
+_which = os.environ.get("GPSBB_PY_LIB")  # "exp", "broken", or the tag of a variant a tuning script built (libgpsbb_<tag>.so)
+LIB_PATH = os.path.join(HERE, "libgpsbb_%s.so" % _which if _which else "libgpsbb.so")
 EXP_LIB_PATH = os.path.join(HERE, "libgpsbb_exp.so")
 
 MAX_CHAN = 16

@@ -679,6 +679,8 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
     delete h;
 }
 
+static hipError_t create_seed_stream(hipStream_t *st);
+
 extern "C" int gpsbb_create(gpsbb_t **out, int device)
 {
     if (!out)
@@ -718,7 +720,7 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail(e);
     h->sm_count = prop.multiProcessorCount;
-    if ((e = hipStreamCreateWithFlags(&h->s_seed, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+    if ((e = create_seed_stream(&h->s_seed)) != hipSuccess) return fail(e);
     if ((e = hipStreamCreateWithFlags(&h->s_compute, hipStreamNonBlocking)) != hipSuccess) return fail(e);
     if ((e = hipStreamCreateWithFlags(&h->s_compute2, hipStreamNonBlocking)) != hipSuccess) return fail(e);
     if ((e = hipStreamCreateWithFlags(&h->s_upload, hipStreamNonBlocking)) != hipSuccess) return fail(e);
@@ -1205,6 +1207,26 @@ static gpsbb_batch *batch_new(gpsbb *h)
     return b;
 }
 
+/* A stream for pre-pass kernels.  Experiments build: GPSBB_SEED_CUS = n confines it to n compute units (every
+ * GPSBB_SEED_CU_STRIDE-th bit of the CU mask, default 1), to see what the pre-pass kernels' presence on a CU costs the
+ * synthesis kernel there. */
+static hipError_t create_seed_stream(hipStream_t *st)
+{
+    const long ncu = GPSBB_KNOB_LONG("GPSBB_SEED_CUS", 0);
+    if (ncu > 0) {
+        const long stride = std::max(1L, GPSBB_KNOB_LONG("GPSBB_SEED_CU_STRIDE", 1));
+        const long first = GPSBB_KNOB_LONG("GPSBB_SEED_CU_FIRST", 0);
+        uint32_t mask[16] = {0};
+        for (long k = 0; k < ncu; k++) {
+            const long bit = first + k * stride;
+            if (bit < 512)
+                mask[bit >> 5] |= 1u << (bit & 31);
+        }
+        return hipExtStreamCreateWithCUMask(st, 16, mask);
+    }
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+
 /* seeding stream k of the handle (0 = s_seed), created on first use */
 static hipError_t seed_stream_at(gpsbb *h, unsigned k, hipStream_t *out)
 {
@@ -1214,7 +1236,7 @@ static hipError_t seed_stream_at(gpsbb *h, unsigned k, hipStream_t *out)
     }
     hipStream_t &st = h->s_more[k - 1];
     if (!st) {
-        hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        hipError_t e = create_seed_stream(&st);
         if (e != hipSuccess)
             return e;
     }

@@ -478,6 +478,12 @@ def main():
                                             "frac": m1_alg / (m1s["synth_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                                   "note": "VALU- and LDS-issue-bound (about 27 VALU issue cycles and 12 bytes of LDS reads per channel-sample), not HBM-bound: DESIGN.md 2.7"},
                      "workload": "12 ch, fs 2.6e6 S/s, 300000-sample blocks, 1000 independent blocks per step; synthesis kernel " + m1_kernel}
+        # the reference built without FLOAT_CARR_PHASE (h:12): 32-bit fixed-point carrier, the same M1 geometry
+        fch = mch.copy()
+        fch["carr_phase"] = np.floor(fch["carr_phase"] * 2.0 ** 32)
+        m1f, _ = resident_leg(pkg, synth, torch, fch, 1.0 / 2.6e6, 300000, pkg.FIXED_CARRIER, 20, 4, dev)
+        m1f["synthesis_kernel"] = {1: "k_synth", 2: "k_synth_pd"}.get(synth.info(pkg.INFO_LAST_KERNEL), "?")
+        res["m1"]["gpu_fixed_point_carrier"] = m1f
         if not args.no_cpu:
             import oracle_binding as ob
             res["cpu_baseline"] = cpu_baseline(ob, mine, delt, nsamp, budget_s=args.cpu_budget)

@@ -53,6 +53,9 @@ def run(pkg, synth, name, nav, motion, max_chan, fs, nsamp, nblocks, push_blocks
             "end_to_end_iq_samples_per_s": nblocks * nsamp / (dt + t_fe), "x_realtime_end_to_end": nblocks * 0.1 / (dt + t_fe)}
 
 
+NB_F = 24000  # 40 minutes of signal: long enough for the ring to reach its steady state (a 3000-block run is over in 13 ms)
+
+
 def main():
     pkg = load_package()
     pkg.build_frontend()
@@ -61,9 +64,9 @@ def main():
         if len(sys.argv) > 1:  # e.g. 3: stream pushes keep pass A (gpsbb.h, GPSBB_OPT_CHAIN_WHERE)
             s.set_option(pkg.OPT_CHAIN_WHERE, int(sys.argv[1]))
         out.append(run(pkg, s, "1/2 static, 2.6 MS/s, reference block (300000 samples)", "synth3540.14n", None, 12,
-                       2.6e6, 300000, 3000, 250))
+                       2.6e6, 300000, NB_F, 1000))
         out.append(run(pkg, s, "4 user motion (10 Hz), 2.6 MS/s", "synth3540.14n", "circle_motion.csv", 12, 2.6e6,
-                       300000, 3000, 250))
+                       300000, NB_F, 1000))
         out.append(run(pkg, s, "3 geometry through the front end: 16 ch, 25 MS/s, 2.5 M-sample blocks", "dense3540.14n",
                        None, 16, 25e6, 2500000, 400, 100))
     print(json.dumps(out, indent=1))

@@ -21,7 +21,7 @@
  *       sums of at most 16 integers below 2^15 are exact in binary32.  No sign extraction, no xor / sub / add chain: the
  *       chips are the upper halves of binary32 +-1.0, read with ds_read_u16_d16_hi into registers whose lower halves
  *       stay zero, and the data bit picks one of two chip tables (the second one negated) through the model's address.
- *   the 16 samples of a channel in ONE block of assembly (pd_channel_fast): six VALU instructions per channel-sample
+ *   the 16 samples of a channel in ONE block of assembly (pd_channel_fast_wide / _narrow): six VALU instructions per channel-sample
  *       (2 v_add_f64, v_and_or, v_and, v_min3, v_pk_fma) and the LDS reads of four samples in flight behind counted
  *       waits — the compiler's own schedule of the same source waited for every pair of reads on the spot, copied the
  *       32 accumulators once per channel and moved both models through a register pair per sample: 12 instructions.

@@ -214,7 +214,7 @@ struct CarrDrift {
  * packed I/Q arithmetic of that kernel needs it; the reference's (short) wrap-around is then unreachable
  * too).  Steps are the individually rounded products the kernels and the reference use (c:2709, 2741).
  */
-bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vector<EvConst> &out)
+bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vector<EvConst> &out, bool fixed = false)
 {
     const size_t nbc = (size_t)nblocks * nch;
     out.resize(nbc);
@@ -229,7 +229,14 @@ bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vec
                 continue;
             amp_sum += 512.0 * std::fabs(c.gain) + 1.0;
             const volatile double sc = c.f_code * delt, sk = c.f_carr * delt;
-            const double S = sk * 512.0, aS = std::fabs(S);
+            double S = sk * 512.0;
+            if (fixed) {
+                /* the 32-bit accumulator (c:2675, 2699): the table index is phase / 2^16 modulo 512, its step exactly
+                 * step / 2^16.  Only k_synth_pd takes it (every channel evaluated per sample: checked below) */
+                const volatile double scaled = 512.0 * 65536.0 * c.f_carr * delt;
+                S = (double)(int)std::round(scaled) * 0x1p-16;
+            }
+            const double aS = std::fabs(S);
             /* more than one chip change per run: the channel is evaluated per sample (ev_dense), as long as the chip
              * table reaches past what a tile covers (which also leaves at most one code roll-over per tile) */
             const bool dense_code = !(sc * reach < 1.0);
@@ -273,6 +280,11 @@ bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vec
             K.pd_dx = sc * 128.0;
             if (dense_code && K.kc > 0)
                 K.kc = EV_KC_DENSE;
+            if (fixed) {
+                if (!dense_code || !(aS < 64.0))
+                    return false; /* (the stepped kernel takes these) */
+                K.kc = EV_KC_DENSE;
+            }
         }
         if (!(amp_sum < 32768.0))
             return false;
@@ -852,7 +864,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
 
     /* Which synthesis kernel: the breakpoint kernel (gpsbb_events.hip.h) where every run of SPT samples holds
      * at most one chip change and at most EV_KC_MAX table-index changes and the I sums stay below 2^15. */
-    b->ev = !fixed && h->opt_synth_kernel != 1 && ev_plan(ch, nblocks, nch, delt, b->h_evc);
+    b->ev = h->opt_synth_kernel != 1 && ev_plan(ch, nblocks, nch, delt, b->h_evc, fixed);
     b->ev_dense = false;
     b->ev_all_dense = b->ev;
     if (b->ev)
@@ -1435,11 +1447,17 @@ bool host_seed_chain(const gpsbb_batch *b, int kind, size_t k, unsigned long lon
         }
         return true;
     }
+    const size_t blk = k / (size_t)b->nch, i = k % (size_t)b->nch;
     if (kind == 1 && fixed) {
         e.carr_phase = (double)(uint32_t)(b->h_kph0[k] + (uint32_t)b->nsamp * (uint32_t)b->h_kstep[k]);
+        if (b->ev) {
+            /* k_synth_pd: the table index at every tile start, in closed form (what k_tiles writes on the device) */
+            double *tx = b->hs_tile_x + (blk * (2 * (size_t)b->nch) + 2 * i + 1) * (size_t)b->ntiles;
+            for (int t = 0; t < b->ntiles; t++)
+                tx[t] = fixed_tile_index(b->h_kph0[k], b->h_kstep[k], t);
+        }
         return true;
     }
-    const size_t blk = k / (size_t)b->nch, i = k % (size_t)b->nch;
     if (b->ev) {
         /* breakpoint kernel: tile-start states instead of rows (what k_seed<true> writes) */
         uint32_t nav = kind == 0 ? nav_pack(c.icode, c.ibit, c.iword) : 0u;

@@ -106,7 +106,8 @@ __device__ __forceinline__ v2f pd_model_sample(const PdModel &M, int lane, int j
  */
 template <bool WIDE>
 __device__ __noinline__ v2f pd_fix_sample(const PdLds<WIDE> &L, int i, const EvConst *kbi, const double *tile_x, int ntiles, double ytg,
-                                          double xtg, uint32_t amp_base, uint32_t roll_addr, uint32_t negs, int lane, int j)
+                                          double xtg, uint32_t amp_base, uint32_t roll_addr, uint32_t negs, int lane, int j, int fixed,
+                                          uint32_t fx_phase, int32_t fx_step)
 {
     PdModel M;
     M.ytg = ytg;
@@ -126,8 +127,13 @@ __device__ __noinline__ v2f pd_fix_sample(const PdLds<WIDE> &L, int i, const EvC
     int64_t wraps = 0;
     const double x = code_jump(xt, sc, (int64_t)n, &wraps);
     const bool neg = wraps > 0 ? M.neg_next != 0 : M.neg != 0; /* at most one roll-over per tile (checked by the host) */
-    const double cp = carr_jump(yt * (1.0 / 512.0), S * (1.0 / 512.0), (int64_t)n);
-    const int it = (int)(cp * 512.0) & 511; /* c:2697; carr_phase == 1.0: index 512 defined as 0 */
+    int it;
+    if (fixed) {
+        it = (int)(((fx_phase + (uint32_t)n * (uint32_t)fx_step) >> 16) & 0x1ffu); /* c:2699: the 32-bit accumulator */
+    } else {
+        const double cp = carr_jump(yt * (1.0 / 512.0), S * (1.0 / 512.0), (int64_t)n);
+        it = (int)(cp * 512.0) & 511; /* c:2697; carr_phase == 1.0: index 512 defined as 0 */
+    }
     const int ci = (int)x;                  /* c:2737 */
     const float sg = __uint_as_float(((uint32_t)L.chipf[0][i][ci] << 16) ^ (neg ? 0x80000000u : 0u));
     const v2f a = L.amp[i][down ? 511 - it : it];
@@ -148,16 +154,27 @@ __device__ __noinline__ v2f pd_fix_sample(const PdLds<WIDE> &L, int i, const EvC
  * tile start is in xtg's table address; where it changes inside the tile (df) the second body moves the addresses past the
  * code's roll-over (>= roll) by delta, into the other table.
  */
-#define GPSBB_PD_ADDR                                                                                                  \
+#define GPSBB_PD_ADDR_F                                                                                                \
     "v_and_or_b32 v92, v73, %[msk], %[ab]\n"                                                                           \
     "v_and_b32 v93, 0xffffe, v75\n"                                                                                    \
     "v_min3_u32 %[m], %[m], v72, v74\n"
-#define GPSBB_PD_ISSUE(A0, A1, C, C1)                                                                                  \
+/* fixed-point carrier: its model is exact (multiples of 2^-13, sums without rounding): only the code model is tested */
+#define GPSBB_PD_ADDR_X                                                                                                \
+    "v_and_or_b32 v92, v73, %[msk], %[ab]\n"                                                                           \
+    "v_and_b32 v93, 0xffffe, v75\n"                                                                                    \
+    "v_min_u32 %[m], %[m], v74\n"
+#define GPSBB_PD_ISSUE(A0, A1, C, C1) GPSBB_PD_ISSUE_(GPSBB_PD_ADDR_F, A0, A1, C, C1)
+#define GPSBB_PD_ISSUE_X(A0, A1, C, C1) GPSBB_PD_ISSUE_(GPSBB_PD_ADDR_X, A0, A1, C, C1)
+#define GPSBB_PD_ISSUE_DFW(A0, A1, C, C1) GPSBB_PD_ISSUE_DFW_(GPSBB_PD_ADDR_F, A0, A1, C, C1)
+#define GPSBB_PD_ISSUE_DFW_X(A0, A1, C, C1) GPSBB_PD_ISSUE_DFW_(GPSBB_PD_ADDR_X, A0, A1, C, C1)
+#define GPSBB_PD_ISSUE_DFN(A0, A1, C, C1) GPSBB_PD_ISSUE_DFN_(GPSBB_PD_ADDR_F, A0, A1, C, C1)
+#define GPSBB_PD_ISSUE_DFN_X(A0, A1, C, C1) GPSBB_PD_ISSUE_DFN_(GPSBB_PD_ADDR_X, A0, A1, C, C1)
+#define GPSBB_PD_ISSUE_(GPSBB_PD_ADDR, A0, A1, C, C1)                                                                  \
     GPSBB_PD_ADDR                                                                                                      \
     "ds_read_b64 v[" #A0 ":" #A1 "], v92\n"                                                                            \
     "ds_read_u16_d16_hi v" #C ", v93\n"
 /* WIDE, the data bit changes: past the roll-over the other table */
-#define GPSBB_PD_ISSUE_DFW(A0, A1, C, C1)                                                                              \
+#define GPSBB_PD_ISSUE_DFW_(GPSBB_PD_ADDR, A0, A1, C, C1)                                                              \
     GPSBB_PD_ADDR                                                                                                      \
     "ds_read_b64 v[" #A0 ":" #A1 "], v92\n"                                                                            \
     "v_cmp_le_u32 vcc, %[roll], v93\n"                                                                                 \
@@ -165,7 +182,7 @@ __device__ __noinline__ v2f pd_fix_sample(const PdLds<WIDE> &L, int i, const EvC
     "v_add_u32 v93, v93, v92\n"                                                                                        \
     "ds_read_u16_d16_hi v" #C ", v93\n"
 /* one table, the data bit changes: the sample's sign bit next to its chip (the upper register of the chip's pair) */
-#define GPSBB_PD_ISSUE_DFN(A0, A1, C, C1)                                                                              \
+#define GPSBB_PD_ISSUE_DFN_(GPSBB_PD_ADDR, A0, A1, C, C1)                                                              \
     GPSBB_PD_ADDR                                                                                                      \
     "ds_read_b64 v[" #A0 ":" #A1 "], v92\n"                                                                            \
     "v_cmp_le_u32 vcc, %[roll], v93\n"                                                                                 \
@@ -222,35 +239,50 @@ __device__ __noinline__ v2f pd_fix_sample(const PdLds<WIDE> &L, int i, const EvC
         "v88", "v89", "v90", "v91", "v92", "v93", "vcc", "scc"
 /* WIDE: two chip tables.  The data bit in force at the tile start is in xtg's table address; where it changes inside the
  * tile (df) the second body moves the addresses past the code's roll-over (>= roll) by delta, into the other table. */
-__device__ __forceinline__ uint32_t pd_channel_fast_wide(const PdModel &M, double xtg, double lf, uint32_t df, uint32_t roll, int32_t delta,
+__device__ __forceinline__ uint32_t pd_channel_fast_wide(const PdModel &M, double xtg, double lf, uint32_t sel, uint32_t roll, int32_t delta,
                                                          v2f (&acc)[SPT])
 {
     static_assert(SPT == 16, "the block below is written for 16 samples per lane");
     uint32_t m = 0xffffffffu;
+    /* sel: bit 0 = the data bit changes inside the tile, bit 1 = fixed-point carrier (no test of the carrier model) */
     asm volatile(GPSBB_PD_HEAD
-                 "s_cmp_lg_u32 %[df], 0\n"
+                 "s_bitcmp1_b32 %[sel], 1\n"
+                 "s_cbranch_scc1 4f\n"
+                 "s_bitcmp1_b32 %[sel], 0\n"
                  "s_cbranch_scc1 1f\n"
                  GPSBB_PD_BODY(GPSBB_PD_ISSUE, GPSBB_PD_FMA)
                  "s_branch 2f\n"
                  "1:\n"
                  GPSBB_PD_BODY(GPSBB_PD_ISSUE_DFW, GPSBB_PD_FMA)
+                 "s_branch 2f\n"
+                 "4:\n"
+                 "s_bitcmp1_b32 %[sel], 0\n"
+                 "s_cbranch_scc1 5f\n"
+                 GPSBB_PD_BODY(GPSBB_PD_ISSUE_X, GPSBB_PD_FMA)
+                 "s_branch 2f\n"
+                 "5:\n"
+                 GPSBB_PD_BODY(GPSBB_PD_ISSUE_DFW_X, GPSBB_PD_FMA)
                  "2:\n"
                  : GPSBB_PD_ACCS
                  : [lf] "v"(lf), [ytg] "v"(M.ytg), [xtg] "v"(xtg), [s8] "s"(M.S8), [sc2] "s"(M.sc2), [dy] "s"(M.dy), [dx] "s"(M.dx),
-                   [ab] "v"(M.amp_base), [msk] "s"(0xff8u), [df] "s"(df), [roll] "s"(roll), [delta] "v"(delta)
+                   [ab] "v"(M.amp_base), [msk] "s"(0xff8u), [sel] "s"(sel), [roll] "s"(roll), [delta] "v"(delta)
                  : GPSBB_PD_CLOBBERS);
     return m;
 }
 /* One chip table (13 to 16 channels): the data bit as a sign modifier of the packed FMA; where it changes inside the tile
  * every sample carries its own sign bit (sgn0 before the roll-over, sgn1 past it). */
-__device__ __forceinline__ uint32_t pd_channel_fast_narrow(const PdModel &M, double lf, v2f (&acc)[SPT])
+__device__ __forceinline__ uint32_t pd_channel_fast_narrow(const PdModel &M, double lf, uint32_t fixed, v2f (&acc)[SPT])
 {
     uint32_t m = 0xffffffffu;
     const uint32_t sgn0 = M.neg ? 0x80000000u : 0u, sgn1 = M.neg_next ? 0x80000000u : 0u;
+    /* sel: bit 0 = the data bit changes inside the tile, bit 1 = fixed-point carrier, bit 2 = the data bit in force is -1 */
+    const uint32_t sel = (M.neg ^ M.neg_next) | (fixed << 1) | (M.neg << 2);
     asm volatile(GPSBB_PD_HEAD
-                 "s_cmp_lg_u32 %[df], 0\n"
+                 "s_bitcmp1_b32 %[sel], 1\n"
+                 "s_cbranch_scc1 4f\n"
+                 "s_bitcmp1_b32 %[sel], 0\n"
                  "s_cbranch_scc1 1f\n"
-                 "s_cmp_lg_u32 %[neg], 0\n"
+                 "s_bitcmp1_b32 %[sel], 2\n"
                  "s_cbranch_scc1 3f\n"
                  GPSBB_PD_BODY(GPSBB_PD_ISSUE, GPSBB_PD_FMA)
                  "s_branch 2f\n"
@@ -259,18 +291,37 @@ __device__ __forceinline__ uint32_t pd_channel_fast_narrow(const PdModel &M, dou
                  "s_branch 2f\n"
                  "1:\n"
                  GPSBB_PD_BODY(GPSBB_PD_ISSUE_DFN, GPSBB_PD_FMA_SGN)
+                 "s_branch 2f\n"
+                 "4:\n"
+                 "s_bitcmp1_b32 %[sel], 0\n"
+                 "s_cbranch_scc1 5f\n"
+                 "s_bitcmp1_b32 %[sel], 2\n"
+                 "s_cbranch_scc1 6f\n"
+                 GPSBB_PD_BODY(GPSBB_PD_ISSUE_X, GPSBB_PD_FMA)
+                 "s_branch 2f\n"
+                 "6:\n"
+                 GPSBB_PD_BODY(GPSBB_PD_ISSUE_X, GPSBB_PD_FMA_NEG)
+                 "s_branch 2f\n"
+                 "5:\n"
+                 GPSBB_PD_BODY(GPSBB_PD_ISSUE_DFN_X, GPSBB_PD_FMA_SGN)
                  "2:\n"
                  : GPSBB_PD_ACCS
                  : [lf] "v"(lf), [ytg] "v"(M.ytg), [xtg] "v"(M.xtg), [s8] "s"(M.S8), [sc2] "s"(M.sc2), [dy] "s"(M.dy), [dx] "s"(M.dx),
-                   [ab] "v"(M.amp_base), [msk] "s"(0xff8u), [df] "s"(M.neg ^ M.neg_next), [neg] "s"(M.neg), [roll] "s"(M.roll_addr),
-                   [sgn0] "v"(sgn0), [sgn1] "v"(sgn1)
+                   [ab] "v"(M.amp_base), [msk] "s"(0xff8u), [sel] "s"(sel), [roll] "s"(M.roll_addr), [sgn0] "v"(sgn0), [sgn1] "v"(sgn1)
                  : GPSBB_PD_CLOBBERS);
     return m;
 }
-#undef GPSBB_PD_ADDR
+#undef GPSBB_PD_ADDR_F
+#undef GPSBB_PD_ADDR_X
 #undef GPSBB_PD_ISSUE
+#undef GPSBB_PD_ISSUE_X
+#undef GPSBB_PD_ISSUE_
 #undef GPSBB_PD_ISSUE_DFW
+#undef GPSBB_PD_ISSUE_DFW_X
+#undef GPSBB_PD_ISSUE_DFW_
 #undef GPSBB_PD_ISSUE_DFN
+#undef GPSBB_PD_ISSUE_DFN_X
+#undef GPSBB_PD_ISSUE_DFN_
 #undef GPSBB_PD_STEP
 #undef GPSBB_PD_FMA
 #undef GPSBB_PD_FMA_NEG
@@ -282,13 +333,13 @@ __device__ __forceinline__ uint32_t pd_channel_fast_narrow(const PdModel &M, dou
 
 /* the smallest low word of a lane's models over its 16 samples of a channel, as the fast path sees it (for the lanes that
  * have to be looked at again) */
-__device__ __forceinline__ uint32_t pd_model_min(const PdModel &M, int lane)
+__device__ __forceinline__ uint32_t pd_model_min(const PdModel &M, int lane, bool fixed)
 {
     double y = __fma_rn((double)lane, M.S8, M.ytg), x = __fma_rn((double)lane, M.sc2, M.xtg);
     uint32_t m = 0xffffffffu;
 #pragma unroll 1
     for (int j = 0; j < SPT; j++) {
-        m = min(m, min((uint32_t)__double2loint(y), (uint32_t)__double2loint(x)));
+        m = min(m, min(fixed ? 0xffffffffu : (uint32_t)__double2loint(y), (uint32_t)__double2loint(x)));
         y = __dadd_rn(y, M.dy);
         x = __dadd_rn(x, M.dx);
     }
@@ -379,6 +430,10 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     constexpr uint32_t neg_table_bytes = (uint32_t)(sizeof(uint16_t) * PdLds<WIDE>::NCH * EV_CHIP_LEN); /* from chipf[0] to the negated table */
     const double neg_table = (double)neg_table_bytes;
     const double lf = (double)lane;
+    /* fixed-point carrier (the reference without FLOAT_CARR_PHASE): the tile states are (phase mod 2^25) / 2^16, the steps
+     * multiples of 2^-16, every sum exact; a falling phase is mirrored bit by bit: (2^25 - 1 - p) / 2^16 */
+    const uint32_t fixed = p.kph0 != nullptr ? 1u : 0u;
+    const double mirror_at = fixed ? 512.0 - 0x1p-16 : 512.0;
     unsigned long long *n_exact = p.hazards + 2;
 
     int base = 0;
@@ -396,7 +451,7 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     while (base < ntw) {
         const int wt = base + pos;
         if (chain_lane)
-            L.tstate[wave][buf][lane] = __fma_rn(mirror ? 512.0 - ts_v : ts_v, g_scale, g_add);
+            L.tstate[wave][buf][lane] = __fma_rn(mirror ? mirror_at - ts_v : ts_v, g_scale, g_add);
         const double *ts = L.tstate[wave][buf];
         const uint32_t dbits = (uint32_t)__ballot(nav_v & 1u), dnext = (uint32_t)__ballot(nav_v & 2u);
         if (pos == 0 && lane == 0)
@@ -431,9 +486,9 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
                 const double xtg = M.xtg + (M.neg ? neg_table : 0.0); /* exact: an integer number of bytes */
                 const uint32_t roll = M.roll_addr + (M.neg ? neg_table_bytes : 0u);
                 const int32_t delta = ((int32_t)M.neg_next - (int32_t)M.neg) * (int32_t)neg_table_bytes;
-                m = pd_channel_fast_wide(M, xtg, lf, M.neg ^ M.neg_next, roll, delta, acc);
+                m = pd_channel_fast_wide(M, xtg, lf, (M.neg ^ M.neg_next) | (fixed << 1), roll, delta, acc);
             } else {
-                m = pd_channel_fast_narrow(M, lf, acc);
+                m = pd_channel_fast_narrow(M, lf, fixed, acc);
             }
             const unsigned long long um = __builtin_amdgcn_uicmp(m, p.pd_danger, 36 /* ult */);
             fixmask |= (um != 0ull || ((exact_mask >> i) & 1u)) ? 1u << i : 0u;
@@ -447,10 +502,14 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
                 const int i = __builtin_ctz(mk);
                 PdModel M;
                 pd_model_of(L, kb, ts, i, dbits, dnext, M);
-                if (((exact_mask >> i) & 1u) || pd_model_min(M, lane) < p.pd_danger) {
+                if (((exact_mask >> i) & 1u) || pd_model_min(M, lane, fixed != 0u) < p.pd_danger) {
+                    const size_t kk = (size_t)b * p.nch + i;
+                    const int32_t fx_step = fixed ? p.kstep[kk] : 0;
+                    const uint32_t fx_phase = fixed ? p.kph0[kk] + (uint32_t)wt * (uint32_t)TILE * (uint32_t)fx_step : 0u;
 #pragma unroll 1
                     for (int j = 0; j < SPT; j++) {
-                        const v2f t = pd_fix_sample(L, i, kb + i, txb + wt, ntw, M.ytg, M.xtg, M.amp_base, M.roll_addr, M.neg | (M.neg_next << 1), lane, j);
+                        const v2f t = pd_fix_sample(L, i, kb + i, txb + wt, ntw, M.ytg, M.xtg, M.amp_base, M.roll_addr, M.neg | (M.neg_next << 1), lane, j,
+                                                    (int)fixed, fx_phase, fx_step);
 #pragma unroll
                         for (int q = 0; q < SPT; q++) {
                             acc[q].x += q == j ? t.x : 0.0f;

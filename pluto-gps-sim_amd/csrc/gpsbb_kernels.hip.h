@@ -546,6 +546,14 @@ __device__ inline ChainDone seed_carr_chain(const BatchDev &p, int b, int i, dou
     return d;
 }
 
+/* fixed-point carrier variant on the model kernel (k_synth_pd): the table index at the first sample of tile t as a
+ * double, fraction included — (phase / 2^16) modulo 512 with phase = start + t*TILE*step modulo 2^32 (c:2699, 2748) */
+GPSBB_HD double fixed_tile_index(uint32_t ph0, int32_t step, int t)
+{
+    const uint32_t ph = ph0 + (uint32_t)t * (uint32_t)TILE * (uint32_t)step;
+    return (double)(ph & 0x1ffffffu) * 0x1p-16;
+}
+
 /* fixed-point carrier variant: the phase after the block is start + nsamp*step modulo 2^32 (c:2748) */
 __device__ inline void seed_carr_fixed(const BatchDev &p, int b, int i)
 {

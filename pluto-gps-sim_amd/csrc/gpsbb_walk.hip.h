@@ -418,7 +418,9 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
         /* the passes of the device-side chain read the 24-byte chain descriptors, the others the descriptors themselves */
         const int prn = PASS >= 1 ? p.cd[k].prn : p.ch[k].prn;
         const double f_carr = PASS >= 1 ? p.cd[k].f_carr : p.ch[k].f_carr;
-        const bool on = is_carr && prn > 0;
+        /* fixed-point carrier (only ever with PASS 0): nothing to walk, the phase is linear in the sample number */
+        const bool fx = PASS == 0 && p.kph0 != nullptr;
+        const bool on = is_carr && prn > 0 && !fx;
         const double x0 = PASS == 1 ? p.start0[k] : (PASS >= 2 ? (p.model_start ? p.start0[k] : p.aux[k].start1) : p.ch[k].carr_phase);
         const int vb = k / p.nch, sgi = PASS >= 1 ? vb % p.nseg : 0;
         const int ns = PASS >= 1 ? seg_nsamp(p, sgi) : p.nsamp; /* lanes of a wavefront may walk segments of different length */
@@ -435,7 +437,8 @@ __global__ __launch_bounds__(GPSBB_WALK_WG) void k_walk(BatchDev p)
                 if (PASS != 3) {
                     p.row_cnt[nbc + k] = on ? (int32_t)(w.cnt < w.cap ? w.cnt : w.cap) : 0;
                     if (PASS == 0)
-                        p.end[k].carr_phase = on ? w.x : 0.0; /* (chained: the fix-up writes the blocks' true end phases) */
+                        p.end[k].carr_phase = fx ? (prn > 0 ? (double)(uint32_t)(p.kph0[k] + (uint32_t)p.nsamp * (uint32_t)p.kstep[k]) : 0.0)
+                                                 : (on ? w.x : 0.0); /* (chained: the fix-up writes the blocks' true end phases) */
                 }
                 if (PASS >= 2) {
                     /* the trajectory walked here is not final: k_chain_fix decides what counts */
@@ -1241,11 +1244,20 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
      * finished: the pre-pass waited for it): saves a memset and its launch gap on the synthesis stream */
     if (chain < p.nblocks && threadIdx.x == 0)
         p.tile_ctr[chain] = 0;
+    const int b = bi / p.nch, i = bi % p.nch;
+    if (kind && p.kph0) {
+        /* fixed-point carrier: the table index at every tile start in closed form (no rows) */
+        if (p.ch[bi].prn > 0) {
+            double *__restrict__ txf = p.tile_x + ((size_t)b * (2 * (size_t)p.nch) + 2 * i + 1) * (size_t)p.ntiles;
+            for (int t = threadIdx.x; t < p.ntiles; t += blockDim.x)
+                txf[t] = fixed_tile_index(p.kph0[bi], p.kstep[bi], t);
+        }
+        return;
+    }
     const int cnt = p.row_cnt[chain];
     if (cnt <= 0)
         return;
     const WalkRow *__restrict__ rows = reinterpret_cast<const WalkRow *>(p.rows) + p.row_off[chain];
-    const int b = bi / p.nch, i = bi % p.nch;
     /* the chain's step (c:2709 / c:2741), from which every row's increment follows (walk_row_step) */
     const double s = kind ? mul_rn(p.ch[bi].f_carr, p.delt) : mul_rn(p.ch[bi].f_code, p.delt);
     double *__restrict__ tx = p.tile_x + ((size_t)b * (2 * (size_t)p.nch) + 2 * i + kind) * (size_t)p.ntiles + t0;

@@ -281,9 +281,24 @@ bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vec
             if (dense_code && K.kc > 0)
                 K.kc = EV_KC_DENSE;
             if (fixed) {
-                if (!dense_code || !(aS < 64.0))
-                    return false; /* (the stepped kernel takes these) */
-                K.kc = EV_KC_DENSE;
+                /* The accumulator's index model is exact (gpsbb_events.hip.h, ev_first<KC, true>): nothing on the carrier side is
+                 * biased or tested, the change positions come from (1 - fraction - 2^-17) / |step|.  Per sample (k_synth_pd) where
+                 * a run holds more than one chip change, per breakpoint otherwise; what neither takes goes to the stepped kernel. */
+                if (dense_code) {
+                    if (!(aS < 64.0))
+                        return false;
+                    K.kc = EV_KC_DENSE;
+                } else {
+                    const double kc = std::floor(reach * aS) + 1.0;
+                    if (kc > (double)EV_KC_MAX)
+                        return false;
+                    K.kc = (int)kc;
+                    K.rS = aS > 0.0 ? 1.0 / aS : 0x1p+1000;
+                    K.W = std::max(wC, EV_T_EPS);
+                    K.danger = K.W >= 0.25 ? 0x80000000u : (uint32_t)std::ceil(2.0 * K.W * 4294967296.0) + 1u;
+                    K.tK0 = K.rS * (1.0 - 0x1p-17) + 0x1p+20;
+                    K.tC0 = K.rsc * (1.0 + K.W) + 0x1p+20 + K.W;
+                }
             }
         }
         if (!(amp_sum < 32768.0))
@@ -752,6 +767,8 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(EvLds))) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev_dense), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(EvLds))) != hipSuccess) return fail(e);
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev_fixed), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(EvLds))) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_pd<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(PdLds<true>))) != hipSuccess) return fail(e);
@@ -1801,6 +1818,8 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
             hipLaunchKernelGGL(k_synth_pd<false>, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(PdLds<false>), sc, p, d_iq);
         else if (b->ev_dense)
             hipLaunchKernelGGL(k_synth_ev_dense, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), sc, p, d_iq);
+        else if (p.kph0)
+            hipLaunchKernelGGL(k_synth_ev_fixed, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), sc, p, d_iq);
         else
             hipLaunchKernelGGL(k_synth_ev, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), sc, p, d_iq);
         h->last_kernel = 2;

@@ -109,7 +109,7 @@ __device__ __forceinline__ T scalar_load(const T *p)
  * the run's first sample.
  */
 __device__ __noinline__ uint32_t ev_exact_run(EvLds &L, int wave, int lane, int i, const EvConst *kbi, const double *tile_x,
-                                              int ntiles, uint32_t nb, int n_off)
+                                              int ntiles, uint32_t nb, int n_off, int fixed = 0, uint32_t fx_phase = 0u, int32_t fx_step = 0)
 {
     const bool down = kbi->down != 0;
     const double S = down ? -kbi->S : kbi->S, sc = kbi->sc;
@@ -123,9 +123,11 @@ __device__ __noinline__ uint32_t ev_exact_run(EvLds &L, int wave, int lane, int 
     const double s = S * (1.0 / 512.0);
     double cp = carr_jump(yt * (1.0 / 512.0), s, (int64_t)n_off);
     uint32_t prev = 0, first = 0;
+    uint32_t ph = fx_phase + (uint32_t)n_off * (uint32_t)fx_step; /* fixed-point carrier: the accumulator at the run's first sample */
 #pragma unroll 1
     for (int j = 0; j < SPT; j++) {
-        const int it = (int)(cp * 512.0) & 511; /* c:2697; carr_phase == 1.0: index 512 defined as 0 */
+        const int it = fixed ? (int)((ph >> 16) & 0x1ffu) /* c:2699 */
+                             : ((int)(cp * 512.0) & 511); /* c:2697; carr_phase == 1.0: index 512 defined as 0 */
         const int ci = (int)x;                  /* c:2737 */
         const uint32_t m = (uint32_t)(int32_t)(int8_t)(L.chip2[i][ci] & 0xffu) ^ dbm;
         const uint32_t v = signed_by(L.amp[i][down ? 511 - it : it], m);
@@ -137,6 +139,7 @@ __device__ __noinline__ uint32_t ev_exact_run(EvLds &L, int wave, int lane, int 
         if (code_step(x, sc)) /* c:2709-2734: the data bit of the next period */
             dbm = dbm_next;
         carr_step(cp, s); /* c:2741-2746 */
+        ph += (uint32_t)fx_step; /* c:2748 */
     }
     return first;
 }
@@ -178,7 +181,12 @@ struct EvHalf {
     uint32_t ch2;
 };
 
-template <int KC>
+/* FIXED: the fixed-point carrier (GPSBB_FIXED_CARRIER).  Its table index (phase mod 2^25) / 2^16 and its step are multiples of
+ * 2^-16 and every product and sum here is exact, so the model IS the truth on the carrier side: no bias, nothing to test.
+ * The k-th index change lies (1 - fraction + k) / step samples on; with one half of 2^-16 taken off the numerator
+ * (EvConst::tK0) that is (2a - 1) / (2b) for integers a, b = |step| < 2^15 — never an integer and at least 1 / (2b) away
+ * from one, against the 2^-32 this format resolves — so floor() is right even where a change falls exactly on a sample. */
+template <int KC, bool FIXED>
 __device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK &K, double xt, double yt, double off)
 {
     EvHalf<KC> h;
@@ -187,12 +195,13 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK 
     const double y0 = __fma_rn(off, K.S, yt); /* guard format, biased: 2^20 + W + phase */
     const double fr = __builtin_amdgcn_fract(y0);
     const int it0 = __double2hiint(y0) & 511;
-    uint32_t m = (uint32_t)__double2loint(y0); /* the previous change lies within the model error of sample 0: low word below 2W */
+    uint32_t m = FIXED ? 0xffffffffu : (uint32_t)__double2loint(y0); /* the previous change lies within the model error of sample 0: low word below 2W */
     double t = __fma_rn(-fr, K.rS, K.tK0);     /* 2^20 + W + (1 - fraction) / |step|: samples until the next index change */
 #pragma unroll
     for (int k = 0; k < KC; k++) {
         const double tq = fmin(t, sat);
-        m = min(m, (uint32_t)__double2loint(tq));
+        if (!FIXED)
+            m = min(m, (uint32_t)__double2loint(tq));
         h.jk[k] = __double2hiint(tq) & 15; /* the change shows at sample floor + 1: rows 0..14, or 15 */
         t += K.rS;
     }
@@ -221,7 +230,8 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK 
 template <int KC, bool DF>
 __device__ __forceinline__ void ev_second(EvLds &L, int wave, int lane, int i, EvHalf<KC> &h, uint32_t db, uint32_t db_next,
                                           bool always_exact, unsigned long long live_mask, const EvConst *kb, const double *tile_x,
-                                          int ntiles, uint32_t nb, double off, uint32_t &acc0, unsigned long long *n_exact)
+                                          int ntiles, uint32_t nb, double off, uint32_t &acc0, unsigned long long *n_exact,
+                                          const uint32_t *fx_ph, const int32_t *fx_st, int fx_n0)
 {
     const uint32_t ma = (uint32_t)(int32_t)(int8_t)(h.ch2 & 0xffu), mb = (uint32_t)(int32_t)(int8_t)(h.ch2 >> 8);
     uint32_t m0, m1;
@@ -246,7 +256,11 @@ __device__ __forceinline__ void ev_second(EvLds &L, int wave, int lane, int i, E
             jc = EV_ROW_DISCARD;
             h.A[0] = 0;
             /* ... and the exact one takes its place */
-            acc0 += ev_exact_run(L, wave, lane, i, kb + i, tile_x, ntiles, nb, (int)off);
+            if (fx_ph) /* fixed-point carrier: the accumulator at the tile's first sample */
+                acc0 += ev_exact_run(L, wave, lane, i, kb + i, tile_x, ntiles, nb, (int)off, 1,
+                                     fx_ph[i] + (uint32_t)fx_n0 * (uint32_t)fx_st[i], fx_st[i]);
+            else
+                acc0 += ev_exact_run(L, wave, lane, i, kb + i, tile_x, ntiles, nb, (int)off);
             atomicAdd(n_exact, 1ull);
         }
     }
@@ -274,6 +288,9 @@ struct EvTile {
     int ntiles;
     uint32_t dbits, dnext; /* bit i: channel i's data bit in force / after the next roll-over is -1 */
     uint32_t exact_mask;   /* bit i: channel i is always recomputed exactly */
+    const uint32_t *fx_ph; /* fixed-point carrier: the block's start phases and steps per channel (else null) ... */
+    const int32_t *fx_st;
+    int fx_n0;             /* ... and the tile's first sample */
 };
 
 /*
@@ -325,7 +342,7 @@ __device__ __forceinline__ void ev_dense(EvLds &L, int wave, int lane, int i, co
 
 /* the channels of `mask` (bit i = channel i), all with KC breakpoints; two at a time, so that one channel's
  * arithmetic covers the other's LDS latency */
-template <int KC, bool DF>
+template <int KC, bool DF, bool FIXED>
 __device__ __forceinline__ void ev_channels(EvLds &L, int wave, int lane, uint32_t mask, const EvConst *kb, const EvTile &T,
                                             double off, unsigned long long live_mask, uint32_t &acc0, unsigned long long *n_exact)
 {
@@ -338,7 +355,7 @@ __device__ __forceinline__ void ev_channels(EvLds &L, int wave, int lane, uint32
         const uint32_t nb_ = ((T.dbits >> i) & 1u) | (((T.dnext >> i) & 1u) << 1);                                     \
         ev_second<KC, DF>(L, wave, lane, i, h, db_, dn_, ((T.exact_mask >> i) & 1u) != 0, live_mask, kb, T.tile_x,      \
                           T.ntiles, nb_,                                                                               \
-                          off, acc0, n_exact);                                                                         \
+                          off, acc0, n_exact, T.fx_ph, T.fx_st, T.fx_n0);                                              \
     }
     while (mask & (mask - 1)) { /* at least two channels left */
         const int i0 = __builtin_ctz(mask);
@@ -347,15 +364,15 @@ __device__ __forceinline__ void ev_channels(EvLds &L, int wave, int lane, uint32
         mask &= mask - 1;
         GPSBB_EV_IN(i0)
         GPSBB_EV_IN(i1)
-        EvHalf<KC> h0 = ev_first<KC>(L, i0, Ki0, xti0, yti0, off);
-        EvHalf<KC> h1 = ev_first<KC>(L, i1, Ki1, xti1, yti1, off);
+        EvHalf<KC> h0 = ev_first<KC, FIXED>(L, i0, Ki0, xti0, yti0, off);
+        EvHalf<KC> h1 = ev_first<KC, FIXED>(L, i1, Ki1, xti1, yti1, off);
         GPSBB_EV_OUT(i0, h0)
         GPSBB_EV_OUT(i1, h1)
     }
     if (mask) {
         const int i0 = __builtin_ctz(mask);
         GPSBB_EV_IN(i0)
-        EvHalf<KC> h0 = ev_first<KC>(L, i0, Ki0, xti0, yti0, off);
+        EvHalf<KC> h0 = ev_first<KC, FIXED>(L, i0, Ki0, xti0, yti0, off);
         GPSBB_EV_OUT(i0, h0)
     }
 #undef GPSBB_EV_IN
@@ -366,7 +383,7 @@ __device__ __forceinline__ void ev_channels(EvLds &L, int wave, int lane, uint32
  * that the common one keeps its register count: at <= 104 VGPRs four of its wavefronts leave room on a SIMD for a
  * wavefront of the pre-pass of the next push; at 120 they do not, and a CU that hosts walk wavefronts cannot take a
  * synthesis workgroup at all (measured: 2.2 -> 2.8 ms per launch beside the pre-passes). */
-template <bool DENSE>
+template <bool DENSE, bool FIXED = false>
 __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__restrict__ iq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -475,7 +492,9 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
     const double *__restrict__ tx = txb + (size_t)(chain_lane ? lane : 0) * ntw;
     const uint32_t *__restrict__ tn = p.tile_nav + ((size_t)b * p.nch + (lane < p.nch ? lane : 0)) * ntw;
     const double off = (double)(lane * SPT);
-    const double guard_w = EV_GUARD + (chain_lane ? kb[lane >> 1].W : 0.0); /* this lane's chain in guard format, biased */
+    /* this lane's chain in guard format, biased (the fixed-point carrier's index is exact: no bias, see ev_first) */
+    const double guard_w = EV_GUARD + ((chain_lane && !(FIXED && (lane & 1))) ? kb[lane >> 1].W : 0.0);
+    const double mirror_at = FIXED ? 512.0 - 0x1p-16 : 512.0; /* a falling fixed-point phase is mirrored bit by bit: (2^25 - 1 - p) / 2^16 */
     unsigned long long *n_exact = p.hazards + 2;
 
     /* chunks of EV_CHUNK consecutive tiles from a per-block counter; the next chunk is asked for while the
@@ -496,7 +515,7 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         const int wt = base + pos;
         /* the tile's states -> this wavefront's LDS slot, its data bits -> scalar masks */
         if (chain_lane)
-            L.tstate[wave][buf][lane] = (mirror ? 512.0 - ts_v : ts_v) + guard_w; /* one rounding, half a unit of 2^-32 */
+            L.tstate[wave][buf][lane] = (mirror ? mirror_at - ts_v : ts_v) + guard_w; /* one rounding, half a unit of 2^-32 */
         EvTile T;
         T.ts = L.tstate[wave][buf];
         T.tile_x = txb + wt;
@@ -504,6 +523,9 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         T.dbits = (uint32_t)__ballot(nav_v & 1u);
         T.dnext = (uint32_t)__ballot(nav_v & 2u);
         T.exact_mask = exact_mask;
+        T.fx_ph = FIXED ? p.kph0 + (size_t)b * p.nch : nullptr;
+        T.fx_st = FIXED ? p.kstep + (size_t)b * p.nch : nullptr;
+        T.fx_n0 = wt * TILE;
         const uint32_t dflip = T.dbits ^ T.dnext;
         /* which tile comes next, and its states on their way */
         if (pos == 0 && lane == 0) {
@@ -529,15 +551,15 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         const bool lane_live = nvalid > 0;
         const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(lane_live);
         uint32_t acc0 = 0x8000u; /* the I sum travels biased by 2^15: never negative, so the low half never borrows from the Q sum */
-        ev_channels<1, false>(L, wave, lane, mk[0] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
-        ev_channels<2, false>(L, wave, lane, mk[1] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
+        ev_channels<1, false, FIXED>(L, wave, lane, mk[0] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
+        ev_channels<2, false, FIXED>(L, wave, lane, mk[1] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
         if (__builtin_expect((mk[2] | mk[3] | dflip) != 0u, 0)) {
-            ev_channels<3, false>(L, wave, lane, mk[2] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
-            ev_channels<4, false>(L, wave, lane, mk[3] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
-            ev_channels<1, true>(L, wave, lane, mk[0] & dflip, kb, T, off, live_mask, acc0, n_exact);
-            ev_channels<2, true>(L, wave, lane, mk[1] & dflip, kb, T, off, live_mask, acc0, n_exact);
-            ev_channels<3, true>(L, wave, lane, mk[2] & dflip, kb, T, off, live_mask, acc0, n_exact);
-            ev_channels<4, true>(L, wave, lane, mk[3] & dflip, kb, T, off, live_mask, acc0, n_exact);
+            ev_channels<3, false, FIXED>(L, wave, lane, mk[2] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
+            ev_channels<4, false, FIXED>(L, wave, lane, mk[3] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
+            ev_channels<1, true, FIXED>(L, wave, lane, mk[0] & dflip, kb, T, off, live_mask, acc0, n_exact);
+            ev_channels<2, true, FIXED>(L, wave, lane, mk[1] & dflip, kb, T, off, live_mask, acc0, n_exact);
+            ev_channels<3, true, FIXED>(L, wave, lane, mk[2] & dflip, kb, T, off, live_mask, acc0, n_exact);
+            ev_channels<4, true, FIXED>(L, wave, lane, mk[3] & dflip, kb, T, off, live_mask, acc0, n_exact);
         }
         /* ---- prefix sum over the run, back to int16 pairs, store (c:2754-2755) ---- */
         uint32_t o[SPT];
@@ -612,6 +634,11 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
 __global__ __launch_bounds__(EV_WG) void k_synth_ev_dense(BatchDev p, int16_t *__restrict__ iq)
 {
     synth_ev_body<true>(p, iq);
+}
+/* the fixed-point carrier (GPSBB_FIXED_CARRIER) above ~15.9 MS/s: the same kernel with an exact carrier model (ev_first) */
+__global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_synth_ev_fixed(BatchDev p, int16_t *__restrict__ iq)
+{
+    synth_ev_body<false, true>(p, iq);
 }
 
 } /* namespace gpsbb_impl */

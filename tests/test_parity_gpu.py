@@ -611,6 +611,35 @@ def test_fixed_carrier_single_block(pkg, synth, oracle, fs, nsamp, nch, seed):
     assert_state_equal(st, want_st[0], ch["prn"] > 0)
 
 
+@pytest.mark.parametrize("fs,nsamp,nch", [(25e6, 70001, 16), (16.368e6, 50000, 9), (2.6e6, 70001, 12), (4.092e6, 30000, 16)])
+def test_fixed_carrier_on_the_model_kernels(pkg, synth, oracle, fs, nsamp, nch, request):
+    """The 32-bit accumulator is exactly linear, so the model kernels take it without guard tests on the carrier side
+    (k_synth_ev_fixed above ~15.9 MS/s, k_synth_pd below).  Steps that are powers of two put index changes exactly ON
+    samples (the tie the 2^-17 in EvConst::tK0 is there for), either sign (a falling phase is mirrored bit by bit), a zero
+    step, start phases with all-zero and all-one low halves."""
+    ch = _fixed_desc(pkg, 3, nch, 977)
+    delt = 1.0 / fs
+    rng = np.random.default_rng(5)
+    steps = np.array([(1 << int(rng.integers(4, 14))) * (1 if i % 2 else -1) for i in range(nch)], dtype=np.float64)
+    steps[0] = 0.0
+    steps[1] = 12345.0
+    steps[2] = -777.0
+    ch["f_carr"] = steps[None, :] / (512.0 * 65536.0 * delt)
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    ch["carr_phase"][0, 3:6] = [0.0, 65536.0 * 17, 65536.0 * 400 + 65535.0]
+    want_iq, want_st, _ = oracle.fill_blocks(ch, delt, nsamp, chain=True, fixed=True)
+    b = synth.batch(ch, delt, nsamp, flags=pkg.CHAIN_CARRIER | pkg.FIXED_CARRIER)
+    b.run()
+    synth.sync()
+    iq, st = b.read()
+    b.close()
+    assert (iq == want_iq).all()
+    for k in range(3):
+        assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
+    if "per-sample" not in request.node.callspec.params["seed_mode"]:
+        assert synth.info(pkg.INFO_LAST_KERNEL) == 2
+
+
 def test_fixed_carrier_chained_batch_and_stream(pkg, synth, oracle):
     ch = _fixed_desc(pkg, 8, 10, 211)
     ch["prn"][5:, 3] = 29

@@ -455,6 +455,12 @@ def main():
         r1, _ = resident_leg(pkg, synth, torch, rch, delt, nsamp, pkg.CHAIN_CARRIER, 20, 5, dev)
         res["resident"] = {"independent_blocks": r0, "chained": r1, "unit": "IQ samples/s",
                            "note": "the stream's first push (%d blocks) as one batch re-run 20 times, descriptors and plans resident in HBM (round 1's kind of value)" % PB}
+        # the reference built without FLOAT_CARR_PHASE (h:12): the 32-bit fixed-point carrier on the same descriptors
+        fxr = rch.copy()
+        fxr["carr_phase"] = np.floor(fxr["carr_phase"] * 2.0 ** 32)
+        r3, _ = resident_leg(pkg, synth, torch, fxr, delt, nsamp, pkg.CHAIN_CARRIER | pkg.FIXED_CARRIER, 20, 4, dev)
+        r3["synthesis_kernel"] = {1: "k_synth", 2: "k_synth_ev_fixed"}.get(synth.info(pkg.INFO_LAST_KERNEL), "?")
+        res["resident"]["fixed_point_carrier_chained"] = r3
         res["roofline"]["write_ceiling_measured_GBs"] = ceil_gbs
         res["roofline"]["frac_of_measured_ceiling"] = achieved / ceil_gbs
         # the same kernel with the GPU to itself (tables already built): what the pre-passes running beside it cost

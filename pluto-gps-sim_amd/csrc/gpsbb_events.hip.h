@@ -108,9 +108,11 @@ __device__ __forceinline__ T scalar_load(const T *p)
  * reference does (c:2697-2746) and add the differences of its contributions.  Returns the contribution at
  * the run's first sample.
  */
-__device__ __noinline__ uint32_t ev_exact_run(EvLds &L, int wave, int lane, int i, const EvConst *kbi, const double *tile_x,
-                                              int ntiles, uint32_t nb, int n_off, int fixed = 0, uint32_t fx_phase = 0u, int32_t fx_step = 0)
+template <bool FIXED>
+__device__ __forceinline__ uint32_t ev_exact_run_body(EvLds &L, int wave, int lane, int i, const EvConst *kbi, const double *tile_x,
+                                                      int ntiles, uint32_t nb, int n_off, uint32_t fx_phase, int32_t fx_step)
 {
+    constexpr bool fixed = FIXED;
     const bool down = kbi->down != 0;
     const double S = down ? -kbi->S : kbi->S, sc = kbi->sc;
     const double xt = tile_x[(size_t)(2 * i) * ntiles], yt = tile_x[(size_t)(2 * i + 1) * ntiles];
@@ -142,6 +144,26 @@ __device__ __noinline__ uint32_t ev_exact_run(EvLds &L, int wave, int lane, int 
         ph += (uint32_t)fx_step; /* c:2748 */
     }
     return first;
+}
+
+/* fixed-point carrier: the block's start phases and steps per channel and the tile's first sample (ev_exact_run's way to the
+ * accumulator; only k_synth_ev_fixed fills it in) */
+struct EvFixed {
+    const uint32_t *ph;
+    const int32_t *st;
+    int n0;
+};
+
+__device__ __noinline__ uint32_t ev_exact_run(EvLds &L, int wave, int lane, int i, const EvConst *kbi, const double *tile_x,
+                                              int ntiles, uint32_t nb, int n_off)
+{
+    return ev_exact_run_body<false>(L, wave, lane, i, kbi, tile_x, ntiles, nb, n_off, 0u, 0);
+}
+/* ... with the fixed-point carrier: the accumulator at the tile's first sample and its step take the carrier NCO's place */
+__device__ __noinline__ uint32_t ev_exact_run_fixed(EvLds &L, int wave, int lane, int i, const EvConst *kbi, const double *tile_x,
+                                                    int ntiles, uint32_t nb, int n_off, uint32_t fx_phase, int32_t fx_step)
+{
+    return ev_exact_run_body<true>(L, wave, lane, i, kbi, tile_x, ntiles, nb, n_off, fx_phase, fx_step);
 }
 
 /* per-channel constants of the fast path (scalar registers) */
@@ -227,11 +249,11 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK 
  * data bit in force at the tile start / after the next code roll-over as masks (0 = +1, -1 = -1; wave-uniform);
  * DF: they differ, so lanes past the roll-over (chip index >= 1023) take the other one.
  */
-template <int KC, bool DF>
+template <int KC, bool DF, bool FIXED>
 __device__ __forceinline__ void ev_second(EvLds &L, int wave, int lane, int i, EvHalf<KC> &h, uint32_t db, uint32_t db_next,
                                           bool always_exact, unsigned long long live_mask, const EvConst *kb, const double *tile_x,
                                           int ntiles, uint32_t nb, double off, uint32_t &acc0, unsigned long long *n_exact,
-                                          const uint32_t *fx_ph, const int32_t *fx_st, int fx_n0)
+                                          const EvFixed &fx)
 {
     const uint32_t ma = (uint32_t)(int32_t)(int8_t)(h.ch2 & 0xffu), mb = (uint32_t)(int32_t)(int8_t)(h.ch2 >> 8);
     uint32_t m0, m1;
@@ -256,9 +278,9 @@ __device__ __forceinline__ void ev_second(EvLds &L, int wave, int lane, int i, E
             jc = EV_ROW_DISCARD;
             h.A[0] = 0;
             /* ... and the exact one takes its place */
-            if (fx_ph) /* fixed-point carrier: the accumulator at the tile's first sample */
-                acc0 += ev_exact_run(L, wave, lane, i, kb + i, tile_x, ntiles, nb, (int)off, 1,
-                                     fx_ph[i] + (uint32_t)fx_n0 * (uint32_t)fx_st[i], fx_st[i]);
+            if (FIXED) /* the accumulator at the tile's first sample */
+                acc0 += ev_exact_run_fixed(L, wave, lane, i, kb + i, tile_x, ntiles, nb, (int)off,
+                                           fx.ph[i] + (uint32_t)fx.n0 * (uint32_t)fx.st[i], fx.st[i]);
             else
                 acc0 += ev_exact_run(L, wave, lane, i, kb + i, tile_x, ntiles, nb, (int)off);
             atomicAdd(n_exact, 1ull);
@@ -288,9 +310,6 @@ struct EvTile {
     int ntiles;
     uint32_t dbits, dnext; /* bit i: channel i's data bit in force / after the next roll-over is -1 */
     uint32_t exact_mask;   /* bit i: channel i is always recomputed exactly */
-    const uint32_t *fx_ph; /* fixed-point carrier: the block's start phases and steps per channel (else null) ... */
-    const int32_t *fx_st;
-    int fx_n0;             /* ... and the tile's first sample */
 };
 
 /*
@@ -344,7 +363,8 @@ __device__ __forceinline__ void ev_dense(EvLds &L, int wave, int lane, int i, co
  * arithmetic covers the other's LDS latency */
 template <int KC, bool DF, bool FIXED>
 __device__ __forceinline__ void ev_channels(EvLds &L, int wave, int lane, uint32_t mask, const EvConst *kb, const EvTile &T,
-                                            double off, unsigned long long live_mask, uint32_t &acc0, unsigned long long *n_exact)
+                                            double off, unsigned long long live_mask, uint32_t &acc0, unsigned long long *n_exact,
+                                            const EvFixed &fx)
 {
 #define GPSBB_EV_IN(i)                                                                                                 \
     const EvK K##i = ev_load_k(kb, i);                                                                                 \
@@ -353,9 +373,9 @@ __device__ __forceinline__ void ev_channels(EvLds &L, int wave, int lane, uint32
     {                                                                                                                  \
         const uint32_t db_ = 0u - ((T.dbits >> i) & 1u), dn_ = 0u - ((T.dnext >> i) & 1u);                             \
         const uint32_t nb_ = ((T.dbits >> i) & 1u) | (((T.dnext >> i) & 1u) << 1);                                     \
-        ev_second<KC, DF>(L, wave, lane, i, h, db_, dn_, ((T.exact_mask >> i) & 1u) != 0, live_mask, kb, T.tile_x,      \
+        ev_second<KC, DF, FIXED>(L, wave, lane, i, h, db_, dn_, ((T.exact_mask >> i) & 1u) != 0, live_mask, kb, T.tile_x, \
                           T.ntiles, nb_,                                                                               \
-                          off, acc0, n_exact, T.fx_ph, T.fx_st, T.fx_n0);                                              \
+                          off, acc0, n_exact, fx);                                                                     \
     }
     while (mask & (mask - 1)) { /* at least two channels left */
         const int i0 = __builtin_ctz(mask);
@@ -523,9 +543,10 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         T.dbits = (uint32_t)__ballot(nav_v & 1u);
         T.dnext = (uint32_t)__ballot(nav_v & 2u);
         T.exact_mask = exact_mask;
-        T.fx_ph = FIXED ? p.kph0 + (size_t)b * p.nch : nullptr;
-        T.fx_st = FIXED ? p.kstep + (size_t)b * p.nch : nullptr;
-        T.fx_n0 = wt * TILE;
+        EvFixed fx;
+        fx.ph = FIXED ? p.kph0 + (size_t)b * p.nch : nullptr;
+        fx.st = FIXED ? p.kstep + (size_t)b * p.nch : nullptr;
+        fx.n0 = wt * TILE;
         const uint32_t dflip = T.dbits ^ T.dnext;
         /* which tile comes next, and its states on their way */
         if (pos == 0 && lane == 0) {
@@ -551,15 +572,15 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         const bool lane_live = nvalid > 0;
         const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(lane_live);
         uint32_t acc0 = 0x8000u; /* the I sum travels biased by 2^15: never negative, so the low half never borrows from the Q sum */
-        ev_channels<1, false, FIXED>(L, wave, lane, mk[0] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
-        ev_channels<2, false, FIXED>(L, wave, lane, mk[1] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
+        ev_channels<1, false, FIXED>(L, wave, lane, mk[0] & ~dflip, kb, T, off, live_mask, acc0, n_exact, fx);
+        ev_channels<2, false, FIXED>(L, wave, lane, mk[1] & ~dflip, kb, T, off, live_mask, acc0, n_exact, fx);
         if (__builtin_expect((mk[2] | mk[3] | dflip) != 0u, 0)) {
-            ev_channels<3, false, FIXED>(L, wave, lane, mk[2] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
-            ev_channels<4, false, FIXED>(L, wave, lane, mk[3] & ~dflip, kb, T, off, live_mask, acc0, n_exact);
-            ev_channels<1, true, FIXED>(L, wave, lane, mk[0] & dflip, kb, T, off, live_mask, acc0, n_exact);
-            ev_channels<2, true, FIXED>(L, wave, lane, mk[1] & dflip, kb, T, off, live_mask, acc0, n_exact);
-            ev_channels<3, true, FIXED>(L, wave, lane, mk[2] & dflip, kb, T, off, live_mask, acc0, n_exact);
-            ev_channels<4, true, FIXED>(L, wave, lane, mk[3] & dflip, kb, T, off, live_mask, acc0, n_exact);
+            ev_channels<3, false, FIXED>(L, wave, lane, mk[2] & ~dflip, kb, T, off, live_mask, acc0, n_exact, fx);
+            ev_channels<4, false, FIXED>(L, wave, lane, mk[3] & ~dflip, kb, T, off, live_mask, acc0, n_exact, fx);
+            ev_channels<1, true, FIXED>(L, wave, lane, mk[0] & dflip, kb, T, off, live_mask, acc0, n_exact, fx);
+            ev_channels<2, true, FIXED>(L, wave, lane, mk[1] & dflip, kb, T, off, live_mask, acc0, n_exact, fx);
+            ev_channels<3, true, FIXED>(L, wave, lane, mk[2] & dflip, kb, T, off, live_mask, acc0, n_exact, fx);
+            ev_channels<4, true, FIXED>(L, wave, lane, mk[3] & dflip, kb, T, off, live_mask, acc0, n_exact, fx);
         }
         /* ---- prefix sum over the run, back to int16 pairs, store (c:2754-2755) ---- */
         uint32_t o[SPT];

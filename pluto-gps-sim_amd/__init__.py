@@ -149,6 +149,8 @@ def exp_lib():
         L.gpsbb_test_row_bound.restype = C.c_ulonglong
         L.gpsbb_test_carr_predict.argtypes = [d, d, i]
         L.gpsbb_test_carr_predict.restype = d
+        L.gpsbb_test_fixed_tile_index.argtypes = [C.c_uint32, C.c_int32, i]
+        L.gpsbb_test_fixed_tile_index.restype = d
         _exp_lib = L
     return _exp_lib
 

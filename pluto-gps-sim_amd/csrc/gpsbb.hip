@@ -2753,6 +2753,12 @@ extern "C" double gpsbb_test_carr_predict(double x0, double s, int n)
     return d.advance(x0, n, s);
 }
 
+/* the fixed-point carrier's table index at the first sample of tile t, as the model kernels' pre-pass writes it */
+extern "C" double gpsbb_test_fixed_tile_index(uint32_t ph0, int32_t step, int t)
+{
+    return fixed_tile_index(ph0, step, t);
+}
+
 extern "C" unsigned long long gpsbb_test_row_bound(int kind, double s_abs, int nsamp)
 {
     return kind == NCO_CODE ? row_bound(s_abs, 1023.0, 9, nsamp) : row_bound(s_abs, 1.0, -1, nsamp);

@@ -29,6 +29,9 @@ int gpsbb_test_build_rows_f64(int kind, double x0, double s, unsigned nav0, int 
 unsigned long long gpsbb_test_row_bound(int kind, double s_abs, int nsamp);
 /* the host's drift model of the carrier recurrence: the predicted phase n steps after x0 (not exact: ~1e-14) */
 double gpsbb_test_carr_predict(double x0, double s, int n);
+/* the fixed-point carrier's table index (fraction included) at the first sample of tile t: what k_tiles / the host hand the
+ * model kernels with GPSBB_FIXED_CARRIER */
+double gpsbb_test_fixed_tile_index(unsigned ph0, int step, int t);
 
 #ifdef __cplusplus
 }

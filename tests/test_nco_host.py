@@ -291,3 +291,23 @@ def test_drift_model_predicts_the_carrier_to_1e13(pkg):
     for s in (0.0, 1e-30, 0.3, -0.3):
         v = L.gpsbb_test_carr_predict(0.25, s, 1000)
         assert 0.0 <= v < 1.0
+
+
+def test_fixed_point_carrier_tile_index_is_the_accumulator(pkg):
+    """What the model kernels start a tile from with GPSBB_FIXED_CARRIER: (phase mod 2^25) / 2^16 of the reference's 32-bit
+    accumulator (c:2699, 2748) after tile * 1024 steps — the index with its fraction, exactly; the mirrored value used for a
+    falling phase, 512 - 2^-16 - y, is the index of the bitwise complement."""
+    L = pkg.exp_lib()
+    rng = np.random.default_rng(11)
+    for _ in range(2000):
+        ph0 = int(rng.integers(0, 2 ** 32))
+        step = int(rng.integers(-2 ** 20, 2 ** 20))
+        t = int(rng.integers(0, 3000))
+        ph = ph0
+        ph = (ph0 + t * 1024 * step) % 2 ** 32
+        y = L.gpsbb_test_fixed_tile_index(ph0, step, t)
+        assert y == (ph % 2 ** 25) / 65536.0
+        assert int(y) == (ph >> 16) & 0x1ff
+        ym = (512.0 - 2.0 ** -16) - y
+        assert int(ym) == 511 - ((ph >> 16) & 0x1ff) and ym == ((2 ** 25 - 1 - ph % 2 ** 25)) / 65536.0
+

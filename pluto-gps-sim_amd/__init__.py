@@ -44,6 +44,9 @@ FIXED_CARRIER = 2
 STREAM_DEVICE_ONLY = 4
 OPT_SEED_WHERE, OPT_SYNTH_KERNEL, OPT_SKIP_SEED, OPT_CHAIN_WHERE = 1, 2, 3, 4
 INFO_LAST_KERNEL, INFO_EXACT_RUNS, INFO_CHAIN_ON_DEVICE, INFO_CHAIN_FALLBACKS, INFO_CHAIN_TIES, INFO_CHAIN_REPAIRS = 1, 2, 3, 4, 5, 6
+INFO_STREAMS, INFO_HW_QUEUES = 7, 8
+NODE_INDEXED, NODE_CONCURRENT, NODE_DEVICE_ONLY, NODE_NO_AFFINITY, NODE_FIXED_CARRIER = 1, 2, 4, 8, 16
+NODE_MAX_SHARDS = 64
 
 ERRORS = {0: "GPSBB_OK", -1: "GPSBB_E_BADARG", -2: "GPSBB_E_BADCHAN", -3: "GPSBB_E_HIP", -4: "GPSBB_E_NOMEM",
           -5: "GPSBB_E_INTERNAL", -6: "GPSBB_E_NODEVICE", -7: "GPSBB_E_STATE"}
@@ -56,8 +59,10 @@ API_SYMBOLS = [
     "gpsbb_get_hazards", "gpsbb_device_read", "gpsbb_batch_last_timing", "gpsbb_batch_timing_stats", "gpsbb_fill_ceiling", "gpsbb_stream_create",
     "gpsbb_stream_destroy", "gpsbb_stream_push", "gpsbb_stream_pop", "gpsbb_stream_pending", "gpsbb_stream_timing_stats",
     "gpsbb_codegen", "gpsbb_sincos_tables", "gpsbb_chain_carrier_host", "gpsbb_chain_carrier", "gpsbb_set_option",
-    "gpsbb_get_info",
+    "gpsbb_get_info", "gpsbb_stream_reset", "gpsbb_device_affinity",
 ]
+# ... and include/gpsbb_node.h
+NODE_API_SYMBOLS = ["gpsbb_node_create", "gpsbb_node_run", "gpsbb_node_destroy", "gpsbb_node_plan"]
 
 
 class GpsbbError(RuntimeError):
@@ -124,6 +129,13 @@ def lib():
         L.gpsbb_sincos_tables.argtypes = [vp, vp]
         L.gpsbb_chain_carrier_host.argtypes = [vp, i, i, d, i, vp, i]
         L.gpsbb_chain_carrier.argtypes = [vp, vp, i, i, d, i, vp, vp]
+        L.gpsbb_stream_reset.argtypes = [vp]
+        L.gpsbb_device_affinity.argtypes = [i, C.POINTER(i), C.c_char_p, C.c_size_t]
+        L.gpsbb_node_create.argtypes = [C.POINTER(vp), vp]
+        L.gpsbb_node_destroy.argtypes = [vp]
+        L.gpsbb_node_destroy.restype = None
+        L.gpsbb_node_run.argtypes = [vp, vp, C.c_long, vp, vp, vp]
+        L.gpsbb_node_plan.argtypes = [C.c_long, i, i, C.POINTER(C.c_long)]
         _lib = L
     return _lib
 
@@ -391,6 +403,84 @@ class Stream:
 
 # ---- synthetic descriptors (BASELINE / SURVEY section 8d, workload M2) -------------------------------
 
+# ---- include/gpsbb_node.h: one process, N handles, one sink ------------------------------------------
+
+class _NodeConfig(C.Structure):
+    _fields_ = [("nshards", C.c_int), ("devices", C.POINTER(C.c_int)), ("nch", C.c_int), ("delt", C.c_double), ("nsamp", C.c_int),
+                ("blocks_per_slot", C.c_int), ("depth", C.c_int), ("flags", C.c_uint)]
+
+
+class _NodeShardStats(C.Structure):
+    _fields_ = [("first_block", C.c_long), ("nblocks", C.c_long), ("device", C.c_int), ("numa_node", C.c_int), ("cpus_bound", C.c_int),
+                ("seed_seconds", C.c_double), ("busy_seconds", C.c_double), ("wait_seconds", C.c_double)]
+
+
+class _NodeStats(C.Structure):
+    _fields_ = [("seconds", C.c_double), ("blocks", C.c_long), ("nshards", C.c_int), ("shard", _NodeShardStats * NODE_MAX_SHARDS)]
+
+
+NODE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int)
+
+
+def node_plan(nblocks, nshards, blocks_per_slot):
+    first = (C.c_long * (nshards + 1))()
+    _chk(lib().gpsbb_node_plan(nblocks, nshards, blocks_per_slot, first), "gpsbb_node_plan")
+    return list(first)
+
+
+def device_affinity(device):
+    """gpsbb_device_affinity -> (numa node, "cpu list")"""
+    node = C.c_int(-1)
+    buf = C.create_string_buffer(512)
+    _chk(lib().gpsbb_device_affinity(device, C.byref(node), buf, 512), "gpsbb_device_affinity")
+    return node.value, buf.value.decode()
+
+
+class Node:
+    """gpsbb_node_*: nshards producer threads (one handle + one ring each, bound next to their GPU), one sink."""
+
+    def __init__(self, nshards, nch, delt, nsamp, blocks_per_slot, depth=3, flags=0, devices=None):
+        self.nshards, self.nch, self.nsamp = nshards, nch, nsamp
+        dev = (C.c_int * nshards)(*(devices if devices is not None else range(nshards)))
+        cfg = _NodeConfig(nshards, dev, nch, delt, nsamp, blocks_per_slot, depth, flags)
+        self._n = C.c_void_p()
+        _chk(lib().gpsbb_node_create(C.byref(self._n), C.byref(cfg)), "gpsbb_node_create")
+
+    def close(self):
+        if self._n:
+            lib().gpsbb_node_destroy(self._n)
+            self._n = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def run(self, ch, sink, expect_stop=False):
+        """sink(iq_ptr, first_block, nblocks, shard) -> int (< 0 stops); returns the run's statistics as a dict.
+        sink may also be a C function pointer (int) for a sink that lives in native code."""
+        ch = _as_chan(ch)
+        if callable(sink):
+            cb = NODE_SINK(lambda user, iq, first, nb, shard: int(sink(iq, first, nb, shard) or 0))
+            fn = C.cast(cb, C.c_void_p)
+        else:
+            cb, fn = None, C.c_void_p(sink)
+        st = _NodeStats()
+        rc = lib().gpsbb_node_run(self._n, ch.ctypes.data, ch.shape[0], fn, None, C.byref(st))
+        del cb
+        if rc != 0 and not (expect_stop and rc == -7):
+            raise GpsbbError(rc, "gpsbb_node_run")
+        return {"rc": rc, "seconds": st.seconds, "blocks": st.blocks,
+                "shards": [{k: getattr(st.shard[g], k) for k, _ in _NodeShardStats._fields_} for g in range(st.nshards)]}
+
+
 class SplitMix64:
     """Counter-mode splitmix64: draw k (k = 1, 2, ...) is mix(seed + k*0x9E3779B97F4A7C15) — the sequence
     the scalar generator produces, evaluated vectorised."""
@@ -435,6 +525,61 @@ def synth_descriptors(nblocks, nch=16, seed=0x5EED, max_doppler=5000.0):
     ch["icode"] = (g.u32((nblocks, nch)) % np.uint64(20)).astype(np.int32)
     ch["dwrd"] = (g.u32((nblocks, nch, N_DWRD)) & np.uint64(0x3FFFFFFF)).astype(np.uint32)
     return ch
+
+
+def grazing_descriptors(nblocks, nch, fs, nsamp, offsets, seed=1, max_doppler=5000.0, fixed=False, samples=None, tol=0.25):
+    """Adversarial descriptors for the model kernels (k_synth_ev / k_synth_pd): every (block, channel) is aimed so that
+    ONE of its NCOs lands within `k` units of 2^-32 of an integer AT a chosen sample n — the reference's own state there,
+    not the linear model's: the phase is refined with the exact jump-ahead (gpsbb_nco.h through the experiments build's
+    host hooks, CPU only) until 512*carr_phase(n) resp. code_phase(n) is m + k*2^-32 to `tol` units (k may be fractional).  That is
+    where floor() of an in-tile model (c:2697 table index, c:2737 chip) can disagree with the reference and where an index
+    or chip change falls (almost) exactly on a sample; k runs over `offsets` (both signs: either side of the integer, inside
+    and outside the kernels' danger band).  Channel i of block b aims its carrier when (b + i) is even, its code NCO
+    otherwise; with `fixed` (the 32-bit accumulator is exact) always the code.  Returns (descriptors, targets)."""
+    from fractions import Fraction
+    L = exp_lib()
+    rng = np.random.default_rng(seed)
+    ch = synth_descriptors(nblocks, nch=nch, seed=seed, max_doppler=max_doppler)
+    delt = 1.0 / fs
+    unit = Fraction(1, 1 << 32)
+    targets = []
+    wr = C.c_longlong(0)
+    for b in range(nblocks):
+        for i in range(nch):
+            k = Fraction(float(offsets[(b * nch + i) % len(offsets)]))
+            n = int(samples[(b * nch + i) % len(samples)]) if samples is not None else int(rng.integers(1, nsamp))
+            n = min(n, nsamp - 1)
+            carrier = (b + i) % 2 == 0 and not fixed
+            if carrier:
+                s = float(ch["f_carr"][b, i]) * delt            # the individually rounded product of c:2741
+                want_frac = unit * k                            # 512*phase(n) = integer + k units
+                cp = float(ch["carr_phase"][b, i])
+                for _ in range(12):
+                    got = Fraction(L.gpsbb_test_carr_jump(cp, s, n)) * 512
+                    m = round(got)
+                    err = (got - m) - want_frac                 # in table-index units
+                    if abs(err) <= unit * Fraction(tol):
+                        break
+                    cp = float((Fraction(cp) - err / 512) % 1)
+                ch["carr_phase"][b, i] = cp
+                got = Fraction(L.gpsbb_test_carr_jump(cp, s, n)) * 512
+                targets.append((b, i, "carr", n, float(k), float((got - round(got)) / unit)))
+            else:
+                s = float(ch["f_code"][b, i]) * delt            # c:2709
+                x = float(ch["code_phase"][b, i])
+                for _ in range(12):
+                    got = Fraction(L.gpsbb_test_code_jump(x, s, n, C.byref(wr)))
+                    m = round(got)
+                    err = (got - m) - unit * k
+                    if abs(err) <= unit * Fraction(tol):
+                        break
+                    x = float((Fraction(x) - err) % 1023)
+                ch["code_phase"][b, i] = x
+                got = Fraction(L.gpsbb_test_code_jump(x, s, n, C.byref(wr)))
+                targets.append((b, i, "code", n, float(k), float((got - round(got)) / unit)))
+    if fixed:
+        ch["carr_phase"] = np.floor(ch["carr_phase"] * 2.0 ** 32)
+    return ch, targets
 
 
 # ---- time sharding (one process per GPU, no data-path collective) ------------------------------------

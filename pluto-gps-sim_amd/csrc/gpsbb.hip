@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +29,9 @@
 #include "gpsbb_walk.hip.h"
 #include "gpsbb_nco.h"
 #include "gpsbb_testhooks.h"
+#ifdef GPSBB_EXPERIMENTS
+#include "gpsbb_modelerr.hip.h"
+#endif
 
 using namespace gpsbb_impl;
 
@@ -207,6 +211,17 @@ struct CarrDrift {
     }
 };
 
+/* A channel's bias W as a whole number of units of 2^-32 (rounded up): the guard format then carries exactly W — 2^20 + W is
+ * representable — and not W rounded to the format's grid, half a unit of error that 1 / step would amplify. */
+double ev_bias_on_grid(double w)
+{
+#ifdef GPSBB_W_OFF_GRID /* (measurement: rounds 2 and 3) */
+    return w;
+#else
+    return w < 0.25 ? std::ceil(w * 4294967296.0) * 0x1p-32 : w;
+#endif
+}
+
 /*
  * Can the breakpoint kernel render these blocks, and with which per-channel constants (EvConst)?  Eligible
  * when, for every active channel, a run of SPT samples holds at most one chip change (sc*15.5 < 1) and at
@@ -253,8 +268,8 @@ bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vec
             if (aS == 0.0) {
                 K.rS = 0x1p+1000; /* the index never changes */
                 K.kc = 1;
-            } else if (aS < 0x1p-28) {
-                K.rS = 0x1p+1000; /* the model error exceeds a quarter of a step: every run is recomputed exactly */
+            } else if (aS < 8.0 * EV_MODEL_ERR) {
+                K.rS = 0x1p+1000; /* the model error exceeds an eighth of a step (W would pass 1/8 sample): every run is recomputed exactly */
                 K.kc = -1;
             } else {
                 K.rS = 1.0 / aS;
@@ -265,6 +280,7 @@ bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vec
             /* one bias W for everything tested in the channel (first-sample fractions: W >= the model error in index units /
              * chips; change positions: W >= wK, wC): the tests are then all "low word of the biased quantity < 2W" */
             K.W = std::max(std::max(wK, wC), EV_T_EPS);
+            K.W = ev_bias_on_grid(K.W);
             K.danger = K.W >= 0.25 ? 0x80000000u : (uint32_t)std::ceil(2.0 * K.W * 4294967296.0) + 1u;
             {
                 /* (test aid, experiments build: a larger threshold sends more lane-runs to the exact path; never a smaller one) */
@@ -294,7 +310,7 @@ bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vec
                         return false;
                     K.kc = (int)kc;
                     K.rS = aS > 0.0 ? 1.0 / aS : 0x1p+1000;
-                    K.W = std::max(wC, EV_T_EPS);
+                    K.W = ev_bias_on_grid(std::max(wC, EV_T_EPS));
                     K.danger = K.W >= 0.25 ? 0x80000000u : (uint32_t)std::ceil(2.0 * K.W * 4294967296.0) + 1u;
                     K.tK0 = K.rS * (1.0 - 0x1p-17) + 0x1p+20;
                     K.tC0 = K.rsc * (1.0 + K.W) + 0x1p+20 + K.W;
@@ -637,6 +653,22 @@ extern "C" int gpsbb_get_info(gpsbb_t *h, int what, uint64_t *out)
     case GPSBB_INFO_CHAIN_ON_DEVICE:
         *out = (uint64_t)h->last_chain_dev;
         return GPSBB_OK;
+    case GPSBB_INFO_STREAMS: {
+        uint64_t n = 0;
+        for (hipStream_t st : {h->s_seed, h->s_upload, h->s_compute, h->s_compute2, h->s_copy})
+            n += st != nullptr;
+        for (hipStream_t st : h->s_more)
+            n += st != nullptr;
+        *out = n;
+        return GPSBB_OK;
+    }
+    case GPSBB_INFO_HW_QUEUES: {
+        /* reported, never acted on: what the runtime was (or will be) told when it maps streams onto hardware queues */
+        const char *e = getenv("GPU_MAX_HW_QUEUES");
+        const long v = e ? atol(e) : 4;
+        *out = (uint64_t)(v > 0 ? v : 4);
+        return GPSBB_OK;
+    }
     default:
         return GPSBB_E_BADARG;
     }
@@ -890,6 +922,14 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
             b->ev_all_dense = b->ev_all_dense && (ch[k].prn <= 0 || b->h_evc[k].kc == EV_KC_DENSE);
         }
     b->ev_all_dense = b->ev_all_dense && b->ev_dense;
+    if (fixed && b->ev_dense && !b->ev_all_dense) {
+        /* The fixed-point carrier has no mixed kernel: k_synth_ev_dense is the IEEE body (a falling phase mirrored as 512 - y,
+         * biased change positions), not the accumulator's (512 - 2^-16 - y, exact).  A batch whose channels straddle the
+         * one-chip-change-per-run limit (fs within ~50 Hz of 15.5 * 1.023e6 once the code Doppler is in) goes to the stepped
+         * kernel. */
+        b->ev = false;
+        b->ev_dense = b->ev_all_dense = false;
+    }
     PUSH_MARK("ev_plan");
 
     /* where the pre-pass runs and where the carrier chain is resolved: decided here, once, for all runs of the batch */
@@ -2196,6 +2236,34 @@ extern "C" int gpsbb_stream_create(gpsbb_t *h, int nch, double delt, int nsamp, 
 
 extern "C" int gpsbb_stream_pending(const gpsbb_stream_t *s) { return s ? (int)(s->head - s->tail) : 0; }
 
+extern "C" int gpsbb_stream_reset(gpsbb_stream_t *s)
+{
+    if (!s)
+        return GPSBB_E_BADARG;
+    if (s->poisoned || s->head != s->tail)
+        return GPSBB_E_STATE;
+    gpsbb *h = s->h;
+    HIPCHK(h, hipSetDevice(h->device));
+    /* everything the last stream left in the queues has completed (its slots were popped), but the chain kernels of its
+     * last push may still be writing the carry: wait for the handle before touching it */
+    const int rc = gpsbb_sync(h);
+    if (rc != GPSBB_OK)
+        return rc;
+    if (s->d_carry)
+        HIPCHK(h, hipMemset(s->d_carry, 0, sizeof(ChainCarryDev)));
+    if (s->carry)
+        memset(s->carry, 0, sizeof *s->carry);
+    s->carry_on_device = false;
+    for (int i = 0; i < GPSBB_MAX_CHAN; i++) {
+        s->last_prn[i] = 0;
+        s->rough_phase[i] = 0.0;
+        s->fx_prn[i] = 0;
+        s->fx_phase[i] = 0;
+    }
+    s->head = s->tail = 0;
+    return GPSBB_OK;
+}
+
 extern "C" int gpsbb_stream_timing_stats(gpsbb_stream_t *s, int *nruns, float *ms_seed_sum, float *ms_synth_sum, int reset)
 {
     if (!s)
@@ -2423,6 +2491,48 @@ extern "C" int gpsbb_stream_pop(gpsbb_stream_t *s, const int16_t **iq, gpsbb_cha
 /* ================================================================================================== */
 /* host helpers                                                                                       */
 /* ================================================================================================== */
+
+extern "C" int gpsbb_device_affinity(int device, int *numa_node, char *cpulist, size_t cpulist_cap)
+{
+    if (device < 0)
+        return GPSBB_E_BADARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device >= count)
+        return GPSBB_E_NODEVICE;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess)
+        return GPSBB_E_HIP;
+    for (char *c = bdf; *c; c++)
+        *c = (char)tolower((unsigned char)*c); /* sysfs spells the address in lower case */
+    if (numa_node)
+        *numa_node = -1;
+    if (cpulist && cpulist_cap)
+        cpulist[0] = 0;
+    char path[160];
+    if (numa_node) {
+        snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+        if (FILE *f = fopen(path, "r")) {
+            int v = -1;
+            if (fscanf(f, "%d", &v) == 1)
+                *numa_node = v;
+            fclose(f);
+        }
+    }
+    if (cpulist && cpulist_cap) {
+        snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+        if (FILE *f = fopen(path, "r")) {
+            if (fgets(cpulist, (int)cpulist_cap, f)) {
+                size_t n = strlen(cpulist);
+                while (n && (cpulist[n - 1] == '\n' || cpulist[n - 1] == ' '))
+                    cpulist[--n] = 0;
+            } else {
+                cpulist[0] = 0;
+            }
+            fclose(f);
+        }
+    }
+    return GPSBB_OK;
+}
 
 static void chain_carrier_host(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp, double *seed,
                                int nthreads, ChainCarry *carry)
@@ -2757,6 +2867,52 @@ extern "C" double gpsbb_test_carr_predict(double x0, double s, int n)
 extern "C" double gpsbb_test_fixed_tile_index(uint32_t ph0, int32_t step, int t)
 {
     return fixed_tile_index(ph0, step, t);
+}
+
+/* The realised error of the model kernels' in-tile models against the reference's own recurrence, over every tile of the
+ * batch's LAST run (gpsbb_modelerr.hip.h).  maxima: [GPSBB_MAX_CHAN][GPSBB_TEST_ME_NQ] doubles, counts:
+ * [GPSBB_MAX_CHAN][GPSBB_TEST_MEC_NQ]; *which = 1 for k_synth_ev / k_synth_ev_dense / k_synth_ev_fixed, 2 for k_synth_pd. */
+extern "C" int gpsbb_test_model_err(gpsbb_batch_t *b, double *maxima, unsigned long long *counts, int *which)
+{
+    if (!b || !maxima || !counts)
+        return GPSBB_E_BADARG;
+    gpsbb *h = b->h;
+    if (!b->ran || !b->ev)
+        return GPSBB_E_STATE; /* only the model kernels have a model */
+    const int rc = gpsbb_sync(h);
+    if (rc != GPSBB_OK)
+        return rc;
+    const BatchDev p = batch_dev(b, b->last_set);
+    double *d_mx = nullptr;
+    unsigned long long *d_cnt = nullptr;
+    const size_t mx_bytes = sizeof(double) * GPSBB_MAX_CHAN * ME_NQ, cnt_bytes = sizeof(unsigned long long) * GPSBB_MAX_CHAN * MEC_NQ;
+    HIPCHK(h, hipMalloc((void **)&d_mx, mx_bytes));
+    HIPCHK(h, hipMalloc((void **)&d_cnt, cnt_bytes));
+    HIPCHK(h, hipMemsetAsync(d_mx, 0, mx_bytes, h->s_compute));
+    HIPCHK(h, hipMemsetAsync(d_cnt, 0, cnt_bytes, h->s_compute));
+    const size_t threads = (size_t)b->nblocks * b->nch * b->ntiles;
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (b->ev_all_dense)
+        hipLaunchKernelGGL(k_model_err_pd, grid, dim3(256), 0, h->s_compute, p, d_mx, d_cnt);
+    else
+        hipLaunchKernelGGL(k_model_err_ev, grid, dim3(256), 0, h->s_compute, p, d_mx, d_cnt);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->s_compute));
+    HIPCHK(h, hipMemcpy(maxima, d_mx, mx_bytes, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(counts, d_cnt, cnt_bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(d_mx);
+    (void)hipFree(d_cnt);
+    if (which)
+        *which = b->ev_all_dense ? 2 : 1;
+    return GPSBB_OK;
+}
+
+/* the derived budgets this build was compiled with, in units of 2^-32: EV_MODEL_ERR, EV_T_EPS, PD_BAND */
+extern "C" void gpsbb_test_budgets(double out[3])
+{
+    out[0] = EV_MODEL_ERR * 0x1p+32;
+    out[1] = EV_T_EPS * 0x1p+32;
+    out[2] = (double)PD_BAND;
 }
 
 extern "C" unsigned long long gpsbb_test_row_bound(int kind, double s_abs, int nsamp)

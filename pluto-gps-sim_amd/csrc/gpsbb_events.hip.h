@@ -12,16 +12,18 @@
  * tile over j then gives the 16 int16 I/Q pairs of all channels at once.
  *
  * Where the breakpoints are.  The reference's NCOs are sequences of rounded IEEE additions, so the state
- * at sample n is not x0 + n*s.  k_seed walks every chain exactly (gpsbb_nco.h) and leaves the exact state
+ * at sample n is not x0 + n*s.  The pre-pass walks every chain exactly (gpsbb_nco.h) and leaves the exact state
  * at the first sample of every 1024-sample tile.  Inside a tile a lane uses the linear model
  *     state(n) ~= state(tile start) + (n - tile start) * step
  * which differs from the true sequence by the roundings of at most 1039 additions (each at most half an
- * ulp of a number below 512 resp. 1024: 2^-45 resp. 2^-44) plus the model's own arithmetic: less than
- * 2^-33.9 table-index units / chips in total (EV_MODEL_ERR below is 2^-32).  floor(model) equals
- * floor(truth) at every sample unless the model passes within that distance of an integer at a sample; a
+ * ulp of a number below 512 resp. 1024: 2^-45 resp. 2^-44): less than 2^-33.9 table-index units / chips (MEASURED over
+ * every tile of 19 corner workloads against the reference's own recurrence, tools/model_err.py: 0.125 resp. 0.25 units of
+ * 2^-32).  What a lane actually tests is that model in guard format (below), with the format's own roundings on top:
+ * EV_MODEL_ERR bounds the total at the first sample of a run.  floor(model) equals floor(truth) at every sample unless
+ * the model passes within that distance of an integer at a sample; a
  * lane tests exactly that for each of its breakpoints (and for its first sample) and, if it cannot rule
  * it out, recomputes its run exactly: jump-ahead from the tile's exact state with the genuine IEEE steps
- * (ev_exact_run).  At 25 MS/s that happens for about one lane-run-channel in 10^5, so the cost is nil,
+ * (ev_exact_run).  At 25 MS/s that happens for about one lane-run-channel in 10^6, so the cost is nil,
  * and the output is bit-exact by construction, not by luck.  Wraps need no special case on the fast
  * path: the carrier's is index 511 -> 0 (the model runs on unwrapped, the index is taken modulo 512), the
  * code's is chip 1022 -> 0 with the next period's data bit.
@@ -57,16 +59,30 @@ constexpr int EV_KC_DENSE = EV_KC_MAX + 1;         /* EvConst::kc of a channel t
 constexpr int EV_CHUNK = GPSBB_EV_CHUNK;           /* consecutive tiles a wavefront takes at a time (default of BatchDev::ev_chunk) */
 constexpr int EV_ROW_DISCARD = 15;                 /* D row of changes that fall behind the run's last sample */
 
-/* bound used for |model - truth| (table-index units / chips); the derivation above gives < 2^-33.9 */
-#define EV_MODEL_ERR 0x1p-32
+/* Bound on |guard-format model - truth| at the first sample of a run, in table-index units / chips: the linear model's own
+ * error (< 2^-33.9 = 0.27 units of 2^-32; measured 0.25) PLUS the roundings of the format on the way there — the tile state
+ * put into guard format (half a unit) and the fma that takes it to the run's first sample (half a unit): 1.27 units, measured
+ * 1.1 (tools/model_err.py, profiles/r04_model_err.json).  Rounds 2 and 3 had 2^-32 here — the model's error alone — and let
+ * EV_T_EPS absorb the format's roundings; but the position of a change is (integer - first-sample model) / step, so EVERYTHING
+ * in the first-sample model is amplified by 1 / step: measured, the change positions were off by up to 1.48 W (index) and
+ * 1.41 W (chip) with the old constants — outside the band the danger test covers, i.e. a truth landing within 0.4 units above
+ * an integer at a sample could be placed one sample late without being flagged (about 1e-13 per channel-sample; no soak had
+ * hit it).  Now 4 units, the channel's bias W is a whole number of units (so that the bias the format carries is W exactly and
+ * not W rounded), and the test suite asserts realised <= W / 2 for everything tested. */
+#ifndef EV_MODEL_ERR
+#define EV_MODEL_ERR 0x1p-30
+#endif
 /* The quantities a lane tests travel in GUARD FORMAT: 2^20 + value, so that one unit in the last place is 2^-32, the
  * double's low word IS the fraction (in units of 2^-32) and the low bits of its high word ARE the integer part — index,
  * chip and row come out with one v_and, and "within the error of an integer" is a comparison of low words.  Every
  * tested quantity also carries the channel's bias +W (EvConst::W >= its error bound): floor(value + W) = floor(truth)
  * unless the low word of the biased value is below 2W (EvConst::danger), and the minimum of the low words of everything
- * a lane tests for a channel is compared once.  EV_T_EPS: the roundings of that format (a handful of operations at half
- * a unit each) on top of the model error. */
-#define EV_T_EPS 0x1p-30
+ * a lane tests for a channel is compared once.  EV_T_EPS: the roundings of a change position's own arithmetic (the constant
+ * tK0 / tC0: one unit; the fma: half a unit; up to three additions of 1 / step: half a unit each — 3 units at most) on top of
+ * EV_MODEL_ERR / step. */
+#ifndef EV_T_EPS
+#define EV_T_EPS 0x1p-29
+#endif
 #define EV_GUARD 0x1p+20
 
 /* A wavefront claims its next chunk of tiles with a returning atomic that it does not wait for (inline assembly: the

@@ -1,0 +1,448 @@
+/*
+ * gpsbb_node.cpp — include/gpsbb_node.h: one process, one producer thread + handle + ring per time shard, one sink.
+ *
+ * Host code only, on top of the public C ABI of gpsbb.h (nothing here knows a kernel): what the reference's main loop and
+ * pluto_tx_thread_ep() are to one CPU (plutogpssim.c:2655-2806, 2146-2158, pinned at 2045-2056 / 2069 / 2289), this is
+ * to the GPUs of a node.
+ */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#include <pthread.h>
+#include <sched.h>
+
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "gpsbb_node.h"
+
+namespace {
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+/* "0-31,128-159" -> cpu_set_t; returns the number of CPUs */
+int parse_cpulist(const char *s, cpu_set_t *set)
+{
+    CPU_ZERO(set);
+    int n = 0;
+    while (*s) {
+        char *end = nullptr;
+        const long a = strtol(s, &end, 10);
+        if (end == s)
+            break;
+        long b = a;
+        s = end;
+        if (*s == '-') {
+            b = strtol(s + 1, &end, 10);
+            s = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (c >= 0 && !CPU_ISSET((int)c, set)) {
+                CPU_SET((int)c, set);
+                n++;
+            }
+        if (*s == ',')
+            s++;
+    }
+    return n;
+}
+
+struct Shard {
+    gpsbb_node *node = nullptr;
+    int index = 0, device = 0;
+    std::thread th;
+    gpsbb_t *h = nullptr;
+    gpsbb_stream_t *st = nullptr;
+    int numa_node = -1, cpus_bound = 0;
+    int create_rc = GPSBB_OK;
+    std::vector<gpsbb_chan_t> slot_desc; /* a push's descriptors where they have to be edited: the shard's first slot (seed) and a padded tail */
+    /* the job of the current run */
+    long first = 0, count = 0;
+    int rc = GPSBB_OK;
+    gpsbb_node_shard_stats_t stats{};
+};
+
+} /* namespace */
+
+struct gpsbb_node {
+    gpsbb_node_config_t cfg{};
+    std::vector<int> devices;
+    std::vector<Shard> shards;
+    std::mutex m;
+    std::condition_variable cv;
+    /* life cycle of the producer threads */
+    int created = 0;       /* threads that have finished setting up (successfully or not) */
+    unsigned long job = 0; /* run number; a thread works when it sees a new one */
+    int done = 0;          /* threads that have finished the current job */
+    bool quit = false;
+    /* the current run */
+    const gpsbb_chan_t *ch = nullptr;
+    long nblocks = 0;
+    gpsbb_node_sink_fn sink = nullptr;
+    void *user = nullptr;
+    long next_block = 0;   /* ordered mode: the block the sink gets next */
+    long delivered = 0;
+    bool stop = false;     /* the sink asked to stop, or a shard failed */
+    std::mutex sink_m;     /* indexed, not concurrent: one sink call at a time */
+};
+
+extern "C" int gpsbb_node_plan(long nblocks, int nshards, int blocks_per_slot, long *first)
+{
+    if (nblocks < 0 || nshards < 1 || nshards > GPSBB_NODE_MAX_SHARDS || blocks_per_slot < 1 || !first)
+        return GPSBB_E_BADARG;
+    /* shard g = slots [g * S / N, (g + 1) * S / N) of the S = ceil(B / bps) slots of the stream: contiguous in time
+     * (BASELINE.json configs[4]: GPU g gets blocks [g * B / G, (g + 1) * B / G)), boundaries on whole pushes */
+    const long slots = (nblocks + blocks_per_slot - 1) / blocks_per_slot;
+    for (int g = 0; g <= nshards; g++) {
+        long b = (slots * g / nshards) * blocks_per_slot;
+        first[g] = b > nblocks ? nblocks : b;
+    }
+    first[nshards] = nblocks;
+    return GPSBB_OK;
+}
+
+namespace {
+
+/* the 32-bit accumulator of the fixed-point carrier at the start of block `first`, per channel (c:2675, 2748): the same
+ * integer recurrence gpsbb_stream_* carries from push to push */
+void fixed_carrier_seed(const gpsbb_chan_t *ch, long first, int nch, double delt, int nsamp, double *seed)
+{
+    for (int i = 0; i < nch; i++) {
+        int prev_prn = 0;
+        uint32_t ph = 0;
+        for (long b = 0; b < first; b++) {
+            const gpsbb_chan_t &c = ch[(size_t)b * nch + i];
+            if (c.prn > 0) {
+                if (c.prn != prev_prn)
+                    ph = (uint32_t)c.carr_phase;
+                const volatile double scaled = 512.0 * 65536.0 * c.f_carr * delt;
+                const int32_t step = (int32_t)std::round(scaled);
+                ph += (uint32_t)nsamp * (uint32_t)step;
+            }
+            prev_prn = c.prn > 0 ? c.prn : 0;
+        }
+        const gpsbb_chan_t &c = ch[(size_t)first * nch + i];
+        seed[i] = (c.prn > 0 && c.prn == prev_prn) ? (double)ph : c.carr_phase;
+    }
+}
+
+/* hand one popped slot to the sink; returns false when the run is to stop */
+bool deliver(gpsbb_node *n, Shard &s, const int16_t *iq, long first_block, int nb)
+{
+    const bool indexed = (n->cfg.flags & GPSBB_NODE_INDEXED) != 0;
+    const bool concurrent = indexed && (n->cfg.flags & GPSBB_NODE_CONCURRENT);
+    const double t0 = now_s();
+    int rc = 0;
+    if (!indexed) {
+        /* one ordered stream: wait until every earlier block has been delivered (plutogpssim.c:2146-2158: one consumer) */
+        std::unique_lock<std::mutex> lk(n->m);
+        n->cv.wait(lk, [&] { return n->stop || n->next_block == first_block; });
+        if (n->stop)
+            return false;
+        lk.unlock();
+        rc = n->sink(n->user, iq, first_block, nb, s.index); /* nobody else can be here: it is this block's turn only */
+        lk.lock();
+        n->next_block = first_block + nb;
+        n->delivered += nb;
+        if (rc < 0)
+            n->stop = true;
+        n->cv.notify_all();
+    } else {
+        {
+            std::lock_guard<std::mutex> lk(n->m);
+            if (n->stop)
+                return false;
+        }
+        if (concurrent) {
+            rc = n->sink(n->user, iq, first_block, nb, s.index);
+        } else {
+            std::lock_guard<std::mutex> g(n->sink_m);
+            rc = n->sink(n->user, iq, first_block, nb, s.index);
+        }
+        std::lock_guard<std::mutex> lk(n->m);
+        n->delivered += nb;
+        if (rc < 0) {
+            n->stop = true;
+            n->cv.notify_all();
+        }
+    }
+    s.stats.wait_seconds += now_s() - t0;
+    return rc >= 0;
+}
+
+int run_shard(gpsbb_node *n, Shard &s)
+{
+    const gpsbb_node_config_t &c = n->cfg;
+    const int bps = c.blocks_per_slot, nch = c.nch;
+    const bool fixed = (c.flags & GPSBB_NODE_FIXED_CARRIER) != 0;
+    s.stats.first_block = s.first;
+    s.stats.nblocks = s.count;
+    s.stats.seed_seconds = s.stats.busy_seconds = s.stats.wait_seconds = 0.0;
+    if (s.count <= 0)
+        return GPSBB_OK;
+    int rc = gpsbb_stream_reset(s.st);
+    if (rc != GPSBB_OK)
+        return rc;
+    /* the exact carrier phase this shard starts from: the chain over everything before it, on this shard's own GPU */
+    double seed[GPSBB_MAX_CHAN];
+    bool seeded = false;
+    if (s.first > 0) {
+        const double t0 = now_s();
+        if (fixed) {
+            fixed_carrier_seed(n->ch, s.first, nch, c.delt, c.nsamp, seed);
+        } else {
+            /* gpsbb_chain_carrier takes int block counts: chain in pieces, carrying the end phases across */
+            double end[GPSBB_MAX_CHAN];
+            long done = 0;
+            bool have_end = false;
+            while (done < s.first) {
+                const long piece = s.first - done > 32768 ? 32768 : s.first - done;
+                const gpsbb_chan_t *src = n->ch + (size_t)done * nch;
+                std::vector<gpsbb_chan_t> patched;
+                if (have_end) {
+                    patched.assign(src, src + (size_t)piece * nch);
+                    for (int i = 0; i < nch; i++) {
+                        const gpsbb_chan_t &prev = n->ch[(size_t)(done - 1) * nch + i];
+                        if (patched[i].prn > 0 && patched[i].prn == prev.prn)
+                            patched[i].carr_phase = end[i];
+                    }
+                    src = patched.data();
+                }
+                rc = gpsbb_chain_carrier(s.h, src, (int)piece, nch, c.delt, c.nsamp, nullptr, end);
+                if (rc != GPSBB_OK)
+                    return rc;
+                have_end = true;
+                done += piece;
+            }
+            for (int i = 0; i < nch; i++) {
+                const gpsbb_chan_t &cur = n->ch[(size_t)s.first * nch + i], &prev = n->ch[(size_t)(s.first - 1) * nch + i];
+                /* a channel that changes satellite at the boundary keeps its own phase (allocateChannel, c:1956-1964) */
+                seed[i] = (cur.prn > 0 && cur.prn == prev.prn) ? end[i] : cur.carr_phase;
+            }
+        }
+        seeded = true;
+        s.stats.seed_seconds = now_s() - t0;
+    }
+    const unsigned depth = (unsigned)c.depth;
+    const long nslots = (s.count + bps - 1) / bps;
+    const double t_busy = now_s();
+    long pushed = 0, popped = 0;
+    bool going = true;
+    while (going && popped < nslots) {
+        while (going && pushed < nslots && (unsigned)gpsbb_stream_pending(s.st) < depth) {
+            const long b0 = s.first + pushed * bps;
+            const long nb = s.first + s.count - b0 < bps ? s.first + s.count - b0 : bps;
+            const gpsbb_chan_t *src = n->ch + (size_t)b0 * nch;
+            if ((pushed == 0 && seeded) || nb < bps) {
+                s.slot_desc.assign((size_t)bps * nch, gpsbb_chan_t{}); /* a short last slot is padded with idle blocks (prn 0) */
+                memcpy(s.slot_desc.data(), src, (size_t)nb * nch * sizeof(gpsbb_chan_t));
+                if (pushed == 0 && seeded)
+                    for (int i = 0; i < nch; i++)
+                        s.slot_desc[i].carr_phase = seed[i];
+                src = s.slot_desc.data();
+            }
+            rc = gpsbb_stream_push(s.st, src);
+            if (rc != GPSBB_OK)
+                return rc;
+            pushed++;
+        }
+        const int16_t *iq = nullptr;
+        rc = gpsbb_stream_pop(s.st, &iq, nullptr);
+        if (rc != GPSBB_OK)
+            return rc;
+        const long b0 = s.first + popped * bps;
+        const long nb = s.first + s.count - b0 < bps ? s.first + s.count - b0 : bps;
+        popped++;
+        going = deliver(n, s, iq, b0, (int)nb);
+    }
+    /* a stopped run leaves slots in the ring: drain them so that the next run can reset the stream */
+    while (gpsbb_stream_pending(s.st) > 0) {
+        const int16_t *iq = nullptr;
+        const int r2 = gpsbb_stream_pop(s.st, &iq, nullptr);
+        if (r2 != GPSBB_OK)
+            return r2;
+    }
+    s.stats.busy_seconds = now_s() - t_busy;
+    return GPSBB_OK;
+}
+
+void shard_main(gpsbb_node *n, Shard *sp)
+{
+    Shard &s = *sp;
+    const gpsbb_node_config_t &c = n->cfg;
+    /* placement first: the thread, and with it everything it allocates and touches from here on — the handle's staging
+     * arenas, the ring's pinned slots — goes next to the GPU */
+    if (!(c.flags & GPSBB_NODE_NO_AFFINITY)) {
+        char cpus[512];
+        int node = -1;
+        if (gpsbb_device_affinity(s.device, &node, cpus, sizeof cpus) == GPSBB_OK) {
+            s.numa_node = node;
+            cpu_set_t set;
+            if (cpus[0] && parse_cpulist(cpus, &set) > 0 && pthread_setaffinity_np(pthread_self(), sizeof set, &set) == 0) {
+                cpu_set_t got;
+                if (pthread_getaffinity_np(pthread_self(), sizeof got, &got) == 0)
+                    s.cpus_bound = CPU_COUNT(&got);
+            }
+        }
+    } else {
+        (void)gpsbb_device_affinity(s.device, &s.numa_node, nullptr, 0);
+    }
+    int rc = gpsbb_create(&s.h, s.device);
+    if (rc == GPSBB_OK) {
+        const unsigned sf = GPSBB_CHAIN_CARRIER | ((c.flags & GPSBB_NODE_FIXED_CARRIER) ? GPSBB_FIXED_CARRIER : 0u) |
+                            ((c.flags & GPSBB_NODE_DEVICE_ONLY) ? GPSBB_STREAM_DEVICE_ONLY : 0u);
+        rc = gpsbb_stream_create(s.h, c.nch, c.delt, c.nsamp, c.blocks_per_slot, c.depth, sf, &s.st);
+    }
+    s.create_rc = rc;
+    unsigned long seen = 0;
+    {
+        std::unique_lock<std::mutex> lk(n->m);
+        n->created++;
+        n->cv.notify_all();
+    }
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(n->m);
+            n->cv.wait(lk, [&] { return n->quit || n->job != seen; });
+            if (n->quit)
+                break;
+            seen = n->job;
+        }
+        s.rc = s.create_rc == GPSBB_OK ? run_shard(n, s) : s.create_rc;
+        std::unique_lock<std::mutex> lk(n->m);
+        if (s.rc != GPSBB_OK)
+            n->stop = true; /* the others wind down: an ordered stream with a hole is no stream */
+        n->done++;
+        n->cv.notify_all();
+    }
+    if (s.st)
+        gpsbb_stream_destroy(s.st);
+    if (s.h)
+        gpsbb_destroy(s.h);
+}
+
+} /* namespace */
+
+extern "C" int gpsbb_node_create(gpsbb_node_t **out, const gpsbb_node_config_t *cfg)
+{
+    if (!out || !cfg || cfg->nshards < 1 || cfg->nshards > GPSBB_NODE_MAX_SHARDS || cfg->nch < 1 || cfg->nch > GPSBB_MAX_CHAN ||
+        !(cfg->delt > 0.0) || cfg->nsamp < 1 || cfg->blocks_per_slot < 1 || cfg->depth < 2 ||
+        (cfg->flags & ~(GPSBB_NODE_INDEXED | GPSBB_NODE_CONCURRENT | GPSBB_NODE_DEVICE_ONLY | GPSBB_NODE_NO_AFFINITY | GPSBB_NODE_FIXED_CARRIER)))
+        return GPSBB_E_BADARG;
+    *out = nullptr;
+    gpsbb_node *n = new (std::nothrow) gpsbb_node;
+    if (!n)
+        return GPSBB_E_NOMEM;
+    n->cfg = *cfg;
+    n->devices.resize(cfg->nshards);
+    for (int g = 0; g < cfg->nshards; g++)
+        n->devices[g] = cfg->devices ? cfg->devices[g] : g;
+    n->cfg.devices = n->devices.data();
+    n->shards.resize(cfg->nshards);
+    for (int g = 0; g < cfg->nshards; g++) {
+        Shard &s = n->shards[g];
+        s.node = n;
+        s.index = g;
+        s.device = n->devices[g];
+    }
+    int started = 0;
+    try {
+        for (int g = 0; g < cfg->nshards; g++) {
+            n->shards[g].th = std::thread(shard_main, n, &n->shards[g]);
+            started++;
+        }
+    } catch (...) {
+        /* fall through: wait for the ones that did start, then tear down */
+    }
+    {
+        std::unique_lock<std::mutex> lk(n->m);
+        n->cv.wait(lk, [&] { return n->created == started; });
+    }
+    int rc = started == cfg->nshards ? GPSBB_OK : GPSBB_E_NOMEM;
+    for (int g = 0; g < started && rc == GPSBB_OK; g++)
+        rc = n->shards[g].create_rc;
+    if (rc != GPSBB_OK) {
+        gpsbb_node_destroy(n);
+        return rc;
+    }
+    *out = n;
+    return GPSBB_OK;
+}
+
+extern "C" void gpsbb_node_destroy(gpsbb_node_t *n)
+{
+    if (!n)
+        return;
+    {
+        std::lock_guard<std::mutex> lk(n->m);
+        n->quit = true;
+        n->cv.notify_all();
+    }
+    for (auto &s : n->shards)
+        if (s.th.joinable())
+            s.th.join();
+    delete n;
+}
+
+extern "C" int gpsbb_node_run(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nblocks, gpsbb_node_sink_fn sink, void *user,
+                              gpsbb_node_stats_t *stats)
+{
+    if (!n || !ch || nblocks < 1 || !sink)
+        return GPSBB_E_BADARG;
+    const int N = n->cfg.nshards;
+    long first[GPSBB_NODE_MAX_SHARDS + 1];
+    int rc = gpsbb_node_plan(nblocks, N, n->cfg.blocks_per_slot, first);
+    if (rc != GPSBB_OK)
+        return rc;
+    const double t0 = now_s();
+    {
+        std::lock_guard<std::mutex> lk(n->m);
+        n->ch = ch;
+        n->nblocks = nblocks;
+        n->sink = sink;
+        n->user = user;
+        n->next_block = 0;
+        n->delivered = 0;
+        n->stop = false;
+        n->done = 0;
+        for (int g = 0; g < N; g++) {
+            n->shards[g].first = first[g];
+            n->shards[g].count = first[g + 1] - first[g];
+            n->shards[g].rc = GPSBB_OK;
+        }
+        n->job++;
+        n->cv.notify_all();
+    }
+    {
+        std::unique_lock<std::mutex> lk(n->m);
+        n->cv.wait(lk, [&] { return n->done == N; });
+    }
+    rc = GPSBB_OK;
+    for (int g = 0; g < N && rc == GPSBB_OK; g++)
+        rc = n->shards[g].rc;
+    if (rc == GPSBB_OK && n->delivered != nblocks)
+        rc = GPSBB_E_STATE; /* the sink stopped the run */
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->seconds = now_s() - t0;
+        stats->blocks = n->delivered;
+        stats->nshards = N;
+        for (int g = 0; g < N; g++) {
+            stats->shard[g] = n->shards[g].stats;
+            stats->shard[g].device = n->shards[g].device;
+            stats->shard[g].numa_node = n->shards[g].numa_node;
+            stats->shard[g].cpus_bound = n->shards[g].cpus_bound;
+        }
+    }
+    return rc;
+}

@@ -33,6 +33,14 @@ double gpsbb_test_carr_predict(double x0, double s, int n);
  * model kernels with GPSBB_FIXED_CARRIER */
 double gpsbb_test_fixed_tile_index(unsigned ph0, int step, int t);
 
+/* The error budgets of the model kernels, measured (gpsbb_modelerr.hip.h): the realised |model - truth| of everything
+ * k_synth_ev / k_synth_pd test, over every tile of the batch's last run, per channel index.  Needs a GPU. */
+#define GPSBB_TEST_ME_NQ 11  /* maxima per channel: y0, y0/W, tk, tk/W, x0, x0/W, tc, tc/W, pure_y, pure_x, W (units of 2^-32) */
+#define GPSBB_TEST_MEC_NQ 4  /* counts per channel: wrong unflagged decisions, lanes flagged, lane-runs looked at, always-exact */
+struct gpsbb_batch;
+int gpsbb_test_model_err(struct gpsbb_batch *b, double *maxima, unsigned long long *counts, int *which);
+void gpsbb_test_budgets(double out[3]); /* EV_MODEL_ERR, EV_T_EPS, PD_BAND of this build, in units of 2^-32 */
+
 #ifdef __cplusplus
 }
 #endif

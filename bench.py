@@ -46,7 +46,7 @@ import zlib
 
 import numpy as np
 
-# The library keeps up to seven HIP streams busy (three pre-pass streams, upload, compute, gather, the null stream); the
+# The library keeps up to nine HIP streams busy (four pre-pass streams, upload, two synthesis streams, gather, the null stream); the
 # runtime's default of four hardware queues would make unrelated streams share a queue and run one after the other.
 # Must be set before the HIP runtime starts (import torch).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
@@ -59,28 +59,33 @@ PUSH_BLOCKS = 400      # blocks per push (1e9 samples, 4 GB of IQ)
 STEP_PUSHES = 8        # pushes per step over all ranks: a step is 3200 blocks
 
 
-def stream_descriptors(pkg, nblocks, nch, seed=0x5EED, max_doppler=5000.0):
+def stream_descriptors(pkg, nblocks, nch, seed=0x5EED, max_doppler=5000.0, first=0, count=None, fields=None):
     """A stream continuous in time: everything from the seeded generator (M2) except the Doppler, which moves
-    slowly and smoothly per channel like a satellite pass (period 1-2 h, both signs, through zero)."""
-    ch = pkg.synth_descriptors(nblocks, nch=nch, seed=seed, max_doppler=max_doppler)
+    slowly and smoothly per channel like a satellite pass (period 1-2 h, both signs, through zero).
+    first / count: blocks [first, first+count) of the nblocks-block stream only (the same rows: the generator is
+    counter-based), so that a rank builds what it renders; fields: see synth_descriptors (the blocks BEFORE a shard are only
+    chained through: prn, f_carr, carr_phase)."""
+    count = nblocks - first if count is None else count
+    ch = pkg.synth_descriptors(nblocks, nch=nch, seed=seed, max_doppler=max_doppler, first=first, count=count, fields=fields)
     g = pkg.SplitMix64(seed ^ 0xD0BB1E5)
     ph = g.u01((nch,)) * 2.0 * np.pi
     per = 36000.0 * (1.0 + g.u01((nch,)))
     amp = max_doppler * (0.35 + 0.65 * g.u01((nch,)))
-    b = np.arange(nblocks, dtype=np.float64)[:, None]
+    b = np.arange(first, first + count, dtype=np.float64)[:, None]
     ch["f_carr"] = amp[None, :] * np.sin(ph[None, :] + 2.0 * np.pi * b / per[None, :])
     ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
     return ch
 
 
-def parity_check(pkg, ob, synth, mine, delt, nsamp, PB, nch, ncheck):
+def parity_check(pkg, ob, synth, mine, delt, nsamp, PB, nch, ncheck, nspot=8):
     """Bytes of evidence on the mode the headline is timed in: the shard through a fresh GPSBB_STREAM_DEVICE_ONLY ring in
-    order; the first `ncheck` blocks and one block of the last push read back from the slots' HBM and compared with
+    order; the first `ncheck` blocks, one block of every (npush / nspot)-th push and one of the last push read back from the slots' HBM and compared with
     the oracle (c:2690-2756 restated), IQ and end-of-block carrier phase, bit for bit (ob None: no oracle, only the
     digests).  Also returns one 32-bit digest per block of its end-of-block NCO states: the concatenation over the
     ranks must not depend on how many ranks the stream was cut into (every shard starts from its seed)."""
     orc = ob.Oracle() if ob else None
     npush = mine.shape[0] // PB
+    spot_every = max(1, npush // max(1, nspot))  # one block of every spot_every-th push, from the phase the stream reports there
     st = synth.stream(nch, delt, nsamp, PB, depth=3, flags=pkg.CHAIN_CARRIER | pkg.STREAM_DEVICE_ONLY)
     checked, bad, digs = 0, [], []
     pushed = 0
@@ -107,8 +112,8 @@ def parity_check(pkg, ob, synth, mine, delt, nsamp, PB, nch, ncheck):
                     sys.stderr.write("bench.py: block %d of the shard: IQ %s (%d samples differ), end-of-block carr_phase %s\n" %
                                      (j, "equal" if ok_iq else "DIFFERS", int((got[j] != want_iq[j]).any(axis=1).sum()),
                                       "equal" if ok_ph else "DIFFERS"))
-        if k == npush - 1 and npush > 1:
-            j = PB // 2
+        if npush > 1 and (k == npush - 1 or (k % spot_every == spot_every - 1 and k < npush - 1)):
+            j = (PB // 2 + 7 * k) % PB or 1  # a different block of the push every time, never its first
             one = mine[k * PB + j:k * PB + j + 1].copy()
             cont = (one["prn"][0] > 0) & (one["prn"][0] == mine["prn"][k * PB + j - 1])
             one["carr_phase"][0] = np.where(cont, ends["carr_phase"][j - 1], one["carr_phase"][0])
@@ -224,7 +229,8 @@ def main():
     ap.add_argument("--nsamp", type=int, default=2500000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (baselines and the parity check against the oracle)")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work per CPU baseline leg (the M1 leg gets half)")
-    ap.add_argument("--parity-blocks", type=int, default=4, help="leading blocks of the shard compared with the oracle (+1 in the last push)")
+    ap.add_argument("--parity-blocks", type=int, default=8, help="leading blocks of the shard compared with the oracle (+ one block in each of --parity-spots pushes spread over the shard, + 1 in the last push)")
+    ap.add_argument("--parity-spots", type=int, default=8)
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling runs)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: sharding / seeds / digest exchange with the CPU oracle")
     args = ap.parse_args()
@@ -249,7 +255,10 @@ def main():
     if backend == "nccl" and world > ndev:
         raise SystemExit("%d ranks but %d GPUs" % (world, ndev))
     local = local % max(ndev, 1)
-    if world > 1:
+    # GPSBB_BENCH_FORCE_DIST: take the N > 1 code path (process group, RCCL all_reduce / all_gather / barrier) with ONE rank
+    # too — what `torchrun --nproc-per-node 1` on a 1-GPU box can exercise of the path an 8-GPU node runs
+    use_dist = world > 1 or (os.environ.get("GPSBB_BENCH_FORCE_DIST") and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             torch.cuda.set_device(local)
@@ -258,7 +267,7 @@ def main():
             dist.init_process_group(backend)
     if args.dry_run:
         dry_run(args, pkg, dist, world, rank)
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
     torch.cuda.set_device(local)
@@ -269,25 +278,27 @@ def main():
     ppr = STEP_PUSHES // world                 # pushes per rank and step
     total = K * STEP_PUSHES * PB               # blocks of the stream
     # ---- the stream and this rank's shard of it (set-up, not timed as throughput; the seed is timed on its own) ----
-    t_gen = time.perf_counter()
-    ch_all = stream_descriptors(pkg, total, nch)
-    t_gen = time.perf_counter() - t_gen
+    # Every rank builds ITS shard in full and, of the blocks before it, only what the carrier chain reads (prn, f_carr,
+    # carr_phase: three of the 69 words of a descriptor) — not the whole stream on every rank.
     b0, b1 = pkg.shard_blocks(total, rank, world)
+    t_gen = time.perf_counter()
+    mine = stream_descriptors(pkg, total, nch, first=b0, count=b1 - b0)
+    before = np.concatenate([stream_descriptors(pkg, total, nch, first=0, count=b0, fields=("prn", "f_carr", "carr_phase")), mine[:1]])
+    t_gen = time.perf_counter() - t_gen
     synth = pkg.Synth(local)
-    synth.shard_seed(ch_all, min(b0, 64), delt, nsamp)   # first use: scratch allocation, kernels loaded (not part of the seed's cost)
+    synth.shard_seed(before, min(b0, 64), delt, nsamp)   # first use: scratch allocation, kernels loaded (not part of the seed's cost)
     synth.sync()
     t_seed = time.perf_counter()
-    seed0 = synth.shard_seed(ch_all, b0, delt, nsamp)    # exact carrier phase at the shard's first block: the device chains the b0 blocks before it
+    seed0 = synth.shard_seed(before, b0, delt, nsamp)    # exact carrier phase at the shard's first block: the device chains the b0 blocks before it
     t_seed = time.perf_counter() - t_seed
-    mine = ch_all[b0:b1].copy()
     mine["carr_phase"][0] = seed0              # the shard starts from the stream's exact phase
     npush = mine.shape[0] // PB                # = K * ppr
-    del ch_all
+    del before
 
     def barrier():
         synth.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def run_ring(st, first, count, depth):
@@ -314,7 +325,7 @@ def main():
         synth.sync()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -361,20 +372,55 @@ def main():
         gst.close()
         per_rank = gslots * gb * nsamp * 4 / gdt / 1e9
         mydig = zlib.crc32(np.asarray(dig, np.uint32).tobytes())
-        if world > 1:
+        if use_dist:
             allg = [None] * world
             dist.all_gather_object(allg, (per_rank, mydig))
             rates, digs = [a[0] for a in allg], [a[1] for a in allg]
         else:
             rates, digs = [per_rank], [mydig]
-        gather = {"value": sum(rates) / 4.0 * 1e9, "unit": "IQ samples/s", "per_rank_GBps_to_host": rates,
+        gather = {"value": sum(rates) / 4.0 * 1e9, "unit": "IQ samples/s", "per_rank_GBps_to_host": rates, "node_GBps_to_host": sum(rates),
+                  "expectation": "per GPU: PCIe Gen5 x16, 63 GB/s raw, ~51 measured; per node min(N x 51 GB/s, what the host's DRAM takes: "
+                                 "8 x 51 = 0.41 TB/s is about the write bandwidth of a 2-socket DDR5 host, so beyond ~4 GPUs the pinned rings "
+                                 "have to sit on their GPU's own NUMA node (gpsbb_node.h binds them there) to keep scaling)",
                   "slot_blocks": gb, "depth": gdepth, "slots": gslots, "chained": True,
                   "digest_of_block_digests": zlib.crc32(np.asarray(digs, np.uint32).tobytes()),
                   "note": "IQ stored into pinned host memory by a copy kernel on the side stream, the first and last 64 KiB of every block digested on arrival; PCIe Gen5 x16 = 63 GB/s raw"}
 
+    # ---- the same pushes through the PRODUCT's node driver (include/gpsbb_node.h): one process, one producer thread +
+    # handle + ring per shard, one sink.  N = 1 on this rank's GPU must agree with the headline (same ring, same pushes,
+    # driven from C instead of from this script); with one rank and several GPUs visible, also all of them in one process,
+    # every shard seeded by the device-side chain, the sink taking slots as they complete ----
+    node = None
+    if rank == 0 and not args.no_extras:
+        def node_leg(devices):
+            nflags = pkg.NODE_DEVICE_ONLY | pkg.NODE_INDEXED | pkg.NODE_CONCURRENT
+            with pkg.Node(len(devices), nch, delt, nsamp, PB, depth=args.depth, flags=nflags, devices=devices) as nd:
+                cnt = [0]
+
+                def sink(iq, first, nb, shard):
+                    cnt[0] += nb
+                    return 0
+                nd.run(mine[:min(mine.shape[0], 2 * PB * len(devices))], sink)   # warm-up: rings allocated, kernels loaded
+                best = None
+                for _ in range(3):
+                    stn = nd.run(mine, sink)
+                    best = stn if best is None or stn["seconds"] < best["seconds"] else best
+            return {"value": mine.shape[0] * nsamp / best["seconds"], "unit": "IQ samples/s", "shards": len(devices), "devices": list(devices),
+                    "seconds": best["seconds"], "blocks": mine.shape[0], "seed_seconds_max": max(x["seed_seconds"] for x in best["shards"]),
+                    "numa_nodes": [x["numa_node"] for x in best["shards"]], "cpus_bound": [x["cpus_bound"] for x in best["shards"]]}
+        try:
+            node = {"one_shard": node_leg([local]),
+                    "note": "gpsbb_node_run (C, one producer thread per shard bound to its GPU's NUMA node), GPSBB_NODE_DEVICE_ONLY rings of the "
+                            "headline's geometry, one pass over this rank's shard, best of 3; includes the shard seeds"}
+            node["one_shard"]["vs_headline"] = node["one_shard"]["value"] / (samples_per_step * K / elapsed / world)
+            if world == 1 and ndev > 1:
+                node["all_visible_gpus"] = node_leg(list(range(ndev)))
+        except Exception as e:  # the headline stands on its own
+            node = {"error": repr(e)}
+
     # ---- the seed of the slowest rank; bytes of evidence on the timed mode's output ----
     def over_ranks(x, op):
-        if world == 1:
+        if not use_dist:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=op)
@@ -386,10 +432,10 @@ def main():
         if not args.no_cpu:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle_binding as ob
-        n_ok, bad, digs = parity_check(pkg, ob, synth, mine, delt, nsamp, PB, nch, max(1, min(args.parity_blocks, PB)))
+        n_ok, bad, digs = parity_check(pkg, ob, synth, mine, delt, nsamp, PB, nch, max(1, min(args.parity_blocks, PB)), args.parity_spots)
         n_all = int(over_ranks(float(n_ok), dist.ReduceOp.SUM))
         n_bad = int(over_ranks(float(len(bad)), dist.ReduceOp.SUM))
-        if world > 1:
+        if use_dist:
             allg = [None] * world
             dist.all_gather_object(allg, digs)
             digs = [d for part in allg for d in part]
@@ -397,7 +443,7 @@ def main():
                   "stream_end_state_digest": zlib.crc32(np.asarray(digs, np.uint32).tobytes()), "blocks_digested": len(digs),
                   "what": "int16 IQ and end-of-block carr_phase of blocks read back from the HBM slots of a "
                           "GPSBB_STREAM_DEVICE_ONLY ring (the timed mode) vs the CPU oracle, bit for bit: the first blocks of "
-                          "every rank's shard and one block of its last push"}
+                          "every rank's shard, one block of every (pushes / %d)-th push and one of its last push" % args.parity_spots}
         if n_bad:
             sys.stderr.write("bench.py: rank %d: IQ differs from the oracle in blocks %s of its shard\n" % (rank, bad))
 
@@ -437,6 +483,8 @@ def main():
             "value_incl_seed": samples_per_step * K / (elapsed + seed_max),
             "parity": parity,
             "parity_checked_blocks": parity["checked_blocks"] if parity else 0,
+            "dist": {"process_group": bool(use_dist), "backend": backend if use_dist else None, "world": world,
+                     "hw_queues": synth.info(pkg.INFO_HW_QUEUES), "streams_of_the_handle": synth.info(pkg.INFO_STREAMS)},
         }
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
@@ -448,6 +496,25 @@ def main():
                 pass
         if gather:
             res["gather"] = gather
+        if node:
+            res["node_driver"] = node
+        sq = os.path.join(ROOT, "profiles", "sq_latest.json")
+        if os.path.exists(sq):
+            try:
+                # the bound the kernel actually runs against: VALU issue.  Wave-instructions per launch from the kept SQ counter
+                # pass (SQ_INSTS_VALU, scaled to this launch's samples), cycles per wave-instruction per SIMD from the
+                # micro-benchmark of the kernel's instruction mix (profiles/r03_valu_rates_ubench.txt), 1024 SIMDs at the clock
+                # measured under load: the time the SIMDs need just to ISSUE the kernel's vector instructions
+                sj = json.load(open(sq))
+                insts = sj["k_synth_ev_valu_wave_insts_per_sample"] * samples_per_launch
+                issue_ms = insts * sj["cycles_per_valu_wave_inst"] / (sj["simds"] * sj["clock_ghz"] * 1e9) * 1e3
+                res["roofline_valu"] = {"bound": "valu_issue", "kernel": "k_synth_ev", "valu_wave_insts_per_launch": insts,
+                                        "cycles_per_wave_inst": sj["cycles_per_valu_wave_inst"], "simds": sj["simds"], "clock_ghz": sj["clock_ghz"],
+                                        "issue_ms_per_launch": issue_ms, "ms_per_launch": ms_synth, "frac": issue_ms / ms_synth,
+                                        "lds_bank_conflict_share_of_lds_active": sj.get("lds_bank_conflict_share"),
+                                        "source": sj.get("source")}
+            except Exception:
+                pass
     if rank == 0 and not args.no_extras:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         rch = mine[:PB]  # the shard's first push: the headline's own descriptors, resident
@@ -468,6 +535,8 @@ def main():
         alone = 4.0 * samples_per_launch / (r2["synth_kernel_ms"] * 1e-3) / 1e9
         res["roofline"]["alone"] = {"ms_per_launch": r2["synth_kernel_ms"], "achieved": alone, "frac": alone / HBM_PEAK_GBS,
                                     "note": "k_synth_ev on resident tables, no pre-pass running beside it"}
+        if "roofline_valu" in res:
+            res["roofline_valu"]["frac_alone"] = res["roofline_valu"]["issue_ms_per_launch"] / r2["synth_kernel_ms"]
         # the reference-faithful geometry (12 ch, 2.6 MS/s, 300 000-sample blocks)
         mch = pkg.synth_descriptors(1000, nch=12, seed=0xF00D)
         m1, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, 0, 30, 4, dev)
@@ -494,12 +563,12 @@ def main():
             import oracle_binding as ob
             res["cpu_baseline"] = cpu_baseline(ob, mine, delt, nsamp, budget_s=args.cpu_budget)
             res["m1"]["cpu"] = cpu_baseline(ob, mch, 1.0 / 2.6e6, 300000, budget_s=args.cpu_budget / 2)
-    if world > 1:
+    if use_dist:
         dist.barrier()   # the other ranks wait for rank 0's legs
     if rank == 0:
         print(json.dumps(res))
     synth.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if parity and parity["mismatching_blocks"]:
         raise SystemExit(3)

@@ -489,13 +489,18 @@ class SplitMix64:
         self.seed = np.uint64(seed)
         self.k = 0
 
-    def take(self, n):
+    def take_at(self, start, n):
+        """draws start+1 .. start+n of the sequence (counter mode: any slice costs what it holds)"""
         with np.errstate(over="ignore"):
-            idx = np.arange(self.k + 1, self.k + n + 1, dtype=np.uint64)
+            idx = np.arange(start + 1, start + n + 1, dtype=np.uint64)
             z = self.seed + idx * np.uint64(0x9E3779B97F4A7C15)
             z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
             z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
             z = z ^ (z >> np.uint64(31))
+        return z
+
+    def take(self, n):
+        z = self.take_at(self.k, n)
         self.k += n
         return z
 
@@ -507,23 +512,55 @@ class SplitMix64:
         n = int(np.prod(shape))
         return (self.take(n) >> np.uint64(32)).reshape(shape)
 
+    def rows(self, nrows, width, first, count):
+        """rows [first, first+count) of the (nrows, width) table the next nrows*width draws fill; the generator moves on
+        past the whole table, so that what follows does not depend on which rows were asked for"""
+        z = self.take_at(self.k + first * width, count * width).reshape(count, width)
+        self.k += nrows * width
+        return z
 
-def synth_descriptors(nblocks, nch=16, seed=0x5EED, max_doppler=5000.0):
+
+def synth_descriptors(nblocks, nch=16, seed=0x5EED, max_doppler=5000.0, first=0, count=None, fields=None):
     """Seeded descriptor-level constellation: PRN 1..nch, f_carr ~ U(-max,max) Hz, f_code = 1.023e6 +
     f_carr/1540, code_phase ~ U[0,1023), carr_phase ~ U[0,1), gain ~ U(0.30,0.80), random 30-bit nav
-    words, iword in [9,58], ibit in 0..29, icode in 0..19."""
+    words, iword in [9,58], ibit in 0..29, icode in 0..19.
+    first / count: only blocks [first, first+count) of the nblocks-block table — the same rows the whole table has, at
+    the cost of those rows (a rank of a time-sharded run builds its own shard only).  fields: only these (the others stay
+    zero): what a carrier-chain-only call reads is ("prn", "f_carr", "carr_phase")."""
+    count = nblocks - first if count is None else count
     g = SplitMix64(seed)
-    ch = np.zeros((nblocks, nch), CHAN_DTYPE)
+    ch = np.zeros((count, nch), CHAN_DTYPE)
+
+    def want(f):
+        return fields is None or f in fields
+
+    def u01(width=nch):
+        return (g.rows(nblocks, width, first, count) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+    def skip(width=nch):
+        g.k += nblocks * width
+
     ch["prn"] = np.arange(1, nch + 1, dtype=np.int32)[None, :]
-    ch["f_carr"] = (g.u01((nblocks, nch)) * 2.0 - 1.0) * max_doppler
-    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
-    ch["code_phase"] = g.u01((nblocks, nch)) * 1023.0
-    ch["carr_phase"] = g.u01((nblocks, nch))
-    ch["gain"] = 0.30 + 0.50 * g.u01((nblocks, nch))
-    ch["iword"] = 9 + (g.u32((nblocks, nch)) % np.uint64(50)).astype(np.int32)
-    ch["ibit"] = (g.u32((nblocks, nch)) % np.uint64(30)).astype(np.int32)
-    ch["icode"] = (g.u32((nblocks, nch)) % np.uint64(20)).astype(np.int32)
-    ch["dwrd"] = (g.u32((nblocks, nch, N_DWRD)) & np.uint64(0x3FFFFFFF)).astype(np.uint32)
+    if want("f_carr") or want("f_code"):
+        ch["f_carr"] = (u01() * 2.0 - 1.0) * max_doppler
+        ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    else:
+        skip()
+    if want("code_phase"):
+        ch["code_phase"] = u01() * 1023.0
+    else:
+        skip()
+    if want("carr_phase"):
+        ch["carr_phase"] = u01()
+    else:
+        skip()
+    if fields is not None and not (set(fields) - {"prn", "f_carr", "f_code", "code_phase", "carr_phase"}):
+        return ch
+    ch["gain"] = 0.30 + 0.50 * u01()
+    ch["iword"] = 9 + ((g.rows(nblocks, nch, first, count) >> np.uint64(32)) % np.uint64(50)).astype(np.int32)
+    ch["ibit"] = ((g.rows(nblocks, nch, first, count) >> np.uint64(32)) % np.uint64(30)).astype(np.int32)
+    ch["icode"] = ((g.rows(nblocks, nch, first, count) >> np.uint64(32)) % np.uint64(20)).astype(np.int32)
+    ch["dwrd"] = ((g.rows(nblocks, nch * N_DWRD, first, count) >> np.uint64(32)) & np.uint64(0x3FFFFFFF)).astype(np.uint32).reshape(count, nch, N_DWRD)
     return ch
 
 

@@ -13,6 +13,10 @@
  * -F ("fast") produces the same bytes faster than real time's structure allows: the front end runs ahead,
  * blocks go through the streaming ring (gpsbb_stream_*, carrier chained exactly on host threads, pinned
  * device-to-host gather on a side stream) and are written as they pop.
+ * -G N renders through the node driver (include/gpsbb_node.h): N contiguous time shards, one producer thread + handle +
+ * ring per shard on the GPUs "-g a,b,c" names (default 0 .. N-1; an ordinal may repeat), each shard seeded with the exact
+ * carrier phase by the device-side chain, ONE output: a regular file is written with pwrite() as slots complete
+ * (GPSBB_NODE_INDEXED), a pipe in stream order.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,13 +24,43 @@
 #include <unistd.h>
 
 #include "gpsbb.h"
+#include "gpsbb_node.h"
 #include "gpsbb_tx.h"
 #include "gpsfe.h"
+
+/* the node driver's one consumer: a file (random access) or a pipe (ordered) */
+struct node_out {
+    FILE *f;
+    int fd;         /* >= 0: pwrite at the block's offset */
+    size_t nsamp;
+};
+
+static int node_sink(void *user, const int16_t *iq, long first_block, int nblocks, int shard)
+{
+    struct node_out *o = user;
+    (void)shard;
+    const size_t bytes = (size_t)nblocks * o->nsamp * 4;
+    if (o->fd >= 0) {
+        const char *p = (const char *)iq;
+        off_t at = (off_t)first_block * (off_t)o->nsamp * 4;
+        size_t left = bytes;
+        while (left) {
+            const ssize_t w = pwrite(o->fd, p, left, at);
+            if (w <= 0)
+                return -1;
+            p += w;
+            at += w;
+            left -= (size_t)w;
+        }
+        return 0;
+    }
+    return fwrite(iq, 1, bytes, o->f) == bytes ? 0 : -1;
+}
 
 static void usage(void)
 {
     fprintf(stderr, "usage: gpsbb-sim -e nav [-l lat,lon,h|-c x,y,z|-u motion.csv] [-t Y/M/D,h:m:s] [-T] [-i] [-3]\n"
-                    "                 [-s fs_hz] [-d seconds] [-n samples_per_block] [-N channels] [-g gpu] [-F] -o out.bin\n");
+                    "                 [-s fs_hz] [-d seconds] [-n samples_per_block] [-N channels] [-g gpu[,gpu...]] [-F] [-G shards] -o out.bin\n");
 }
 
 int main(int argc, char **argv)
@@ -43,10 +77,11 @@ int main(int argc, char **argv)
     long fs_hz = 3000000; /* TX_SAMPLE_FREQ c:43 */
     long nsamp = 300000;  /* NUM_SAMPLES c:44 */
     double duration = 1.0;
-    int gpu = 0, opt, fast = 0;
+    int gpu = 0, opt, fast = 0, nshards = 0, ndev = 0;
+    int devs[GPSBB_NODE_MAX_SHARDS];
     const char *out_path = NULL;
 
-    while ((opt = getopt(argc, argv, "e:u:c:l:s:Tt:in:N:d:o:g:3F")) != -1) {
+    while ((opt = getopt(argc, argv, "e:u:c:l:s:Tt:in:N:d:o:g:3FG:")) != -1) {
         switch (opt) {
         case 'e': cfg.navfile = optarg; break;
         case 'u': cfg.motion_file = optarg; break;
@@ -79,7 +114,13 @@ int main(int argc, char **argv)
         case 'N': cfg.max_chan = atoi(optarg); break;
         case 'd': duration = atof(optarg); break;
         case 'o': out_path = optarg; break;
-        case 'g': gpu = atoi(optarg); break;
+        case 'g': /* one ordinal, or the list of the node driver's shards */
+            ndev = 0;
+            for (char *t = strtok(optarg, ","); t && ndev < GPSBB_NODE_MAX_SHARDS; t = strtok(NULL, ","))
+                devs[ndev++] = atoi(t);
+            gpu = ndev ? devs[0] : 0;
+            break;
+        case 'G': nshards = atoi(optarg); break;
         case 'F': fast = 1; break;
         default: usage(); return 1;
         }
@@ -98,6 +139,53 @@ int main(int argc, char **argv)
     if (rc != GPSFE_OK) {
         fprintf(stderr, "ERROR: %s\n", gpsfe_strerror(rc));
         return 1;
+    }
+    if (nshards > 0) {
+        /* the whole descriptor sequence first (the host range solver runs ahead of everything: 296 bytes per block-channel),
+         * then N time shards on N handles into one output */
+        if (nshards > GPSBB_NODE_MAX_SHARDS || (ndev > 1 && ndev != nshards) || nblocks < 1) {
+            fprintf(stderr, "ERROR: -G wants 1..%d shards and as many -g ordinals\n", GPSBB_NODE_MAX_SHARDS);
+            return 1;
+        }
+        for (int g = 0; g < nshards; g++)
+            devs[g] = ndev > 1 ? devs[g] : (ndev == 1 && nshards == 1 ? devs[0] : (ndev == 1 ? devs[0] + g : g));
+        gpsbb_chan_t *all = malloc((size_t)nblocks * cfg.max_chan * sizeof *all);
+        FILE *fo = strcmp(out_path, "-") ? fopen(out_path, "wb") : stdout;
+        if (!all || !fo) {
+            fprintf(stderr, "ERROR: cannot allocate the descriptors / open %s\n", out_path);
+            return 1;
+        }
+        gpsfe_generate(fe, (int)nblocks, all);
+        struct node_out o = {fo, -1, (size_t)nsamp};
+        unsigned nflags = 0;
+        if (fo != stdout && ftruncate(fileno(fo), (off_t)nblocks * nsamp * 4) == 0) {
+            o.fd = fileno(fo); /* a regular file: blocks are placed by index as they complete, from every shard at once */
+            nflags = GPSBB_NODE_INDEXED | GPSBB_NODE_CONCURRENT;
+        }
+        const int bps = nblocks < 16 ? (int)nblocks : 16;
+        gpsbb_node_config_t nc = {nshards, devs, cfg.max_chan, delt, (int)nsamp, bps, 3, nflags};
+        gpsbb_node_t *node = NULL;
+        gpsbb_node_stats_t ns;
+        rc = gpsbb_node_create(&node, &nc);
+        if (rc == GPSBB_OK)
+            rc = gpsbb_node_run(node, all, nblocks, node_sink, &o, &ns);
+        if (rc != GPSBB_OK)
+            fprintf(stderr, "ERROR: node driver: %s\n", gpsbb_strerror(rc));
+        else
+            for (int g = 0; g < ns.nshards; g++)
+                fprintf(stderr, "shard %d: gpu %d (numa node %d, %d cpus), blocks %ld..%ld, seed %.3f s, busy %.3f s\n", g,
+                        ns.shard[g].device, ns.shard[g].numa_node, ns.shard[g].cpus_bound, ns.shard[g].first_block,
+                        ns.shard[g].first_block + ns.shard[g].nblocks, ns.shard[g].seed_seconds, ns.shard[g].busy_seconds);
+        gpsbb_node_destroy(node);
+        free(all);
+        if (fo != stdout)
+            fclose(fo);
+        else
+            fflush(fo);
+        gpsfe_close(fe);
+        if (rc == GPSBB_OK)
+            fprintf(stderr, "%ld blocks of %ld samples written\n", nblocks, nsamp);
+        return rc == GPSBB_OK ? 0 : 1;
     }
     gpsbb_t *bb = NULL;
     rc = gpsbb_create(&bb, gpu);

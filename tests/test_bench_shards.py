@@ -67,13 +67,36 @@ def test_two_ranks_through_the_device_path(pkg):
         assert r["config"]["carrier_chain"] == "device" and r["config"]["synthesis_kernel"] == "k_synth_ev"
         assert r["value"] > 0 and r["roofline"]["frac"] > 0 and len(r["repeats"]["seconds"]) == 2
         assert len(r["gather"]["per_rank_GBps_to_host"]) == n
-        assert r["parity"]["mismatching_blocks"] == 0 and r["parity_checked_blocks"] == 3 * n
+        assert r["parity"]["mismatching_blocks"] == 0 and r["parity_checked_blocks"] >= 3 * n
         assert r["parity"]["blocks_digested"] == 2 * 8 * 8
         assert r["shard_seed_s"] >= r["shard_seed"]["seconds_rank0"] and 0 < r["value_incl_seed"] <= r["value"]
         assert r["m1"]["gpu"]["value"] > 0 and r["cpu_baseline"]["value"] > 0 and r["m1"]["cpu"]["value"] > 0
     assert two["shard_seed"]["blocks_before_the_last_shard"] == 64
     assert one["parity"]["stream_end_state_digest"] == two["parity"]["stream_end_state_digest"]
     assert one["config"]["global_samples_per_step"] == two["config"]["global_samples_per_step"]
+
+
+@pytest.mark.gpu
+def test_one_rank_through_the_rccl_path(pkg):
+    """What a 1-GPU box can run of the path an 8-GPU node takes: bench.py under torch.distributed.run with ONE rank and the
+    nccl (= RCCL) backend, GPSBB_BENCH_FORCE_DIST making it take the N > 1 branches anyway — process group on the device,
+    all_reduce of device tensors for the max-over-ranks times, all_gather_object of the digests, barriers — so that the
+    driver's multi-GPU run is not the first execution of that code.  The line also carries the node driver's leg."""
+    env = dict(os.environ, GPSBB_BENCH_FORCE_DIST="1")
+    env.pop("GPSBB_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--repeats", "2", "--push-blocks", "8", "--nsamp", "200000", "--depth", "3", "--cpu-budget", "0.3", "--parity-blocks", "2",
+           "--parity-spots", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["dist"] == {"process_group": True, "backend": "nccl", "world": 1, "hw_queues": 12, "streams_of_the_handle": r["dist"]["streams_of_the_handle"]}
+    assert r["n_gpus"] == 1 and r["value"] > 0 and r["parity"]["mismatching_blocks"] == 0
+    assert len(r["gather"]["per_rank_GBps_to_host"]) == 1 and r["gather"]["node_GBps_to_host"] > 0
+    assert r["node_driver"]["one_shard"]["value"] > 0 and r["node_driver"]["one_shard"]["shards"] == 1
 
 
 @pytest.mark.gpu
@@ -86,4 +109,4 @@ def test_a_wrong_kernel_fails_the_bench(pkg):
     args = ["--steps", "1", "--warmup", "1", "--repeats", "1", "--push-blocks", "8", "--nsamp", "200000", "--depth", "3",
             "--cpu-budget", "0.2", "--parity-blocks", "2"]
     r = _run(1, args, {"GPSBB_PY_LIB": "broken"}, expect_rc=3)
-    assert r["parity"]["mismatching_blocks"] == 1 and r["parity_checked_blocks"] == 3
+    assert r["parity"]["mismatching_blocks"] >= 1 and r["parity_checked_blocks"] >= 3

@@ -1,0 +1,174 @@
+"""include/gpsbb_node.h: one process, N producer threads / handles / rings, ONE sink (the reference has one consumer of one
+stream, plutogpssim.c:2146-2158).  On the one GPU of the test box the N shards share device 0; what is checked is what N
+GPUs would have to get right: contiguous time shards seeded with the exact carrier phase by the device-side chain, blocks
+delivered once each and — in the default mode — strictly in stream order, the same bytes whatever N is, equal to the golden
+vectors of the reference's own code and to the CPU oracle."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+class Collect:
+    """a sink that copies every delivery into one host array and records the order of arrival"""
+
+    def __init__(self, nblocks, nsamp):
+        self.iq = np.zeros((nblocks, nsamp, 2), np.int16)
+        self.calls = []
+        self.nsamp = nsamp
+
+    def __call__(self, iq_ptr, first, nb, shard):
+        src = (C.c_int16 * (nb * self.nsamp * 2)).from_address(iq_ptr)
+        self.iq[first:first + nb] = np.frombuffer(src, np.int16).reshape(nb, self.nsamp, 2)
+        self.calls.append((first, nb, shard))
+        return 0
+
+
+def render(pkg, ch, fs, nsamp, nshards, bps, depth=2, flags=0):
+    sink = Collect(ch.shape[0], nsamp)
+    with pkg.Node(nshards, ch.shape[1], 1.0 / fs, nsamp, bps, depth=depth, flags=flags, devices=[0] * nshards) as node:
+        st = node.run(ch, sink)
+    assert st["blocks"] == ch.shape[0] and sum(c[1] for c in sink.calls) == ch.shape[0]
+    return sink, st
+
+
+def test_reference_scenario_in_1_2_and_4_shards_equals_the_golden_vectors(pkg):
+    """BASELINE configs 1/2 end to end: RINEX -> front end -> 301 blocks (30.1 s, across the 30 s nav refresh) -> node
+    driver.  The golden blocks 0, 1, 2, 149, 299, 300 of the reference's own code fall into different shards."""
+    pkg.build_frontend()
+    z = np.load(os.path.join(GOLDEN, "static_F.npz"))
+    fs, nsamp = float(z["fs"]), int(z["nsamp"])
+    blocks = [int(b) for b in z["blocks"]]
+    fe = pkg.FrontEnd(os.path.join(GOLDEN, "synth3540.14n"), llh=(30.286502, 120.032669, 100.0), max_chan=12)
+    ch = fe.generate(max(blocks) + 1)
+    fe.close()
+    first = None
+    for nshards in (1, 2, 4):
+        sink, st = render(pkg, ch, fs, nsamp, nshards, bps=8)
+        # one ordered stream: every delivery starts where the one before ended
+        pos = 0
+        for f, nb, _ in sink.calls:
+            assert f == pos
+            pos += nb
+        assert len({c[2] for c in sink.calls}) == nshards
+        for k, blk in enumerate(blocks):
+            assert sha(sink.iq[blk]) == str(z["iq_sha256"][k]), (nshards, blk)
+        if first is None:
+            first = sink.iq
+        else:
+            assert (sink.iq == first).all(), nshards
+        plan = pkg.node_plan(ch.shape[0], nshards, 8)
+        assert [s["first_block"] for s in st["shards"]] == plan[:-1]
+        assert all(s["seed_seconds"] > 0 for s in st["shards"][1:]) and st["shards"][0]["seed_seconds"] == 0
+
+
+def test_dense_25_MSps_blocks_indexed_sink_and_oracle(pkg, oracle):
+    """config 3/5 geometry (16 channels, 25 MS/s, 2.5 M-sample blocks) through the front end: golden blocks 0 and 1, then
+    every block against N = 1 and a sample of them against the oracle's sequential render; the sink takes slots in
+    completion order (GPSBB_NODE_INDEXED) from several threads at once (GPSBB_NODE_CONCURRENT)."""
+    pkg.build_frontend()
+    z = np.load(os.path.join(GOLDEN, "dense_S.npz"))
+    fs, nsamp = float(z["fs"]), int(z["nsamp"])
+    fe = pkg.FrontEnd(os.path.join(GOLDEN, "dense3540.14n"), llh=(30.286502, 120.032669, 100.0), max_chan=16)
+    ch = fe.generate(8)
+    fe.close()
+    one, _ = render(pkg, ch, fs, nsamp, 1, bps=1)
+    for k in (0, 1):
+        assert sha(one.iq[k]) == str(z["iq_sha256"][k]), k
+    four, st = render(pkg, ch, fs, nsamp, 4, bps=1, flags=pkg.NODE_INDEXED | pkg.NODE_CONCURRENT)
+    assert (four.iq == one.iq).all()
+    assert sorted(c[0] for c in four.calls) == list(range(8))
+    # the first 200 000 samples of blocks 0..6 from their exact start phases: cheap for the oracle
+    seeds = pkg.chain_carrier_host(ch, 1.0 / fs, nsamp)
+    chs = ch.copy()
+    chs["carr_phase"] = seeds
+    want, _, _ = oracle.fill_blocks(chs[:7], 1.0 / fs, 200000)
+    assert (four.iq[:7, :200000] == want).all()
+
+
+def test_shard_boundaries_prn_changes_padding_fixed_carrier_and_stop(pkg, oracle):
+    """Small streams against the oracle's sequential render: a channel that changes satellite exactly at a shard
+    boundary (it must start from its own phase, c:1956-1964), one that goes idle and comes back, a block count that is
+    not a multiple of the push size (the last slot is padded), the 32-bit accumulator; a sink that stops the run."""
+    fs, nsamp, nch, nb, bps = 4.0e6, 30000, 6, 23, 3
+    ch = pkg.synth_descriptors(nb, nch=nch, seed=99)
+    ch["f_carr"] = ch["f_carr"][0][None, :] + np.arange(nb)[:, None] * 3.0
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    plan = pkg.node_plan(nb, 3, bps)
+    assert plan == [0, 6, 15, 23]
+    ch["prn"][plan[1]:, 2] = 30          # hand-over exactly at the first boundary
+    ch["prn"][plan[2] - 2:plan[2] + 1, 4] = 0   # idle across the second one
+    want, _, _ = oracle.fill_blocks(ch, 1.0 / fs, nsamp, chain=True)
+    for nshards in (1, 3):
+        sink, _ = render(pkg, ch, fs, nsamp, nshards, bps=bps)
+        assert (sink.iq == want).all(), nshards
+    chf = ch.copy()
+    chf["carr_phase"] = np.floor(chf["carr_phase"] * 2.0 ** 32)
+    wantf, _, _ = oracle.fill_blocks(chf, 1.0 / fs, nsamp, chain=True, fixed=True)
+    sink, _ = render(pkg, chf, fs, nsamp, 3, bps=bps, flags=pkg.NODE_FIXED_CARRIER)
+    assert (sink.iq == wantf).all()
+    # the sink stops the stream after the third delivery (plutogpssim.c:2153-2157: a negative push ends the loop)
+    seen = []
+
+    def stopper(iq_ptr, first, n, shard):
+        seen.append(first)
+        return -1 if len(seen) == 3 else 0
+
+    with pkg.Node(3, nch, 1.0 / fs, nsamp, bps, depth=2, devices=[0, 0, 0]) as node:
+        st = node.run(ch, stopper, expect_stop=True)
+        assert st["rc"] == -7 and seen == [0, 3, 6] and st["blocks"] == 9
+        sink = Collect(nb, nsamp)      # ... and the node is usable again afterwards
+        node.run(ch, sink)
+        assert (sink.iq == want).all()
+
+
+def test_placement_is_reported(pkg):
+    """The producer threads bind themselves next to their GPU before they allocate (plutogpssim.c:2045-2056 pins the
+    reference's two threads): the statistics say where."""
+    node_id, cpus = pkg.device_affinity(0)
+    ch = pkg.synth_descriptors(4, nch=4, seed=5)
+    with pkg.Node(2, 4, 1 / 4e6, 20000, 2, devices=[0, 0]) as node:
+        st = node.run(ch, lambda *a: 0)
+    for s in st["shards"]:
+        assert s["device"] == 0 and s["numa_node"] == node_id
+        if cpus:
+            assert s["cpus_bound"] > 0
+    with pkg.Node(1, 4, 1 / 4e6, 20000, 2, flags=pkg.NODE_NO_AFFINITY) as node:
+        st = node.run(ch, lambda *a: 0)
+    assert st["shards"][0]["cpus_bound"] == 0
+    with pkg.Synth(0) as s:
+        s.fill_block(ch[0], 1 / 4e6, 20000)
+        assert s.info(pkg.INFO_HW_QUEUES) == int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+        assert 4 <= s.info(pkg.INFO_STREAMS) <= 12
+
+
+def test_gpsbb_sim_over_several_shards_writes_the_same_file(pkg, tmp_path):
+    """gpsbb-sim -G N: the C program renders through the node driver (pwrite sink for a file, ordered fwrite for a pipe);
+    the file equals the single-handle -F output and the golden blocks."""
+    pkg.build_frontend()
+    exe = os.path.join(os.path.dirname(pkg.LIB_PATH), "gpsbb-sim")
+    z = np.load(os.path.join(GOLDEN, "static_F.npz"))
+    nsamp = int(z["nsamp"])
+    common = [exe, "-e", os.path.join(GOLDEN, "synth3540.14n"), "-l", "30.286502,120.032669,100", "-s", "2600000", "-d", "30.1"]
+    ref = str(tmp_path / "one.bin")
+    subprocess.run(common + ["-F", "-o", ref], check=True, stderr=subprocess.DEVNULL)
+    want = np.fromfile(ref, np.int16)
+    for k, blk in enumerate(int(b) for b in z["blocks"]):
+        assert sha(want.reshape(-1, nsamp, 2)[blk]) == str(z["iq_sha256"][k]), blk
+    for n in (1, 3):
+        out = str(tmp_path / ("g%d.bin" % n))
+        subprocess.run(common + ["-G", str(n), "-g", ",".join(["0"] * n), "-o", out], check=True, stderr=subprocess.DEVNULL)
+        assert (np.fromfile(out, np.int16) == want).all(), n
+    piped = subprocess.run(common + ["-G", "2", "-g", "0,0", "-o", "-"], check=True, stderr=subprocess.DEVNULL, stdout=subprocess.PIPE).stdout
+    assert np.frombuffer(piped, np.int16).tobytes() == want.tobytes()

@@ -71,8 +71,14 @@ int gpsfe_next_block(gpsfe_t *fe, gpsbb_chan_t *ch);
  * rendered), exactly as the reference's loop updates chan[i].carr_phase in place. */
 int gpsfe_feed_back(gpsfe_t *fe, const gpsbb_chan_state_t *end_state);
 
-/* nblocks consecutive blocks, block-major into ch[nblocks*max_chan] (no feedback). */
+/* nblocks consecutive blocks, block-major into ch[nblocks*max_chan] (no feedback).  The blocks between two 30 s
+ * maintenances (c:2764-2798) are independent given the ranges at their ends, so they are spread over threads: the same
+ * descriptors, bit for bit, as nblocks calls of gpsfe_next_block. */
 int gpsfe_generate(gpsfe_t *fe, int nblocks, gpsbb_chan_t *ch);
+
+/* threads gpsfe_generate uses: 0 = the machine's cores up to 16 (default), 1 = none (the reference's one generator thread,
+ * c:2286-2289), up to 32 */
+int gpsfe_set_threads(gpsfe_t *fe, int nthreads);
 
 /* introspection for tests / logging: current receiver GPS time and the visible-satellite table */
 int gpsfe_time(const gpsfe_t *fe, int *week, double *sec);

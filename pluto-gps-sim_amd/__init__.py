@@ -54,7 +54,7 @@ ERRORS = {0: "GPSBB_OK", -1: "GPSBB_E_BADARG", -2: "GPSBB_E_BADCHAN", -3: "GPSBB
 # every symbol include/gpsbb.h declares
 API_SYMBOLS = [
     "gpsbb_create", "gpsbb_destroy", "gpsbb_strerror", "gpsbb_last_hip_error", "gpsbb_version",
-    "gpsbb_fill_block", "gpsbb_fill_block_ex", "gpsbb_fill_block_ref", "gpsbb_batch_create", "gpsbb_batch_destroy",
+    "gpsbb_fill_block", "gpsbb_fill_block_ex", "gpsbb_fill_block_ref", "gpsbb_fill_block_ref_fixed", "gpsbb_batch_create", "gpsbb_batch_destroy",
     "gpsbb_batch_iq_bytes", "gpsbb_batch_run", "gpsbb_sync", "gpsbb_batch_read", "gpsbb_batch_device_iq",
     "gpsbb_get_hazards", "gpsbb_device_read", "gpsbb_batch_last_timing", "gpsbb_batch_timing_stats", "gpsbb_fill_ceiling", "gpsbb_stream_create",
     "gpsbb_stream_destroy", "gpsbb_stream_push", "gpsbb_stream_pop", "gpsbb_stream_pending", "gpsbb_stream_timing_stats",
@@ -102,6 +102,7 @@ def lib():
         L.gpsbb_fill_block.argtypes = [vp, vp, i, d, i, vp, vp]
         L.gpsbb_fill_block_ex.argtypes = [vp, vp, i, d, i, u, vp, vp]
         L.gpsbb_fill_block_ref.argtypes = [vp, vp, vp, i, vp, d, i, vp]
+        L.gpsbb_fill_block_ref_fixed.argtypes = [vp, vp, vp, C.c_size_t, i, vp, d, i, vp]
         L.gpsbb_batch_create.argtypes = [vp, vp, i, i, d, i, u, C.POINTER(vp)]
         L.gpsbb_batch_destroy.argtypes = [vp]
         L.gpsbb_batch_destroy.restype = None
@@ -674,6 +675,7 @@ def fe_lib():
         L.gpsfe_next_block.argtypes = [C.c_void_p, C.c_void_p]
         L.gpsfe_feed_back.argtypes = [C.c_void_p, C.c_void_p]
         L.gpsfe_generate.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.gpsfe_set_threads.argtypes = [C.c_void_p, C.c_int]
         L.gpsfe_time.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.gpsfe_channel_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)] + [C.POINTER(C.c_double)] * 4
         _fe_lib = L
@@ -718,6 +720,12 @@ class FrontEnd:
             self.close()
         except Exception:
             pass
+
+    def set_threads(self, n):
+        """gpsfe_set_threads: 0 = default (cores up to 16), 1 = the sequential loop"""
+        rc = fe_lib().gpsfe_set_threads(self._fe, n)
+        if rc != 0:
+            raise RuntimeError("gpsfe_set_threads: %d" % rc)
 
     def generate(self, nblocks):
         ch = np.zeros((nblocks, self.max_chan), CHAN_DTYPE)

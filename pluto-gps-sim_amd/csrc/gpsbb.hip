@@ -2079,8 +2079,10 @@ extern "C" int gpsbb_fill_block_ex(gpsbb_t *h, const gpsbb_chan_t *ch, int nch, 
     return gpsbb_sync(h);
 }
 
-extern "C" int gpsbb_fill_block_ref(gpsbb_t *h, void *chan, const gpsbb_refchan_layout_t *L, int max_chan,
-                                    const double *gain, double delt, int nsamp, int16_t *iq_buff)
+/* the reference's own channel_t[] / gain[] in, rendered, updated in place as its loop leaves them; fixed: the build without
+ * FLOAT_CARR_PHASE (h:160-161: a 32-bit accumulator and its step instead of the double) */
+static int fill_block_ref(gpsbb_t *h, void *chan, const gpsbb_refchan_layout_t *L, bool fixed, size_t off_step, int max_chan,
+                          const double *gain, double delt, int nsamp, int16_t *iq_buff)
 {
     if (!h || !chan || !L || !gain || !iq_buff || max_chan < 1 || max_chan > GPSBB_MAX_CHAN ||
         (L->sizeof_dwrd_elem != 4 && L->sizeof_dwrd_elem != 8))
@@ -2089,6 +2091,7 @@ extern "C" int gpsbb_fill_block_ref(gpsbb_t *h, void *chan, const gpsbb_refchan_
     gpsbb_chan_state_t st[GPSBB_MAX_CHAN];
     char *base = static_cast<char *>(chan);
     auto ld_i = [](const char *p) { int v; memcpy(&v, p, sizeof v); return v; };
+    auto ld_u = [](const char *p) { unsigned v; memcpy(&v, p, sizeof v); return v; };
     auto ld_d = [](const char *p) { double v; memcpy(&v, p, sizeof v); return v; };
     for (int i = 0; i < max_chan; i++) {
         const char *c = base + (size_t)i * L->stride;
@@ -2100,7 +2103,7 @@ extern "C" int gpsbb_fill_block_ref(gpsbb_t *h, void *chan, const gpsbb_refchan_
         }
         d[i].f_carr = ld_d(c + L->off_f_carr);
         d[i].f_code = ld_d(c + L->off_f_code);
-        d[i].carr_phase = ld_d(c + L->off_carr_phase);
+        d[i].carr_phase = fixed ? (double)ld_u(c + L->off_carr_phase) : ld_d(c + L->off_carr_phase);
         d[i].code_phase = ld_d(c + L->off_code_phase);
         d[i].iword = ld_i(c + L->off_iword);
         d[i].ibit = ld_i(c + L->off_ibit);
@@ -2111,15 +2114,27 @@ extern "C" int gpsbb_fill_block_ref(gpsbb_t *h, void *chan, const gpsbb_refchan_
             memcpy(&w, c + L->off_dwrd + (size_t)k * L->sizeof_dwrd_elem, L->sizeof_dwrd_elem);
             d[i].dwrd[k] = (uint32_t)w;
         }
+        if (fixed && off_step != (size_t)-1 && std::isfinite(d[i].f_carr) && std::fabs(d[i].f_carr * delt) <= 0.125) {
+            /* the step the host computed (c:2675) must be the one the accumulator is advanced by here (c:2748): a host that
+             * put anything else into carr_phasestep would get different samples from its own loop */
+            const volatile double scaled = 512.0 * 65536.0 * d[i].f_carr * delt;
+            if (ld_i(c + off_step) != (int)std::round(scaled))
+                return GPSBB_E_BADCHAN;
+        }
     }
-    int rc = gpsbb_fill_block(h, d, max_chan, delt, nsamp, iq_buff, st);
+    int rc = gpsbb_fill_block_ex(h, d, max_chan, delt, nsamp, fixed ? GPSBB_FIXED_CARRIER : 0u, iq_buff, st);
     if (rc != GPSBB_OK)
         return rc;
     for (int i = 0; i < max_chan; i++) {
         if (d[i].prn <= 0)
             continue;
         char *c = base + (size_t)i * L->stride;
-        memcpy(c + L->off_carr_phase, &st[i].carr_phase, 8);
+        if (fixed) {
+            const unsigned ph = (unsigned)st[i].carr_phase; /* the accumulator's value, an integer below 2^32 */
+            memcpy(c + L->off_carr_phase, &ph, 4);
+        } else {
+            memcpy(c + L->off_carr_phase, &st[i].carr_phase, 8);
+        }
         memcpy(c + L->off_code_phase, &st[i].code_phase, 8);
         memcpy(c + L->off_iword, &st[i].iword, 4);
         memcpy(c + L->off_ibit, &st[i].ibit, 4);
@@ -2128,6 +2143,18 @@ extern "C" int gpsbb_fill_block_ref(gpsbb_t *h, void *chan, const gpsbb_refchan_
         memcpy(c + L->off_codeCA, &st[i].codeCA, 4);
     }
     return GPSBB_OK;
+}
+
+extern "C" int gpsbb_fill_block_ref(gpsbb_t *h, void *chan, const gpsbb_refchan_layout_t *L, int max_chan,
+                                    const double *gain, double delt, int nsamp, int16_t *iq_buff)
+{
+    return fill_block_ref(h, chan, L, false, (size_t)-1, max_chan, gain, delt, nsamp, iq_buff);
+}
+
+extern "C" int gpsbb_fill_block_ref_fixed(gpsbb_t *h, void *chan, const gpsbb_refchan_layout_t *L, size_t off_carr_phasestep,
+                                          int max_chan, const double *gain, double delt, int nsamp, int16_t *iq_buff)
+{
+    return fill_block_ref(h, chan, L, true, off_carr_phasestep, max_chan, gain, delt, nsamp, iq_buff);
 }
 
 /* ================================================================================================== */

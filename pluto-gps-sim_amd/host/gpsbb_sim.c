@@ -17,10 +17,17 @@
  * ring per shard on the GPUs "-g a,b,c" names (default 0 .. N-1; an ordinal may repeat), each shard seeded with the exact
  * carrier phase by the device-side chain, ONE output: a regular file is written with pwrite() as slots complete
  * (GPSBB_NODE_INDEXED), a pipe in stream order.
+ * -P usec paces the consumer like the radio does: the TX surface's sink takes one block every `usec` microseconds (the
+ * reference's iio_buffer_push blocks until the hardware has room, c:2152; 100000 = real time, less = compressed time), counts
+ * the blocks that were not there when their turn came (under-runs) and, with -S file, writes the latency distribution of
+ * the drop-in call gpsbb_fill_block (p50 / p99 / max over all blocks) as JSON.  -Q n: blocks the device queues (libiio's
+ * kernel buffers: 4 by default; a push only blocks when all are taken).  -k a,b,c keeps only those blocks in the
+ * output file (a soak of hours of signal need not write them all).
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "gpsbb.h"
@@ -57,10 +64,72 @@ static int node_sink(void *user, const int16_t *iq, long first_block, int nblock
     return fwrite(iq, 1, bytes, o->f) == bytes ? 0 : -1;
 }
 
+/* the paced consumer of the soak: what sits behind the TX surface instead of the Pluto */
+struct paced_sink {
+    FILE *f;
+    long period_ns;         /* 0: not paced */
+    int queue;              /* blocks the device holds: libiio hands a pushed buffer to the kernel and blocks only when all
+                               of its kernel buffers (4 by default) are queued, so the generator may run that far ahead */
+    long keep[64];
+    int nkeep;              /* 0: keep everything */
+    long seen;              /* blocks taken so far */
+    long underruns;         /* blocks that arrived after their slot had begun */
+    double worst_late_ms;
+    struct timespec t0;     /* the first block's arrival: slot k begins at t0 + k * period */
+};
+
+static double ts_ms(const struct timespec *a, const struct timespec *b)
+{
+    return (double)(a->tv_sec - b->tv_sec) * 1e3 + (double)(a->tv_nsec - b->tv_nsec) * 1e-6;
+}
+
+static int paced_push(void *user, const int16_t *iq, size_t nsamp)
+{
+    struct paced_sink *p = user;
+    const long k = p->seen++;
+    if (p->period_ns > 0) {
+        struct timespec now;
+        clock_gettime(CLOCK_MONOTONIC, &now);
+        if (k == 0)
+            p->t0 = now;
+        /* block k goes on the air at t0 + k * period; the push returns when the device has room again, i.e. when block
+         * k - (queue - 1) has started playing */
+        struct timespec due = p->t0, room = p->t0;
+        const long long ns = (long long)p->t0.tv_nsec + (long long)k * p->period_ns;
+        due.tv_sec += (time_t)(ns / 1000000000LL);
+        due.tv_nsec = (long)(ns % 1000000000LL);
+        const long long kr = k - (p->queue - 1) > 0 ? k - (p->queue - 1) : 0;
+        const long long nr = (long long)p->t0.tv_nsec + kr * p->period_ns;
+        room.tv_sec += (time_t)(nr / 1000000000LL);
+        room.tv_nsec = (long)(nr % 1000000000LL);
+        const double late = ts_ms(&now, &due);
+        if (late > 0.0) { /* the radio had nothing to send when this block's slot began */
+            p->underruns++;
+            if (late > p->worst_late_ms)
+                p->worst_late_ms = late;
+        }
+        if (ts_ms(&now, &room) < 0.0)
+            clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &room, NULL); /* iio_buffer_push blocks until there is room (c:2152) */
+    }
+    int want = p->nkeep == 0;
+    for (int i = 0; i < p->nkeep; i++)
+        want = want || p->keep[i] == k;
+    if (want && fwrite(iq, 4, nsamp, p->f) != nsamp)
+        return -1;
+    return 0;
+}
+
+static int cmp_double(const void *a, const void *b)
+{
+    const double x = *(const double *)a, y = *(const double *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
 static void usage(void)
 {
     fprintf(stderr, "usage: gpsbb-sim -e nav [-l lat,lon,h|-c x,y,z|-u motion.csv] [-t Y/M/D,h:m:s] [-T] [-i] [-3]\n"
-                    "                 [-s fs_hz] [-d seconds] [-n samples_per_block] [-N channels] [-g gpu[,gpu...]] [-F] [-G shards] -o out.bin\n");
+                    "                 [-s fs_hz] [-d seconds] [-n samples_per_block] [-N channels] [-g gpu[,gpu...]] [-F] [-G shards]\n"
+                    "                 [-P usec_per_block] [-Q device_queue_blocks] [-S stats.json] [-k keep,blocks] -o out.bin\n");
 }
 
 int main(int argc, char **argv)
@@ -79,9 +148,13 @@ int main(int argc, char **argv)
     double duration = 1.0;
     int gpu = 0, opt, fast = 0, nshards = 0, ndev = 0;
     int devs[GPSBB_NODE_MAX_SHARDS];
+    struct paced_sink paced;
+    memset(&paced, 0, sizeof paced);
+    paced.queue = 4; /* libiio's default number of kernel buffers */
+    const char *stats_path = NULL;
     const char *out_path = NULL;
 
-    while ((opt = getopt(argc, argv, "e:u:c:l:s:Tt:in:N:d:o:g:3FG:")) != -1) {
+    while ((opt = getopt(argc, argv, "e:u:c:l:s:Tt:in:N:d:o:g:3FG:P:S:k:Q:")) != -1) {
         switch (opt) {
         case 'e': cfg.navfile = optarg; break;
         case 'u': cfg.motion_file = optarg; break;
@@ -121,6 +194,13 @@ int main(int argc, char **argv)
             gpu = ndev ? devs[0] : 0;
             break;
         case 'G': nshards = atoi(optarg); break;
+        case 'P': paced.period_ns = atol(optarg) * 1000L; break;
+        case 'S': stats_path = optarg; break;
+        case 'Q': paced.queue = atoi(optarg) > 0 ? atoi(optarg) : 1; break;
+        case 'k':
+            for (char *t = strtok(optarg, ","); t && paced.nkeep < 64; t = strtok(NULL, ","))
+                paced.keep[paced.nkeep++] = atol(t);
+            break;
         case 'F': fast = 1; break;
         default: usage(); return 1;
         }
@@ -236,7 +316,9 @@ int main(int argc, char **argv)
     }
 
     gpsbb_tx_t *tx = NULL;
-    if (gpsbb_tx_create(&tx, (size_t)nsamp, gpsbb_tx_push_to_file, fout) != 0) {
+    paced.f = fout;
+    double *lat_ms = calloc((size_t)(nblocks > 0 ? nblocks : 1), sizeof *lat_ms);
+    if (gpsbb_tx_create(&tx, (size_t)nsamp, paced_push, &paced) != 0 || !lat_ms) {
         fprintf(stderr, "ERROR: cannot start the TX surface\n");
         return 1;
     }
@@ -255,8 +337,21 @@ int main(int argc, char **argv)
     long blk;
     for (blk = 0; blk < nblocks; blk++) { /* while (!plutotx.exit), c:2655 */
         gpsfe_next_block(fe, ch);                                   /* c:2656-2687 (+ c:2764-2805) */
+        if (blk == 0) {
+            /* The first two calls on a handle pay for what every later one finds in place (code objects loaded, scratch
+             * and both table sets allocated: 18 and 10 ms against 0.3): render the first block twice into a scratch buffer
+             * before the consumer's clock starts.  A fill has no side effects besides its outputs. */
+            int16_t *scratch = malloc((size_t)nsamp * 4);
+            for (int w = 0; scratch && w < 2; w++)
+                (void)gpsbb_fill_block(bb, ch, cfg.max_chan, delt, (int)nsamp, scratch, NULL);
+            free(scratch);
+        }
         int16_t *iq = gpsbb_tx_begin(tx);                           /* c:2689 */
+        struct timespec ta, tb;
+        clock_gettime(CLOCK_MONOTONIC, &ta);
         rc = gpsbb_fill_block(bb, ch, cfg.max_chan, delt, (int)nsamp, iq, st); /* replaces c:2690-2756 */
+        clock_gettime(CLOCK_MONOTONIC, &tb);
+        lat_ms[blk] = ts_ms(&tb, &ta);
         if (rc != GPSBB_OK) { /* the buffer holds no valid block: it must not reach the sink */
             gpsbb_tx_cancel(tx);
             fprintf(stderr, "ERROR: gpsbb_fill_block: %s\n", gpsbb_strerror(rc));
@@ -270,6 +365,35 @@ int main(int argc, char **argv)
     gpsbb_tx_destroy(tx);
     if (fout != stdout)
         fclose(fout);
+    if (stats_path && blk > 0) {
+        /* the drop-in call's latency over the whole run, and what the paced consumer saw */
+        /* which blocks were slow (before the sort loses the order): the first 32 above 2 ms */
+        char slow[2048];
+        size_t so = 0;
+        int nslow = 0;
+        slow[0] = 0;
+        for (long i = 0; i < blk; i++)
+            if (lat_ms[i] > 2.0) {
+                if (nslow < 32 && so + 40 < sizeof slow)
+                    so += (size_t)snprintf(slow + so, sizeof slow - so, "%s[%ld, %.2f]", nslow ? ", " : "", i, lat_ms[i]);
+                nslow++;
+            }
+        qsort(lat_ms, (size_t)blk, sizeof *lat_ms, cmp_double);
+        double sum = 0.0;
+        for (long i = 0; i < blk; i++)
+            sum += lat_ms[i];
+        FILE *sf = fopen(stats_path, "w");
+        if (sf) {
+            fprintf(sf, "{\"blocks\": %ld, \"nsamp\": %ld, \"channels\": %d, \"fs_hz\": %ld, \"period_us\": %.1f, \"device_queue_blocks\": %d, "
+                        "\"fill_block_ms\": {\"mean\": %.4f, \"p50\": %.4f, \"p90\": %.4f, \"p99\": %.4f, \"p999\": %.4f, \"max\": %.4f}, "
+                        "\"underruns\": %ld, \"worst_late_ms\": %.4f, \"delivered\": %ld, \"blocks_over_2ms\": %d, \"first_slow_blocks\": [%s]}\n",
+                    blk, nsamp, cfg.max_chan, fs_hz, (double)paced.period_ns / 1e3, paced.queue, sum / (double)blk, lat_ms[blk / 2],
+                    lat_ms[(long)((double)blk * 0.9)], lat_ms[(long)((double)blk * 0.99)], lat_ms[(long)((double)blk * 0.999)],
+                    lat_ms[blk - 1], paced.underruns, paced.worst_late_ms, paced.seen, nslow, slow);
+            fclose(sf);
+        }
+    }
+    free(lat_ms);
     gpsbb_hazards_t hz;
     if (gpsbb_get_hazards(bb, &hz, 0) == GPSBB_OK && (hz.itable_512 || hz.dwrd_oob))
         fprintf(stderr, "note: latent out-of-bounds cases of the reference hit: table %llu, nav words %llu\n",

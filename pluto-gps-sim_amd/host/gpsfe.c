@@ -13,9 +13,11 @@
 #include "gpsfe.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <zlib.h>
 
 /* ---- constants (h:40-76) --------------------------------------------------------------------------- */
@@ -97,6 +99,8 @@ struct gpsfe {
     chan_t chan[GPSBB_MAX_CHAN];
     int sat_chan[N_SAT]; /* allocatedSat c:171 */
     double ant_pat[37];
+    int nthreads;          /* gpsfe_generate: threads the blocks of a span are spread over (gpsfe_set_threads) */
+    struct fe_pool *pool;  /* ... started on first use */
 };
 
 /* receiver antenna attenuation in dB for boresight angle 0:5:180 deg (c:164-169) */
@@ -380,121 +384,184 @@ static uint32_t popcnt32(uint32_t v) /* countBits c:729-744 (32-bit masks there 
     return v;
 }
 
-/* GPS (32,26) Hamming parity; nib = word carries the two non-information-bearing bits (words 2 and 10)
- * that are solved so that D29 = D30 = 0 (computeChecksum c:751-814) */
-static uint32_t nav_parity(uint32_t source, int nib)
+/*
+ * The (32,26) Hamming code of the navigation message (IS-GPS-200 20.3.5.2; computeChecksum c:751-814).  Word layout here
+ * as in the reference: bits 31..30 = D29*, D30* of the previous word, 29..6 = d1..d24, 5..0 = D25..D30.  Parity bit
+ * D(25+k) = (D29* or D30*) xor the parity of the data bits selected by row k of the generator below; the data bits go
+ * out inverted when D30* is set.  nib: words 2 and 10 carry two non-information-bearing bits (d23, d24) that are
+ * solved for so that the word's own D29 and D30 come out zero.
+ */
+static const struct {
+    uint32_t taps; /* d1..d24 entering this parity bit, in word position */
+    int prev;      /* which bit of the previous word enters: 31 = D29*, 30 = D30* */
+} k_parity_row[6] = {
+    {0x3B1F3480u, 31}, {0x1D8F9A40u, 30}, {0x2EC7CD00u, 31}, {0x1763E680u, 30}, {0x2BB1F340u, 30}, {0x0B7A89C0u, 31}};
+
+static uint32_t parity_bit(uint32_t source, uint32_t d, int k)
 {
-    static const uint32_t mask[6] = {0x3B1F3480u, 0x1D8F9A40u, 0x2EC7CD00u, 0x1763E680u, 0x2BB1F340u, 0x0B7A89C0u};
-    uint32_t d = source & 0x3FFFFFC0u;
-    const uint32_t D29 = (source >> 31) & 1u, D30 = (source >> 30) & 1u;
-    if (nib) {
-        if ((D30 + popcnt32(mask[4] & d)) % 2)
-            d ^= (1u << 6);
-        if ((D29 + popcnt32(mask[5] & d)) % 2)
-            d ^= (1u << 7);
-    }
-    uint32_t D = d;
-    if (D30)
-        D ^= 0x3FFFFFC0u;
-    D |= ((D29 + popcnt32(mask[0] & d)) % 2) << 5;
-    D |= ((D30 + popcnt32(mask[1] & d)) % 2) << 4;
-    D |= ((D29 + popcnt32(mask[2] & d)) % 2) << 3;
-    D |= ((D30 + popcnt32(mask[3] & d)) % 2) << 2;
-    D |= ((D30 + popcnt32(mask[4] & d)) % 2) << 1;
-    D |= ((D29 + popcnt32(mask[5] & d)) % 2);
-    return D & 0x3FFFFFFFu;
+    return ((source >> k_parity_row[k].prev) ^ popcnt32(k_parity_row[k].taps & d)) & 1u;
 }
 
-/* ephemeris + iono/UTC -> the 24 data bits of each of 5 x 10 words, left-justified in 30 (eph2sbf c:552-723).
- * The scaled integers are truncated toward zero (casts to long), only the iono/UTC ones are rounded. */
+static uint32_t nav_parity(uint32_t source, int nib)
+{
+    uint32_t d = source & 0x3FFFFFC0u;
+    if (nib) {
+        /* d24 (bit 6) so that D29 = 0, then d23 (bit 7) so that D30 = 0 — in that order: row 5 taps d24 */
+        d ^= parity_bit(source, d, 4) << 6;
+        d ^= parity_bit(source, d, 5) << 7;
+    }
+    uint32_t word = (source >> 30) & 1u ? d ^ 0x3FFFFFC0u : d;
+    for (int k = 0; k < 6; k++)
+        word |= parity_bit(source, d, k) << (5 - k);
+    return word & 0x3FFFFFFFu;
+}
+
+/*
+ * Ephemeris + iono/UTC -> the 24 data bits of each of 5 x 10 words, left-justified in 30 (eph2sbf c:552-723).
+ *
+ * Two steps.  (1) The broadcast quantities as scaled integers — FLOATING POINT, so the statements keep the reference's
+ * operation order (x / 2^-n / pi, truncation toward zero by the cast; only the iono/UTC terms are rounded): a different
+ * order can change the last bit of a navigation word.  (2) Where each integer goes in the frame — pure bit layout, taken
+ * from IS-GPS-200 figures 20-1 (subframes 1-3) and 40-1 (pages 18 and 25) as a table: {subframe, word, position of the
+ * field's lowest bit in the 30-bit word, width, which quantity, how many of its low bits were sent elsewhere}.
+ */
+enum nav_quantity {
+    Q_PREAMBLE, Q_SF_ID_1, Q_SF_ID_2, Q_SF_ID_3, Q_SF_ID_4, Q_SF_ID_5,
+    Q_WN, Q_CODE_L2, Q_URA, Q_SV_HEALTH, Q_IODC, Q_TGD, Q_TOC, Q_AF2, Q_AF1, Q_AF0,
+    Q_IODE, Q_CRS, Q_DELTA_N, Q_M0, Q_CUC, Q_ECC, Q_CUS, Q_SQRT_A, Q_TOE,
+    Q_CIC, Q_OMEGA0, Q_CIS, Q_I0, Q_CRC, Q_OMEGA, Q_OMEGA_DOT, Q_IDOT,
+    Q_DATA_ID, Q_PAGE_18, Q_PAGE_25_SF4, Q_PAGE_25_SF5,
+    Q_ALPHA0, Q_ALPHA1, Q_ALPHA2, Q_ALPHA3, Q_BETA0, Q_BETA1, Q_BETA2, Q_BETA3,
+    Q_A1, Q_A0, Q_TOT, Q_WNT, Q_DT_LS, Q_WN_LSF, Q_DN, Q_DT_LSF, Q_TOA, Q_WNA,
+    Q_COUNT
+};
+
+typedef struct {
+    uint8_t sf, word, lsb, width, what, sent_below;
+} nav_field_t;
+
+#define EVERY_SUBFRAME(sf, id) {sf, 0, 22, 8, Q_PREAMBLE, 0}, {sf, 1, 8, 3, id, 0}
+
+static const nav_field_t k_frame_layout[] = {
+    /* subframe 1: clock */
+    EVERY_SUBFRAME(0, Q_SF_ID_1),
+    {0, 2, 20, 10, Q_WN, 0}, {0, 2, 18, 2, Q_CODE_L2, 0}, {0, 2, 14, 4, Q_URA, 0}, {0, 2, 8, 6, Q_SV_HEALTH, 0}, {0, 2, 6, 2, Q_IODC, 8},
+    {0, 6, 6, 8, Q_TGD, 0},
+    {0, 7, 22, 8, Q_IODC, 0}, {0, 7, 6, 16, Q_TOC, 0},
+    {0, 8, 22, 8, Q_AF2, 0}, {0, 8, 6, 16, Q_AF1, 0},
+    {0, 9, 8, 22, Q_AF0, 0},
+    /* subframe 2: orbit, first half */
+    EVERY_SUBFRAME(1, Q_SF_ID_2),
+    {1, 2, 22, 8, Q_IODE, 0}, {1, 2, 6, 16, Q_CRS, 0},
+    {1, 3, 14, 16, Q_DELTA_N, 0}, {1, 3, 6, 8, Q_M0, 24},
+    {1, 4, 6, 24, Q_M0, 0},
+    {1, 5, 14, 16, Q_CUC, 0}, {1, 5, 6, 8, Q_ECC, 24},
+    {1, 6, 6, 24, Q_ECC, 0},
+    {1, 7, 14, 16, Q_CUS, 0}, {1, 7, 6, 8, Q_SQRT_A, 24},
+    {1, 8, 6, 24, Q_SQRT_A, 0},
+    {1, 9, 14, 16, Q_TOE, 0},
+    /* subframe 3: orbit, second half */
+    EVERY_SUBFRAME(2, Q_SF_ID_3),
+    {2, 2, 14, 16, Q_CIC, 0}, {2, 2, 6, 8, Q_OMEGA0, 24},
+    {2, 3, 6, 24, Q_OMEGA0, 0},
+    {2, 4, 14, 16, Q_CIS, 0}, {2, 4, 6, 8, Q_I0, 24},
+    {2, 5, 6, 24, Q_I0, 0},
+    {2, 6, 14, 16, Q_CRC, 0}, {2, 6, 6, 8, Q_OMEGA, 24},
+    {2, 7, 6, 24, Q_OMEGA, 0},
+    {2, 8, 6, 24, Q_OMEGA_DOT, 0},
+    {2, 9, 22, 8, Q_IODE, 0}, {2, 9, 8, 14, Q_IDOT, 0},
+    /* subframe 5, page 25: almanac reference time and week */
+    EVERY_SUBFRAME(4, Q_SF_ID_5),
+    {4, 2, 28, 2, Q_DATA_ID, 0}, {4, 2, 22, 6, Q_PAGE_25_SF5, 0}, {4, 2, 14, 8, Q_TOA, 0}, {4, 2, 6, 8, Q_WNA, 0},
+    /* subframe 4 */
+    EVERY_SUBFRAME(3, Q_SF_ID_4),
+    {3, 2, 28, 2, Q_DATA_ID, 0},
+};
+/* ... page 18 (ionosphere, UTC) when the file's header had both, */
+static const nav_field_t k_page_18[] = {
+    {3, 2, 22, 6, Q_PAGE_18, 0}, {3, 2, 14, 8, Q_ALPHA0, 0}, {3, 2, 6, 8, Q_ALPHA1, 0},
+    {3, 3, 22, 8, Q_ALPHA2, 0}, {3, 3, 14, 8, Q_ALPHA3, 0}, {3, 3, 6, 8, Q_BETA0, 0},
+    {3, 4, 22, 8, Q_BETA1, 0}, {3, 4, 14, 8, Q_BETA2, 0}, {3, 4, 6, 8, Q_BETA3, 0},
+    {3, 5, 6, 24, Q_A1, 0},
+    {3, 6, 6, 24, Q_A0, 8},
+    {3, 7, 22, 8, Q_A0, 0}, {3, 7, 14, 8, Q_TOT, 0}, {3, 7, 6, 8, Q_WNT, 0},
+    {3, 8, 22, 8, Q_DT_LS, 0}, {3, 8, 14, 8, Q_WN_LSF, 0}, {3, 8, 6, 8, Q_DN, 0},
+    {3, 9, 22, 8, Q_DT_LSF, 0},
+};
+/* ... else the empty page 25 */
+static const nav_field_t k_page_25_sf4[] = {{3, 2, 22, 6, Q_PAGE_25_SF4, 0}};
+#undef EVERY_SUBFRAME
+
+static void place_fields(uint32_t sbf[5][10], const nav_field_t *f, size_t n, const int64_t *q)
+{
+    for (size_t k = 0; k < n; k++) {
+        /* two's complement, low `width` bits of what is left after the bits sent in another word (>> of a negative
+         * int64_t is arithmetic with gcc, as the reference's casts assume) */
+        const uint64_t bits = (uint64_t)(q[f[k].what] >> f[k].sent_below) & ((1ull << f[k].width) - 1ull);
+        sbf[f[k].sf][f[k].word] |= (uint32_t)(bits << f[k].lsb);
+    }
+}
+
 static void build_subframes(const eph_t *e, const iono_t *io, uint32_t sbf[5][10])
 {
-    const uint64_t wn = 0; /* transmission week is inserted per frame (c:1877-1878) */
-    const uint64_t toe = (uint64_t)(e->toe.sec / 16.0), toc = (uint64_t)(e->toc.sec / 16.0);
-    const uint64_t iode = (uint64_t)(e->iode), iodc = (uint64_t)(e->iodc);
-    const int64_t deltan = (int64_t)(e->deltan / P2_43 / K_PI);
-    const int64_t cuc = (int64_t)(e->cuc / P2_29), cus = (int64_t)(e->cus / P2_29);
-    const int64_t cic = (int64_t)(e->cic / P2_29), cis = (int64_t)(e->cis / P2_29);
-    const int64_t crc = (int64_t)(e->crc / P2_5), crs = (int64_t)(e->crs / P2_5);
-    const uint64_t ecc = (uint64_t)(e->ecc / P2_33), sqrta = (uint64_t)(e->sqrta / P2_19);
-    const int64_t m0 = (int64_t)(e->m0 / P2_31 / K_PI), omg0 = (int64_t)(e->omg0 / P2_31 / K_PI);
-    const int64_t inc0 = (int64_t)(e->inc0 / P2_31 / K_PI), aop = (int64_t)(e->aop / P2_31 / K_PI);
-    const int64_t omgdot = (int64_t)(e->omgdot / P2_43 / K_PI), idot = (int64_t)(e->idot / P2_43 / K_PI);
-    const int64_t af0 = (int64_t)(e->af0 / P2_31), af1 = (int64_t)(e->af1 / P2_43), af2 = (int64_t)(e->af2 / P2_55);
-    const int64_t tgd = (int64_t)(e->tgd / P2_31);
-    const int svhlth = (int)(uint64_t)(e->svhlth), codeL2 = (int)(uint64_t)(e->codeL2);
-    const uint64_t wna = (uint64_t)(e->toe.week % 256), toa = (uint64_t)(e->toe.sec / 4096.0);
-    const uint64_t ura = 0, data_id = 1, sv_p25_sf4 = 63, sv_p25_sf5 = 51, sv_p18 = 56;
-
-    const int64_t alpha0 = (int64_t)round(io->alpha[0] / P2_30), alpha1 = (int64_t)round(io->alpha[1] / P2_27);
-    const int64_t alpha2 = (int64_t)round(io->alpha[2] / P2_24), alpha3 = (int64_t)round(io->alpha[3] / P2_24);
-    const int64_t beta0 = (int64_t)round(io->beta[0] / 2048.0), beta1 = (int64_t)round(io->beta[1] / 16384.0);
-    const int64_t beta2 = (int64_t)round(io->beta[2] / 65536.0), beta3 = (int64_t)round(io->beta[3] / 65536.0);
-    const int64_t A0 = (int64_t)round(io->A0 / P2_30), A1 = (int64_t)round(io->A1 / P2_50);
-    const int64_t dtls = (int64_t)(io->dtls), dtlsf = 18; /* fixed leap-second schedule c:643-645 */
-    const uint64_t tot = (uint64_t)(io->tot / 4096), wnt = (uint64_t)(io->wnt % 256);
-    const uint64_t wnlsf = 1929 % 256, dn = 7;
-
-    const uint64_t preamble = 0x8B0000ull << 6;
-#define W(s, k, v) sbf[s][k] = (uint32_t)(v)
-    /* subframe 1 */
-    W(0, 0, preamble);
-    W(0, 1, 0x1ull << 8);
-    W(0, 2, ((wn & 0x3FFull) << 20) | (((uint64_t)codeL2 & 0x3ull) << 18) | ((ura & 0xFull) << 14) |
-                (((uint64_t)svhlth & 0x3Full) << 8) | (((iodc >> 8) & 0x3ull) << 6));
-    W(0, 3, 0);
-    W(0, 4, 0);
-    W(0, 5, 0);
-    W(0, 6, ((uint64_t)tgd & 0xFFull) << 6);
-    W(0, 7, ((iodc & 0xFFull) << 22) | ((toc & 0xFFFFull) << 6));
-    W(0, 8, (((uint64_t)af2 & 0xFFull) << 22) | (((uint64_t)af1 & 0xFFFFull) << 6));
-    W(0, 9, ((uint64_t)af0 & 0x3FFFFFull) << 8);
-    /* subframe 2 */
-    W(1, 0, preamble);
-    W(1, 1, 0x2ull << 8);
-    W(1, 2, ((iode & 0xFFull) << 22) | (((uint64_t)crs & 0xFFFFull) << 6));
-    W(1, 3, (((uint64_t)deltan & 0xFFFFull) << 14) | ((((uint64_t)(m0 >> 24)) & 0xFFull) << 6));
-    W(1, 4, ((uint64_t)m0 & 0xFFFFFFull) << 6);
-    W(1, 5, (((uint64_t)cuc & 0xFFFFull) << 14) | (((ecc >> 24) & 0xFFull) << 6));
-    W(1, 6, (ecc & 0xFFFFFFull) << 6);
-    W(1, 7, (((uint64_t)cus & 0xFFFFull) << 14) | (((sqrta >> 24) & 0xFFull) << 6));
-    W(1, 8, (sqrta & 0xFFFFFFull) << 6);
-    W(1, 9, (toe & 0xFFFFull) << 14);
-    /* subframe 3 */
-    W(2, 0, preamble);
-    W(2, 1, 0x3ull << 8);
-    W(2, 2, (((uint64_t)cic & 0xFFFFull) << 14) | ((((uint64_t)(omg0 >> 24)) & 0xFFull) << 6));
-    W(2, 3, ((uint64_t)omg0 & 0xFFFFFFull) << 6);
-    W(2, 4, (((uint64_t)cis & 0xFFFFull) << 14) | ((((uint64_t)(inc0 >> 24)) & 0xFFull) << 6));
-    W(2, 5, ((uint64_t)inc0 & 0xFFFFFFull) << 6);
-    W(2, 6, (((uint64_t)crc & 0xFFFFull) << 14) | ((((uint64_t)(aop >> 24)) & 0xFFull) << 6));
-    W(2, 7, ((uint64_t)aop & 0xFFFFFFull) << 6);
-    W(2, 8, ((uint64_t)omgdot & 0xFFFFFFull) << 6);
-    W(2, 9, ((iode & 0xFFull) << 22) | (((uint64_t)idot & 0x3FFFull) << 8));
-    /* subframe 4: page 18 (iono/UTC) when the header had them, else page 25 */
-    W(3, 0, preamble);
-    W(3, 1, 0x4ull << 8);
-    if (io->valid) {
-        W(3, 2, (data_id << 28) | (sv_p18 << 22) | (((uint64_t)alpha0 & 0xFFull) << 14) | (((uint64_t)alpha1 & 0xFFull) << 6));
-        W(3, 3, (((uint64_t)alpha2 & 0xFFull) << 22) | (((uint64_t)alpha3 & 0xFFull) << 14) | (((uint64_t)beta0 & 0xFFull) << 6));
-        W(3, 4, (((uint64_t)beta1 & 0xFFull) << 22) | (((uint64_t)beta2 & 0xFFull) << 14) | (((uint64_t)beta3 & 0xFFull) << 6));
-        W(3, 5, ((uint64_t)A1 & 0xFFFFFFull) << 6);
-        W(3, 6, (((uint64_t)(A0 >> 8)) & 0xFFFFFFull) << 6);
-        W(3, 7, (((uint64_t)A0 & 0xFFull) << 22) | ((tot & 0xFFull) << 14) | ((wnt & 0xFFull) << 6));
-        W(3, 8, (((uint64_t)dtls & 0xFFull) << 22) | ((wnlsf & 0xFFull) << 14) | ((dn & 0xFFull) << 6));
-        W(3, 9, ((uint64_t)dtlsf & 0xFFull) << 22);
-    } else {
-        W(3, 2, (data_id << 28) | (sv_p25_sf4 << 22));
-        for (int k = 3; k < 10; k++)
-            W(3, k, 0);
-    }
-    /* subframe 5, page 25 */
-    W(4, 0, preamble);
-    W(4, 1, 0x5ull << 8);
-    W(4, 2, (data_id << 28) | (sv_p25_sf5 << 22) | ((toa & 0xFFull) << 14) | ((wna & 0xFFull) << 6));
-    for (int k = 3; k < 10; k++)
-        W(4, k, 0);
-#undef W
+    int64_t q[Q_COUNT];
+    /* ---- (1) scaling: the reference's statements (c:580-645), operation for operation ---- */
+    q[Q_PREAMBLE] = 0x8B;
+    q[Q_SF_ID_1] = 1, q[Q_SF_ID_2] = 2, q[Q_SF_ID_3] = 3, q[Q_SF_ID_4] = 4, q[Q_SF_ID_5] = 5;
+    q[Q_WN] = 0; /* the transmission week is put in per frame (build_nav_words; c:1877-1878) */
+    q[Q_TOE] = (int64_t)(uint64_t)(e->toe.sec / 16.0);
+    q[Q_TOC] = (int64_t)(uint64_t)(e->toc.sec / 16.0);
+    q[Q_IODE] = (int64_t)(uint64_t)(e->iode);
+    q[Q_IODC] = (int64_t)(uint64_t)(e->iodc);
+    q[Q_DELTA_N] = (int64_t)(e->deltan / P2_43 / K_PI);
+    q[Q_CUC] = (int64_t)(e->cuc / P2_29);
+    q[Q_CUS] = (int64_t)(e->cus / P2_29);
+    q[Q_CIC] = (int64_t)(e->cic / P2_29);
+    q[Q_CIS] = (int64_t)(e->cis / P2_29);
+    q[Q_CRC] = (int64_t)(e->crc / P2_5);
+    q[Q_CRS] = (int64_t)(e->crs / P2_5);
+    q[Q_ECC] = (int64_t)(uint64_t)(e->ecc / P2_33);
+    q[Q_SQRT_A] = (int64_t)(uint64_t)(e->sqrta / P2_19);
+    q[Q_M0] = (int64_t)(e->m0 / P2_31 / K_PI);
+    q[Q_OMEGA0] = (int64_t)(e->omg0 / P2_31 / K_PI);
+    q[Q_I0] = (int64_t)(e->inc0 / P2_31 / K_PI);
+    q[Q_OMEGA] = (int64_t)(e->aop / P2_31 / K_PI);
+    q[Q_OMEGA_DOT] = (int64_t)(e->omgdot / P2_43 / K_PI);
+    q[Q_IDOT] = (int64_t)(e->idot / P2_43 / K_PI);
+    q[Q_AF0] = (int64_t)(e->af0 / P2_31);
+    q[Q_AF1] = (int64_t)(e->af1 / P2_43);
+    q[Q_AF2] = (int64_t)(e->af2 / P2_55);
+    q[Q_TGD] = (int64_t)(e->tgd / P2_31);
+    q[Q_SV_HEALTH] = (int)(uint64_t)(e->svhlth);
+    q[Q_CODE_L2] = (int)(uint64_t)(e->codeL2);
+    q[Q_WNA] = (int64_t)(uint64_t)(e->toe.week % 256);
+    q[Q_TOA] = (int64_t)(uint64_t)(e->toe.sec / 4096.0);
+    q[Q_URA] = 0;
+    q[Q_DATA_ID] = 1;
+    q[Q_PAGE_25_SF4] = 63, q[Q_PAGE_25_SF5] = 51, q[Q_PAGE_18] = 56; /* the SV (page) IDs of c:576-578 */
+    q[Q_ALPHA0] = (int64_t)round(io->alpha[0] / P2_30);
+    q[Q_ALPHA1] = (int64_t)round(io->alpha[1] / P2_27);
+    q[Q_ALPHA2] = (int64_t)round(io->alpha[2] / P2_24);
+    q[Q_ALPHA3] = (int64_t)round(io->alpha[3] / P2_24);
+    q[Q_BETA0] = (int64_t)round(io->beta[0] / 2048.0);
+    q[Q_BETA1] = (int64_t)round(io->beta[1] / 16384.0);
+    q[Q_BETA2] = (int64_t)round(io->beta[2] / 65536.0);
+    q[Q_BETA3] = (int64_t)round(io->beta[3] / 65536.0);
+    q[Q_A0] = (int64_t)round(io->A0 / P2_30);
+    q[Q_A1] = (int64_t)round(io->A1 / P2_50);
+    q[Q_DT_LS] = (int64_t)(io->dtls);
+    q[Q_DT_LSF] = 18; /* fixed leap-second schedule c:643-645 */
+    q[Q_TOT] = (int64_t)(uint64_t)(io->tot / 4096);
+    q[Q_WNT] = (int64_t)(uint64_t)(io->wnt % 256);
+    q[Q_WN_LSF] = 1929 % 256;
+    q[Q_DN] = 7;
+    /* ---- (2) layout ---- */
+    memset(sbf, 0, 50 * sizeof(uint32_t));
+    place_fields(sbf, k_frame_layout, sizeof k_frame_layout / sizeof k_frame_layout[0], q);
+    if (io->valid)
+        place_fields(sbf, k_page_18, sizeof k_page_18 / sizeof k_page_18[0], q);
+    else
+        place_fields(sbf, k_page_25_sf4, sizeof k_page_25_sf4 / sizeof k_page_25_sf4[0], q);
 }
 
 /* one 30 s frame (plus the previous subframe 5 in front) with TOW, week and parity (generateNavMsg c:1820-1894) */
@@ -601,21 +668,49 @@ static int allocate_channels(gpsfe_t *fe, const eph_t *eph, gtime_t grx, const d
     return nsat;
 }
 
-/* computeCodePhase c:1754-1787 */
+/* computeCodePhase c:1754-1787: what a block's descriptor holds of the code and carrier NCOs, from the ranges at the
+ * block's start (rho0) and end (rho1) and the frame the nav words were built for (g0).  A pure function: the blocks of a
+ * span between two 30 s maintenances can be seeded in any order (gpsfe_generate does so on several threads). */
+typedef struct {
+    double f_carr, f_code, code_phase;
+    int iword, ibit, icode;
+} nco_seed_t;
+
+static nco_seed_t seed_ncos(const range_t *rho0, const range_t *rho1, gtime_t g0, double dt)
+{
+    nco_seed_t s;
+    const double rhorate = (rho1->range - rho0->range) / dt;
+    s.f_carr = -rhorate / K_LAMBDA;
+    s.f_code = 1.023e6 + s.f_carr * (1.0 / 1540.0);
+    const double ms = ((gps_diff(rho0->g, g0) + 6.0) - rho0->range / K_C) * 1000.0;
+    int ims = (int)ms;
+    s.code_phase = (ms - (double)ims) * GPSBB_CA_LEN;
+    s.iword = ims / 600;
+    ims -= s.iword * 600;
+    s.ibit = ims / 20;
+    ims -= s.ibit * 20;
+    s.icode = ims;
+    return s;
+}
+
 static void seed_code_phase(chan_t *c, const range_t *rho1, double dt)
 {
-    const double rhorate = (rho1->range - c->rho0.range) / dt;
-    c->f_carr = -rhorate / K_LAMBDA;
-    c->f_code = 1.023e6 + c->f_carr * (1.0 / 1540.0);
-    const double ms = ((gps_diff(c->rho0.g, c->g0) + 6.0) - c->rho0.range / K_C) * 1000.0;
-    int ims = (int)ms;
-    c->code_phase = (ms - (double)ims) * GPSBB_CA_LEN;
-    c->iword = ims / 600;
-    ims -= c->iword * 600;
-    c->ibit = ims / 20;
-    ims -= c->ibit * 20;
-    c->icode = ims;
+    const nco_seed_t s = seed_ncos(&c->rho0, rho1, c->g0, dt);
+    c->f_carr = s.f_carr;
+    c->f_code = s.f_code;
+    c->code_phase = s.code_phase;
+    c->iword = s.iword;
+    c->ibit = s.ibit;
+    c->icode = s.icode;
     c->rho0 = *rho1;
+}
+
+/* gain[i] of c:2677-2685 */
+static double channel_gain(const gpsfe_t *fe, const range_t *rho)
+{
+    const double path_loss = 20200000.0 / rho->d;
+    const int ibs = (int)((90.0 - rho->azel[1] * K_R2D) / 5.0); /* elevation -> boresight bin */
+    return (double)(path_loss * fe->ant_pat[ibs]);
 }
 
 /* ---- RINEX-2 navigation reader (readRinex2 c:874-1233) ----------------------------------------------------- */
@@ -840,6 +935,8 @@ static int read_motion(gpsfe_t *fe, const char *path)
 
 /* ---- public API ------------------------------------------------------------------------------------------------ */
 
+static void fe_pool_stop(struct fe_pool *p);
+
 const char *gpsfe_strerror(int err)
 {
     switch (err) {
@@ -858,6 +955,7 @@ void gpsfe_close(gpsfe_t *fe)
 {
     if (!fe)
         return;
+    fe_pool_stop(fe->pool);
     free(fe->xyz);
     free(fe);
 }
@@ -978,42 +1076,10 @@ int gpsfe_open(const gpsfe_config_t *cfg, gpsfe_t **out)
     return GPSFE_OK;
 }
 
-int gpsfe_next_block(gpsfe_t *fe, gpsbb_chan_t *ch)
+/* every 30 s: next nav frame, ephemeris roll-over, channel re-allocation (c:2764-2798); then on to the next block's time
+ * and position (c:2800-2805) */
+static void end_of_block(gpsfe_t *fe, const double *xyz)
 {
-    if (!fe || !ch)
-        return GPSFE_E_BADARG;
-    const double *xyz = fe->static_mode ? fe->xyz[0] : fe->xyz[fe->iumd];
-
-    /* refresh code phase, counters, frequencies and gain of every allocated channel (c:2656-2687) */
-    for (int i = 0; i < fe->max_chan; i++) {
-        chan_t *c = &fe->chan[i];
-        gpsbb_chan_t *d = &ch[i];
-        memset(d, 0, sizeof *d);
-        fe->emitted_prn[i] = c->prn > 0 ? c->prn : 0;
-        if (c->prn <= 0)
-            continue;
-        range_t rho;
-        pseudorange(&rho, &fe->eph[fe->ieph][c->prn - 1], &fe->iono, fe->grx, xyz);
-        c->azel[0] = rho.azel[0];
-        c->azel[1] = rho.azel[1];
-        seed_code_phase(c, &rho, 0.1);
-        const double path_loss = 20200000.0 / rho.d;
-        const int ibs = (int)((90.0 - rho.azel[1] * K_R2D) / 5.0); /* elevation -> boresight bin */
-        c->gain = (double)(path_loss * fe->ant_pat[ibs]);
-
-        d->prn = c->prn;
-        d->iword = c->iword;
-        d->ibit = c->ibit;
-        d->icode = c->icode;
-        d->f_carr = c->f_carr;
-        d->f_code = c->f_code;
-        d->carr_phase = c->carr_phase;
-        d->code_phase = c->code_phase;
-        d->gain = c->gain;
-        memcpy(d->dwrd, c->dwrd, sizeof d->dwrd);
-    }
-
-    /* every 30 s: next nav frame, ephemeris roll-over, channel re-allocation (c:2764-2798) */
     const int igrx = (int)(fe->grx.sec * 10.0 + 0.5);
     if (igrx % 300 == 0) {
         for (int i = 0; i < fe->max_chan; i++)
@@ -1034,6 +1100,46 @@ int gpsfe_next_block(gpsfe_t *fe, gpsbb_chan_t *ch)
     fe->grx = gps_add(fe->grx, 0.1); /* c:2800 */
     if (++fe->iumd >= fe->numd)      /* c:2802-2805 */
         fe->iumd = 0;
+}
+
+static void fill_descriptor(gpsbb_chan_t *d, const chan_t *c, const nco_seed_t *s, double gain)
+{
+    d->prn = c->prn;
+    d->iword = s->iword;
+    d->ibit = s->ibit;
+    d->icode = s->icode;
+    d->f_carr = s->f_carr;
+    d->f_code = s->f_code;
+    d->carr_phase = c->carr_phase;
+    d->code_phase = s->code_phase;
+    d->gain = gain;
+    memcpy(d->dwrd, c->dwrd, sizeof d->dwrd);
+}
+
+int gpsfe_next_block(gpsfe_t *fe, gpsbb_chan_t *ch)
+{
+    if (!fe || !ch)
+        return GPSFE_E_BADARG;
+    const double *xyz = fe->static_mode ? fe->xyz[0] : fe->xyz[fe->iumd];
+
+    /* refresh code phase, counters, frequencies and gain of every allocated channel (c:2656-2687) */
+    for (int i = 0; i < fe->max_chan; i++) {
+        chan_t *c = &fe->chan[i];
+        gpsbb_chan_t *d = &ch[i];
+        memset(d, 0, sizeof *d);
+        fe->emitted_prn[i] = c->prn > 0 ? c->prn : 0;
+        if (c->prn <= 0)
+            continue;
+        range_t rho;
+        pseudorange(&rho, &fe->eph[fe->ieph][c->prn - 1], &fe->iono, fe->grx, xyz);
+        c->azel[0] = rho.azel[0];
+        c->azel[1] = rho.azel[1];
+        seed_code_phase(c, &rho, 0.1);
+        c->gain = channel_gain(fe, &rho);
+        const nco_seed_t s = {c->f_carr, c->f_code, c->code_phase, c->iword, c->ibit, c->icode};
+        fill_descriptor(d, c, &s, c->gain);
+    }
+    end_of_block(fe, xyz);
     return GPSFE_OK;
 }
 
@@ -1051,15 +1157,231 @@ int gpsfe_feed_back(gpsfe_t *fe, const gpsbb_chan_state_t *end_state)
     return GPSFE_OK;
 }
 
+/* ---- gpsfe_generate on several threads ------------------------------------------------------------------------
+ * Between two 30 s maintenances (c:2764-2798) nothing of the scenario changes but the time: channel allocation,
+ * ephemeris set, nav words and the frame time g0 stand still, and a block's descriptor is a pure function of the
+ * ranges at its start and its end.  So a span of up to 300 blocks is done in two parallel sweeps — (1) the range to
+ * every allocated satellite at every block time (orbit, clock, Klobuchar: where the time goes), (2) each block's
+ * descriptor from range k-1 and range k — and the state the sequential loop would have left is put back before the
+ * maintenance of the span's last block runs.  Same arithmetic per value, so the same bits (tests/test_frontend.py). */
+#define FE_MAX_THREADS 32
+#define FE_SPAN_MAX 512
+
+typedef struct fe_pool {
+    int n; /* parties: n - 1 workers and the caller */
+    pthread_t th[FE_MAX_THREADS];
+    int tid_of[FE_MAX_THREADS];
+    pthread_mutex_t m;
+    pthread_cond_t cv;
+    pthread_barrier_t bar;
+    unsigned long gen;
+    int quit;
+    void (*fn)(void *arg, int tid, int n, pthread_barrier_t *bar);
+    void *arg;
+    struct fe_pool_arg { struct fe_pool *p; int tid; } args[FE_MAX_THREADS];
+} fe_pool_t;
+
+static void *fe_worker(void *v)
+{
+    struct fe_pool_arg *a = v;
+    fe_pool_t *p = a->p;
+    unsigned long seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&p->m);
+        while (p->gen == seen && !p->quit)
+            pthread_cond_wait(&p->cv, &p->m);
+        if (p->quit) {
+            pthread_mutex_unlock(&p->m);
+            return NULL;
+        }
+        seen = p->gen;
+        pthread_mutex_unlock(&p->m);
+        p->fn(p->arg, a->tid, p->n, &p->bar);
+        pthread_barrier_wait(&p->bar);
+    }
+}
+
+static fe_pool_t *fe_pool_start(int n)
+{
+    fe_pool_t *p = calloc(1, sizeof *p);
+    if (!p)
+        return NULL;
+    pthread_mutex_init(&p->m, NULL);
+    pthread_cond_init(&p->cv, NULL);
+    int started = 1;
+    for (int t = 1; t < n; t++) {
+        p->args[t].p = p;
+        p->args[t].tid = started;
+        if (pthread_create(&p->th[started], NULL, fe_worker, &p->args[t]) != 0)
+            break; /* fewer threads than asked for: still correct */
+        started++;
+    }
+    p->n = started;
+    pthread_barrier_init(&p->bar, NULL, (unsigned)p->n);
+    return p;
+}
+
+static void fe_pool_run(fe_pool_t *p, void (*fn)(void *, int, int, pthread_barrier_t *), void *arg)
+{
+    pthread_mutex_lock(&p->m);
+    p->fn = fn;
+    p->arg = arg;
+    p->gen++;
+    pthread_cond_broadcast(&p->cv);
+    pthread_mutex_unlock(&p->m);
+    fn(arg, 0, p->n, &p->bar);
+    pthread_barrier_wait(&p->bar);
+}
+
+static void fe_pool_stop(fe_pool_t *p)
+{
+    if (!p)
+        return;
+    pthread_mutex_lock(&p->m);
+    p->quit = 1;
+    pthread_cond_broadcast(&p->cv);
+    pthread_mutex_unlock(&p->m);
+    for (int t = 1; t < p->n; t++)
+        pthread_join(p->th[t], NULL);
+    pthread_barrier_destroy(&p->bar);
+    pthread_mutex_destroy(&p->m);
+    pthread_cond_destroy(&p->cv);
+    free(p);
+}
+
+typedef struct {
+    const gpsfe_t *fe;
+    int n;                    /* blocks in the span */
+    const gtime_t *grx;       /* [n] block times */
+    const int *ipos;          /* [n] index into fe->xyz */
+    range_t *rho;             /* [n][max_chan] */
+    gpsbb_chan_t *ch;         /* [n][max_chan] out */
+    nco_seed_t last[GPSBB_MAX_CHAN]; /* what the last block left in chan[] */
+    double last_gain[GPSBB_MAX_CHAN];
+} span_job_t;
+
+static void span_work(void *v, int tid, int nthr, pthread_barrier_t *bar)
+{
+    span_job_t *j = v;
+    const gpsfe_t *fe = j->fe;
+    const int mc = fe->max_chan;
+    const int k0 = (int)((long)j->n * tid / nthr), k1 = (int)((long)j->n * (tid + 1) / nthr);
+    for (int k = k0; k < k1; k++)
+        for (int i = 0; i < mc; i++) {
+            const chan_t *c = &fe->chan[i];
+            if (c->prn > 0)
+                pseudorange(&j->rho[(size_t)k * mc + i], &fe->eph[fe->ieph][c->prn - 1], &fe->iono, j->grx[k], fe->xyz[j->ipos[k]]);
+        }
+    pthread_barrier_wait(bar); /* block k needs the range of block k - 1, which another thread may have computed */
+    for (int k = k0; k < k1; k++)
+        for (int i = 0; i < mc; i++) {
+            const chan_t *c = &fe->chan[i];
+            gpsbb_chan_t *d = &j->ch[(size_t)k * mc + i];
+            memset(d, 0, sizeof *d);
+            if (c->prn <= 0)
+                continue;
+            const range_t *r1 = &j->rho[(size_t)k * mc + i];
+            const range_t *r0 = k ? &j->rho[(size_t)(k - 1) * mc + i] : &c->rho0;
+            const nco_seed_t s = seed_ncos(r0, r1, c->g0, 0.1);
+            const double gain = channel_gain(fe, r1);
+            fill_descriptor(d, c, &s, gain);
+            if (k == j->n - 1) {
+                j->last[i] = s;
+                j->last_gain[i] = gain;
+            }
+        }
+}
+
+int gpsfe_set_threads(gpsfe_t *fe, int nthreads)
+{
+    if (!fe || nthreads < 0 || nthreads > FE_MAX_THREADS)
+        return GPSFE_E_BADARG;
+    if (fe->pool && fe->pool->n != nthreads) {
+        fe_pool_stop(fe->pool);
+        fe->pool = NULL;
+    }
+    fe->nthreads = nthreads;
+    return GPSFE_OK;
+}
+
 int gpsfe_generate(gpsfe_t *fe, int nblocks, gpsbb_chan_t *ch)
 {
     if (!fe || !ch || nblocks < 0)
         return GPSFE_E_BADARG;
-    for (int b = 0; b < nblocks; b++) {
-        int rc = gpsfe_next_block(fe, ch + (size_t)b * fe->max_chan);
-        if (rc != GPSFE_OK)
-            return rc;
+    int nthr = fe->nthreads;
+    if (nthr == 0) { /* default: the machine's cores, up to 16 */
+        const long on = sysconf(_SC_NPROCESSORS_ONLN);
+        nthr = on < 1 ? 1 : (on > 16 ? 16 : (int)on);
     }
+    gtime_t *grx = NULL;
+    int *ipos = NULL;
+    range_t *rho = NULL;
+    if (nthr > 1 && nblocks >= 64) {
+        grx = malloc(FE_SPAN_MAX * sizeof *grx);
+        ipos = malloc(FE_SPAN_MAX * sizeof *ipos);
+        rho = malloc((size_t)FE_SPAN_MAX * fe->max_chan * sizeof *rho);
+        if (!fe->pool)
+            fe->pool = fe_pool_start(nthr);
+    }
+    const int parallel = grx && ipos && rho && fe->pool && fe->pool->n > 1;
+    int b = 0;
+    while (b < nblocks) {
+        if (!parallel) {
+            const int rc = gpsfe_next_block(fe, ch + (size_t)b * fe->max_chan);
+            if (rc != GPSFE_OK)
+                return rc;
+            b++;
+            continue;
+        }
+        /* the span: up to and including the block whose end runs the 30 s maintenance */
+        int n = 0, iumd = fe->iumd;
+        gtime_t g = fe->grx;
+        while (b + n < nblocks && n < FE_SPAN_MAX) {
+            grx[n] = g;
+            ipos[n] = iumd; /* (0 throughout for a static position: numd is 0 there) */
+            n++;
+            const int igrx = (int)(g.sec * 10.0 + 0.5);
+            if (igrx % 300 == 0)
+                break;
+            g = gps_add(g, 0.1);
+            if (++iumd >= fe->numd)
+                iumd = 0;
+        }
+        span_job_t job;
+        memset(&job, 0, sizeof job);
+        job.fe = fe;
+        job.n = n;
+        job.grx = grx;
+        job.ipos = ipos;
+        job.rho = rho;
+        job.ch = ch + (size_t)b * fe->max_chan;
+        fe_pool_run(fe->pool, span_work, &job);
+        /* the state the sequential loop would be in before the maintenance of the span's last block */
+        for (int i = 0; i < fe->max_chan; i++) {
+            chan_t *c = &fe->chan[i];
+            fe->emitted_prn[i] = c->prn > 0 ? c->prn : 0;
+            if (c->prn <= 0)
+                continue;
+            const range_t *r = &rho[(size_t)(n - 1) * fe->max_chan + i];
+            c->azel[0] = r->azel[0];
+            c->azel[1] = r->azel[1];
+            c->f_carr = job.last[i].f_carr;
+            c->f_code = job.last[i].f_code;
+            c->code_phase = job.last[i].code_phase;
+            c->iword = job.last[i].iword;
+            c->ibit = job.last[i].ibit;
+            c->icode = job.last[i].icode;
+            c->rho0 = *r;
+            c->gain = job.last_gain[i];
+        }
+        fe->grx = grx[n - 1];
+        fe->iumd = ipos[n - 1];
+        end_of_block(fe, fe->xyz[ipos[n - 1]]);
+        b += n;
+    }
+    free(grx);
+    free(ipos);
+    free(rho);
     return GPSFE_OK;
 }
 

@@ -68,3 +68,11 @@ REF_CHANNEL_DTYPE = _np.dtype([("prn", "<i4"), ("ca", "<i4", (1023,)), ("f_carr"
                                ("g0_sec", "<f8"), ("sbf", "<u8", (50,)), ("dwrd", "<u8", (60,)), ("iword", "<i4"),
                                ("ibit", "<i4"), ("icode", "<i4"), ("dataBit", "<i4"), ("codeCA", "<i4"), ("_p1", "<i4"),
                                ("azel", "<f8", (2,)), ("rho0", "<f8", (8,))])
+
+# ... and the same struct of a reference built WITHOUT FLOAT_CARR_PHASE (h:12 removed): h:160-161 put a 32-bit accumulator
+# and its step where the double was (same size, so nothing else moves): what gpsbb_fill_block_ref_fixed is handed
+REF_CHANNEL_FIXED_DTYPE = _np.dtype([("prn", "<i4"), ("ca", "<i4", (1023,)), ("f_carr", "<f8"), ("f_code", "<f8"),
+                                     ("carr_phase", "<u4"), ("carr_phasestep", "<i4"), ("code_phase", "<f8"), ("g0_week", "<i4"),
+                                     ("_p0", "<i4"), ("g0_sec", "<f8"), ("sbf", "<u8", (50,)), ("dwrd", "<u8", (60,)),
+                                     ("iword", "<i4"), ("ibit", "<i4"), ("icode", "<i4"), ("dataBit", "<i4"), ("codeCA", "<i4"),
+                                     ("_p1", "<i4"), ("azel", "<f8", (2,)), ("rho0", "<f8", (8,))])

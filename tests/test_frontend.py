@@ -182,3 +182,27 @@ def test_feed_back_keeps_a_newly_allocated_channels_own_phase(fe_pkg):
                 st["dataBit"][i] = 1
         fe.feed_back(st)
     fe.close()
+
+
+@pytest.mark.parametrize("motion,max_chan,nav", [(None, 12, "synth3540.14n"), ("circle.csv", 12, "synth3540.14n"), (None, 16, "dense3540.14n")])
+def test_generate_on_threads_equals_the_sequential_loop(pkg, motion, max_chan, nav):
+    """gpsfe_generate spreads the blocks between two 30 s maintenances (c:2764-2798) over threads (ranges first, then every
+    block's descriptor from the ranges at its ends): the same bytes as one gpsfe_next_block per block, across
+    maintenances, ephemeris roll-overs, the wrap of the motion file, and when the two calls are mixed."""
+    pkg.build_frontend()
+    kw = dict(llh=SITE, max_chan=max_chan, motion=os.path.join(GOLDEN, motion) if motion else None)
+    n = 3700  # 370 s: twelve maintenances; circle.csv (3000 points) wraps
+    seq = pkg.FrontEnd(os.path.join(GOLDEN, nav), **kw)
+    want = np.stack([seq.next_block() for _ in range(n)])
+    seq.close()
+    for threads in (1, 2, 7, 0):
+        fe = pkg.FrontEnd(os.path.join(GOLDEN, nav), **kw)
+        fe.set_threads(threads)
+        got = fe.generate(n)
+        assert got.tobytes() == want.tobytes(), threads
+        fe.close()
+    fe = pkg.FrontEnd(os.path.join(GOLDEN, nav), **kw)
+    fe.set_threads(5)
+    parts = [fe.generate(100), np.stack([fe.next_block() for _ in range(3)]), fe.generate(299), fe.generate(1), fe.generate(n - 403)]
+    assert np.concatenate(parts).tobytes() == want.tobytes()
+    fe.close()

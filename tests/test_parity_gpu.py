@@ -481,6 +481,54 @@ def test_reference_struct_layout_entry_point(pkg, synth, oracle):
         assert chan[f][act].tobytes() == want_st[f][0][act].astype(chan[f].dtype).tobytes(), f
 
 
+def test_reference_struct_layout_entry_point_without_float_carr_phase(pkg, synth, oracle):
+    """gpsbb_fill_block_ref_fixed: the caller keeps the channel_t of a reference built without FLOAT_CARR_PHASE (h:12
+    removed; h:160-161: `unsigned int carr_phase; int carr_phasestep;`).  Two consecutive blocks through the struct, the
+    accumulator updated in place in between like the loop does (c:2748); a host whose carr_phasestep is not the step of
+    c:2675 is refused."""
+    import ctypes as C
+    from conftest import REF_CHANNEL_FIXED_DTYPE as chan_t   # checked against offsetof() on the real header: test_ref_layout.py
+    nsamp, delt = 300000, 1 / 2.6e6
+    d = _fixed_desc(pkg, 2, 12, 122)
+    d["prn"][:, 7] = 0
+    d[1] = d[0]
+    chan = np.zeros(12, chan_t)
+    for f in ("prn", "f_carr", "f_code", "code_phase", "iword", "ibit", "icode"):
+        chan[f] = d[f][0]
+    chan["carr_phase"] = d["carr_phase"][0].astype(np.uint32)
+    chan["carr_phasestep"] = np.round(512.0 * 65536.0 * d["f_carr"][0] * delt).astype(np.int32)
+    chan["dwrd"] = d["dwrd"][0]
+    gain = np.ascontiguousarray(d["gain"][0])
+
+    class Layout(C.Structure):
+        _fields_ = [(n, C.c_size_t) for n in ("stride", "off_prn", "off_f_carr", "off_f_code", "off_carr_phase",
+                                              "off_code_phase", "off_dwrd", "sizeof_dwrd_elem", "off_iword",
+                                              "off_ibit", "off_icode", "off_dataBit", "off_codeCA")]
+    off = lambda n: chan_t.fields[n][1]
+    lay = Layout(chan_t.itemsize, off("prn"), off("f_carr"), off("f_code"), off("carr_phase"), off("code_phase"),
+                 off("dwrd"), 8, off("iword"), off("ibit"), off("icode"), off("dataBit"), off("codeCA"))
+    want_iq, want_st, _ = oracle.fill_blocks(d, delt, nsamp, chain=True, fixed=True)
+    act = d["prn"][0] > 0
+    for blk in range(2):
+        iq = np.zeros((nsamp, 2), np.int16)
+        rc = pkg.lib().gpsbb_fill_block_ref_fixed(synth._h, chan.ctypes.data, C.byref(lay), off("carr_phasestep"), 12,
+                                                  gain.ctypes.data, delt, nsamp, iq.ctypes.data)
+        assert rc == 0
+        assert (iq == want_iq[blk]).all(), blk
+        assert (chan["carr_phase"][act] == want_st["carr_phase"][blk][act].astype(np.uint32)).all()
+        for f in ("code_phase", "iword", "ibit", "icode", "dataBit", "codeCA"):
+            assert chan[f][act].tobytes() == want_st[f][blk][act].astype(chan[f].dtype).tobytes(), f
+        # the host's per-block update (computeCodePhase, c:2673) puts the descriptor's values back; the accumulator stays
+        for f in ("code_phase", "iword", "ibit", "icode"):
+            chan[f] = d[f][1]
+    chan["carr_phasestep"][0] += 1
+    iq = np.zeros((nsamp, 2), np.int16)
+    assert pkg.lib().gpsbb_fill_block_ref_fixed(synth._h, chan.ctypes.data, C.byref(lay), off("carr_phasestep"), 12,
+                                                gain.ctypes.data, delt, nsamp, iq.ctypes.data) == -2
+    assert pkg.lib().gpsbb_fill_block_ref_fixed(synth._h, chan.ctypes.data, C.byref(lay), C.c_size_t(-1).value, 12,
+                                                gain.ctypes.data, delt, nsamp, iq.ctypes.data) == 0
+
+
 def test_full_size_blocks_and_linearity(pkg, synth, oracle):
     """BASELINE config 3 size (16 channels, 25 MS/s, 2.5 M samples per block): two blocks compared sample
     for sample with the oracle, plus the size-independent property that the sum over channels is linear

@@ -67,16 +67,6 @@ struct PdLds {
                                               phase, 2*channel + 1 = 2^20 + band + 8 * carrier phase (mirrored) */
 };
 
-__device__ __forceinline__ uint32_t lds_addr_of(const void *p)
-{
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
-}
-template <class T>
-__device__ __forceinline__ T lds_read_at(uint32_t a)
-{
-    return *(__attribute__((address_space(3))) const T *)(uintptr_t)a;
-}
-
 /* what the fast path added for sample j*64 + lane of a channel: the models exactly as pd_channel_fast advances them (one
  * fma, then j additions), index and chip as floor(model), the data bit before / after the code's roll-over */
 struct PdModel {

@@ -98,12 +98,49 @@ struct EvLds {
                                                     channels with a falling carrier: of index 511 - k */
     uint32_t D[EV_WAVES][16][64];                /* difference arrays: row j-1 holds the change at sample j of the lane's
                                                     run (row 15 = discard), one column per lane */
-    double tstate[EV_WAVES][2][2 * GPSBB_MAX_CHAN]; /* per wavefront, two tiles deep: the tile's exact states in guard format
-                                                    with the channel's bias (2^20 + W + state), column 2*channel = code
-                                                    phase, 2*channel+1 = carrier phase*512 (512 - that for a falling carrier) */
+    double tstate[EV_WAVES][2][2 * GPSBB_MAX_CHAN]; /* per wavefront.  [0]: the tile's exact states in guard format with the
+                                                    channel's bias (2^20 + W + state), column 2*channel = code phase,
+                                                    2*channel+1 = carrier phase*512 (512 - that for a falling carrier): written
+                                                    at the top of every tile from registers — one buffer is enough, a
+                                                    wavefront's LDS operations execute in order.  [1]: EvConst::tK0, tC0 of
+                                                    the block's channels, the addends of the two position fmas, 256 bytes
+                                                    behind the states of the same channel.  A VALU instruction of gfx9 reads
+                                                    ONE scalar register pair, and fma(-fraction, 1 / step, constant) has two
+                                                    scalar constants: out of scalar registers the compiler had to copy one
+                                                    into a vector pair first (a v_mov_b64 per fma); out of LDS — a second
+                                                    broadcast ds_read_b128 off the same address register — it arrives where
+                                                    the fma wants it */
     uint16_t chip2[GPSBB_MAX_CHAN][EV_CHIP_LEN]; /* low byte: 0 where codeCA of chip c mod 1023 is +1, 0xff where -1;
                                                     high byte: the same for chip c+1 */
 };
+
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+template <class T>
+__device__ __forceinline__ T lds_read_at(uint32_t a)
+{
+    return *(__attribute__((address_space(3))) const T *)(uintptr_t)a;
+}
+
+/* Measurement builds (tools/bound_hunt.sh): deliberately WRONG variants of k_synth_ev that take one resource out of the
+ * picture each, to see what the kernel's time is made of.  Never defined in the product. */
+#if defined(GPSBB_X_NOATOMIC)
+#define GPSBB_EV_DADD(ptr, v) (*(ptr) = (v))
+#elif defined(GPSBB_X_NOADD)
+#define GPSBB_EV_DADD(ptr, v) ((void)(v))
+#else
+#define GPSBB_EV_DADD(ptr, v) __hip_atomic_fetch_add((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#endif
+
+typedef uint32_t ev_u32x4 __attribute__((ext_vector_type(4))); /* 16 bytes: one ds_read_b128 / ds_write_b128 / global_store_dwordx4 */
+
+template <class T>
+__device__ __forceinline__ void lds_write_at(uint32_t a, T v)
+{
+    *(__attribute__((address_space(3))) T *)(uintptr_t)a = v;
+}
 
 /* (x ^ m) - m: x where m = 0, -x where m = -1 */
 __device__ __forceinline__ uint32_t signed_by(uint32_t x, uint32_t m) { return (x ^ m) - m; }
@@ -184,19 +221,22 @@ __device__ __noinline__ uint32_t ev_exact_run_fixed(EvLds &L, int wave, int lane
 
 /* per-channel constants of the fast path (scalar registers) */
 struct EvK {
-    double S, rS, tK0, sc, rsc, tC0;
+    double S, rS, sc, rsc;
     uint32_t danger;
+    uint32_t chip_base; /* LDS address of the channel's chip table, minus what the exponent bits of a guard-format high word
+                           contribute when it is shifted into a byte offset (see ev_first) */
 };
-__device__ __forceinline__ EvK ev_load_k(const EvConst *kb, int i)
+/* the high word of a double in [2^20, 2^21) is 0x41300000 + its integer part */
+constexpr uint32_t EV_GUARD_HI = 0x41300000u;
+__device__ __forceinline__ EvK ev_load_k(const EvLds &L, const EvConst *kb, int i)
 {
     EvK k;
     k.S = scalar_load(&kb[i].S);
     k.rS = scalar_load(&kb[i].rS);
-    k.tK0 = scalar_load(&kb[i].tK0);
     k.sc = scalar_load(&kb[i].sc);
     k.rsc = scalar_load(&kb[i].rsc);
-    k.tC0 = scalar_load(&kb[i].tC0);
     k.danger = scalar_load(&kb[i].danger);
+    k.chip_base = lds_addr_of(&L.chip2[i][0]) - (EV_GUARD_HI << 1);
     return k;
 }
 
@@ -225,7 +265,7 @@ struct EvHalf {
  * (EvConst::tK0) that is (2a - 1) / (2b) for integers a, b = |step| < 2^15 — never an integer and at least 1 / (2b) away
  * from one, against the 2^-32 this format resolves — so floor() is right even where a change falls exactly on a sample. */
 template <int KC, bool FIXED>
-__device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK &K, double xt, double yt, double off)
+__device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK &K, double xt, double yt, double tK0, double tC0, double off)
 {
     EvHalf<KC> h;
     const double sat = 15.5 + EV_GUARD; /* a change past the run's last sample: row 15, fraction one half */
@@ -234,7 +274,7 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK 
     const double fr = __builtin_amdgcn_fract(y0);
     const int it0 = __double2hiint(y0) & 511;
     uint32_t m = FIXED ? 0xffffffffu : (uint32_t)__double2loint(y0); /* the previous change lies within the model error of sample 0: low word below 2W */
-    double t = __fma_rn(-fr, K.rS, K.tK0);     /* 2^20 + W + (1 - fraction) / |step|: samples until the next index change */
+    double t = __fma_rn(-fr, K.rS, tK0);       /* 2^20 + W + (1 - fraction) / |step|: samples until the next index change */
 #pragma unroll
     for (int k = 0; k < KC; k++) {
         const double tq = fmin(t, sat);
@@ -246,15 +286,27 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK 
     const uint32_t *ampi = &L.amp[i][it0];
 #pragma unroll
     for (int k = 0; k <= KC; k++)
+#ifdef GPSBB_X_NOAMP
+        h.A[k] = (uint32_t)(it0 + k);
+#else
         h.A[k] = ampi[k];
+#endif
     /* ---- code: chip of the first sample and the sample at which it changes ---- */
     const double x0 = __fma_rn(off, K.sc, xt);
     const double frc = __builtin_amdgcn_fract(x0);
-    h.c0 = __double2hiint(x0) & 2047;
-    const double tc = fmin(__fma_rn(-frc, K.rsc, K.tC0), sat);
+    h.c0 = __double2hiint(x0) & 2047;          /* (only the tiles in which the data bit changes look at it) */
+    const double tc = fmin(__fma_rn(-frc, K.rsc, tC0), sat);
     m = min(m, min((uint32_t)__double2loint(x0), (uint32_t)__double2loint(tc)));
     h.jc = __double2hiint(tc) & 15;
-    h.ch2 = L.chip2[i][h.c0];
+    /* the chip pair's address straight from the high word: shifted left by one its integer part is the byte offset and its
+     * exponent bits a constant that the channel's base already has taken off — no masking instruction */
+    uint32_t chip_at;
+    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(chip_at) : "v"(__double2hiint(x0)), "s"(K.chip_base));
+#ifdef GPSBB_X_NOAMP
+    h.ch2 = (uint16_t)chip_at;
+#else
+    h.ch2 = lds_read_at<uint16_t>(chip_at);
+#endif
     /* lanes that cannot rule out a disagreement between the model and the reference: one comparison for everything tested */
     h.um = __builtin_amdgcn_uicmp(m, K.danger, 36 /* ult */);
     return h;
@@ -304,18 +356,22 @@ __device__ __forceinline__ void ev_second(EvLds &L, int wave, int lane, int i, E
     }
 
     /* ---- the contribution at sample 0 and its changes ---- */
-    acc0 += signed_by(h.A[0], m0);
+    {
+        /* += signed_by(A[0], m0) as (A ^ m) + (acc - m): two instructions (the compiler's own choice is xor, sub, add) */
+        const uint32_t c = acc0 - m0;
+        asm("v_xad_u32 %0, %1, %2, %3" : "=v"(acc0) : "v"(h.A[0]), "v"(m0), "v"(c));
+    }
     uint32_t Ax = h.A[KC];
 #pragma unroll
     for (int k = KC - 1; k >= 0; k--) {
         const bool before = h.jk[k] < jc; /* the index change comes before the chip change */
         const uint32_t mk = before ? m0 : m1;
         const uint32_t dk = signed_by(h.A[k + 1] - h.A[k], mk);
-        __hip_atomic_fetch_add(&L.D[wave][h.jk[k]][lane], dk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        GPSBB_EV_DADD(&L.D[wave][h.jk[k]][lane], dk);
         Ax = before ? Ax : h.A[k]; /* amplitude in force just before the chip change */
     }
     /* the chip change flips the sign: -s0*A -> s1*A = 2*s1*A more */
-    __hip_atomic_fetch_add(&L.D[wave][jc][lane], signed_by(Ax << 1, m1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    GPSBB_EV_DADD(&L.D[wave][jc][lane], signed_by(Ax << 1, m1));
 }
 
 /* what a wavefront knows about the tile it is working on */
@@ -382,9 +438,15 @@ __device__ __forceinline__ void ev_channels(EvLds &L, int wave, int lane, uint32
                                             double off, unsigned long long live_mask, uint32_t &acc0, unsigned long long *n_exact,
                                             const EvFixed &fx)
 {
+#ifdef GPSBB_X_NOSMEM
+#define GPSBB_EV_KIDX(i) 0
+#else
+#define GPSBB_EV_KIDX(i) i
+#endif
 #define GPSBB_EV_IN(i)                                                                                                 \
-    const EvK K##i = ev_load_k(kb, i);                                                                                 \
-    const double xt##i = T.ts[2 * i], yt##i = T.ts[2 * i + 1];
+    const EvK K##i = ev_load_k(L, kb, GPSBB_EV_KIDX(i));                                                               \
+    const double xt##i = T.ts[2 * i], yt##i = T.ts[2 * i + 1];                                                         \
+    const double tc##i = T.ts[2 * GPSBB_MAX_CHAN + 2 * i], tk##i = T.ts[2 * GPSBB_MAX_CHAN + 2 * i + 1];
 #define GPSBB_EV_OUT(i, h)                                                                                             \
     {                                                                                                                  \
         const uint32_t db_ = 0u - ((T.dbits >> i) & 1u), dn_ = 0u - ((T.dnext >> i) & 1u);                             \
@@ -400,15 +462,15 @@ __device__ __forceinline__ void ev_channels(EvLds &L, int wave, int lane, uint32
         mask &= mask - 1;
         GPSBB_EV_IN(i0)
         GPSBB_EV_IN(i1)
-        EvHalf<KC> h0 = ev_first<KC, FIXED>(L, i0, Ki0, xti0, yti0, off);
-        EvHalf<KC> h1 = ev_first<KC, FIXED>(L, i1, Ki1, xti1, yti1, off);
+        EvHalf<KC> h0 = ev_first<KC, FIXED>(L, i0, Ki0, xti0, yti0, tki0, tci0, off);
+        EvHalf<KC> h1 = ev_first<KC, FIXED>(L, i1, Ki1, xti1, yti1, tki1, tci1, off);
         GPSBB_EV_OUT(i0, h0)
         GPSBB_EV_OUT(i1, h1)
     }
     if (mask) {
         const int i0 = __builtin_ctz(mask);
         GPSBB_EV_IN(i0)
-        EvHalf<KC> h0 = ev_first<KC, FIXED>(L, i0, Ki0, xti0, yti0, off);
+        EvHalf<KC> h0 = ev_first<KC, FIXED>(L, i0, Ki0, xti0, yti0, tki0, tci0, off);
         GPSBB_EV_OUT(i0, h0)
     }
 #undef GPSBB_EV_IN
@@ -498,6 +560,13 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
     }
     for (int e = tid; e < EV_WAVES * 16 * 64; e += EV_WG)
         (&L.D[0][0][0])[e] = 0u;
+    {
+        const int l = tid & 63;
+        if (l < p.nch) { /* every wavefront's own copy of the position constants (see EvLds::tstate) */
+            L.tstate[tid >> 6][1][2 * l] = kb[l].tC0;     /* beside the code state */
+            L.tstate[tid >> 6][1][2 * l + 1] = kb[l].tK0; /* beside the carrier state */
+        }
+    }
     __syncthreads();
 #ifdef GPSBB_EV_TIMING
     const unsigned long long t_staged = wall_clock64();
@@ -532,6 +601,12 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
     const double guard_w = EV_GUARD + ((chain_lane && !(FIXED && (lane & 1))) ? kb[lane >> 1].W : 0.0);
     const double mirror_at = FIXED ? 512.0 - 0x1p-16 : 512.0; /* a falling fixed-point phase is mirrored bit by bit: (2^25 - 1 - p) / 2^16 */
     unsigned long long *n_exact = p.hazards + 2;
+    /* this wavefront's difference arrays as raw LDS addresses (see the store at the end of a tile) */
+    const uint32_t dwave = lds_addr_of(&L.D[wave][0][0]);
+    const uint32_t d_col = dwave + (uint32_t)lane * 4u;                                    /* row j of this lane's column: + 256 j */
+    const uint32_t t_wr = (dwave + (uint32_t)lane * 64u) ^ ((((uint32_t)lane >> 1) & 3u) << 4); /* piece q of this lane's 64 bytes: ^ 16 q */
+    const uint32_t t_rd = dwave + ((uint32_t)lane >> 2) * 64u + ((((uint32_t)lane & 3u) ^ (((uint32_t)lane >> 3) & 3u)) << 4); /* + 1024 k */
+    const uint32_t t_zero = dwave + (uint32_t)lane * 16u;
 
     /* chunks of EV_CHUNK consecutive tiles from a per-block counter; the next chunk is asked for while the
      * current one is worked on, and a tile's states are fetched while the previous tile is worked on */
@@ -539,7 +614,7 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
     if (lane == 0)
         base = atomicAdd(&p.tile_ctr[b], p.ev_chunk);
     base = __builtin_amdgcn_readfirstlane(base);
-    int pos = 0, buf = 0;
+    int pos = 0;
     int pending = 0; /* lane 0: the next chunk, asked for at the first tile of the current one */
     double ts_v = 0.0;
     uint32_t nav_v = 0;
@@ -551,9 +626,9 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         const int wt = base + pos;
         /* the tile's states -> this wavefront's LDS slot, its data bits -> scalar masks */
         if (chain_lane)
-            L.tstate[wave][buf][lane] = (mirror ? mirror_at - ts_v : ts_v) + guard_w; /* one rounding, half a unit of 2^-32 */
+            L.tstate[wave][0][lane] = (mirror ? mirror_at - ts_v : ts_v) + guard_w; /* one rounding, half a unit of 2^-32 */
         EvTile T;
-        T.ts = L.tstate[wave][buf];
+        T.ts = L.tstate[wave][0];
         T.tile_x = txb + wt;
         T.ntiles = ntw;
         T.dbits = (uint32_t)__ballot(nav_v & 1u);
@@ -598,55 +673,80 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
             ev_channels<3, true, FIXED>(L, wave, lane, mk[2] & dflip, kb, T, off, live_mask, acc0, n_exact, fx);
             ev_channels<4, true, FIXED>(L, wave, lane, mk[3] & dflip, kb, T, off, live_mask, acc0, n_exact, fx);
         }
-        /* ---- prefix sum over the run, back to int16 pairs, store (c:2754-2755) ---- */
+        /* ---- prefix sum over the run, back to int16 pairs (c:2754-2755) ---- */
         uint32_t o[SPT];
         uint32_t P = acc0;
-        if (DENSE && mkd != 0u) {
-            /* channels evaluated per sample: their sums per sample, on top of the prefix sums of the others */
-            uint32_t accd[SPT];
+        uint32_t accd[DENSE ? SPT : 1];
+        if (DENSE) {
 #pragma unroll
             for (int j = 0; j < SPT; j++)
                 accd[j] = 0u;
+            /* channels evaluated per sample: their sums per sample, on top of the prefix sums of the others */
             for (uint32_t m = mkd; m; m &= m - 1) {
                 const int i = __builtin_ctz(m);
                 if ((dflip >> i) & 1u)
-                    ev_dense<true>(L, wave, lane, i, kb, T, off, live_mask, P, accd, n_exact);
+                    ev_dense<true>(L, wave, lane, i, kb, T, off, live_mask, P, *reinterpret_cast<uint32_t (*)[SPT]>(&accd[0]), n_exact);
                 else
-                    ev_dense<false>(L, wave, lane, i, kb, T, off, live_mask, P, accd, n_exact);
+                    ev_dense<false>(L, wave, lane, i, kb, T, off, live_mask, P, *reinterpret_cast<uint32_t (*)[SPT]>(&accd[0]), n_exact);
             }
+        }
+        asm volatile("" ::: "memory");
 #pragma unroll
-            for (int j = 0; j < SPT; j++) {
-                if (j)
-                    P += __hip_atomic_exchange(&L.D[wave][j - 1][lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                o[j] = (P + accd[j]) ^ 0x8000u;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < SPT; j++) {
-                if (j)
-                    P += __hip_atomic_exchange(&L.D[wave][j - 1][lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                o[j] = P ^ 0x8000u; /* the bias off again: the low half is I + 2^15 in [0, 2^16), the high half Q */
-            }
+        for (int j = 0; j < SPT; j++) {
+            if (j)
+                P += lds_read_at<uint32_t>(d_col + (uint32_t)(j - 1) * 256u); /* this lane's column of the difference arrays */
+            o[j] = (DENSE ? P + accd[j] : P) ^ 0x8000u; /* the bias off again: the low half is I + 2^15 in [0, 2^16), the high half Q */
         }
 #ifdef GPSBB_SABOTAGE /* a deliberately wrong build (make broken): bench.py's parity check must refuse it (tests/test_bench_shards.py) */
         if (b == 1 && wt == 3 && lane == 5)
             o[7] ^= 1u;
 #endif
-        uint32_t *out = reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + n0;
-        if (nvalid == SPT && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) {
-            uint4 *o4 = reinterpret_cast<uint4 *>(out);
+        /* ---- store.  A lane holds 16 consecutive samples = 64 bytes, and a store instruction moves 16 bytes per lane: written
+         * straight from the registers, every instruction touches 64 different 64-byte pieces a quarter full, four times the
+         * write requests the data needs — measured, that pattern alone cost 0.27 ms of the kernel's 1.86 (tools/bound_hunt.sh:
+         * the same bytes stored 1 KB-contiguous per instruction, 1.61 ms).  So the tile is transposed on the way out, through
+         * the wavefront's own 4 KB of difference arrays — the tile's 1024 int16 pairs are exactly that big, and the arrays have
+         * just been read and have to be zeroed for the next tile anyway: every lane writes its 64 bytes as four 16-byte pieces
+         * (piece q at slot q ^ (lane / 2 & 3): conflict-free), reads back the piece of the run 16 k + lane / 4 that instruction k
+         * stores, and the region is zeroed with four 16-byte stores per lane instead of fifteen exchanges.  A wavefront's LDS
+         * operations execute in order and the region is its own: no barrier. ---- */
+        uint32_t *const tile_out = reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + (size_t)wt * TILE;
+        const bool whole = (wt + 1) * TILE <= p.nsamp && (reinterpret_cast<uintptr_t>(tile_out) & 15u) == 0; /* wave-uniform */
+        asm volatile("" ::: "memory");
+#ifdef GPSBB_X_NOSTORE
+        if (o[3] == 0x12345678u && o[9] == 0x9abcdef0u) /* (practically never) */
+#endif
+        if (__builtin_expect(whole, 1)) {
 #pragma unroll
-            for (int j = 0; j < SPT; j += 4)
-                o4[j >> 2] = make_uint4(o[j], o[j + 1], o[j + 2], o[j + 3]);
+            for (int q = 0; q < 4; q++)
+                lds_write_at<ev_u32x4>(t_wr ^ ((uint32_t)q << 4), ev_u32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]});
+            asm volatile("" ::: "memory");
+            ev_u32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                v[k] = lds_read_at<ev_u32x4>(t_rd + (uint32_t)k * 1024u);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                lds_write_at<ev_u32x4>(t_zero + (uint32_t)k * 1024u, ev_u32x4{0u, 0u, 0u, 0u});
+            ev_u32x4 *g = reinterpret_cast<ev_u32x4 *>(tile_out) + lane;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                g[k * 64] = v[k]; /* 1 KB of consecutive addresses per instruction */
         } else {
+            /* the block's last, partial tile (or a block that does not start on a 16-byte boundary): from the registers */
+#pragma unroll
+            for (int j = 1; j < SPT; j++)
+                lds_write_at<uint32_t>(d_col + (uint32_t)(j - 1) * 256u, 0u);
+            uint32_t *out = tile_out + lane * SPT;
 #pragma unroll
             for (int j = 0; j < SPT; j++)
                 if (j < nvalid)
                     out[j] = o[j];
         }
+        asm volatile("" ::: "memory");
         base = next_base;
         pos = next_pos;
-        buf ^= 1;
 #ifdef GPSBB_EV_TIMING
         n_tiles_done++;
 #endif

@@ -1,0 +1,21 @@
+#!/bin/bash
+# What is k_synth_ev's time made of?  Builds deliberately wrong variants of the kernel that take one resource out of the
+# picture each (gpsbb_events.hip.h, GPSBB_X_*) and times the synthesis kernel alone on the headline geometry, interleaved
+# with the product, on this box.  usage: tools/bound_hunt.sh [variant flags ...]   (run from the repo root on the GPU box)
+set -e
+V=${@:-"NOATOMIC NOADD NOAMP NOSMEM NOSTORE"}
+cd pluto-gps-sim_amd/csrc
+for v in $V; do
+  fl=""; for f in ${v//+/ }; do fl="$fl -DGPSBB_X_$f"; done
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -I. $fl -shared gpsbb.hip gpsbb_node.cpp -o ../libgpsbb_x$v.so &
+done
+wait
+cd ../..
+for rep in 1 2; do
+  for v in product $V; do
+    if [ "$v" = "product" ]; then unset GPSBB_PY_LIB; else export GPSBB_PY_LIB=x$v; fi
+    a=$(python tools/kbench.py --no-cpu --steps 8 --synth-only 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4f' % d['roofline']['ms_per_launch'])")
+    echo "$v alone_ms $a"
+  done
+done
+rm -f pluto-gps-sim_amd/libgpsbb_x*.so

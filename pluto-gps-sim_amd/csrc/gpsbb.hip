@@ -797,11 +797,11 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(SynthLds))) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)sizeof(EvLds))) != hipSuccess) return fail(e);
+                                 (int)sizeof(EvLdsLean))) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev_dense), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(EvLds))) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev_fixed), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)sizeof(EvLds))) != hipSuccess) return fail(e);
+                                 (int)sizeof(EvLdsLean))) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_pd<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(PdLds<true>))) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_pd<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1859,9 +1859,9 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         else if (b->ev_dense)
             hipLaunchKernelGGL(k_synth_ev_dense, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), sc, p, d_iq);
         else if (p.kph0)
-            hipLaunchKernelGGL(k_synth_ev_fixed, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), sc, p, d_iq);
+            hipLaunchKernelGGL(k_synth_ev_fixed, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLdsLean), sc, p, d_iq);
         else
-            hipLaunchKernelGGL(k_synth_ev, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), sc, p, d_iq);
+            hipLaunchKernelGGL(k_synth_ev, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLdsLean), sc, p, d_iq);
         h->last_kernel = 2;
         h->last_chain_dev = b->chain_dev && !b->chain_indep ? 1 : 0;
     } else {

@@ -519,6 +519,9 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
         /* ---- the low halves of the two sums side by side, store (c:2754-2755): sample wt*TILE + j*64 + lane ---- */
         uint32_t *out = reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + (size_t)wt * TILE + lane;
         const int left = p.nsamp - wt * TILE - lane; /* samples j*64 < left exist */
+#ifdef GPSBB_X_PD_NOSTORE /* (measurement: tools/bound_hunt.sh) */
+        if (__float_as_uint(acc[3].x) == 0x12345678u && __float_as_uint(acc[9].y) == 0x9abcdef0u)
+#endif
         if (__builtin_expect(p.nsamp - wt * TILE >= TILE, 1)) {
 #pragma unroll
             for (int j = 0; j < SPT; j++)

@@ -38,6 +38,9 @@
 #ifndef GPSBB_EVENTS_HIP_H
 #define GPSBB_EVENTS_HIP_H
 
+#include <cstddef>
+#include <type_traits>
+
 #include "gpsbb_kernels.hip.h"
 
 namespace gpsbb_impl {
@@ -92,9 +95,18 @@ constexpr int EV_ROW_DISCARD = 15;                 /* D row of changes that fall
  * path forced on every tile: the call then comes a few hundred cycles after the claim). */
 #define GPSBB_EV_SETTLE_CLAIM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-/* LDS image of one workgroup */
-struct EvLds {
-    uint32_t amp[GPSBB_MAX_CHAN][EV_AMP_STRIDE]; /* P = Q*65536 + I of table index k mod 512 at [k], k = 0 .. 511+PAD;
+/* LDS image of one workgroup.  Two shapes: the mixed kernel (k_synth_ev_dense) needs the long chip table of the channels it
+ * evaluates per sample (code steps up to 0.52 chips per sample) and takes its amplitude index modulo 512; the breakpoint
+ * kernels proper (at most one chip change per run: steps below 0.0646, chip index below 1093) spend what the short chip table
+ * saves on an amplitude table that simply goes on past 511 — 512 + 1040 * 4 / 15.5 entries cover a tile's unwrapped model —
+ * so that the table index needs no masking instruction (see ev_first). */
+constexpr int EV_CHIP_LEN_SHORT = 1104;
+constexpr int EV_AMP_STRIDE_LONG = 512 + 272 + EV_AMP_PAD; /* 788 */
+template <int AMP_STRIDE, int CHIP_LEN>
+struct EvLdsT {
+    static constexpr int AMP = AMP_STRIDE, CHIPS = CHIP_LEN;
+    static constexpr bool UNMASKED = AMP_STRIDE >= EV_AMP_STRIDE_LONG; /* the amplitude index is not reduced modulo 512 */
+    uint32_t amp[GPSBB_MAX_CHAN][AMP_STRIDE];    /* P = Q*65536 + I of table index k mod 512 at [k];
                                                     channels with a falling carrier: of index 511 - k */
     uint32_t D[EV_WAVES][16][64];                /* difference arrays: row j-1 holds the change at sample j of the lane's
                                                     run (row 15 = discard), one column per lane */
@@ -110,9 +122,17 @@ struct EvLds {
                                                     into a vector pair first (a v_mov_b64 per fma); out of LDS — a second
                                                     broadcast ds_read_b128 off the same address register — it arrives where
                                                     the fma wants it */
-    uint16_t chip2[GPSBB_MAX_CHAN][EV_CHIP_LEN]; /* low byte: 0 where codeCA of chip c mod 1023 is +1, 0xff where -1;
+    uint16_t chip2[GPSBB_MAX_CHAN][CHIP_LEN];    /* low byte: 0 where codeCA of chip c mod 1023 is +1, 0xff where -1;
                                                     high byte: the same for chip c+1 */
 };
+typedef EvLdsT<EV_AMP_STRIDE, EV_CHIP_LEN> EvLds;                   /* k_synth_ev_dense */
+#ifdef GPSBB_X_MASKED
+typedef EvLdsT<EV_AMP_STRIDE, EV_CHIP_LEN> EvLdsLean;
+#else
+typedef EvLdsT<EV_AMP_STRIDE_LONG, EV_CHIP_LEN_SHORT> EvLdsLean;    /* k_synth_ev, k_synth_ev_fixed */
+#endif
+static_assert(sizeof(EvLds) <= 160 * 1024 && sizeof(EvLdsLean) <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
+static_assert(offsetof(EvLdsLean, D) < 65536 && offsetof(EvLds, D) < 65536, "the difference arrays are addressed with a 16-bit offset");
 
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 {
@@ -125,14 +145,9 @@ __device__ __forceinline__ T lds_read_at(uint32_t a)
 }
 
 /* Measurement builds (tools/bound_hunt.sh): deliberately WRONG variants of k_synth_ev that take one resource out of the
- * picture each, to see what the kernel's time is made of.  Never defined in the product. */
-#if defined(GPSBB_X_NOATOMIC)
-#define GPSBB_EV_DADD(ptr, v) (*(ptr) = (v))
-#elif defined(GPSBB_X_NOADD)
-#define GPSBB_EV_DADD(ptr, v) ((void)(v))
-#else
-#define GPSBB_EV_DADD(ptr, v) __hip_atomic_fetch_add((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#endif
+ * picture each (GPSBB_X_NOADD / NOATOMIC / DOUBLEADD: the differences; NOAMP: the table reads; NOSMEM: the scalar loads;
+ * NOSTORE / COALESCED: the stores; MOREVALU: more arithmetic), to see what the kernel's time is made of.  Never defined in
+ * the product. */
 
 typedef uint32_t ev_u32x4 __attribute__((ext_vector_type(4))); /* 16 bytes: one ds_read_b128 / ds_write_b128 / global_store_dwordx4 */
 
@@ -140,6 +155,43 @@ template <class T>
 __device__ __forceinline__ void lds_write_at(uint32_t a, T v)
 {
     *(__attribute__((address_space(3))) T *)(uintptr_t)a = v;
+}
+
+constexpr uint32_t EV_SAT_HI_C = 0x4130000fu; /* the high word of a position clamped to 15.5 (row 15: discard) */
+#define EV_SAT_HI EV_SAT_HI_C
+
+/*
+ * One difference into this lane's column of the wavefront's arrays, at the row a position's high word names.  The arrays'
+ * byte offset inside the 64 KB they occupy is  wavefront * 4096 + row * 256 + lane * 4: byte 0 is the lane, byte 1 is
+ * (wavefront << 4) + row.  `drow` holds that offset with bytes 0, 2, 3 constant; one SDWA add puts
+ * (wavefront << 4) + (low byte of the position's high word) into byte 1 — an address in ONE instruction, where the
+ * compiler's own code masks the row out (v_and) and shifts it in (v_lshl_add).  The row is below 16: positions are
+ * clamped to 15.5.  The arrays themselves sit at a compile-time offset of the image (the instruction's offset field).
+ */
+template <class LDS>
+__device__ __forceinline__ void ev_d_add(uint32_t &drow, int wave, uint32_t pos_hi, uint32_t v)
+{
+#if defined(GPSBB_X_NOADD)
+    (void)v;
+#else
+    /* volatile, no memory clobber: the differences keep their order among themselves and stay before the fence the
+     * tile's epilogue starts with, but the compiler may still issue the next channel's table reads ahead of them */
+    asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_0\n\t"
+#if defined(GPSBB_X_NOATOMIC)
+                 "ds_write_b32 %0, %3 offset:%4"
+#else
+                 "ds_add_u32 %0, %3 offset:%4"
+#endif
+#if defined(GPSBB_X_DOUBLEADD)
+                 "\n\tds_add_u32 %0, %5 offset:%4"
+#endif
+                 : "+v"(drow)
+                 : "s"(wave << 4), "v"(pos_hi), "v"(v), "n"(offsetof(LDS, D))
+#if defined(GPSBB_X_DOUBLEADD)
+                   , "v"(0u)
+#endif
+                 );
+#endif
 }
 
 /* (x ^ m) - m: x where m = 0, -x where m = -1 */
@@ -161,8 +213,8 @@ __device__ __forceinline__ T scalar_load(const T *p)
  * reference does (c:2697-2746) and add the differences of its contributions.  Returns the contribution at
  * the run's first sample.
  */
-template <bool FIXED>
-__device__ __forceinline__ uint32_t ev_exact_run_body(EvLds &L, int wave, int lane, int i, const EvConst *kbi, const double *tile_x,
+template <bool FIXED, class LDS>
+__device__ __forceinline__ uint32_t ev_exact_run_body(LDS &L, int wave, int lane, int i, const EvConst *kbi, const double *tile_x,
                                                       int ntiles, uint32_t nb, int n_off, uint32_t fx_phase, int32_t fx_step)
 {
     constexpr bool fixed = FIXED;
@@ -207,13 +259,15 @@ struct EvFixed {
     int n0;
 };
 
-__device__ __noinline__ uint32_t ev_exact_run(EvLds &L, int wave, int lane, int i, const EvConst *kbi, const double *tile_x,
+template <class LDS>
+__device__ __noinline__ uint32_t ev_exact_run(LDS &L, int wave, int lane, int i, const EvConst *kbi, const double *tile_x,
                                               int ntiles, uint32_t nb, int n_off)
 {
     return ev_exact_run_body<false>(L, wave, lane, i, kbi, tile_x, ntiles, nb, n_off, 0u, 0);
 }
 /* ... with the fixed-point carrier: the accumulator at the tile's first sample and its step take the carrier NCO's place */
-__device__ __noinline__ uint32_t ev_exact_run_fixed(EvLds &L, int wave, int lane, int i, const EvConst *kbi, const double *tile_x,
+template <class LDS>
+__device__ __noinline__ uint32_t ev_exact_run_fixed(LDS &L, int wave, int lane, int i, const EvConst *kbi, const double *tile_x,
                                                     int ntiles, uint32_t nb, int n_off, uint32_t fx_phase, int32_t fx_step)
 {
     return ev_exact_run_body<true>(L, wave, lane, i, kbi, tile_x, ntiles, nb, n_off, fx_phase, fx_step);
@@ -225,10 +279,12 @@ struct EvK {
     uint32_t danger;
     uint32_t chip_base; /* LDS address of the channel's chip table, minus what the exponent bits of a guard-format high word
                            contribute when it is shifted into a byte offset (see ev_first) */
+    uint32_t amp_base;  /* ... of its amplitude table, likewise (EvLdsLean) */
 };
 /* the high word of a double in [2^20, 2^21) is 0x41300000 + its integer part */
 constexpr uint32_t EV_GUARD_HI = 0x41300000u;
-__device__ __forceinline__ EvK ev_load_k(const EvLds &L, const EvConst *kb, int i)
+template <class LDS>
+__device__ __forceinline__ EvK ev_load_k(const LDS &L, const EvConst *kb, int i)
 {
     EvK k;
     k.S = scalar_load(&kb[i].S);
@@ -237,6 +293,7 @@ __device__ __forceinline__ EvK ev_load_k(const EvLds &L, const EvConst *kb, int 
     k.rsc = scalar_load(&kb[i].rsc);
     k.danger = scalar_load(&kb[i].danger);
     k.chip_base = lds_addr_of(&L.chip2[i][0]) - (EV_GUARD_HI << 1);
+    k.amp_base = lds_addr_of(&L.amp[i][0]) - (EV_GUARD_HI << 2);
     return k;
 }
 
@@ -250,8 +307,9 @@ __device__ __forceinline__ EvK ev_load_k(const EvLds &L, const EvConst *kb, int 
  */
 template <int KC>
 struct EvHalf {
-    int jk[KC]; /* row of D (= sample - 1) of the k-th index change, 15 = not in this run */
-    int jc;     /* ... of the chip change */
+    uint32_t hk[KC]; /* the k-th index change as the HIGH WORD of its position in guard format (clamped to 15.5): the low byte
+                        is the row of D (= sample - 1), 15 = not in this run; high words of one binade compare like the positions */
+    uint32_t hc;     /* ... of the chip change */
     int c0;     /* chip of the first sample, not reduced modulo 1023 */
     unsigned long long um; /* lanes that cannot rule out a disagreement between the model and the reference (wave mask:
                               the comparisons land in scalar registers and are combined there) */
@@ -264,8 +322,8 @@ struct EvHalf {
  * The k-th index change lies (1 - fraction + k) / step samples on; with one half of 2^-16 taken off the numerator
  * (EvConst::tK0) that is (2a - 1) / (2b) for integers a, b = |step| < 2^15 — never an integer and at least 1 / (2b) away
  * from one, against the 2^-32 this format resolves — so floor() is right even where a change falls exactly on a sample. */
-template <int KC, bool FIXED>
-__device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK &K, double xt, double yt, double tK0, double tC0, double off)
+template <int KC, bool FIXED, class LDS>
+__device__ __forceinline__ EvHalf<KC> ev_first(const LDS &L, int i, const EvK &K, double xt, double yt, double tK0, double tC0, double off)
 {
     EvHalf<KC> h;
     const double sat = 15.5 + EV_GUARD; /* a change past the run's last sample: row 15, fraction one half */
@@ -280,24 +338,37 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK 
         const double tq = fmin(t, sat);
         if (!FIXED)
             m = min(m, (uint32_t)__double2loint(tq));
-        h.jk[k] = __double2hiint(tq) & 15; /* the change shows at sample floor + 1: rows 0..14, or 15 */
+        h.hk[k] = (uint32_t)__double2hiint(tq); /* the change shows at sample floor + 1: rows 0..14, or 15 */
         t += K.rS;
     }
-    const uint32_t *ampi = &L.amp[i][it0];
+    if (LDS::UNMASKED) {
+        /* the table goes on past 511: the entry's address straight from the high word, like the chip pair's below */
+        uint32_t amp_at;
+        asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(amp_at) : "v"(__double2hiint(y0)), "s"(K.amp_base));
 #pragma unroll
-    for (int k = 0; k <= KC; k++)
+        for (int k = 0; k <= KC; k++)
 #ifdef GPSBB_X_NOAMP
-        h.A[k] = (uint32_t)(it0 + k);
+            h.A[k] = amp_at + k;
 #else
-        h.A[k] = ampi[k];
+            h.A[k] = lds_read_at<uint32_t>(amp_at + 4u * (uint32_t)k);
 #endif
+    } else {
+        const uint32_t *ampi = &L.amp[i][it0];
+#pragma unroll
+        for (int k = 0; k <= KC; k++)
+#ifdef GPSBB_X_NOAMP
+            h.A[k] = (uint32_t)(it0 + k);
+#else
+            h.A[k] = ampi[k];
+#endif
+    }
     /* ---- code: chip of the first sample and the sample at which it changes ---- */
     const double x0 = __fma_rn(off, K.sc, xt);
     const double frc = __builtin_amdgcn_fract(x0);
     h.c0 = __double2hiint(x0) & 2047;          /* (only the tiles in which the data bit changes look at it) */
     const double tc = fmin(__fma_rn(-frc, K.rsc, tC0), sat);
     m = min(m, min((uint32_t)__double2loint(x0), (uint32_t)__double2loint(tc)));
-    h.jc = __double2hiint(tc) & 15;
+    h.hc = (uint32_t)__double2hiint(tc);
     /* the chip pair's address straight from the high word: shifted left by one its integer part is the byte offset and its
      * exponent bits a constant that the channel's base already has taken off — no masking instruction */
     uint32_t chip_at;
@@ -308,6 +379,15 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK 
     h.ch2 = lds_read_at<uint16_t>(chip_at);
 #endif
     /* lanes that cannot rule out a disagreement between the model and the reference: one comparison for everything tested */
+#ifdef GPSBB_X_MOREVALU /* eight more f64 operations per channel-run that the compiler cannot drop (about +20 % VALU) */
+    {
+        double z = y0;
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            asm volatile("v_add_f64 %0, %0, %1" : "+v"(z) : "v"(x0));
+        m = min(m, (uint32_t)__double2loint(z) | 0x80000000u);
+    }
+#endif
     h.um = __builtin_amdgcn_uicmp(m, K.danger, 36 /* ult */);
     return h;
 }
@@ -317,8 +397,8 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const EvLds &L, int i, const EvK 
  * data bit in force at the tile start / after the next code roll-over as masks (0 = +1, -1 = -1; wave-uniform);
  * DF: they differ, so lanes past the roll-over (chip index >= 1023) take the other one.
  */
-template <int KC, bool DF, bool FIXED>
-__device__ __forceinline__ void ev_second(EvLds &L, int wave, int lane, int i, EvHalf<KC> &h, uint32_t db, uint32_t db_next,
+template <int KC, bool DF, bool FIXED, class LDS>
+__device__ __forceinline__ void ev_second(LDS &L, uint32_t &drow, int wave, int lane, int i, EvHalf<KC> &h, uint32_t db, uint32_t db_next,
                                           bool always_exact, unsigned long long live_mask, const EvConst *kb, const double *tile_x,
                                           int ntiles, uint32_t nb, double off, uint32_t &acc0, unsigned long long *n_exact,
                                           const EvFixed &fx)
@@ -332,7 +412,7 @@ __device__ __forceinline__ void ev_second(EvLds &L, int wave, int lane, int i, E
         m0 = ma ^ db;
         m1 = mb ^ db;
     }
-    int jc = m0 == m1 ? EV_ROW_DISCARD : h.jc; /* equal neighbours: nothing changes at the chip boundary */
+    uint32_t hc = m0 == m1 ? EV_SAT_HI : h.hc; /* equal neighbours: nothing changes at the chip boundary */
 
     /* ---- rare: this lane cannot rule out that the model and the reference disagree ---- */
     const unsigned long long um = (always_exact ? ~0ull : h.um) & live_mask;
@@ -342,8 +422,8 @@ __device__ __forceinline__ void ev_second(EvLds &L, int wave, int lane, int i, E
             /* its fast-path contribution becomes nothing ... */
 #pragma unroll
             for (int k = 0; k < KC; k++)
-                h.jk[k] = EV_ROW_DISCARD;
-            jc = EV_ROW_DISCARD;
+                h.hk[k] = EV_SAT_HI;
+            hc = EV_SAT_HI;
             h.A[0] = 0;
             /* ... and the exact one takes its place */
             if (FIXED) /* the accumulator at the tile's first sample */
@@ -364,14 +444,22 @@ __device__ __forceinline__ void ev_second(EvLds &L, int wave, int lane, int i, E
     uint32_t Ax = h.A[KC];
 #pragma unroll
     for (int k = KC - 1; k >= 0; k--) {
-        const bool before = h.jk[k] < jc; /* the index change comes before the chip change */
+        const bool before = h.hk[k] < hc; /* the index change comes before the chip change */
         const uint32_t mk = before ? m0 : m1;
         const uint32_t dk = signed_by(h.A[k + 1] - h.A[k], mk);
-        GPSBB_EV_DADD(&L.D[wave][h.jk[k]][lane], dk);
+#ifdef GPSBB_X_NOSDWA
+        __hip_atomic_fetch_add(&L.D[wave][h.hk[k] & 15u][lane], dk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        ev_d_add<LDS>(drow, wave, h.hk[k], dk);
+#endif
         Ax = before ? Ax : h.A[k]; /* amplitude in force just before the chip change */
     }
     /* the chip change flips the sign: -s0*A -> s1*A = 2*s1*A more */
-    GPSBB_EV_DADD(&L.D[wave][jc][lane], signed_by(Ax << 1, m1));
+#ifdef GPSBB_X_NOSDWA
+    __hip_atomic_fetch_add(&L.D[wave][hc & 15u][lane], signed_by(Ax << 1, m1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    ev_d_add<LDS>(drow, wave, hc, signed_by(Ax << 1, m1));
+#endif
 }
 
 /* what a wavefront knows about the tile it is working on */
@@ -391,8 +479,8 @@ struct EvTile {
  * integer, else the lane's run is recomputed exactly as on the other path — and accumulated per sample in registers
  * (accd), which the prefix sum of the difference arrays is added to at the end.  No rows, no NCO stepping.
  */
-template <bool DF>
-__device__ __forceinline__ void ev_dense(EvLds &L, int wave, int lane, int i, const EvConst *kb, const EvTile &T, double off,
+template <bool DF, class LDS>
+__device__ __forceinline__ void ev_dense(LDS &L, int wave, int lane, int i, const EvConst *kb, const EvTile &T, double off,
                                          unsigned long long live_mask, uint32_t &acc0, uint32_t (&accd)[SPT],
                                          unsigned long long *n_exact)
 {
@@ -433,8 +521,8 @@ __device__ __forceinline__ void ev_dense(EvLds &L, int wave, int lane, int i, co
 
 /* the channels of `mask` (bit i = channel i), all with KC breakpoints; two at a time, so that one channel's
  * arithmetic covers the other's LDS latency */
-template <int KC, bool DF, bool FIXED>
-__device__ __forceinline__ void ev_channels(EvLds &L, int wave, int lane, uint32_t mask, const EvConst *kb, const EvTile &T,
+template <int KC, bool DF, bool FIXED, class LDS>
+__device__ __forceinline__ void ev_channels(LDS &L, uint32_t &drow, int wave, int lane, uint32_t mask, const EvConst *kb, const EvTile &T,
                                             double off, unsigned long long live_mask, uint32_t &acc0, unsigned long long *n_exact,
                                             const EvFixed &fx)
 {
@@ -451,7 +539,7 @@ __device__ __forceinline__ void ev_channels(EvLds &L, int wave, int lane, uint32
     {                                                                                                                  \
         const uint32_t db_ = 0u - ((T.dbits >> i) & 1u), dn_ = 0u - ((T.dnext >> i) & 1u);                             \
         const uint32_t nb_ = ((T.dbits >> i) & 1u) | (((T.dnext >> i) & 1u) << 1);                                     \
-        ev_second<KC, DF, FIXED>(L, wave, lane, i, h, db_, dn_, ((T.exact_mask >> i) & 1u) != 0, live_mask, kb, T.tile_x, \
+        ev_second<KC, DF, FIXED>(L, drow, wave, lane, i, h, db_, dn_, ((T.exact_mask >> i) & 1u) != 0, live_mask, kb, T.tile_x, \
                           T.ntiles, nb_,                                                                               \
                           off, acc0, n_exact, fx);                                                                     \
     }
@@ -485,9 +573,15 @@ template <bool DENSE, bool FIXED = false>
 __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__restrict__ iq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    EvLds &L = *reinterpret_cast<EvLds *>(smem_raw);
+    typedef typename std::conditional<DENSE, EvLds, EvLdsLean>::type LDS;
+    LDS &L = *reinterpret_cast<LDS *>(smem_raw);
 
     const int tid = threadIdx.x;
+    if (lds_addr_of(smem_raw) != 0u) { /* ev_d_add addresses the image from LDS address 0 (the kernel has no static LDS) */
+        if (tid == 0)
+            atomicOr(p.status, 1u);
+        return;
+    }
     /* The block is the FAST grid dimension: the first workgroups dispatched are one per block, on as many
      * CUs as there are; the workgroups with blockIdx.y > 0 come after them and join blocks that are still
      * being worked on (tiles are handed out from a per-block counter), or leave at once if theirs is done.
@@ -519,9 +613,9 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         const double g = cb[i].gain;
         /* fully unrolled: all table loads of a wavefront are in flight at once (a workgroup that joins a block late
          * idles its CU for as long as this staging takes) */
-        int32_t tc[(EV_AMP_STRIDE + 63) / 64], ts[(EV_AMP_STRIDE + 63) / 64];
+        int32_t tc[(LDS::AMP + 63) / 64], ts[(LDS::AMP + 63) / 64];
 #pragma unroll
-        for (int j = 0; j < (EV_AMP_STRIDE + 63) / 64; j++) {
+        for (int j = 0; j < (LDS::AMP + 63) / 64; j++) {
             const int e = (tid & 63) + 64 * j;
             const int k = down ? 511 - (e & 511) : (e & 511);
             tc[j] = p.tabs[k];
@@ -530,7 +624,7 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         /* the PRN's 1023 chips are 32 words: one per lane, fetched once, handed round with ds_bpermute */
         const uint32_t my_word = p.ca_bits[(prn > 0 ? prn : 0) * 32 + (tid & 31)];
 #pragma unroll
-        for (int j = 0; j < (EV_AMP_STRIDE + 63) / 64; j++) {
+        for (int j = 0; j < (LDS::AMP + 63) / 64; j++) {
             const int e = (tid & 63) + 64 * j;
             uint32_t v = 0;
             if (prn > 0) {
@@ -539,11 +633,11 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
                 const int qp = (int)mul_rn((double)ts[j], g);
                 v = ((uint32_t)qp << 16) + (uint32_t)ip;
             }
-            if (e < EV_AMP_STRIDE)
+            if (e < LDS::AMP)
                 L.amp[i][e] = v;
         }
 #pragma unroll 4
-        for (int j = 0; j < (EV_CHIP_LEN + 63) / 64; j++) {
+        for (int j = 0; j < (LDS::CHIPS + 63) / 64; j++) {
             const int c = (tid & 63) + 64 * j;
             const int ca = c >= GPSBB_CA_LEN ? c - GPSBB_CA_LEN : c; /* c < 2 * 1023 */
             const int cb1 = c + 1 >= GPSBB_CA_LEN ? c + 1 - GPSBB_CA_LEN : c + 1;
@@ -554,7 +648,7 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
                 const uint32_t b1 = (w1 >> (cb1 & 31)) & 1u;
                 v = (b0 ? 0x00u : 0xffu) | (b1 ? 0x0000u : 0xff00u);
             }
-            if (c < EV_CHIP_LEN)
+            if (c < LDS::CHIPS)
                 L.chip2[i][c] = (uint16_t)v;
         }
     }
@@ -574,7 +668,7 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
 #endif
 
     /* ---- from here on every wavefront works alone ---- */
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int ntw = p.ntiles;
     const int nch2 = 2 * p.nch;
     /* channels by the number of carrier breakpoints a run can hold (bit i = channel i) */
@@ -607,6 +701,7 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
     const uint32_t t_wr = (dwave + (uint32_t)lane * 64u) ^ ((((uint32_t)lane >> 1) & 3u) << 4); /* piece q of this lane's 64 bytes: ^ 16 q */
     const uint32_t t_rd = dwave + ((uint32_t)lane >> 2) * 64u + ((((uint32_t)lane & 3u) ^ (((uint32_t)lane >> 3) & 3u)) << 4); /* + 1024 k */
     const uint32_t t_zero = dwave + (uint32_t)lane * 16u;
+    uint32_t drow = (uint32_t)lane * 4u; /* ev_d_add's address register: byte 0 = this lane's column, byte 1 rewritten per difference */
 
     /* chunks of EV_CHUNK consecutive tiles from a per-block counter; the next chunk is asked for while the
      * current one is worked on, and a tile's states are fetched while the previous tile is worked on */
@@ -663,15 +758,15 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         const bool lane_live = nvalid > 0;
         const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(lane_live);
         uint32_t acc0 = 0x8000u; /* the I sum travels biased by 2^15: never negative, so the low half never borrows from the Q sum */
-        ev_channels<1, false, FIXED>(L, wave, lane, mk[0] & ~dflip, kb, T, off, live_mask, acc0, n_exact, fx);
-        ev_channels<2, false, FIXED>(L, wave, lane, mk[1] & ~dflip, kb, T, off, live_mask, acc0, n_exact, fx);
+        ev_channels<1, false, FIXED>(L, drow, wave, lane, mk[0] & ~dflip, kb, T, off, live_mask, acc0, n_exact, fx);
+        ev_channels<2, false, FIXED>(L, drow, wave, lane, mk[1] & ~dflip, kb, T, off, live_mask, acc0, n_exact, fx);
         if (__builtin_expect((mk[2] | mk[3] | dflip) != 0u, 0)) {
-            ev_channels<3, false, FIXED>(L, wave, lane, mk[2] & ~dflip, kb, T, off, live_mask, acc0, n_exact, fx);
-            ev_channels<4, false, FIXED>(L, wave, lane, mk[3] & ~dflip, kb, T, off, live_mask, acc0, n_exact, fx);
-            ev_channels<1, true, FIXED>(L, wave, lane, mk[0] & dflip, kb, T, off, live_mask, acc0, n_exact, fx);
-            ev_channels<2, true, FIXED>(L, wave, lane, mk[1] & dflip, kb, T, off, live_mask, acc0, n_exact, fx);
-            ev_channels<3, true, FIXED>(L, wave, lane, mk[2] & dflip, kb, T, off, live_mask, acc0, n_exact, fx);
-            ev_channels<4, true, FIXED>(L, wave, lane, mk[3] & dflip, kb, T, off, live_mask, acc0, n_exact, fx);
+            ev_channels<3, false, FIXED>(L, drow, wave, lane, mk[2] & ~dflip, kb, T, off, live_mask, acc0, n_exact, fx);
+            ev_channels<4, false, FIXED>(L, drow, wave, lane, mk[3] & ~dflip, kb, T, off, live_mask, acc0, n_exact, fx);
+            ev_channels<1, true, FIXED>(L, drow, wave, lane, mk[0] & dflip, kb, T, off, live_mask, acc0, n_exact, fx);
+            ev_channels<2, true, FIXED>(L, drow, wave, lane, mk[1] & dflip, kb, T, off, live_mask, acc0, n_exact, fx);
+            ev_channels<3, true, FIXED>(L, drow, wave, lane, mk[2] & dflip, kb, T, off, live_mask, acc0, n_exact, fx);
+            ev_channels<4, true, FIXED>(L, drow, wave, lane, mk[3] & dflip, kb, T, off, live_mask, acc0, n_exact, fx);
         }
         /* ---- prefix sum over the run, back to int16 pairs (c:2754-2755) ---- */
         uint32_t o[SPT];

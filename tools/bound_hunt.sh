@@ -1,7 +1,8 @@
 #!/bin/bash
 # What is k_synth_ev's time made of?  Builds deliberately wrong variants of the kernel that take one resource out of the
 # picture each (gpsbb_events.hip.h, GPSBB_X_*) and times the synthesis kernel alone on the headline geometry, interleaved
-# with the product, on this box.  usage: tools/bound_hunt.sh [variant flags ...]   (run from the repo root on the GPU box)
+# with the product, on this box.  usage: [KARGS="--fs 2.6e6 --nsamp 300000 --nch 12 --blocks 1000"] tools/bound_hunt.sh [variant flags ...]
+# (run from the repo root on the GPU box; KARGS: kbench.py's geometry options, e.g. the reference's own for k_synth_pd)
 set -e
 V=${@:-"NOATOMIC NOADD NOAMP NOSMEM NOSTORE"}
 cd pluto-gps-sim_amd/csrc
@@ -14,7 +15,7 @@ cd ../..
 for rep in 1 2; do
   for v in product $V; do
     if [ "$v" = "product" ]; then unset GPSBB_PY_LIB; else export GPSBB_PY_LIB=x$v; fi
-    a=$(python tools/kbench.py --no-cpu --steps 8 --synth-only 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4f' % d['roofline']['ms_per_launch'])")
+    a=$(python tools/kbench.py --no-cpu --steps 8 --synth-only $KARGS 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4f' % d['roofline']['ms_per_launch'])")
     echo "$v alone_ms $a"
   done
 done

@@ -534,6 +534,7 @@ struct gpsbb_batch {
     DevBuf<unsigned long long> d_fix_end; /* k_chain_fix_par: the hand-off between its chunks (BatchDev::fix_end) */
     DevBuf<int> d_fix_flag;
     int fix_epoch = 0, fix_chunks = 0, fix_wg = FIXP_WG_BATCH;
+    bool fix_flags_zeroed = false; /* d_fix_flag has been cleared since it was last (re)allocated */
     bool chain_indep = false;    /* the chain machinery runs on a batch whose blocks are independent: only the segments of a block are chained */
     bool chain_model = false;    /* pass B starts from the host's drift model of the carrier (no pass A, no k_chain_prefix) */
     bool chain_fix_seq = false;  /* k_chain_fix (blocks in order) instead of k_chain_fix_par: GPSBB_OPT_CHAIN_WHERE 2 */
@@ -642,10 +643,11 @@ extern "C" int gpsbb_get_info(gpsbb_t *h, int what, uint64_t *out)
     case GPSBB_INFO_EXACT_RUNS:
     case GPSBB_INFO_CHAIN_FALLBACKS:
     case GPSBB_INFO_CHAIN_TIES:
-    case GPSBB_INFO_CHAIN_REPAIRS: {
+    case GPSBB_INFO_CHAIN_REPAIRS:
+    case GPSBB_INFO_TILES_RENDERED: {
         HIPCHK(h, hipSetDevice(h->device));
         unsigned long long v = 0;
-        HIPCHK(h, hipMemcpy(&v, h->d_hz + (what == GPSBB_INFO_EXACT_RUNS ? 2 : (what == GPSBB_INFO_CHAIN_FALLBACKS ? 4 : (what == GPSBB_INFO_CHAIN_TIES ? 5 : 6))), 8,
+        HIPCHK(h, hipMemcpy(&v, h->d_hz + (what == GPSBB_INFO_EXACT_RUNS ? 2 : (what == GPSBB_INFO_CHAIN_FALLBACKS ? 4 : (what == GPSBB_INFO_CHAIN_TIES ? 5 : (what == GPSBB_INFO_TILES_RENDERED ? 7 : 6)))), 8,
                             hipMemcpyDeviceToHost));
         *out = v;
         return GPSBB_OK;
@@ -1147,11 +1149,15 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
             b->fix_chunks = (nblocks * b->nseg + b->fix_wg - 1) / b->fix_wg;
             /* one set of flags per table set: runs of a resident batch overlap, each on its own table set */
             const size_t nf = (size_t)NSETS * GPSBB_MAX_CHAN * b->fix_chunks;
-            if (nf > b->d_fix_flag.cap) {
+            if (nf > b->d_fix_flag.cap || b->d_fix_end.cap < b->d_fix_flag.cap || !b->fix_flags_zeroed) {
+                /* (all three steps or none: a set-up that failed half-way must not leave flags that were never zeroed, or no
+                 * buffer for the end phases, behind a capacity that says "nothing to do") */
+                b->fix_flags_zeroed = false;
                 HIPCHK(h, (hipError_t)b->d_fix_flag.reserve(nf));
                 HIPCHK(h, (hipError_t)b->d_fix_end.reserve(b->d_fix_flag.cap));
                 HIPCHK(h, hipMemsetAsync(b->d_fix_flag.p, 0, b->d_fix_flag.cap * sizeof(int), upload_stream));
                 b->fix_epoch = 0;
+                b->fix_flags_zeroed = true;
             }
         }
         HIPCHK(h, stage_upload(b, b->d_cd.p, b->h_cd.data(), nvbc * sizeof(ChainDesc), upload_stream));
@@ -2625,8 +2631,10 @@ struct ChainOnly {
     DevBuf<double> d_start0;
     DevBuf<ChainAux> d_aux;
     ChainCarryDev *d_carry = nullptr;
+    uint32_t *d_status = nullptr; /* a self-check word of its own: the handle's may belong to a push still in flight */
     DevBuf<unsigned long long> d_fix_end;
     DevBuf<int> d_fix_flag;
+    bool fix_flags_zeroed = false;
     int fix_epoch = 0;
     std::vector<ChainDesc> h_cd;
     std::vector<double> h_start0;
@@ -2645,6 +2653,8 @@ static void chain_only_free(gpsbb *h)
     c->d_fix_flag.release();
     if (c->d_carry)
         (void)hipFree(c->d_carry);
+    if (c->d_status)
+        (void)hipFree(c->d_status);
     delete c;
     h->chain_only = nullptr;
 }
@@ -2663,7 +2673,10 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
     ChainOnly *c = h->chain_only;
     if (!c->d_carry)
         HIPCHK(h, hipMalloc((void **)&c->d_carry, sizeof(ChainCarryDev)));
+    if (!c->d_status)
+        HIPCHK(h, hipMalloc((void **)&c->d_status, 4));
     HIPCHK(h, hipMemsetAsync(c->d_carry, 0, sizeof(ChainCarryDev), h->s_seed));
+    HIPCHK(h, hipMemsetAsync(c->d_status, 0, 4, h->s_seed));
     /* what the chain reads of a descriptor, and the rough start phases (plain double arithmetic; pass A takes it from
      * there): one host thread per channel, the blocks in order */
     const size_t nbc_all = (size_t)nblocks * nch;
@@ -2729,11 +2742,13 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
         const int fix_chunks = (nb + FIXP_WG_ALONE - 1) / FIXP_WG_ALONE;
         {
             const size_t nf = (size_t)GPSBB_MAX_CHAN * ((CHAIN_ONLY_BLOCKS + FIXP_WG_ALONE - 1) / FIXP_WG_ALONE);
-            if (nf > c->d_fix_flag.cap) {
+            if (nf > c->d_fix_flag.cap || c->d_fix_end.cap < c->d_fix_flag.cap || !c->fix_flags_zeroed) {
+                c->fix_flags_zeroed = false;
                 HIPCHK(h, (hipError_t)c->d_fix_flag.reserve(nf));
                 HIPCHK(h, (hipError_t)c->d_fix_end.reserve(c->d_fix_flag.cap));
                 HIPCHK(h, hipMemsetAsync(c->d_fix_flag.p, 0, c->d_fix_flag.cap * sizeof(int), ss));
                 c->fix_epoch = 0;
+                c->fix_flags_zeroed = true;
             }
         }
         HIPCHK(h, hipMemcpyAsync(c->d_cd.p, c->h_cd.data() + k0, nbc * sizeof(ChainDesc), hipMemcpyHostToDevice, ss));
@@ -2746,7 +2761,7 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
         p.ntiles = (nsamp + TILE - 1) / TILE;
         p.delt = delt;
         p.flags = GPSBB_CHAIN_CARRIER;
-        p.status = h->d_status;
+        p.status = c->d_status;
         p.hazards = h->d_hz;
         p.chain_dev = 1;
         p.chain_starts = 1;
@@ -2794,12 +2809,8 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
     }
     h->last_chain_dev = 1;
     uint32_t st = 0;
-    HIPCHK(h, hipMemcpy(&st, h->d_status, 4, hipMemcpyDeviceToHost));
-    if (st) {
-        HIPCHK(h, hipMemset(h->d_status, 0, 4));
-        return GPSBB_E_INTERNAL;
-    }
-    return GPSBB_OK;
+    HIPCHK(h, hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
+    return st ? GPSBB_E_INTERNAL : GPSBB_OK;
 }
 
 #ifdef GPSBB_EXPERIMENTS

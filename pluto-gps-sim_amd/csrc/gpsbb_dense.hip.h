@@ -438,6 +438,7 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     base = __builtin_amdgcn_readfirstlane(base);
     int pos = 0, buf = 0;
     int pending = 0;
+    unsigned tiles_rendered = 0;
     double ts_v = 0.0;
     uint32_t nav_v = 0;
     if (base < ntw) {
@@ -535,7 +536,10 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
         base = next_base;
         pos = next_pos;
         buf ^= 1;
+        tiles_rendered++;
     }
+    if (lane == 0 && tiles_rendered)
+        atomicAdd(p.hazards + 7, (unsigned long long)tiles_rendered); /* see synth_ev_body */
 }
 
 } /* namespace gpsbb_impl */

@@ -526,6 +526,14 @@ __device__ __forceinline__ void ev_channels(LDS &L, uint32_t &drow, int wave, in
                                             double off, unsigned long long live_mask, uint32_t &acc0, unsigned long long *n_exact,
                                             const EvFixed &fx)
 {
+#ifdef GPSBB_X_NOTSTATE /* (measurement: the tile states and position constants out of thin air instead of LDS) */
+#define GPSBB_EV_STATES(i)                                                                                             \
+    const double xt##i = off * 0.25 + 0x1p+20, yt##i = off * 0.125 + 0x1p+20, tc##i = 0x1p+20 + 3.0, tk##i = 0x1p+20 + 5.0;
+#else
+#define GPSBB_EV_STATES(i)                                                                                             \
+    const double xt##i = T.ts[2 * i], yt##i = T.ts[2 * i + 1];                                                         \
+    const double tc##i = T.ts[2 * GPSBB_MAX_CHAN + 2 * i], tk##i = T.ts[2 * GPSBB_MAX_CHAN + 2 * i + 1];
+#endif
 #ifdef GPSBB_X_NOSMEM
 #define GPSBB_EV_KIDX(i) 0
 #else
@@ -533,8 +541,7 @@ __device__ __forceinline__ void ev_channels(LDS &L, uint32_t &drow, int wave, in
 #endif
 #define GPSBB_EV_IN(i)                                                                                                 \
     const EvK K##i = ev_load_k(L, kb, GPSBB_EV_KIDX(i));                                                               \
-    const double xt##i = T.ts[2 * i], yt##i = T.ts[2 * i + 1];                                                         \
-    const double tc##i = T.ts[2 * GPSBB_MAX_CHAN + 2 * i], tk##i = T.ts[2 * GPSBB_MAX_CHAN + 2 * i + 1];
+    GPSBB_EV_STATES(i)
 #define GPSBB_EV_OUT(i, h)                                                                                             \
     {                                                                                                                  \
         const uint32_t db_ = 0u - ((T.dbits >> i) & 1u), dn_ = 0u - ((T.dnext >> i) & 1u);                             \
@@ -563,6 +570,7 @@ __device__ __forceinline__ void ev_channels(LDS &L, uint32_t &drow, int wave, in
     }
 #undef GPSBB_EV_IN
 #undef GPSBB_EV_OUT
+#undef GPSBB_EV_STATES
 }
 
 /* DENSE: the batch has channels that are evaluated per sample (ev_dense): a kernel of its own (k_synth_ev_dense), so
@@ -579,7 +587,7 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
     const int tid = threadIdx.x;
     if (lds_addr_of(smem_raw) != 0u) { /* ev_d_add addresses the image from LDS address 0 (the kernel has no static LDS) */
         if (tid == 0)
-            atomicOr(p.status, 1u);
+            atomicOr(p.status, ST_LDS_LAYOUT);
         return;
     }
     /* The block is the FAST grid dimension: the first workgroups dispatched are one per block, on as many
@@ -711,6 +719,9 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
     base = __builtin_amdgcn_readfirstlane(base);
     int pos = 0;
     int pending = 0; /* lane 0: the next chunk, asked for at the first tile of the current one */
+    unsigned tiles_rendered = 0; /* this wavefront's; summed into hazards[7] on the way out: every tile of every block exactly
+                                    once is what the claim protocol (a returning atomic that is not waited for) has to deliver,
+                                    and the host can check it (GPSBB_INFO_TILES_RENDERED) */
     double ts_v = 0.0;
     uint32_t nav_v = 0;
     if (base < ntw) {
@@ -842,10 +853,13 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         asm volatile("" ::: "memory");
         base = next_base;
         pos = next_pos;
+        tiles_rendered++;
 #ifdef GPSBB_EV_TIMING
         n_tiles_done++;
 #endif
     }
+    if (lane == 0 && tiles_rendered)
+        atomicAdd(p.hazards + 7, (unsigned long long)tiles_rendered);
 #ifdef GPSBB_EV_TIMING
     __syncthreads(); /* the workgroup leaves when its last wavefront does */
     if (threadIdx.x == 0) {

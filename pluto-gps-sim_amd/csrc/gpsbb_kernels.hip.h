@@ -67,6 +67,8 @@ constexpr int TILE_CHUNK = GPSBB_TILE_CHUNK;               /* consecutive tiles 
 constexpr int WAVE_ROW_CAP = GPSBB_ROW_CAP;           /* rows of all chains of one tile staged in a wavefront's LDS slice */
 
 constexpr uint32_t ST_ROW_OVERFLOW = 1u;
+constexpr uint32_t ST_LDS_LAYOUT = 4u;  /* k_synth_ev's LDS image does not start at LDS address 0 (see ev_d_add) */
+constexpr uint32_t ST_CHAIN_STALL = 2u; /* k_chain_fix_par gave up waiting for the chunk before it (see there) */
 
 /*
  * One row of a chain's table as the device pool holds it (24 bytes, the same slots as gpsbb_nco.h's NcoRow

@@ -1083,8 +1083,17 @@ __global__ __launch_bounds__(FIXP_WG) __attribute__((amdgpu_waves_per_eu(4, 4)))
         if (chunk > 0) {
             const size_t at = (size_t)i * p.fix_chunks + (chunk - 1);
             __builtin_amdgcn_s_setprio(0); /* waiting must not cost the wavefronts it shares the SIMD with anything */
-            while (__hip_atomic_load(&p.fix_flag[at], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.fix_epoch)
+            /* Chunk c - 1 is a workgroup of the same launch with a lower blockIdx: the hardware dispatches those first, but HIP
+             * does not promise it.  Should that order ever change (CU masks, another dispatcher) the wait is bounded — about a
+             * second — and ends in the status word (GPSBB_E_INTERNAL at the next sync / pop) instead of a hung stream. */
+            unsigned long long spins = 0;
+            while (__hip_atomic_load(&p.fix_flag[at], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.fix_epoch) {
                 __builtin_amdgcn_s_sleep(32);
+                if (++spins > (1ull << 22)) {
+                    atomicOr(p.status, ST_CHAIN_STALL);
+                    break;
+                }
+            }
             __builtin_amdgcn_s_setprio(3);
             cs = bits_f64(__hip_atomic_load(&p.fix_end[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }

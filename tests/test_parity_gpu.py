@@ -797,6 +797,7 @@ def test_randomised_shapes_and_dopplers(pkg, synth, oracle):
             ch["carr_phase"] = np.floor(ch["carr_phase"] * 2.0 ** 32)
         flags = (pkg.FIXED_CARRIER if fixed else 0) | (pkg.CHAIN_CARRIER if chain else 0)
         want_iq, want_st, _ = oracle.fill_blocks(ch, 1.0 / fs, nsamp, chain=chain, fixed=fixed)
+        tiles0 = synth.info(pkg.INFO_TILES_RENDERED)
         b = synth.batch(ch, 1.0 / fs, nsamp, flags=flags)
         b.run()
         synth.sync()
@@ -804,6 +805,8 @@ def test_randomised_shapes_and_dopplers(pkg, synth, oracle):
         b.close()
         what = (case, fs, nsamp, nch, nblocks, fixed, chain)
         assert (iq == want_iq).all(), what
+        if synth.info(pkg.INFO_LAST_KERNEL) == 2:  # the model kernels hand tiles out by an atomic they do not wait for: each exactly once
+            assert synth.info(pkg.INFO_TILES_RENDERED) - tiles0 == nblocks * ((nsamp + 1023) // 1024), what
         for k in range(nblocks):
             assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
     synth.hazards(reset=True)

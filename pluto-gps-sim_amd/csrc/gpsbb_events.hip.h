@@ -88,11 +88,12 @@ constexpr int EV_ROW_DISCARD = 15;                 /* D row of changes that fall
 #endif
 #define EV_GUARD 0x1p+20
 
-/* A wavefront claims its next chunk of tiles with a returning atomic that it does not wait for (inline assembly: the
- * compiler does not know that the destination register is still in flight).  Before anything that can make the compiler
- * save or move registers — the out-of-line exact paths — the claim has to have landed: a register saved while the atomic is
- * under way is restored with what it held BEFORE, and the chunk is lost (seen with one channel per block and the exact
- * path forced on every tile: the call then comes a few hundred cycles after the claim). */
+/* A wavefront claims its next chunk of tiles with a returning atomic.  Rounds 2 and 3 issued it in inline assembly and did not
+ * wait for it until the chunk's last tile — invisible to the compiler, which is free to copy or spill a register it believes
+ * to be idle: round 3 lost chunks that way once (patched at the call sites with this macro) and round 4 again, as a hang, when
+ * one more variable changed the allocation of k_synth_pd.  The claim is an ordinary atomic now: the compiler waits for it where
+ * it issues it (it aggregates the wavefront's lanes and needs the value at once), which costs 1.2 % of the kernel
+ * (tools/bound_hunt.sh CLAIM_ASM) and depends on nobody's register allocator.  GPSBB_X_CLAIM_ASM: the old way, for measuring. */
 #define GPSBB_EV_SETTLE_CLAIM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 /* LDS image of one workgroup.  Two shapes: the mixed kernel (k_synth_ev_dense) needs the long chip table of the channels it
@@ -720,7 +721,7 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
     int pos = 0;
     int pending = 0; /* lane 0: the next chunk, asked for at the first tile of the current one */
     unsigned tiles_rendered = 0; /* this wavefront's; summed into hazards[7] on the way out: every tile of every block exactly
-                                    once is what the claim protocol (a returning atomic that is not waited for) has to deliver,
+                                    once is what the claim protocol (chunks handed out by an atomic per block) has to deliver,
                                     and the host can check it (GPSBB_INFO_TILES_RENDERED) */
     double ts_v = 0.0;
     uint32_t nav_v = 0;
@@ -747,14 +748,19 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         const uint32_t dflip = T.dbits ^ T.dnext;
         /* which tile comes next, and its states on their way */
         if (pos == 0 && lane == 0) {
-            /* a returning atomic whose result is not waited for here (written in assembly: the compiler would
-             * wait for it on the spot) */
+            /* the next chunk (see GPSBB_EV_SETTLE_CLAIM) */
+#ifdef GPSBB_X_CLAIM_ASM
             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(pending) : "v"(p.tile_ctr + b), "v"(p.ev_chunk) : "memory");
+#else
+            pending = __hip_atomic_fetch_add(p.tile_ctr + b, p.ev_chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         }
         const bool last_of_chunk = pos + 1 >= p.ev_chunk || wt + 1 >= ntw;
         int next_base = base, next_pos = pos + 1;
         if (last_of_chunk) {
+#ifdef GPSBB_X_CLAIM_ASM
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(pending)::"memory");
+#endif
             next_base = __builtin_amdgcn_readfirstlane(pending);
             next_pos = 0;
         }

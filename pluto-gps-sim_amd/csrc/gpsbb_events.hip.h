@@ -125,6 +125,10 @@ struct EvLdsT {
                                                     the fma wants it */
     uint16_t chip2[GPSBB_MAX_CHAN][CHIP_LEN];    /* low byte: 0 where codeCA of chip c mod 1023 is +1, 0xff where -1;
                                                     high byte: the same for chip c+1 */
+#ifdef GPSBB_X_ALLLDS
+    double kc[GPSBB_MAX_CHAN][4];                /* (measurement) sc, rsc, S, rS of the block's channels */
+    uint32_t kdanger[GPSBB_MAX_CHAN];
+#endif
 };
 typedef EvLdsT<EV_AMP_STRIDE, EV_CHIP_LEN> EvLds;                   /* k_synth_ev_dense */
 #ifdef GPSBB_X_MASKED
@@ -288,11 +292,19 @@ template <class LDS>
 __device__ __forceinline__ EvK ev_load_k(const LDS &L, const EvConst *kb, int i)
 {
     EvK k;
+#ifdef GPSBB_X_ALLLDS
+    k.sc = L.kc[i][0];
+    k.rsc = L.kc[i][1];
+    k.S = L.kc[i][2];
+    k.rS = L.kc[i][3];
+    k.danger = L.kdanger[i];
+#else
     k.S = scalar_load(&kb[i].S);
     k.rS = scalar_load(&kb[i].rS);
     k.sc = scalar_load(&kb[i].sc);
     k.rsc = scalar_load(&kb[i].rsc);
     k.danger = scalar_load(&kb[i].danger);
+#endif
     k.chip_base = lds_addr_of(&L.chip2[i][0]) - (EV_GUARD_HI << 1);
     k.amp_base = lds_addr_of(&L.amp[i][0]) - (EV_GUARD_HI << 2);
     return k;
@@ -529,7 +541,7 @@ __device__ __forceinline__ void ev_channels(LDS &L, uint32_t &drow, int wave, in
 {
 #ifdef GPSBB_X_NOTSTATE /* (measurement: the tile states and position constants out of thin air instead of LDS) */
 #define GPSBB_EV_STATES(i)                                                                                             \
-    const double xt##i = off * 0.25 + 0x1p+20, yt##i = off * 0.125 + 0x1p+20, tc##i = 0x1p+20 + 3.0, tk##i = 0x1p+20 + 5.0;
+    const double xt##i = off * 0.25 + (0x1p+20 + 0.37), yt##i = off * 0.125 + (0x1p+20 + 0.41), tc##i = 0x1p+20 + 3.3, tk##i = 0x1p+20 + 5.7;
 #else
 #define GPSBB_EV_STATES(i)                                                                                             \
     const double xt##i = T.ts[2 * i], yt##i = T.ts[2 * i + 1];                                                         \
@@ -665,6 +677,15 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         (&L.D[0][0][0])[e] = 0u;
     {
         const int l = tid & 63;
+#ifdef GPSBB_X_ALLLDS
+        if (tid < p.nch) {
+            L.kc[tid][0] = kb[tid].sc;
+            L.kc[tid][1] = kb[tid].rsc;
+            L.kc[tid][2] = kb[tid].S;
+            L.kc[tid][3] = kb[tid].rS;
+            L.kdanger[tid] = kb[tid].danger;
+        }
+#endif
         if (l < p.nch) { /* every wavefront's own copy of the position constants (see EvLds::tstate) */
             L.tstate[tid >> 6][1][2 * l] = kb[l].tC0;     /* beside the code state */
             L.tstate[tid >> 6][1][2 * l + 1] = kb[l].tK0; /* beside the carrier state */

@@ -472,7 +472,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_synth_ev" if last_kernel == 2 else "k_synth", "ms_per_launch": ms_synth,
                          "launches_timed": stats["runs"], "algorithmic_bytes_per_launch": 4 * samples_per_launch,
-                         "note": "VALU-issue-bound, not HBM-bound: see DESIGN.md"},
+                         "note": "not HBM-bound: 31 VALU instructions per channel-run on four wavefronts per SIMD whose per-pair loads "
+                                 "(scalar cache + LDS) are not hidden; what the time is made of was measured by taking one resource out "
+                                 "at a time (tools/bound_hunt.sh, DESIGN.md 3.1)"},
             "prepass_ms_per_launch": ms_seed,
             "device_chain": chain_info,
             "shard_seed_s": seed_max, "descriptor_generation_s": t_gen,
@@ -551,7 +553,9 @@ def main():
                                   "frac": m1_alg / (m1["synth_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "alone": {"ms_per_launch": m1s["synth_kernel_ms"],
                                             "frac": m1_alg / (m1s["synth_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                                  "note": "VALU- and LDS-issue-bound (about 27 VALU issue cycles and 12 bytes of LDS reads per channel-sample), not HBM-bound: DESIGN.md 2.7"},
+                                  "bound_measured": "valu+lds issue",
+                                  "note": "VALU- and LDS-issue-bound (about 27 VALU issue cycles and 12 bytes of LDS reads per channel-sample), not HBM-bound: "
+                                          "DESIGN.md 2.7; the stores cost it 7 % (tools/bound_hunt.sh PD_NOSTORE)"},
                      "workload": "12 ch, fs 2.6e6 S/s, 300000-sample blocks, 1000 independent blocks per step; synthesis kernel " + m1_kernel}
         # the reference built without FLOAT_CARR_PHASE (h:12): 32-bit fixed-point carrier, the same M1 geometry
         fch = mch.copy()

@@ -20,7 +20,9 @@
  *     contract of the reference's single consumer — whichever GPU rendered them; a shard whose turn has not come
  *     fills its ring and waits.  A sink that can place blocks itself (a file written with pwrite, a host buffer)
  *     asks for GPSBB_NODE_INDEXED and gets every slot as soon as it is complete, with its block index: that is
- *     what lets N GPUs deliver N times the blocks per second into one output.
+ *     what lets N GPUs deliver N times the blocks per second into one output from contiguous shards.  A consumer that
+ *     needs the order AND the rate (a radio fed faster than real time, a pipe) asks for GPSBB_NODE_INTERLEAVED: the
+ *     slots go round the GPUs, so the next ones are always being rendered while the current one is consumed.
  *
  * Plain C ABI like gpsbb.h; lives in libgpsbb.so.  A node object is driven by one thread at a time.
  */
@@ -42,6 +44,12 @@ extern "C" {
                                        the shard's GPU, for a consumer there */
 #define GPSBB_NODE_NO_AFFINITY 8u   /* do not bind the producer threads (a host that manages placement itself) */
 #define GPSBB_NODE_FIXED_CARRIER 16u /* GPSBB_FIXED_CARRIER streams (plutogpssim.h:160-161, c:2675 / 2699 / 2748) */
+#define GPSBB_NODE_INTERLEAVED 32u  /* slot k of the stream (blocks [k * blocks_per_slot, (k + 1) * blocks_per_slot)) goes to shard
+                                       k mod nshards instead of contiguous shards: every slot starts a chain of its own from the
+                                       exact phase of its first block (each producer chains the whole stream once on its GPU,
+                                       0.1 s per 100 000 blocks, and pushes with GPSBB_PUSH_NEW_CHAIN).  With this layout the
+                                       ORDERED sink scales too: while the consumer takes slot k from one GPU the others are
+                                       rendering k + 1 ... k + nshards * depth - 1 */
 
 /*
  * The one consumer.  `iq` = nblocks consecutive blocks (nblocks * nsamp int16 I/Q pairs, interleaved), the first of them

@@ -45,7 +45,8 @@ STREAM_DEVICE_ONLY = 4
 OPT_SEED_WHERE, OPT_SYNTH_KERNEL, OPT_SKIP_SEED, OPT_CHAIN_WHERE = 1, 2, 3, 4
 INFO_LAST_KERNEL, INFO_EXACT_RUNS, INFO_CHAIN_ON_DEVICE, INFO_CHAIN_FALLBACKS, INFO_CHAIN_TIES, INFO_CHAIN_REPAIRS = 1, 2, 3, 4, 5, 6
 INFO_STREAMS, INFO_HW_QUEUES, INFO_TILES_RENDERED = 7, 8, 9
-NODE_INDEXED, NODE_CONCURRENT, NODE_DEVICE_ONLY, NODE_NO_AFFINITY, NODE_FIXED_CARRIER = 1, 2, 4, 8, 16
+NODE_INDEXED, NODE_CONCURRENT, NODE_DEVICE_ONLY, NODE_NO_AFFINITY, NODE_FIXED_CARRIER, NODE_INTERLEAVED = 1, 2, 4, 8, 16, 32
+PUSH_NEW_CHAIN = 1
 NODE_MAX_SHARDS = 64
 
 ERRORS = {0: "GPSBB_OK", -1: "GPSBB_E_BADARG", -2: "GPSBB_E_BADCHAN", -3: "GPSBB_E_HIP", -4: "GPSBB_E_NOMEM",
@@ -59,7 +60,7 @@ API_SYMBOLS = [
     "gpsbb_get_hazards", "gpsbb_device_read", "gpsbb_batch_last_timing", "gpsbb_batch_timing_stats", "gpsbb_fill_ceiling", "gpsbb_stream_create",
     "gpsbb_stream_destroy", "gpsbb_stream_push", "gpsbb_stream_pop", "gpsbb_stream_pending", "gpsbb_stream_timing_stats",
     "gpsbb_codegen", "gpsbb_sincos_tables", "gpsbb_chain_carrier_host", "gpsbb_chain_carrier", "gpsbb_set_option",
-    "gpsbb_get_info", "gpsbb_stream_reset", "gpsbb_device_affinity",
+    "gpsbb_get_info", "gpsbb_stream_reset", "gpsbb_device_affinity", "gpsbb_stream_push_ex",
 ]
 # ... and include/gpsbb_node.h
 NODE_API_SYMBOLS = ["gpsbb_node_create", "gpsbb_node_run", "gpsbb_node_destroy", "gpsbb_node_plan"]
@@ -131,6 +132,7 @@ def lib():
         L.gpsbb_chain_carrier_host.argtypes = [vp, i, i, d, i, vp, i]
         L.gpsbb_chain_carrier.argtypes = [vp, vp, i, i, d, i, vp, vp]
         L.gpsbb_stream_reset.argtypes = [vp]
+        L.gpsbb_stream_push_ex.argtypes = [vp, vp, u]
         L.gpsbb_device_affinity.argtypes = [i, C.POINTER(i), C.c_char_p, C.c_size_t]
         L.gpsbb_node_create.argtypes = [C.POINTER(vp), vp]
         L.gpsbb_node_destroy.argtypes = [vp]
@@ -373,11 +375,14 @@ class Stream:
         except Exception:
             pass
 
-    def push(self, ch):
+    def push(self, ch, new_chain=False):
         ch = _as_chan(ch)
         if ch.shape != (self.bps, self.nch):
             raise ValueError("push expects [blocks_per_slot, nch] descriptors")
-        _chk(lib().gpsbb_stream_push(self._s, ch.ctypes.data), "gpsbb_stream_push")
+        if new_chain:
+            _chk(lib().gpsbb_stream_push_ex(self._s, ch.ctypes.data, PUSH_NEW_CHAIN), "gpsbb_stream_push_ex")
+        else:
+            _chk(lib().gpsbb_stream_push(self._s, ch.ctypes.data), "gpsbb_stream_push")
 
     def pop(self, copy=True):
         """(IQ [blocks_per_slot, nsamp, 2] int16 in the slot's pinned host buffer, end states); a stream created with

@@ -2319,12 +2319,33 @@ extern "C" int gpsbb_stream_timing_stats(gpsbb_stream_t *s, int *nruns, float *m
     return GPSBB_OK;
 }
 
-extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch)
+static int stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch, bool new_chain);
+
+extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch) { return stream_push(s, ch, false); }
+
+extern "C" int gpsbb_stream_push_ex(gpsbb_stream_t *s, const gpsbb_chan_t *ch, unsigned flags)
+{
+    if (flags & ~GPSBB_PUSH_NEW_CHAIN)
+        return GPSBB_E_BADARG;
+    return stream_push(s, ch, (flags & GPSBB_PUSH_NEW_CHAIN) != 0);
+}
+
+static int stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch, bool new_chain)
 {
     if (!s || !ch)
         return GPSBB_E_BADARG;
     if (s->poisoned || s->head - s->tail >= (uint64_t)s->depth)
         return GPSBB_E_STATE; /* ring full: pop first */
+    if (new_chain) {
+        /* this push does not continue the one before: every channel of its first block starts from its descriptor's phase,
+         * as if it had just been allocated (c:1956-1964) — "no satellite was here before" is all the chain has to be told */
+        for (int i = 0; i < GPSBB_MAX_CHAN; i++) {
+            s->last_prn[i] = 0;
+            s->fx_prn[i] = 0;
+            if (s->carry)
+                s->carry->prn[i] = 0;
+        }
+    }
     gpsbb *h = s->h;
     g_push_trace.start();
     HIPCHK(h, hipSetDevice(h->device));

@@ -180,8 +180,109 @@ bool deliver(gpsbb_node *n, Shard &s, const int16_t *iq, long first_block, int n
     return rc >= 0;
 }
 
+/* GPSBB_NODE_INTERLEAVED: shard g renders slots g, g + N, g + 2N ... of the stream, each a chain of its own */
+int run_shard_interleaved(gpsbb_node *n, Shard &s)
+{
+    const gpsbb_node_config_t &c = n->cfg;
+    const int bps = c.blocks_per_slot, nch = c.nch, N = c.nshards;
+    const bool fixed = (c.flags & GPSBB_NODE_FIXED_CARRIER) != 0;
+    const long B = n->nblocks, nslots_all = (B + bps - 1) / bps;
+    const long mine = s.index < nslots_all ? (nslots_all - s.index + N - 1) / N : 0; /* slots g, g + N, ... */
+    s.stats.first_block = (long)s.index * bps;
+    s.stats.nblocks = 0;
+    s.stats.seed_seconds = s.stats.busy_seconds = s.stats.wait_seconds = 0.0;
+    if (mine <= 0)
+        return GPSBB_OK;
+    int rc = gpsbb_stream_reset(s.st);
+    if (rc != GPSBB_OK)
+        return rc;
+    /* the exact start phase of every block of the stream, on this shard's own GPU (every shard does: no GPU talks to
+     * another one); what it needs of it are the first blocks of its slots */
+    const double t0 = now_s();
+    std::vector<double> seeds((size_t)B * nch);
+    if (fixed) {
+        for (int i = 0; i < nch; i++) {
+            int prev_prn = 0;
+            uint32_t ph = 0;
+            for (long b = 0; b < B; b++) {
+                const gpsbb_chan_t &d = n->ch[(size_t)b * nch + i];
+                if (d.prn > 0) {
+                    if (d.prn != prev_prn)
+                        ph = (uint32_t)d.carr_phase;
+                    seeds[(size_t)b * nch + i] = (double)ph;
+                    const volatile double scaled = 512.0 * 65536.0 * d.f_carr * c.delt;
+                    ph += (uint32_t)c.nsamp * (uint32_t)(int32_t)std::round(scaled);
+                } else {
+                    seeds[(size_t)b * nch + i] = 0.0;
+                }
+                prev_prn = d.prn > 0 ? d.prn : 0;
+            }
+        }
+    } else {
+        double end[GPSBB_MAX_CHAN];
+        long done = 0;
+        std::vector<gpsbb_chan_t> patched;
+        while (done < B) {
+            const long piece = B - done > 32768 ? 32768 : B - done;
+            const gpsbb_chan_t *src = n->ch + (size_t)done * nch;
+            if (done > 0) { /* carry the end phases of the piece before into this piece's first block */
+                patched.assign(src, src + (size_t)piece * nch);
+                for (int i = 0; i < nch; i++) {
+                    const gpsbb_chan_t &prev = n->ch[(size_t)(done - 1) * nch + i];
+                    if (patched[i].prn > 0 && patched[i].prn == prev.prn)
+                        patched[i].carr_phase = end[i];
+                }
+                src = patched.data();
+            }
+            rc = gpsbb_chain_carrier(s.h, src, (int)piece, nch, c.delt, c.nsamp, seeds.data() + (size_t)done * nch, end);
+            if (rc != GPSBB_OK)
+                return rc;
+            done += piece;
+        }
+    }
+    s.stats.seed_seconds = now_s() - t0;
+    const unsigned depth = (unsigned)c.depth;
+    const double t_busy = now_s();
+    long pushed = 0, popped = 0;
+    bool going = true;
+    while (going && popped < mine) {
+        while (going && pushed < mine && (unsigned)gpsbb_stream_pending(s.st) < depth) {
+            const long b0 = ((long)s.index + pushed * N) * bps;
+            const long nb = B - b0 < bps ? B - b0 : bps;
+            s.slot_desc.assign((size_t)bps * nch, gpsbb_chan_t{}); /* (a short last slot is padded with idle blocks) */
+            memcpy(s.slot_desc.data(), n->ch + (size_t)b0 * nch, (size_t)nb * nch * sizeof(gpsbb_chan_t));
+            for (int i = 0; i < nch; i++)
+                if (s.slot_desc[i].prn > 0)
+                    s.slot_desc[i].carr_phase = seeds[(size_t)b0 * nch + i];
+            rc = gpsbb_stream_push_ex(s.st, s.slot_desc.data(), GPSBB_PUSH_NEW_CHAIN);
+            if (rc != GPSBB_OK)
+                return rc;
+            pushed++;
+        }
+        const int16_t *iq = nullptr;
+        rc = gpsbb_stream_pop(s.st, &iq, nullptr);
+        if (rc != GPSBB_OK)
+            return rc;
+        const long b0 = ((long)s.index + popped * N) * bps;
+        const long nb = B - b0 < bps ? B - b0 : bps;
+        popped++;
+        s.stats.nblocks += nb;
+        going = deliver(n, s, iq, b0, (int)nb);
+    }
+    while (gpsbb_stream_pending(s.st) > 0) {
+        const int16_t *iq = nullptr;
+        const int r2 = gpsbb_stream_pop(s.st, &iq, nullptr);
+        if (r2 != GPSBB_OK)
+            return r2;
+    }
+    s.stats.busy_seconds = now_s() - t_busy;
+    return GPSBB_OK;
+}
+
 int run_shard(gpsbb_node *n, Shard &s)
 {
+    if (n->cfg.flags & GPSBB_NODE_INTERLEAVED)
+        return run_shard_interleaved(n, s);
     const gpsbb_node_config_t &c = n->cfg;
     const int bps = c.blocks_per_slot, nch = c.nch;
     const bool fixed = (c.flags & GPSBB_NODE_FIXED_CARRIER) != 0;
@@ -337,7 +438,7 @@ extern "C" int gpsbb_node_create(gpsbb_node_t **out, const gpsbb_node_config_t *
 {
     if (!out || !cfg || cfg->nshards < 1 || cfg->nshards > GPSBB_NODE_MAX_SHARDS || cfg->nch < 1 || cfg->nch > GPSBB_MAX_CHAN ||
         !(cfg->delt > 0.0) || cfg->nsamp < 1 || cfg->blocks_per_slot < 1 || cfg->depth < 2 ||
-        (cfg->flags & ~(GPSBB_NODE_INDEXED | GPSBB_NODE_CONCURRENT | GPSBB_NODE_DEVICE_ONLY | GPSBB_NODE_NO_AFFINITY | GPSBB_NODE_FIXED_CARRIER)))
+        (cfg->flags & ~(GPSBB_NODE_INDEXED | GPSBB_NODE_CONCURRENT | GPSBB_NODE_DEVICE_ONLY | GPSBB_NODE_NO_AFFINITY | GPSBB_NODE_FIXED_CARRIER | GPSBB_NODE_INTERLEAVED)))
         return GPSBB_E_BADARG;
     *out = nullptr;
     gpsbb_node *n = new (std::nothrow) gpsbb_node;

@@ -16,7 +16,8 @@
  * -G N renders through the node driver (include/gpsbb_node.h): N contiguous time shards, one producer thread + handle +
  * ring per shard on the GPUs "-g a,b,c" names (default 0 .. N-1; an ordinal may repeat), each shard seeded with the exact
  * carrier phase by the device-side chain, ONE output: a regular file is written with pwrite() as slots complete
- * (GPSBB_NODE_INDEXED), a pipe in stream order.
+ * (GPSBB_NODE_INDEXED), a pipe in stream order; -I: the slots go round the GPUs instead of contiguous shards
+ * (GPSBB_NODE_INTERLEAVED), so that an ordered output gets all the GPUs' rate too.
  * -P usec paces the consumer like the radio does: the TX surface's sink takes one block every `usec` microseconds (the
  * reference's iio_buffer_push blocks until the hardware has room, c:2152; 100000 = real time, less = compressed time), counts
  * the blocks that were not there when their turn came (under-runs) and, with -S file, writes the latency distribution of
@@ -128,7 +129,7 @@ static int cmp_double(const void *a, const void *b)
 static void usage(void)
 {
     fprintf(stderr, "usage: gpsbb-sim -e nav [-l lat,lon,h|-c x,y,z|-u motion.csv] [-t Y/M/D,h:m:s] [-T] [-i] [-3]\n"
-                    "                 [-s fs_hz] [-d seconds] [-n samples_per_block] [-N channels] [-g gpu[,gpu...]] [-F] [-G shards]\n"
+                    "                 [-s fs_hz] [-d seconds] [-n samples_per_block] [-N channels] [-g gpu[,gpu...]] [-F] [-G shards [-I]]\n"
                     "                 [-P usec_per_block] [-Q device_queue_blocks] [-S stats.json] [-k keep,blocks] -o out.bin\n");
 }
 
@@ -146,7 +147,7 @@ int main(int argc, char **argv)
     long fs_hz = 3000000; /* TX_SAMPLE_FREQ c:43 */
     long nsamp = 300000;  /* NUM_SAMPLES c:44 */
     double duration = 1.0;
-    int gpu = 0, opt, fast = 0, nshards = 0, ndev = 0;
+    int gpu = 0, opt, fast = 0, nshards = 0, ndev = 0, interleaved = 0;
     int devs[GPSBB_NODE_MAX_SHARDS];
     struct paced_sink paced;
     memset(&paced, 0, sizeof paced);
@@ -154,7 +155,7 @@ int main(int argc, char **argv)
     const char *stats_path = NULL;
     const char *out_path = NULL;
 
-    while ((opt = getopt(argc, argv, "e:u:c:l:s:Tt:in:N:d:o:g:3FG:P:S:k:Q:")) != -1) {
+    while ((opt = getopt(argc, argv, "e:u:c:l:s:Tt:in:N:d:o:g:3FG:P:S:k:Q:I")) != -1) {
         switch (opt) {
         case 'e': cfg.navfile = optarg; break;
         case 'u': cfg.motion_file = optarg; break;
@@ -194,6 +195,7 @@ int main(int argc, char **argv)
             gpu = ndev ? devs[0] : 0;
             break;
         case 'G': nshards = atoi(optarg); break;
+        case 'I': interleaved = 1; break;
         case 'P': paced.period_ns = atol(optarg) * 1000L; break;
         case 'S': stats_path = optarg; break;
         case 'Q': paced.queue = atoi(optarg) > 0 ? atoi(optarg) : 1; break;
@@ -237,10 +239,10 @@ int main(int argc, char **argv)
         }
         gpsfe_generate(fe, (int)nblocks, all);
         struct node_out o = {fo, -1, (size_t)nsamp};
-        unsigned nflags = 0;
+        unsigned nflags = interleaved ? GPSBB_NODE_INTERLEAVED : 0u; /* -I: the slots go round the GPUs (an ordered output scales) */
         if (fo != stdout && ftruncate(fileno(fo), (off_t)nblocks * nsamp * 4) == 0) {
             o.fd = fileno(fo); /* a regular file: blocks are placed by index as they complete, from every shard at once */
-            nflags = GPSBB_NODE_INDEXED | GPSBB_NODE_CONCURRENT;
+            nflags |= GPSBB_NODE_INDEXED | GPSBB_NODE_CONCURRENT;
         }
         const int bps = nblocks < 16 ? (int)nblocks : 16;
         gpsbb_node_config_t nc = {nshards, devs, cfg.max_chan, delt, (int)nsamp, bps, 3, nflags};

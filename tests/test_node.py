@@ -133,6 +133,67 @@ def test_shard_boundaries_prn_changes_padding_fixed_carrier_and_stop(pkg, oracle
         assert (sink.iq == want).all()
 
 
+def test_interleaved_shards_keep_the_order_and_the_bytes(pkg, oracle):
+    """GPSBB_NODE_INTERLEAVED: the slots of the stream go round the shards, every slot a chain of its own from the exact
+    phase of its first block (gpsbb_chain_carrier over the whole stream + GPSBB_PUSH_NEW_CHAIN) — the layout in which an
+    ORDERED consumer gets N GPUs' rate.  Same bytes as the contiguous layout, the golden blocks and the oracle's sequential
+    render; deliveries strictly in stream order, the shards taking turns; PRN changes and idle channels at slot edges; a
+    block count that is not a multiple of the slot size; the 32-bit accumulator."""
+    pkg.build_frontend()
+    z = np.load(os.path.join(GOLDEN, "static_F.npz"))
+    fs, nsamp = float(z["fs"]), int(z["nsamp"])
+    blocks = [int(b) for b in z["blocks"]]
+    fe = pkg.FrontEnd(os.path.join(GOLDEN, "synth3540.14n"), llh=(30.286502, 120.032669, 100.0), max_chan=12)
+    ch = fe.generate(max(blocks) + 1)
+    fe.close()
+    for nshards in (1, 3):
+        sink, st = render(pkg, ch, fs, nsamp, nshards, bps=8, flags=pkg.NODE_INTERLEAVED)
+        pos = 0
+        for k, (f, nb, shard) in enumerate(sink.calls):
+            assert f == pos and shard == k % nshards
+            pos += nb
+        for k, blk in enumerate(blocks):
+            assert sha(sink.iq[blk]) == str(z["iq_sha256"][k]), (nshards, blk)
+        assert sum(s["nblocks"] for s in st["shards"]) == ch.shape[0]
+    fs, nsamp, nch, nb, bps = 4.0e6, 30000, 6, 23, 3
+    ch = pkg.synth_descriptors(nb, nch=nch, seed=98)
+    ch["f_carr"] = ch["f_carr"][0][None, :] + np.arange(nb)[:, None] * 3.0
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    ch["prn"][6:, 2] = 30          # hand-over exactly at a slot edge
+    ch["prn"][11, 1] = 27          # ... and inside a slot
+    ch["prn"][13:16, 4] = 0        # idle across one
+    want, _, _ = oracle.fill_blocks(ch, 1.0 / fs, nsamp, chain=True)
+    for nshards, flags in ((2, pkg.NODE_INTERLEAVED), (4, pkg.NODE_INTERLEAVED | pkg.NODE_INDEXED | pkg.NODE_CONCURRENT)):
+        sink, _ = render(pkg, ch, fs, nsamp, nshards, bps=bps, flags=flags)
+        assert (sink.iq == want).all(), nshards
+    chf = ch.copy()
+    chf["carr_phase"] = np.floor(chf["carr_phase"] * 2.0 ** 32)
+    wantf, _, _ = oracle.fill_blocks(chf, 1.0 / fs, nsamp, chain=True, fixed=True)
+    sink, _ = render(pkg, chf, fs, nsamp, 3, bps=bps, flags=pkg.NODE_INTERLEAVED | pkg.NODE_FIXED_CARRIER)
+    assert (sink.iq == wantf).all()
+
+
+def test_a_push_that_starts_a_new_chain(pkg, oracle):
+    """gpsbb_stream_push_ex(GPSBB_PUSH_NEW_CHAIN) on a plain stream: pushes that are NOT consecutive in time, each from exact
+    seeds in its descriptors, through the device-side chain and through the host-side one."""
+    fs, nsamp, nch, bps = 25e6, 40000, 8, 4
+    ch = pkg.synth_descriptors(6 * bps, nch=nch, seed=321)
+    seeds = pkg.chain_carrier_host(ch, 1.0 / fs, nsamp)
+    want, _, _ = oracle.fill_blocks(ch, 1.0 / fs, nsamp, chain=True)
+    order = [4, 1, 5, 0, 3, 2]
+    for where in (1, 2):
+        with pkg.Synth(0) as s:
+            s.set_option(pkg.OPT_SEED_WHERE, where)
+            st = s.stream(nch, 1.0 / fs, nsamp, bps, depth=2, flags=pkg.CHAIN_CARRIER)
+            for k in order:
+                slot = ch[k * bps:(k + 1) * bps].copy()
+                slot["carr_phase"][0] = seeds[k * bps]
+                st.push(slot, new_chain=True)
+                iq, _ = st.pop()
+                assert (iq == want[k * bps:(k + 1) * bps]).all(), (where, k)
+            st.close()
+
+
 def test_placement_is_reported(pkg):
     """The producer threads bind themselves next to their GPU before they allocate (plutogpssim.c:2045-2056 pins the
     reference's two threads): the statistics say where."""
@@ -170,5 +231,7 @@ def test_gpsbb_sim_over_several_shards_writes_the_same_file(pkg, tmp_path):
         out = str(tmp_path / ("g%d.bin" % n))
         subprocess.run(common + ["-G", str(n), "-g", ",".join(["0"] * n), "-o", out], check=True, stderr=subprocess.DEVNULL)
         assert (np.fromfile(out, np.int16) == want).all(), n
+    piped = subprocess.run(common + ["-G", "3", "-I", "-g", "0,0,0", "-o", "-"], check=True, stderr=subprocess.DEVNULL, stdout=subprocess.PIPE).stdout
+    assert np.frombuffer(piped, np.int16).tobytes() == want.tobytes()   # interleaved slots, ordered pipe
     piped = subprocess.run(common + ["-G", "2", "-g", "0,0", "-o", "-"], check=True, stderr=subprocess.DEVNULL, stdout=subprocess.PIPE).stdout
     assert np.frombuffer(piped, np.int16).tobytes() == want.tobytes()

@@ -1,0 +1,10 @@
+export GPSBB_PY_LIB=exp
+run() { a=$(python tools/kbench.py --no-cpu --steps 8 --synth-only 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4f' % d['roofline']['ms_per_launch'])"); p=$(python tools/kbench.py --no-cpu --steps 8 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4f %.4f' % (d['roofline']['ms_per_launch'], d['ms_per_step']))"); echo "$1 alone $a pipelined $p"; }
+run default
+GPSBB_EV_CHUNK=1 run chunk1
+GPSBB_EV_CHUNK=3 run chunk3
+GPSBB_EV_CHUNK=4 run chunk4
+GPSBB_EV_MIN_WG=2 run minwg2
+GPSBB_EV_MIN_WG=4 run minwg4
+GPSBB_EV_MIN_WG=5 run minwg5
+run default

@@ -316,6 +316,10 @@ bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vec
                     K.tC0 = K.rsc * (1.0 + K.W) + 0x1p+20 + K.W;
                 }
             }
+            /* what k_synth_ev's channel loop would otherwise work out per channel and tile in scalar instructions */
+            K.danger_le = K.kc < 0 ? 0xffffffffu : K.danger - 1u; /* danger >= 1 */
+            K.chip_at = (uint32_t)(offsetof(EvLdsLean, chip2) + (size_t)i * sizeof(uint16_t) * EvLdsLean::CHIPS) - (EV_GUARD_HI << 1);
+            K.amp_at = (uint32_t)(offsetof(EvLdsLean, amp) + (size_t)i * sizeof(uint32_t) * EvLdsLean::AMP) - (EV_GUARD_HI << 2);
         }
         if (!(amp_sum < 32768.0))
             return false;

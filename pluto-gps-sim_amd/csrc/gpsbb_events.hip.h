@@ -281,7 +281,7 @@ __device__ __noinline__ uint32_t ev_exact_run_fixed(LDS &L, int wave, int lane, 
 /* per-channel constants of the fast path (scalar registers) */
 struct EvK {
     double S, rS, sc, rsc;
-    uint32_t danger;
+    uint32_t danger;    /* EvConst::danger_le: a lane whose smallest low word is <= this goes to the exact path */
     uint32_t chip_base; /* LDS address of the channel's chip table, minus what the exponent bits of a guard-format high word
                            contribute when it is shifted into a byte offset (see ev_first) */
     uint32_t amp_base;  /* ... of its amplitude table, likewise (EvLdsLean) */
@@ -299,14 +299,31 @@ __device__ __forceinline__ EvK ev_load_k(const LDS &L, const EvConst *kb, int i)
     k.rS = L.kc[i][3];
     k.danger = L.kdanger[i];
 #else
-    k.S = scalar_load(&kb[i].S);
-    k.rS = scalar_load(&kb[i].rS);
-    k.sc = scalar_load(&kb[i].sc);
-    k.rsc = scalar_load(&kb[i].rsc);
-    k.danger = scalar_load(&kb[i].danger);
+    /* the record's address as base + (i << 7): one shift, which the two loads take as their scalar offset; the fields in
+     * the order of the record (gpsbb_kernels.hip.h), 32 + 16 bytes */
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const char *ki = reinterpret_cast<const char *>(kb) + ((uint32_t)i << 7);
+    const u32x8 a = scalar_load(reinterpret_cast<const u32x8 *>(ki));
+    const u32x4 c = scalar_load(reinterpret_cast<const u32x4 *>(ki + offsetof(EvConst, danger_le)));
+    k.S = __hiloint2double((int)a[1], (int)a[0]);
+    k.rS = __hiloint2double((int)a[3], (int)a[2]);
+    k.sc = __hiloint2double((int)a[5], (int)a[4]);
+    k.rsc = __hiloint2double((int)a[7], (int)a[6]);
+    k.danger = c[0];
 #endif
-    k.chip_base = lds_addr_of(&L.chip2[i][0]) - (EV_GUARD_HI << 1);
-    k.amp_base = lds_addr_of(&L.amp[i][0]) - (EV_GUARD_HI << 2);
+    if (LDS::UNMASKED) { /* (EvLdsLean: the host put the two table addresses into the record, next to the threshold) */
+#ifdef GPSBB_X_ALLLDS
+        k.chip_base = scalar_load(&kb[i].chip_at);
+        k.amp_base = scalar_load(&kb[i].amp_at);
+#else
+        k.chip_base = c[1];
+        k.amp_base = c[2];
+#endif
+    } else {
+        k.chip_base = lds_addr_of(&L.chip2[i][0]) - (EV_GUARD_HI << 1);
+        k.amp_base = lds_addr_of(&L.amp[i][0]) - (EV_GUARD_HI << 2);
+    }
     return k;
 }
 
@@ -401,7 +418,7 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const LDS &L, int i, const EvK &K
         m = min(m, (uint32_t)__double2loint(z) | 0x80000000u);
     }
 #endif
-    h.um = __builtin_amdgcn_uicmp(m, K.danger, 36 /* ult */);
+    h.um = __builtin_amdgcn_uicmp(m, K.danger, 37 /* ule */);
     return h;
 }
 
@@ -412,7 +429,7 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const LDS &L, int i, const EvK &K
  */
 template <int KC, bool DF, bool FIXED, class LDS>
 __device__ __forceinline__ void ev_second(LDS &L, uint32_t &drow, int wave, int lane, int i, EvHalf<KC> &h, uint32_t db, uint32_t db_next,
-                                          bool always_exact, unsigned long long live_mask, const EvConst *kb, const double *tile_x,
+                                          unsigned long long live_mask, const EvConst *kb, const double *tile_x,
                                           int ntiles, uint32_t nb, double off, uint32_t &acc0, unsigned long long *n_exact,
                                           const EvFixed &fx)
 {
@@ -427,9 +444,11 @@ __device__ __forceinline__ void ev_second(LDS &L, uint32_t &drow, int wave, int 
     }
     uint32_t hc = m0 == m1 ? EV_SAT_HI : h.hc; /* equal neighbours: nothing changes at the chip boundary */
 
-    /* ---- rare: this lane cannot rule out that the model and the reference disagree ---- */
-    const unsigned long long um = (always_exact ? ~0ull : h.um) & live_mask;
-    if (__builtin_expect(um != 0ull, 0)) {
+    /* ---- rare: this lane cannot rule out that the model and the reference disagree (a channel that is always recomputed
+     * exactly has a threshold every low word is below: EvConst::danger_le).  The branch is on the comparison as it comes
+     * out of the vector unit; that the lane holds samples of the block at all is only looked at behind it ---- */
+    if (__builtin_expect(h.um != 0ull, 0)) {
+        const unsigned long long um = h.um & live_mask;
         GPSBB_EV_SETTLE_CLAIM();
         if ((um >> lane) & 1ull) {
             /* its fast-path contribution becomes nothing ... */
@@ -482,7 +501,6 @@ struct EvTile {
                              tile_x[c * ntiles] */
     int ntiles;
     uint32_t dbits, dnext; /* bit i: channel i's data bit in force / after the next roll-over is -1 */
-    uint32_t exact_mask;   /* bit i: channel i is always recomputed exactly */
 };
 
 /*
@@ -559,7 +577,7 @@ __device__ __forceinline__ void ev_channels(LDS &L, uint32_t &drow, int wave, in
     {                                                                                                                  \
         const uint32_t db_ = 0u - ((T.dbits >> i) & 1u), dn_ = 0u - ((T.dnext >> i) & 1u);                             \
         const uint32_t nb_ = ((T.dbits >> i) & 1u) | (((T.dnext >> i) & 1u) << 1);                                     \
-        ev_second<KC, DF, FIXED>(L, drow, wave, lane, i, h, db_, dn_, ((T.exact_mask >> i) & 1u) != 0, live_mask, kb, T.tile_x, \
+        ev_second<KC, DF, FIXED>(L, drow, wave, lane, i, h, db_, dn_, live_mask, kb, T.tile_x,                 \
                           T.ntiles, nb_,                                                                               \
                           off, acc0, n_exact, fx);                                                                     \
     }
@@ -683,7 +701,7 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
             L.kc[tid][1] = kb[tid].rsc;
             L.kc[tid][2] = kb[tid].S;
             L.kc[tid][3] = kb[tid].rS;
-            L.kdanger[tid] = kb[tid].danger;
+            L.kdanger[tid] = kb[tid].danger_le;
         }
 #endif
         if (l < p.nch) { /* every wavefront's own copy of the position constants (see EvLds::tstate) */
@@ -703,14 +721,13 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
     const int nch2 = 2 * p.nch;
     /* channels by the number of carrier breakpoints a run can hold (bit i = channel i) */
     uint32_t mk[EV_KC_MAX];
-    uint32_t exact_mask, mkd; /* always recomputed exactly; evaluated per sample */
+    uint32_t mkd; /* evaluated per sample (channels that are always recomputed exactly are in mk[0]: EvConst::danger_le) */
     {
         const bool act = lane < p.nch && cb[lane < p.nch ? lane : 0].prn > 0;
         const int kc = act ? kb[lane].kc : 0;
 #pragma unroll
         for (int k = 0; k < EV_KC_MAX; k++)
             mk[k] = (uint32_t)__ballot(act && (kc == k + 1 || (k == 0 && kc < 1)));
-        exact_mask = (uint32_t)__ballot(act && kc < 0);
         mkd = DENSE ? (uint32_t)__ballot(act && kc == EV_KC_DENSE) : 0u;
     }
     /* lane c < 2*nch holds chain c = (channel c >> 1, kind c & 1) of the tile being staged */
@@ -761,7 +778,6 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         T.ntiles = ntw;
         T.dbits = (uint32_t)__ballot(nav_v & 1u);
         T.dnext = (uint32_t)__ballot(nav_v & 2u);
-        T.exact_mask = exact_mask;
         EvFixed fx;
         fx.ph = FIXED ? p.kph0 + (size_t)b * p.nch : nullptr;
         fx.st = FIXED ? p.kstep + (size_t)b * p.nch : nullptr;

@@ -89,25 +89,32 @@ static_assert(sizeof(SynRow) == sizeof(NcoRow), "row pool is sized for NcoRow");
 /* Per (block, channel) constants of the breakpoint kernel (gpsbb_events.hip.h), built on the host at batch
  * set-up from the descriptors with the same individually rounded products the kernels use. */
 struct EvConst {
+    /* what k_synth_ev's channel loop takes into scalar registers comes first, in the order it is loaded: 32 + 16 bytes,
+     * two scalar loads per channel, and records of 128 bytes so that a channel's address is a shift (gpsbb_events.hip.h:
+     * the loop's time follows its instruction count, scalar ones included) */
     double S;     /* |carrier step| per sample in table-index units: 512 * |fl(f_carr*delt)|, exact        */
     double rS;    /* 1/|S| (2^1000 where S == 0: no index change is ever in reach)                        */
-    double tK0;   /* rS*(1 + W) + 2^20 + W: what turns the fraction of the (biased) first-sample model into the position
-                     of the next index change, in guard format (gpsbb_events.hip.h)                         */
     double sc;    /* code step per sample in chips: fl(f_code*delt)                                       */
     double rsc;   /* 1/sc                                                                                  */
+    uint32_t danger_le; /* danger - 1, and 0xffffffff where every run is recomputed exactly (kc < 0): "low word <= this"    */
+    uint32_t chip_at;   /* k_synth_ev / k_synth_ev_fixed (EvLdsLean): LDS address of the channel's chip table, minus what the
+                           exponent bits of a guard-format high word contribute when it is shifted into a byte offset    */
+    uint32_t amp_at;    /* ... of its amplitude table, likewise                                                          */
+    uint32_t danger; /* a low word (fraction in units of 2^-32) below this: the model cannot be trusted (= 2W)  */
+    double tK0;   /* rS*(1 + W) + 2^20 + W: what turns the fraction of the (biased) first-sample model into the position
+                     of the next index change, in guard format (gpsbb_events.hip.h)                         */
     double tC0;   /* as tK0, for the chip change                                                           */
     double W;     /* the channel's bias: every tested quantity carries +W, W >= its model error             */
     int32_t kc;   /* carrier breakpoints a run of SPT samples can hold (1..4); -1: always recompute exactly */
     int32_t down; /* the carrier step is negative                                                         */
-    uint32_t danger; /* a low word (fraction in units of 2^-32) below this: the model cannot be trusted (= 2W)  */
-    uint32_t _pad;
     /* k_synth_pd's steps, scaled to LDS byte addresses (exact: powers of two): per sample and per 64 samples */
     double pd_S8;   /* 8 * S: the amplitude table has 8 bytes per entry   */
     double pd_dy;   /* 64 * pd_S8                                          */
     double pd_sc2;  /* 2 * sc: the chip tables have 2 bytes per chip      */
     double pd_dx;   /* 64 * pd_sc2                                         */
+    uint32_t _pad[4];
 };
-static_assert(sizeof(EvConst) == 104, "EvConst layout");
+static_assert(sizeof(EvConst) == 128 && offsetof(EvConst, danger_le) == 32, "EvConst layout");
 
 /* Per (block, channel) scratch of the device-side carrier chain (gpsbb_walk.hip.h, k_chain_fix). */
 constexpr int CHAIN_MAX_CROSS = 20;

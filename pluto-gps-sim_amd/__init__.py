@@ -400,6 +400,10 @@ class Stream:
     def pending(self):
         return lib().gpsbb_stream_pending(self._s)
 
+    def reset(self):
+        """gpsbb_stream_reset: a new stream on the same ring (every slot popped); the next push is block 0 again"""
+        _chk(lib().gpsbb_stream_reset(self._s), "gpsbb_stream_reset")
+
     def timing_stats(self, reset=True):
         n, a, b = C.c_int(), C.c_float(), C.c_float()
         _chk(lib().gpsbb_stream_timing_stats(self._s, C.byref(n), C.byref(a), C.byref(b), int(reset)),

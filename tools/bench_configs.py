@@ -53,6 +53,60 @@ def run(pkg, synth, name, nav, motion, max_chan, fs, nsamp, nblocks, push_blocks
             "end_to_end_iq_samples_per_s": nblocks * nsamp / (dt + t_fe), "x_realtime_end_to_end": nblocks * 0.1 / (dt + t_fe)}
 
 
+def run_overlapped(pkg, synth, nav, motion, max_chan, fs, nsamp, nblocks, push_blocks, span):
+    """the same work with the front end as a producer thread `span` blocks ahead of the pushes (what gpsbb-sim's loop does:
+    the ring is asynchronous, the host builds the next descriptors while the GPU renders): RINEX file -> IQ in HBM, one clock"""
+    import queue
+    import threading
+    depth = 6
+    # the ring and its device buffers exist before the clock starts (as in run(): allocated on first use), warmed by one
+    # ring's worth of pushes from a front end of their own
+    fe0 = pkg.FrontEnd(os.path.join(GOLD, nav), llh=SITE, motion=os.path.join(GOLD, motion) if motion else None,
+                       max_chan=max_chan)
+    ch0 = fe0.generate(depth * push_blocks)
+    fe0.close()
+    st = synth.stream(ch0.shape[1], 1.0 / fs, nsamp, push_blocks, depth=depth, flags=pkg.CHAIN_CARRIER | pkg.STREAM_DEVICE_ONLY)
+    for k in range(depth):
+        st.push(ch0[k * push_blocks:(k + 1) * push_blocks])
+    for k in range(depth):
+        st.pop(copy=False)
+    synth.sync()
+    st.reset()
+    t0 = time.perf_counter()
+    fe = pkg.FrontEnd(os.path.join(GOLD, nav), llh=SITE, motion=os.path.join(GOLD, motion) if motion else None,
+                      max_chan=max_chan)
+    q = queue.Queue(maxsize=8)
+
+    def produce():
+        for _ in range(nblocks // span):
+            q.put(fe.generate(span))
+        q.put(None)
+
+    th = threading.Thread(target=produce)
+    th.start()
+    pushed = popped = 0
+    while True:
+        ch = q.get()
+        if ch is None:
+            break
+        for k in range(span // push_blocks):
+            if st.pending >= depth:
+                st.pop(copy=False)
+                popped += 1
+            st.push(ch[k * push_blocks:(k + 1) * push_blocks])
+            pushed += 1
+    while popped < pushed:
+        st.pop(copy=False)
+        popped += 1
+    synth.sync()
+    dt = time.perf_counter() - t0
+    th.join()
+    fe.close()
+    st.close()
+    return {"end_to_end_overlapped_s": dt, "end_to_end_overlapped_iq_samples_per_s": nblocks * nsamp / dt,
+            "x_realtime_overlapped": nblocks * 0.1 / dt, "front_end_span_blocks": span}
+
+
 NB_F = 24000  # 40 minutes of signal: long enough for the ring to reach its steady state (a 3000-block run is over in 13 ms)
 
 
@@ -65,8 +119,10 @@ def main():
             s.set_option(pkg.OPT_CHAIN_WHERE, int(sys.argv[1]))
         out.append(run(pkg, s, "1/2 static, 2.6 MS/s, reference block (300000 samples)", "synth3540.14n", None, 12,
                        2.6e6, 300000, NB_F, 1000))
+        out[-1].update(run_overlapped(pkg, s, "synth3540.14n", None, 12, 2.6e6, 300000, NB_F, 1000, 1000))
         out.append(run(pkg, s, "4 user motion (10 Hz), 2.6 MS/s", "synth3540.14n", "circle_motion.csv", 12, 2.6e6,
                        300000, NB_F, 1000))
+        out[-1].update(run_overlapped(pkg, s, "synth3540.14n", "circle_motion.csv", 12, 2.6e6, 300000, NB_F, 1000, 1000))
         out.append(run(pkg, s, "3 geometry through the front end: 16 ch, 25 MS/s, 2.5 M-sample blocks", "dense3540.14n",
                        None, 16, 25e6, 2500000, 400, 100))
     print(json.dumps(out, indent=1))

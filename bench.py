@@ -272,6 +272,23 @@ def main():
         return
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
+    # this rank next to its GPU: the thread that builds descriptors, pushes, and touches the pinned ring of the gather leg runs
+    # on the CPUs local to the GPU's PCI function (the reference pins its threads: plutogpssim.c:2045-2056); the node driver's
+    # producer threads do the same for themselves (gpsbb_node.h)
+    affinity = {"numa_node": -1, "cpus_bound": 0}
+    if not os.environ.get("GPSBB_BENCH_NO_AFFINITY"):
+        try:
+            node, cpulist = pkg.device_affinity(local)
+            cpus = set()
+            for part in filter(None, cpulist.split(",")):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+            cpus &= os.sched_getaffinity(0)
+            if cpus:
+                os.sched_setaffinity(0, cpus)
+                affinity = {"numa_node": node, "cpus_bound": len(cpus)}
+        except (OSError, RuntimeError, ValueError):
+            pass
 
     delt, nsamp, nch, PB = 1.0 / args.fs, args.nsamp, args.nch, args.push_blocks
     K, W, R = args.steps, args.warmup, args.repeats
@@ -486,7 +503,8 @@ def main():
             "parity": parity,
             "parity_checked_blocks": parity["checked_blocks"] if parity else 0,
             "dist": {"process_group": bool(use_dist), "backend": backend if use_dist else None, "world": world,
-                     "hw_queues": synth.info(pkg.INFO_HW_QUEUES), "streams_of_the_handle": synth.info(pkg.INFO_STREAMS)},
+                     "hw_queues": synth.info(pkg.INFO_HW_QUEUES), "streams_of_the_handle": synth.info(pkg.INFO_STREAMS),
+                     "rank0_affinity": affinity},
         }
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):

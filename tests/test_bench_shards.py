@@ -93,6 +93,8 @@ def test_one_rank_through_the_rccl_path(pkg):
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     r = json.loads(lines[0])
+    aff = r["dist"].pop("rank0_affinity")
+    assert aff["cpus_bound"] >= 0 and aff["numa_node"] >= -1  # the rank sits on the CPUs local to its GPU where sysfs names them
     assert r["dist"] == {"process_group": True, "backend": "nccl", "world": 1, "hw_queues": 12, "streams_of_the_handle": r["dist"]["streams_of_the_handle"]}
     assert r["n_gpus"] == 1 and r["value"] > 0 and r["parity"]["mismatching_blocks"] == 0
     assert len(r["gather"]["per_rank_GBps_to_host"]) == 1 and r["gather"]["node_GBps_to_host"] > 0

@@ -89,6 +89,30 @@ def test_high_doppler_and_slow_channels(pkg, synth, oracle):
     assert_state_equal(st, want_st[0], ch["prn"] > 0)
 
 
+def test_carrier_steps_the_breakpoint_kernel_always_recomputes(pkg, synth, oracle, request):
+    """At 25 MS/s the breakpoint kernel takes the block.  A carrier whose step per sample is below eight times the in-tile
+    model's error has no usable model (EvConst::kc = -1): its threshold is one no low word is above (danger_le = 0xffffffff)
+    and every lane-run goes through the exact path; a carrier that does not move at all has no index change to place.  Beside
+    ordinary channels of both signs, in one batch."""
+    fs, nsamp = 25e6, 120000
+    ch = pkg.synth_descriptors(2, nch=12, seed=77)
+    for b in range(2):
+        ch[b]["f_carr"] = [0.0, 1e-5, -1e-5, 3e-4, -3e-4, 2e-3, -2e-3, 4999.0, -4999.0, 1200.0, -0.0, 5e-324]
+        ch[b]["f_code"] = 1.023e6 + ch[b]["f_carr"] / 1540.0
+    want_iq, want_st, _ = oracle.fill_blocks(ch, 1.0 / fs, nsamp)
+    b = synth.batch(ch, 1.0 / fs, nsamp)
+    b.run()
+    synth.sync()
+    iq, st = b.read()
+    b.close()
+    assert (iq == want_iq).all()
+    for k in range(2):
+        assert_state_equal(st[k], want_st[k], ch["prn"][k] > 0)
+    if "per-sample" not in request.node.callspec.params["seed_mode"]:
+        assert synth.info(pkg.INFO_LAST_KERNEL) == 2  # the breakpoint kernel
+        assert synth.info(pkg.INFO_EXACT_RUNS) >= 2 * 4 * (nsamp // 16)  # four always-exact channels per block at least
+
+
 def test_steps_that_hit_chip_and_table_boundaries_exactly(pkg, synth, oracle):
     """Sample rates at which a run of 16 samples holds at most one chip boundary take the path that locates
     the boundary instead of stepping the code NCO.  With f_code*delt and f_carr*delt binary fractions the

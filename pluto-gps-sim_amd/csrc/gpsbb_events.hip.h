@@ -501,6 +501,9 @@ struct EvTile {
                              tile_x[c * ntiles] */
     int ntiles;
     uint32_t dbits, dnext; /* bit i: channel i's data bit in force / after the next roll-over is -1 */
+#ifdef GPSBB_X_TSTATE_VMEM
+    uint32_t vzero; /* a zero the compiler cannot see through: makes the address a vector one */
+#endif
 };
 
 /*
@@ -557,7 +560,13 @@ __device__ __forceinline__ void ev_channels(LDS &L, uint32_t &drow, int wave, in
                                             double off, unsigned long long live_mask, uint32_t &acc0, unsigned long long *n_exact,
                                             const EvFixed &fx)
 {
-#ifdef GPSBB_X_NOTSTATE /* (measurement: the tile states and position constants out of thin air instead of LDS) */
+#ifdef GPSBB_X_TSTATE_VMEM /* (measurement: the same 2 x 16 bytes per channel through the vector memory path — uniform addresses
+                              of the tile-state array and of the channel's record — instead of two LDS broadcasts) */
+#define GPSBB_EV_STATES(i)                                                                                             \
+    const double2 sv##i = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T.tile_x) + T.vzero + (size_t)i * 16);  \
+    const double2 cv##i = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(kb) + T.vzero + (size_t)i * 128 + offsetof(EvConst, tK0)); \
+    const double xt##i = sv##i.x + 0x1p+20, yt##i = sv##i.y + 0x1p+20, tk##i = cv##i.x, tc##i = cv##i.y;
+#elif defined(GPSBB_X_NOTSTATE) /* (measurement: the tile states and position constants out of thin air instead of LDS) */
 #define GPSBB_EV_STATES(i)                                                                                             \
     const double xt##i = off * 0.25 + (0x1p+20 + 0.37), yt##i = off * 0.125 + (0x1p+20 + 0.41), tc##i = 0x1p+20 + 3.3, tk##i = 0x1p+20 + 5.7;
 #else
@@ -775,6 +784,10 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         EvTile T;
         T.ts = L.tstate[wave][0];
         T.tile_x = txb + wt;
+#ifdef GPSBB_X_TSTATE_VMEM
+        asm volatile("v_mov_b32 %0, 0" : "=v"(T.vzero));
+        T.tile_x = txb + (size_t)wt * nch2; /* (wrong data, right footprint: 16 bytes per channel and tile, tile-major) */
+#endif
         T.ntiles = ntw;
         T.dbits = (uint32_t)__ballot(nav_v & 1u);
         T.dnext = (uint32_t)__ballot(nav_v & 2u);

@@ -746,6 +746,17 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
 
 static hipError_t create_seed_stream(hipStream_t *st);
 
+/* Zero device memory NOW.  The library's streams are non-blocking ones: nothing orders them behind the null stream, and a
+ * hipMemset of device memory returns before it has happened — a kernel launched afterwards on one of those streams can run
+ * first and have its result wiped (found by the node driver's stress, tools/stress_node.py: four handles on one GPU, the
+ * cleared carry of a fresh stream landing after the first push's fix-up had written it — every later block of the shard off
+ * by that push's phase, once in a hundred runs).  So: on a stream of the handle, and waited for. */
+static hipError_t zero_now(gpsbb *h, void *ptr, size_t bytes)
+{
+    const hipError_t e = hipMemsetAsync(ptr, 0, bytes, h->s_upload);
+    return e != hipSuccess ? e : hipStreamSynchronize(h->s_upload);
+}
+
 extern "C" int gpsbb_create(gpsbb_t **out, int device)
 {
     if (!out)
@@ -796,9 +807,10 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     if ((e = hipMalloc((void **)&h->d_hz, 64)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h->d_tabs, tabs, sizeof tabs, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h->d_ca, ca.data(), ca.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail(e); /* (the tables are there before any non-blocking stream runs) */
     h->h_ca = ca;
-    if ((e = hipMemset(h->d_status, 0, 4)) != hipSuccess) return fail(e);
-    if ((e = hipMemset(h->d_hz, 0, 64)) != hipSuccess) return fail(e);
+    if ((e = zero_now(h, h->d_status, 4)) != hipSuccess) return fail(e);
+    if ((e = zero_now(h, h->d_hz, 64)) != hipSuccess) return fail(e);
     /* k_synth carves ~76 KB of dynamic LDS per workgroup: above the 64 KB default limit */
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(SynthLds))) != hipSuccess) return fail(e);
@@ -1937,7 +1949,7 @@ extern "C" int gpsbb_sync(gpsbb_t *h)
     uint32_t st = 0;
     HIPCHK(h, hipMemcpy(&st, h->d_status, 4, hipMemcpyDeviceToHost));
     if (st) {
-        HIPCHK(h, hipMemset(h->d_status, 0, 4));
+        HIPCHK(h, zero_now(h, h->d_status, 4));
         return GPSBB_E_INTERNAL;
     }
     return GPSBB_OK;
@@ -1981,7 +1993,7 @@ extern "C" int gpsbb_get_hazards(gpsbb_t *h, gpsbb_hazards_t *out, int reset)
     out->itable_512 += h->host_itable_512;
     out->dwrd_oob = v[1] + h->host_dwrd_oob;
     if (reset) {
-        HIPCHK(h, hipMemset(h->d_hz, 0, 16));
+        HIPCHK(h, zero_now(h, h->d_hz, 16));
         h->host_dwrd_oob = 0;
         h->host_itable_512 = 0;
     }
@@ -2287,7 +2299,7 @@ extern "C" int gpsbb_stream_reset(gpsbb_stream_t *s)
     if (rc != GPSBB_OK)
         return rc;
     if (s->d_carry)
-        HIPCHK(h, hipMemset(s->d_carry, 0, sizeof(ChainCarryDev)));
+        HIPCHK(h, zero_now(h, s->d_carry, sizeof(ChainCarryDev)));
     if (s->carry)
         memset(s->carry, 0, sizeof *s->carry);
     s->carry_on_device = false;
@@ -2389,7 +2401,7 @@ static int stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch, bool new_chain
         if (dev) {
             if (!s->d_carry) {
                 HIPCHK(h, hipMalloc((void **)&s->d_carry, sizeof(ChainCarryDev)));
-                HIPCHK(h, hipMemset(s->d_carry, 0, sizeof(ChainCarryDev)));
+                HIPCHK(h, zero_now(h, s->d_carry, sizeof(ChainCarryDev)));
                 HIPCHK(h, hipEventCreateWithFlags(&s->ev_prefix, hipEventDisableTiming));
                 HIPCHK(h, hipEventCreateWithFlags(&s->ev_fix, hipEventDisableTiming));
             }
@@ -2402,6 +2414,7 @@ static int stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch, bool new_chain
                 if (rc_ != GPSBB_OK)
                     return rc_;
                 HIPCHK(h, hipMemcpy(s->d_carry, &c, sizeof c, hipMemcpyHostToDevice));
+                HIPCHK(h, hipStreamSynchronize(nullptr)); /* (see zero_now) */
                 for (int i = 0; i < s->nch; i++) {
                     s->last_prn[i] = s->carry->prn[i];
                     s->rough_phase[i] = s->carry->phase[i];
@@ -2540,7 +2553,7 @@ extern "C" int gpsbb_stream_pop(gpsbb_stream_t *s, const int16_t **iq, gpsbb_cha
     uint32_t st = 0;
     memcpy(&st, (const char *)sl.h_end + (((size_t)s->bps * s->nch * sizeof(gpsbb_chan_state_t) + 15) & ~(size_t)15), 4);
     if (st) {
-        HIPCHK(h, hipMemset(h->d_status, 0, 4));
+        HIPCHK(h, zero_now(h, h->d_status, 4));
         return GPSBB_E_INTERNAL;
     }
     return GPSBB_OK;

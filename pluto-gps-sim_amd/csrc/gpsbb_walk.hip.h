@@ -1233,8 +1233,15 @@ __global__ __launch_bounds__(FIXP_WG) __attribute__((amdgpu_waves_per_eu(4, 4)))
  * n0[r] .. n0[r+1]-1 (the last one: to the end of the block); every tile whose first sample is one of them
  * gets fma(tile start - n0, S, x), exactly the chain's state there.
  */
+/* One wavefront per chain, two rows per lane and turn.  A chain keeps a few hundred rows (those that hold a tile's first
+ * sample): with 256 lanes x 4 rows a turn's 1 024 slots were 60 % full and the kernel issued 2.81e7 vector instructions per
+ * 400-block push; 64 x 2: 1.92e7, in less time (tools/tiles_geom.sh: exact counters, 64 / 128 / 192 / 256 lanes x 1..6 rows).
+ * The pre-pass's instructions are what the synthesis kernel beside it pays for. */
 #ifndef GPSBB_TILES_WG
-#define GPSBB_TILES_WG 256
+#define GPSBB_TILES_WG 64
+#endif
+#ifndef GPSBB_TILES_U
+#define GPSBB_TILES_U 2 /* rows per lane and turn */
 #endif
 __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
 {
@@ -1292,9 +1299,8 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
                 tx[t] = mul_rn(__fma_rn((double)(t * TILE - row.n0), walk_row_step(row.x, s), row.x), 512.0);
         }
     }
-    /* four rows per lane and turn, their loads issued together: the kernel is bound by the latency of these
-     * loads, not by their number */
-    constexpr int U = 4;
+    /* a few rows per lane and turn, their loads issued together */
+    constexpr int U = GPSBB_TILES_U;
     for (int r0 = threadIdx.x; r0 < cnt; r0 += U * GPSBB_TILES_WG) {
         WalkRow row[U];
         int n_next[U];

@@ -73,6 +73,23 @@ def test_reference_scenario_in_1_2_and_4_shards_equals_the_golden_vectors(pkg):
         assert all(s["seed_seconds"] > 0 for s in st["shards"][1:]) and st["shards"][0]["seed_seconds"] == 0
 
 
+def test_fresh_streams_four_to_a_gpu_over_and_over(pkg):
+    """A statistical guard (tools/stress_node.py is the long version): the library's streams are non-blocking ones, and the
+    cleared carry of a fresh stream used to be a null-stream hipMemset — which could land after the first push's fix-up had
+    written the exact end phase, leaving every later block of the shard off by one push's phase: about one run in a hundred
+    with four handles on one GPU, never with one.  Forty fresh nodes of four shards against the one-shard bytes."""
+    pkg.build_frontend()
+    fs, nsamp = 2.6e6, 300000
+    fe = pkg.FrontEnd(os.path.join(GOLDEN, "synth3540.14n"), llh=(30.286502, 120.032669, 100.0), max_chan=12)
+    ch = fe.generate(301)
+    fe.close()
+    ref, _ = render(pkg, ch, fs, nsamp, 1, bps=8)
+    for r in range(40):
+        sink, _ = render(pkg, ch, fs, nsamp, 4, bps=8)
+        bad = [b for b in range(ch.shape[0]) if not (sink.iq[b] == ref.iq[b]).all()]
+        assert not bad, (r, bad[:8])
+
+
 def test_dense_25_MSps_blocks_indexed_sink_and_oracle(pkg, oracle):
     """config 3/5 geometry (16 channels, 25 MS/s, 2.5 M-sample blocks) through the front end: golden blocks 0 and 1, then
     every block against N = 1 and a sample of them against the oracle's sequential render; the sink takes slots in

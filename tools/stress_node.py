@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The reference scenario (RINEX -> front end -> 301 blocks) through the node driver, over and over in one process: 1 shard once
 (the reference bytes), then N shards `runs` times; any block that differs is listed with where it differs.
-usage: tools/stress_node.py [runs] [nshards] [depth] [reference|dense|reference-interleaved|dense-interleaved]"""
+usage: tools/stress_node.py [runs] [nshards] [depth] [reference|dense][-interleaved|-indexed]"""
 import ctypes as C
 import os
 import sys
@@ -40,6 +40,8 @@ def main():
     mode = sys.argv[4] if len(sys.argv) > 4 else "reference"   # or: dense (16 ch, 25 MS/s: the breakpoint kernel), + "-interleaved"
     pkg = load_package()
     flags = pkg.NODE_INTERLEAVED if mode.endswith("-interleaved") else 0
+    if mode.endswith("-indexed"):   # slots as they complete, from several producer threads at once
+        flags = pkg.NODE_INDEXED | pkg.NODE_CONCURRENT
     if mode.startswith("dense"):
         fs, nsamp, bps = 25e6, 250000, 4
         ch = pkg.synth_descriptors(101, nch=16, seed=0x5EED)

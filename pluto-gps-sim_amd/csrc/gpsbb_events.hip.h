@@ -625,6 +625,9 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
     LDS &L = *reinterpret_cast<LDS *>(smem_raw);
 
     const int tid = threadIdx.x;
+#ifdef GPSBB_EV_PRIO /* (measurement: the synthesis wavefronts' issue priority against the pre-pass's, GPSBB_SEED_PRIO) */
+    __builtin_amdgcn_s_setprio(GPSBB_EV_PRIO);
+#endif
     if (lds_addr_of(smem_raw) != 0u) { /* ev_d_add addresses the image from LDS address 0 (the kernel has no static LDS) */
         if (tid == 0)
             atomicOr(p.status, ST_LDS_LAYOUT);

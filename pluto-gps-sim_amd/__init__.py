@@ -44,7 +44,7 @@ FIXED_CARRIER = 2
 STREAM_DEVICE_ONLY = 4
 OPT_SEED_WHERE, OPT_SYNTH_KERNEL, OPT_SKIP_SEED, OPT_CHAIN_WHERE = 1, 2, 3, 4
 INFO_LAST_KERNEL, INFO_EXACT_RUNS, INFO_CHAIN_ON_DEVICE, INFO_CHAIN_FALLBACKS, INFO_CHAIN_TIES, INFO_CHAIN_REPAIRS = 1, 2, 3, 4, 5, 6
-INFO_STREAMS, INFO_HW_QUEUES, INFO_TILES_RENDERED = 7, 8, 9
+INFO_STREAMS, INFO_HW_QUEUES, INFO_TILES_RENDERED, INFO_PREPASS = 7, 8, 9, 10
 NODE_INDEXED, NODE_CONCURRENT, NODE_DEVICE_ONLY, NODE_NO_AFFINITY, NODE_FIXED_CARRIER, NODE_INTERLEAVED = 1, 2, 4, 8, 16, 32
 PUSH_NEW_CHAIN = 1
 NODE_MAX_SHARDS = 64

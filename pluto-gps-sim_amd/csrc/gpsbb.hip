@@ -27,6 +27,7 @@
 #include "gpsbb_events.hip.h"
 #include "gpsbb_dense.hip.h"
 #include "gpsbb_walk.hip.h"
+#include "gpsbb_laps.hip.h"
 #include "gpsbb_nco.h"
 #include "gpsbb_testhooks.h"
 #ifdef GPSBB_EXPERIMENTS
@@ -327,6 +328,67 @@ bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vec
     return true;
 }
 
+/* Can a sum of this step be rounded exactly half-way on the coarsest grid its chain meets (the one the wrap sums are rounded
+ * on: 2^-52 / 2^-53 for a rising / falling carrier, 2^-43 for the code)?  Then the offset between two trajectories changes at
+ * every wrap with its parity, and the lap-parallel pre-pass would guess wrong lap after lap (gpsbb_laps.hip.h; fix_block's
+ * tie_top is the same test).  A property of the step's low bits: steps that are multiples of (half) that grid. */
+bool lap_step_ties_on_top(double s, int grid_exp_biased /* biased exponent of a number whose last place is the grid */)
+{
+    const uint64_t sb = f64_bits(s);
+    const int es = (int)((sb >> 52) & 0x7ff);
+    const int dt = grid_exp_biased - es; /* the step's last place is 2^dt times finer than the grid */
+    if (dt <= 0)
+        return false; /* the step is a multiple of the grid: sums are never between grid points */
+    if (dt > 52)
+        return true;
+    const uint64_t low = ((sb & F64_MANT) | F64_HID) & ((1ull << dt) - 1);
+    return low == 0ull || low == (1ull << (dt - 1));
+}
+
+/* Does the lap-parallel pre-pass take these blocks (gpsbb_laps.hip.h, Eligibility)?  It is exact for any step; what is
+ * excluded is what it would be slow for (a guess that fails at every lap) or what its turn does not cover (steps more than
+ * 50 binades below the state: |step| < 2^-50, zero). */
+bool lap_eligible(const gpsbb_chan_t *ch, size_t nbc, double delt, bool fixed)
+{
+    for (size_t k = 0; k < nbc; k++) {
+        const gpsbb_chan_t &c = ch[k];
+        if (c.prn <= 0)
+            continue;
+        const volatile double sc = c.f_code * delt, sk = c.f_carr * delt;
+        if (!(sc >= 0x1p-20) || lap_step_ties_on_top(sc, 1023 + 9))
+            return false;
+        if (fixed)
+            continue;
+        const double sa = std::fabs(sk);
+        if (!(sa >= 0x1p-50) || lap_step_ties_on_top(sk, sk < 0.0 ? 1022 : 1023))
+            return false;
+    }
+    return true;
+}
+
+/* room for the laps of every channel, in chunks of LAP_WG lanes: a chain of n steps of size s wraps at most floor(n * s / range)
+ * + 1 times, a block may start a chain (one more lap), and the model's step differs from s by parts in 10^12 */
+void lap_bound(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp, bool fixed, uint32_t chunk0[2][GPSBB_MAX_CHAN + 1])
+{
+    for (int kind = 0; kind < 2; kind++) {
+        chunk0[kind][0] = kind == 0 ? 0u : chunk0[0][GPSBB_MAX_CHAN]; /* one array of chunks: the code chains', then the carriers' */
+        for (int i = 0; i < nch; i++) {
+            double laps = 0.0;
+            for (int blk = 0; blk < nblocks; blk++) {
+                const gpsbb_chan_t &c = ch[(size_t)blk * nch + i];
+                if (c.prn <= 0 || (kind == NCO_CARR && fixed))
+                    continue;
+                const double s = kind == NCO_CARR ? std::fabs(c.f_carr * delt) : c.f_code * delt * (1.0 / 1023.0);
+                laps += std::floor((double)nsamp * s * (1.0 + 0x1p-30)) + 3.0;
+            }
+            const uint32_t chunks = (uint32_t)((laps + (double)(LAP_WG - 1)) / (double)LAP_WG) + 1u;
+            chunk0[kind][i + 1] = chunk0[kind][i] + chunks;
+        }
+        for (int i = nch; i < GPSBB_MAX_CHAN; i++)
+            chunk0[kind][i + 1] = chunk0[kind][i];
+    }
+}
+
 } /* namespace */
 
 /* ================================================================================================== */
@@ -434,13 +496,15 @@ struct gpsbb {
     struct ChainOnly *chain_only = nullptr; /* device scratch of gpsbb_chain_carrier, kept between calls */
     int sm_count = 0;
     /* per-handle options (gpsbb_set_option) */
-    int opt_seed_where = 0;   /* 0 by size, 1 always k_seed, 2 always host threads */
+    int opt_seed_where = 0;   /* 0 by size (on the device: lap-parallel where eligible), 1 always the row walks (k_seed / k_walk), 2 always
+                                 host threads, 3 always on the device, lap-parallel where eligible */
     int opt_synth_kernel = 0; /* 0 automatic, 1 always the per-sample kernel */
     int opt_skip_seed = 0;    /* measurement: re-use the tables of the first two runs of a batch */
     int opt_chain_where = 0;  /* GPSBB_CHAIN_CARRIER: 0 automatic (on the device wherever the pre-pass runs there), 1 host threads,
                                  2 as 0 with the fix-up walking the blocks in order (k_chain_fix instead of k_chain_fix_par) */
     int last_kernel = 0;      /* synthesis kernel of the last launch: 1 per-sample, 2 breakpoint */
     int last_chain_dev = 0;   /* the last launch resolved GPSBB_CHAIN_CARRIER on the device */
+    int last_prepass = 0;     /* pre-pass of the last launch: 1 row walks on the device, 2 host threads, 3 lap-parallel on the device */
 };
 
 template <class T>
@@ -545,6 +609,14 @@ struct gpsbb_batch {
     bool host_seed = false;      /* the NCO tables of this batch are built on host threads: decided at set-up, like the
                                     chain (a run never re-reads the handle's options) */
     int carr_lanes = 0; /* lanes of the seed plan that walk carrier chains (they come first) */
+    /* the lap-parallel pre-pass (gpsbb_laps.hip.h): one lane per lap of every chain; scratch per table set */
+    bool laps = false;
+    uint32_t lap_chunk0[2][GPSBB_MAX_CHAN + 1] = {};
+    DevBuf<LapBC> d_lap_bc[NSETS];
+    DevBuf<uint32_t> d_lap_lane0[NSETS], d_lap_cnt[NSETS], d_lap_chunk_bad[NSETS];
+    DevBuf<LapRec> d_lap_rec[NSETS];
+    DevBuf<LapAgg> d_lap_agg[NSETS];
+    DevBuf<double> d_lap_chunk_m[NSETS];
     /* a stream's slot: the carrier continues from the push before (set by gpsbb_stream_push around set-up / launch) */
     ChainCarryDev *d_carry = nullptr;
     const int *carry_prn = nullptr;        /* in: prn per channel in the last block pushed before */
@@ -614,7 +686,7 @@ extern "C" int gpsbb_set_option(gpsbb_t *h, int option, long value)
         return GPSBB_E_BADARG;
     switch (option) {
     case GPSBB_OPT_SEED_WHERE:
-        if (value < 0 || value > 2)
+        if (value < 0 || value > 3)
             return GPSBB_E_BADARG;
         h->opt_seed_where = (int)value;
         return GPSBB_OK;
@@ -658,6 +730,9 @@ extern "C" int gpsbb_get_info(gpsbb_t *h, int what, uint64_t *out)
     }
     case GPSBB_INFO_CHAIN_ON_DEVICE:
         *out = (uint64_t)h->last_chain_dev;
+        return GPSBB_OK;
+    case GPSBB_INFO_PREPASS:
+        *out = (uint64_t)h->last_prepass;
         return GPSBB_OK;
     case GPSBB_INFO_STREAMS: {
         uint64_t n = 0;
@@ -952,6 +1027,10 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
 
     /* where the pre-pass runs and where the carrier chain is resolved: decided here, once, for all runs of the batch */
     b->host_seed = host_seeding_wanted(b);
+    /* on the device: lap-parallel (gpsbb_laps.hip.h) wherever the model kernels render and the steps are ordinary ones; the
+     * row walks (k_walk and the chain kernels) for the rest and where GPSBB_OPT_SEED_WHERE / _CHAIN_WHERE ask for them */
+    b->laps = b->ev && !b->host_seed && h->opt_seed_where != 1 && h->opt_chain_where != 2 && h->opt_chain_where != 3 &&
+              !GPSBB_KNOB_SET("GPSBB_NO_LAPS") && lap_eligible(ch, nbc, delt, fixed);
     const bool chained = !fixed && (flags & GPSBB_CHAIN_CARRIER) && (nblocks > 1 || b->d_carry);
     b->chain_dev = chained && h->opt_chain_where != 1 && !b->host_seed;
     b->chain_fix_seq = h->opt_chain_where == 2;
@@ -971,7 +1050,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
      * segments costs more than the walks save (1.72e11 -> 1.61e11): those keep k_walk<0>. */
     const bool indep_ok = !chained && !b->d_carry && b->ev && !fixed && !b->host_seed && h->opt_chain_where == 0 &&
                           b->ntiles >= (int)GPSBB_KNOB_LONG("GPSBB_INDEP_MIN_TILES", CHAIN_INDEP_MIN_TILES);
-    if ((b->chain_dev && !b->chain_starts) || indep_ok) { /* (k_seed, the per-sample kernel's pre-pass, walks whole blocks) */
+    if (!b->laps && ((b->chain_dev && !b->chain_starts) || indep_ok)) { /* (k_seed, the per-sample kernel's pre-pass, walks whole blocks) */
         double rows_max = 0.0;
         for (size_t k = 0; k < nbc; k++)
             if (ch[k].prn > 0) {
@@ -1000,14 +1079,14 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
      * batches of up to CHAIN_MODEL_MAX_SEGS segments.  Not the pushes of a stream — the belief can only be re-anchored on
      * end states that are a ring's depth of pushes old (measured: 3.3 segment walks per 400-block push, stream 4.48e11 ->
      * 4.26e11 samples/s), and not chains over tens of thousands of blocks (gpsbb_chain_carrier): those keep pass A. */
-    b->chain_model = b->chain_dev && !b->chain_starts && !b->d_carry && h->opt_chain_where != 3 &&
+    b->chain_model = !b->laps && b->chain_dev && !b->chain_starts && !b->d_carry && h->opt_chain_where != 3 &&
                      (long)nblocks * b->nseg <= CHAIN_MODEL_MAX_SEGS;
     const size_t nvbc = nbc * (size_t)b->nseg; /* carrier chains: one per (segment, channel) */
 
     /* row pool plan: the code chains (block*nch + channel), then the carrier chains ((block*nseg + segment)*nch + channel) */
     b->row_off.assign(nbc + nvbc + 1, 0);
     uint64_t off = 0;
-    for (size_t k = 0; k < nbc; k++) {
+    for (size_t k = 0; k < nbc && !b->laps; k++) { /* (the lap-parallel pre-pass keeps no rows) */
         b->row_off[k] = off;
         if (ch[k].prn > 0) {
             off += row_bound(ch[k].f_code * delt, 1023.0, 9, nsamp) + 1;
@@ -1017,7 +1096,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
             off += 1;
         }
     }
-    {
+    if (!b->laps) {
         /* a segment's bound depends on the block-channel's step and the segment's length only: one evaluation per
          * block-channel for the full segments, one for the (shorter) last */
         const int full = b->seg_tiles * TILE, last = nsamp - (b->nseg - 1) * full;
@@ -1106,7 +1185,26 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     }
     b->h_ch.assign(ch, ch + nbc);
     b->cont0_mask = 0;
-    if (b->chain_dev) {
+    if (b->laps) {
+        /* the lap-parallel pre-pass: room for the laps of every channel, scratch per table set; a stream's push: which
+         * channels of its first block go on from the push before (the exact phase is on the device) */
+        lap_bound(ch, nblocks, nch, delt, nsamp, fixed, b->lap_chunk0);
+        const size_t chunks = (size_t)b->lap_chunk0[1][nch];
+        for (int set = 0; set < b->nsets; set++) {
+            HIPCHK(h, (hipError_t)b->d_lap_bc[set].reserve(2 * nbc));
+            HIPCHK(h, (hipError_t)b->d_lap_lane0[set].reserve(2 * (size_t)nch * ((size_t)nblocks + 1)));
+            HIPCHK(h, (hipError_t)b->d_lap_cnt[set].reserve(4 * GPSBB_MAX_CHAN));
+            HIPCHK(h, (hipError_t)b->d_lap_rec[set].reserve(chunks * LAP_WG, b->max_sets == 1 ? chunks * LAP_WG / 4 : 0));
+            HIPCHK(h, (hipError_t)b->d_lap_agg[set].reserve(chunks, b->max_sets == 1 ? chunks / 4 : 0));
+            HIPCHK(h, (hipError_t)b->d_lap_chunk_m[set].reserve(chunks, b->max_sets == 1 ? chunks / 4 : 0));
+            HIPCHK(h, (hipError_t)b->d_lap_chunk_bad[set].reserve(chunks, b->max_sets == 1 ? chunks / 4 : 0));
+        }
+        if (b->chain_dev && b->d_carry && b->carry_prn)
+            for (int i = 0; i < nch; i++)
+                if (ch[i].prn > 0 && ch[i].prn == b->carry_prn[i])
+                    b->cont0_mask |= 1u << i;
+    }
+    if (b->chain_dev && !b->laps) {
         /* The carrier chain is resolved exactly on the device, in parallel over the blocks (k_walk pass A,
          * k_chain_prefix, k_walk pass B, k_chain_fix).  All the host contributes is a rough start phase per block:
          * the descriptor's phase carried forward by nsamp*step in plain double arithmetic (good to ~1e-7 cycles
@@ -1192,8 +1290,12 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     PUSH_MARK("aux");
     HIPCHK(h, stage_upload(b, b->d_ch.p, b->h_ch.data(), nbc * sizeof(gpsbb_chan_t), upload_stream));
     PUSH_MARK("up_ch");
-    HIPCHK(h, stage_upload(b, b->d_row_off.p, b->row_off.data(), (nbc + nvbc + 1) * 8, upload_stream));
-    {
+    if (!b->laps)
+        HIPCHK(h, stage_upload(b, b->d_row_off.p, b->row_off.data(), (nbc + nvbc + 1) * 8, upload_stream));
+    if (b->laps) {
+        b->h_seed_order.clear();
+        b->carr_lanes = 0;
+    } else {
         /* which chain each lane of k_seed walks (BatchDev::seed_order).  k_seed takes as long as its slowest
          * wavefront: rows of its longest chain x the time of one turn of the loop, which grows with the
          * number of lanes that are out of step.  Measured (400 x 16 chains, |f_carr| uniform up to 5 kHz):
@@ -1373,6 +1475,13 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
         b->d_fix_end.release();
         b->d_fix_flag.release();
         b->d_prefix[k].release();
+        b->d_lap_bc[k].release();
+        b->d_lap_lane0[k].release();
+        b->d_lap_cnt[k].release();
+        b->d_lap_chunk_bad[k].release();
+        b->d_lap_rec[k].release();
+        b->d_lap_agg[k].release();
+        b->d_lap_chunk_m[k].release();
         b->d_chain_order.release();
         b->d_evc.release();
     }
@@ -1728,6 +1837,23 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     return p;
 }
 
+static LapDev lap_dev(const gpsbb_batch *b, int set)
+{
+    LapDev L;
+    L.bc = b->d_lap_bc[set].p;
+    L.lane0 = b->d_lap_lane0[set].p;
+    L.nlaps = b->d_lap_cnt[set].p;
+    L.nbad = b->d_lap_cnt[set].p + 2 * GPSBB_MAX_CHAN;
+    L.rec = b->d_lap_rec[set].p;
+    L.agg = b->d_lap_agg[set].p;
+    L.chunk_m = b->d_lap_chunk_m[set].p;
+    L.chunk_bad = b->d_lap_chunk_bad[set].p;
+    memcpy(L.chunk0, b->lap_chunk0, sizeof L.chunk0);
+    L.chained = b->chain_dev ? 1 : 0;
+    L.jitter = (uint32_t)GPSBB_KNOB_LONG("GPSBB_LAP_JITTER", 0);
+    return L;
+}
+
 static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
 {
     gpsbb *h = b->h;
@@ -1779,6 +1905,34 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         const int rc = host_seed_run(b, set, ss);
         if (rc != GPSBB_OK)
             return rc;
+    } else if (b->ev && b->laps) {
+        /* the lap-parallel pre-pass (gpsbb_laps.hip.h): plan, reference walks, scan, true walks, repair — the code chains
+         * first (nothing of theirs waits for another push), then the carriers: a stream's push starts from the exact phase the
+         * push before it left on the device, so its plan follows that push's repair kernel */
+        const LapDev L = lap_dev(b, set);
+        const unsigned cc = b->lap_chunk0[NCO_CODE][b->nch] - b->lap_chunk0[NCO_CODE][0];
+        const unsigned ck = b->lap_chunk0[NCO_CARR][b->nch] - b->lap_chunk0[NCO_CARR][0];
+        hipLaunchKernelGGL(k_lap_plan<NCO_CODE>, dim3(b->nch), dim3(64), 0, ss, p, L);
+        hipLaunchKernelGGL(k_lap_pass1<NCO_CODE>, dim3(cc), dim3(LAP_WG), 0, ss, p, L);
+        hipLaunchKernelGGL(k_lap_scan<NCO_CODE>, dim3(b->nch), dim3(64), 0, ss, p, L);
+        hipLaunchKernelGGL(k_lap_pass2<NCO_CODE>, dim3(cc), dim3(LAP_WG), 0, ss, p, L);
+        hipLaunchKernelGGL(k_lap_repair<NCO_CODE>, dim3(b->nch), dim3(64), 0, ss, p, L);
+        if (p.kph0) {
+            /* fixed-point carrier: no chain to walk; the plan kernel leaves the end states, the tile states are a closed form */
+            hipLaunchKernelGGL(k_lap_plan<NCO_CARR>, dim3(b->nch), dim3(64), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_fixed_tiles, dim3(b->nblocks * b->nch), dim3(256), 0, ss, p);
+        } else {
+            if (b->d_carry && b->ev_fix)
+                HIPCHK(h, hipStreamWaitEvent(ss, b->ev_fix, 0));
+            hipLaunchKernelGGL(k_lap_plan<NCO_CARR>, dim3(b->nch), dim3(64), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_pass1<NCO_CARR>, dim3(ck), dim3(LAP_WG), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_scan<NCO_CARR>, dim3(b->nch), dim3(64), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_pass2<NCO_CARR>, dim3(ck), dim3(LAP_WG), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_repair<NCO_CARR>, dim3(b->nch), dim3(64), 0, ss, p, L);
+            if (b->d_carry && b->ev_fix)
+                HIPCHK(h, hipEventRecord(b->ev_fix, ss));
+        }
+        ctr_reset_by_prepass = true; /* k_lap_plan zeroes the set's tile counters */
     } else if (b->ev) {
         const bool old_seed = GPSBB_KNOB_SET("GPSBB_EV_KSEED"); /* experiment: the one-kernel pre-pass */
         if (old_seed) {
@@ -1846,6 +2000,7 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(ev[1], ss));
+    h->last_prepass = b->host_seed ? 2 : (b->ev && b->laps ? 3 : 1);
     PUSH_MARK("l_pre");
 
     /* off by default: +2 % on a stream of pushes, but overlapping kernels make the per-launch time (the roofline figure)
@@ -2391,7 +2546,7 @@ static int stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch, bool new_chain
         const size_t host_lim = (size_t)GPSBB_KNOB_LONG("GPSBB_HOST_SEED_MAX", HOST_SEED_MAX_CHANNELS);
         const bool dev_only = GPSBB_KNOB_SET("GPSBB_DEVICE_SEED_ONLY");
         const bool dev = h->opt_chain_where != 1 &&
-                         (h->opt_seed_where == 1 || (h->opt_seed_where == 0 && (dev_only || nbc > host_lim)));
+                         (h->opt_seed_where == 1 || h->opt_seed_where == 3 || (h->opt_seed_where == 0 && (dev_only || nbc > host_lim)));
         if (!s->carry) {
             s->carry = new (std::nothrow) ChainCarry();
             if (!s->carry)

@@ -24,9 +24,11 @@ def assert_state_equal(got, want, active):
 
 
 @pytest.fixture(autouse=True, params=["k_seed+auto", "host+auto", "k_seed+per-sample", "host+per-sample",
-                                      "k_seed+auto+seqfix", "k_seed+per-sample+seqfix", "k_seed+auto+passA"])
+                                      "k_seed+auto+seqfix", "k_seed+per-sample+seqfix", "k_seed+auto+passA", "laps+auto"])
 def seed_mode(pkg, synth, request):
-    """Every test below runs seven ways.  The exact NCO pre-pass of a run is computed by k_seed on the device or,
+    """Every test below runs eight ways.  The exact NCO pre-pass of a run is computed on the device — by the row walks of
+    rounds 1-4 (k_seed / k_walk + the chain kernels: "k_seed") or lap-parallel (gpsbb_laps.hip.h, round 5: "laps"; what the
+    library picks by itself for anything but a handful of blocks) — or,
     for small batches, by host threads running the same code (by default the batch size decides); the
     synthesis kernel is chosen automatically (the model-based kernels k_synth_ev / k_synth_ev_dense wherever they are
     eligible: sample rates above ~2 MS/s) or forced to the per-sample kernel k_synth; and the last step of the
@@ -34,7 +36,7 @@ def seed_mode(pkg, synth, request):
     the start phases its one walk (pass B) begins from come from the host's drift model (the default) or from a first
     walk (pass A + k_chain_prefix)."""
     where, kernel = request.param.split("+")[:2]
-    synth.set_option(pkg.OPT_SEED_WHERE, 1 if where == "k_seed" else 2)
+    synth.set_option(pkg.OPT_SEED_WHERE, {"k_seed": 1, "host": 2, "laps": 3}[where])
     synth.set_option(pkg.OPT_SYNTH_KERNEL, 1 if kernel == "per-sample" else 0)
     synth.set_option(pkg.OPT_CHAIN_WHERE, 2 if request.param.endswith("seqfix") else (3 if request.param.endswith("passA") else 0))
     yield

@@ -328,26 +328,8 @@ bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vec
     return true;
 }
 
-/* Can a sum of this step be rounded exactly half-way on the coarsest grid its chain meets (the one the wrap sums are rounded
- * on: 2^-52 / 2^-53 for a rising / falling carrier, 2^-43 for the code)?  Then the offset between two trajectories changes at
- * every wrap with its parity, and the lap-parallel pre-pass would guess wrong lap after lap (gpsbb_laps.hip.h; fix_block's
- * tie_top is the same test).  A property of the step's low bits: steps that are multiples of (half) that grid. */
-bool lap_step_ties_on_top(double s, int grid_exp_biased /* biased exponent of a number whose last place is the grid */)
-{
-    const uint64_t sb = f64_bits(s);
-    const int es = (int)((sb >> 52) & 0x7ff);
-    const int dt = grid_exp_biased - es; /* the step's last place is 2^dt times finer than the grid */
-    if (dt <= 0)
-        return false; /* the step is a multiple of the grid: sums are never between grid points */
-    if (dt > 52)
-        return true;
-    const uint64_t low = ((sb & F64_MANT) | F64_HID) & ((1ull << dt) - 1);
-    return low == 0ull || low == (1ull << (dt - 1));
-}
-
-/* Does the lap-parallel pre-pass take these blocks (gpsbb_laps.hip.h, Eligibility)?  It is exact for any step; what is
- * excluded is what it would be slow for (a guess that fails at every lap) or what its turn does not cover (steps more than
- * 50 binades below the state: |step| < 2^-50, zero). */
+/* Does the lap-parallel pre-pass take these blocks (gpsbb_laps.hip.h, Eligibility)?  It is exact for any step it walks; what is
+ * excluded is what its turn of the walk does not cover: steps more than 50 binades below the state (|step| < 2^-50, zero). */
 bool lap_eligible(const gpsbb_chan_t *ch, size_t nbc, double delt, bool fixed)
 {
     for (size_t k = 0; k < nbc; k++) {
@@ -355,12 +337,9 @@ bool lap_eligible(const gpsbb_chan_t *ch, size_t nbc, double delt, bool fixed)
         if (c.prn <= 0)
             continue;
         const volatile double sc = c.f_code * delt, sk = c.f_carr * delt;
-        if (!(sc >= 0x1p-20) || lap_step_ties_on_top(sc, 1023 + 9))
+        if (!(sc >= 0x1p-20))
             return false;
-        if (fixed)
-            continue;
-        const double sa = std::fabs(sk);
-        if (!(sa >= 0x1p-50) || lap_step_ties_on_top(sk, sk < 0.0 ? 1022 : 1023))
+        if (!fixed && !(std::fabs(sk) >= 0x1p-50))
             return false;
     }
     return true;

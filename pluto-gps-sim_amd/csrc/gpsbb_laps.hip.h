@@ -21,8 +21,8 @@
  *                exact jump-ahead, gpsbb_nco.h, then one genuine IEEE step; ~15 turns per lap) and finds
  *                where the reference trajectory ends: y'.  The next lap's reference start is A_next, so the offset of
  *                the true trajectory to the reference one changes by (y' - A_next) / u from lap to lap: an exact
- *                integer.  (A falling carrier's "+ 1.0" can be an exact tie, and then the change depends on the
- *                parity of the offset: the link is a map m -> m + a[m odd].)  The links are composed by a scan
+ *                integer.  (Where a sum on the coarsest grid is an exact tie the change depends on the offset's residue
+ *                modulo 4: the link is a map m -> m + g + o[m mod 4], see LapMap.)  The links are composed by a scan
  *                over each workgroup's 256 laps,
  *   k_lap_scan   ... and over the workgroups of a chain: the offset m of every lap.  A chain's first lap (a block that
  *                starts a chain, or the first block of a stream's push: the exact phase the push before left in
@@ -44,8 +44,10 @@
  * machine instead of 1 750 turns in a row on 500 wavefronts.  The walks are exact (genuine IEEE adds, the jump-ahead
  * of gpsbb_nco.h); the model decides only how often the repair kernel has work.
  *
- * Eligibility (lap_eligible, host): steps whose rounding on the coarsest grid can tie at every wrap (a property of
- * the step's low bits: power-of-two-ish steps), steps below 2^-50, zero steps — the old pre-pass keeps those.
+ * Eligibility (lap_eligible, host): carrier steps below 2^-50 and zero steps (the turn of the walk covers states up to
+ * 50 binades above the step) stay with the row walks.  Steps whose sums tie on the coarsest grid — a property of the
+ * step's low bits, one block-channel in 2^12 — are walked like any other; what they do to the offset is part of the link
+ * (LapMap: the change depends on the offset modulo 4).
  */
 #ifndef GPSBB_LAPS_HIP_H
 #define GPSBB_LAPS_HIP_H
@@ -75,18 +77,20 @@ static_assert(sizeof(LapBC) == 32, "LapBC layout");
 /* one lap, written by pass 1, read by pass 2 and the repair */
 struct LapRec {
     double A;       /* reference start state (a head: the exact start) */
-    double v0, v1;  /* pass 1: the composition of the links from the chunk's first lap up to and including the link
-                       that leaves this lap: m_next = CONST ? v0 : m_first + (m_first odd ? v1 : v0).
-                       pass 2: v0 = the offset m this lap was walked from */
+    double g;       /* pass 1: the composition of the links from the chunk's first lap up to and including the link that leaves
+                       this lap, as a LapMap {g, ov, CONST}: the offset of the lap after this one from the chunk's first.
+                       pass 2: the offset m this lap was walked from */
     int32_t b, n0;  /* where it starts: block, sample in the block (0 <= n0 < nsamp) */
     uint32_t flags;
     uint32_t hz;    /* hazards pass 2 counted in this lap */
+    uint32_t ov;    /* pass 1: LapMap::o1..o3 as three signed bytes */
+    uint32_t _pad;
 };
 static_assert(sizeof(LapRec) == 40, "LapRec layout");
 
 struct LapAgg {
-    double v0, v1;
-    uint32_t isconst, _pad;
+    double g;
+    uint32_t ov, isconst;
 };
 
 struct LapDev {
@@ -114,15 +118,23 @@ __device__ __forceinline__ double lap_unit() { return KIND == NCO_CARR ? 0x1p-53
 template <int KIND>
 __device__ __forceinline__ double lap_runit() { return KIND == NCO_CARR ? 0x1p+53 : 0x1p+43; }
 
-/* ---- link maps: m -> CONST ? v0 : m + (m odd ? v1 : v0) ---------------------------------------------------- */
+/* ---- link maps ------------------------------------------------------------------------------------------------
+ * How the offset of the next lap follows from this lap's: m -> CONST ? g : m + g + o[m mod 4], o[0] = 0.  A plain
+ * translation is {g, 0, 0, 0}.  The residue matters where a sum is rounded on the coarsest grid exactly half-way (or, for an
+ * offset that is not a whole number of steps of that grid, anywhere near it): the "+ 1.0" of a falling carrier's wrap (odd
+ * offsets), the sum that passes 1.0 on the two-unit grid of [1, 2) (offsets that are 2 mod 4 where it ties — steps whose low
+ * bits make every other wrap tie exist: one block-channel in 2^12 —, odd ones always), the first step of a lap whose step
+ * ties on the grid of [0.5, 1).  Maps of this form compose to maps of this form; the offsets stay small integers. */
 struct LapMap {
-    double v0, v1;
+    double g;
+    int o1, o2, o3;
     int isconst;
 };
-__device__ __forceinline__ int lap_odd(double m) { return (int)((long long)m & 1ll); }
+__device__ __forceinline__ int lap_res(double m) { return (int)((long long)m & 3ll); }
+__device__ __forceinline__ int lap_o(const LapMap &A, int r) { return r == 1 ? A.o1 : (r == 2 ? A.o2 : (r == 3 ? A.o3 : 0)); }
 __device__ __forceinline__ double lap_apply(const LapMap &A, double m)
 {
-    return A.isconst ? A.v0 : m + (lap_odd(m) ? A.v1 : A.v0);
+    return A.isconst ? A.g : m + A.g + (double)lap_o(A, lap_res(m));
 }
 /* "first B, then A" */
 __device__ __forceinline__ LapMap lap_compose(const LapMap &A, const LapMap &B)
@@ -132,29 +144,66 @@ __device__ __forceinline__ LapMap lap_compose(const LapMap &A, const LapMap &B)
         return A;
     if (B.isconst) {
         R.isconst = 1;
-        R.v0 = lap_apply(A, B.v0);
-        R.v1 = R.v0;
+        R.g = lap_apply(A, B.g);
+        R.o1 = R.o2 = R.o3 = 0;
         return R;
     }
     R.isconst = 0;
-    /* an even m goes to m + B.v0, whose parity is B.v0's; an odd m to m + B.v1, odd iff B.v1 is even */
-    R.v0 = B.v0 + (lap_odd(B.v0) ? A.v1 : A.v0);
-    R.v1 = B.v1 + (lap_odd(B.v1) ? A.v0 : A.v1);
+    const int gb = lap_res(B.g);
+    const int a0 = lap_o(A, gb & 3);
+    R.g = B.g + A.g + (double)a0;
+    R.o1 = B.o1 + lap_o(A, (1 + gb + B.o1) & 3) - a0;
+    R.o2 = B.o2 + lap_o(A, (2 + gb + B.o2) & 3) - a0;
+    R.o3 = B.o3 + lap_o(A, (3 + gb + B.o3) & 3) - a0;
     return R;
+}
+__device__ __forceinline__ uint32_t lap_pack_o(const LapMap &m)
+{
+    return ((uint32_t)m.o1 & 0xffu) | (((uint32_t)m.o2 & 0xffu) << 8) | (((uint32_t)m.o3 & 0xffu) << 16);
+}
+__device__ __forceinline__ LapMap lap_unpack(double g, uint32_t ov, int isconst)
+{
+    LapMap m;
+    m.g = g;
+    m.o1 = (int)(int8_t)(ov & 0xffu);
+    m.o2 = (int)(int8_t)((ov >> 8) & 0xffu);
+    m.o3 = (int)(int8_t)((ov >> 16) & 0xffu);
+    m.isconst = isconst;
+    return m;
 }
 __device__ __forceinline__ LapMap lap_map_shfl_up(const LapMap &m, int delta)
 {
     LapMap r;
     r.isconst = __shfl_up(m.isconst, delta);
-    r.v0 = __shfl_up(m.v0, delta);
-    r.v1 = __shfl_up(m.v1, delta);
+    r.g = __shfl_up(m.g, delta);
+    r.o1 = __shfl_up(m.o1, delta);
+    r.o2 = __shfl_up(m.o2, delta);
+    r.o3 = __shfl_up(m.o3, delta);
+    return r;
+}
+__device__ __forceinline__ LapMap lap_map_shfl(const LapMap &m, int src)
+{
+    LapMap r;
+    r.isconst = __shfl(m.isconst, src);
+    r.g = __shfl(m.g, src);
+    r.o1 = __shfl(m.o1, src);
+    r.o2 = __shfl(m.o2, src);
+    r.o3 = __shfl(m.o3, src);
     return r;
 }
 __device__ __forceinline__ LapMap lap_identity()
 {
     LapMap r;
     r.isconst = 0;
-    r.v0 = r.v1 = 0.0;
+    r.g = 0.0;
+    r.o1 = r.o2 = r.o3 = 0;
+    return r;
+}
+__device__ __forceinline__ LapMap lap_const(double g)
+{
+    LapMap r = lap_identity();
+    r.isconst = 1;
+    r.g = g;
     return r;
 }
 /* inclusive scan over the lanes of a wavefront */
@@ -328,7 +377,9 @@ struct LapLane {
     uint32_t hz;       /* hazards met: carrier, samples whose phase is exactly 1.0; code, data-bit fetches past dwrd[59] */
     uint32_t bcflags;
     int outcome;
-    int tie_adj;       /* pass 1, falling carrier: the closing wrap's "+ 1.0" was an exact tie: an odd offset changes by this on top */
+    int eo1, eo2, eo3; /* pass 1: what the closing wrap adds to an offset that is 1, 2, 3 mod 4, on top of the translation */
+    int so;            /* pass 1: what the first step in the top binade adds to an odd offset, where the step ties on that binade's grid */
+    bool tt;           /* the block's step ties on the grid of the top binade ([0.5, 1) / [512, 1024)): every sum there is half-way */
     bool active, neg;
     bool fresh;        /* code: the walk starts on the first sample after a roll-over (whose data-bit fetch is this lap's to count) */
 };
@@ -359,6 +410,7 @@ __device__ __forceinline__ void lap_enter_block(const BatchDev &p, const LapDev 
     w.es = (int)((sb >> 52) & 0x7ff);
     w.tiemask = walk_tiemask(sb);
     w.neg = bc.s < 0.0;
+    w.tt = ((w.tiemask >> (((KIND == NCO_CARR ? 1022 : 1023 + 9) - w.es) & 63)) & 1ull) != 0ull;
     w.nmax = (w.b == w.bt) ? w.nt : p.nsamp;
 }
 
@@ -434,6 +486,16 @@ __device__ __forceinline__ void lap_turn(const BatchDev &p, int i, LapLane<KIND>
     } else {
         room = add_rn(x, -__hiloint2double((int)(hi & 0xfff00000u), 1)); /* 2^e + ulp */
     }
+    if (TIES && __ballot(on && w.tt && !w.so)) {
+        /* A step that lies exactly half-way between two multiples of the top binade's last place (the coarsest grid: the unit
+         * offsets are counted in): every sum there is a tie.  From an even mantissa a step adds the even neighbour S of the two,
+         * from an odd one (once: the sum is even) the other, 2s - S.  A trajectory an odd number of units away has the other
+         * parity, so its first step up here differs by 2(s - S): one unit — and from then on the two are an even number apart. */
+        if (on && w.tt && !w.so && ex == (KIND == NCO_CARR ? 1022 : 1023 + 9)) {
+            const bool pos = add_rn(s, -S) > 0.0, even = !(__double2loint(x) & 1);
+            w.so = (even == pos) ? 1 : -1;
+        }
+    }
     const double Sa = SNEG ? -S : S;
     double rs = __builtin_amdgcn_rcp(Sa);
     rs = __fma_rn(__fma_rn(-Sa, rs, 1.0), rs, rs);
@@ -461,16 +523,26 @@ __device__ __forceinline__ void lap_turn(const BatchDev &p, int i, LapLane<KIND>
              * to the even one; a trajectory an odd number of grid steps away goes to the other side of ITS half-way point */
             const double err = add_rn(add_rn(xw, -1.0), -x2);
             if (step && wrapped && fabs(err) == 0x1p-54)
-                w.tie_adj = err < 0.0 ? 1 : -1;
+                w.eo1 = w.eo3 = err < 0.0 ? 1 : -1;
         }
         if (TIES && !SNEG) {
             /* The sum that passes 1.0 is rounded on the grid of [1, 2): 2^-52, two units.  A rising chain's offsets are even — its
              * post-wrap states are multiples of 2^-52 — except in the lap in which a falling phase turned round (the step changed
              * sign with the block): an odd offset then comes out one unit further or nearer, by the side of the grid point the
              * exact sum lies on (Fast2Sum again; exactly on it: a tie the guess leaves alone). */
-            const double err = add_rn(add_rn(x2, -x1), -s);
-            if (step && wrapped && err != 0.0)
-                w.tie_adj = err < 0.0 ? 1 : -1;
+            const double err = add_rn(add_rn(x2, -x1), -s); /* the sum as rounded minus the exact sum, within a unit (2^-53) */
+            if (step && wrapped) {
+                if (err != 0.0) {
+                    w.eo1 = w.eo3 = err < 0.0 ? 1 : -1;
+                    /* ... and exactly half-way: it went to the even grid point; two units further on (2 mod 4) the even one is the other */
+                    w.eo2 = fabs(err) == 0x1p-53 ? (err < 0.0 ? 2 : -2) : 0;
+                } else {
+                    /* the sum is a grid point a: an odd offset lands half-way between two and takes the even one */
+                    const bool a_even = !(__double2loint(x2) & 1);
+                    w.eo1 = a_even ? -1 : 1;
+                    w.eo3 = a_even ? 1 : -1;
+                }
+            }
         }
         x2 = wrapped ? xw : x2;
     } else {
@@ -478,6 +550,17 @@ __device__ __forceinline__ void lap_turn(const BatchDev &p, int i, LapLane<KIND>
         x2 = wrapped ? add_rn(x2, -1023.0) : x2; /* c:2711-2712 */
     }
     wrapped = wrapped && step;
+    if (TIES && __ballot(step && w.tt && !w.so)) {
+        /* ... or the step INTO the top binade from below is the tie (a state on the finer grid below plus a half-way step is half-way
+         * exactly when that state is a multiple of the top grid): both trajectories then arrive with even mantissas, an odd offset
+         * has already moved by one unit, to the side opposite the one the reference was rounded to */
+        constexpr int TOP = KIND == NCO_CARR ? 1022 : 1023 + 9;
+        if (step && w.tt && !w.so && !wrapped && ex < TOP && (int)((uint32_t)__double2hiint(x2) >> 20) == TOP) {
+            const double err = add_rn(add_rn(x2, -x1), -s);
+            if (fabs(err) == (KIND == NCO_CARR ? 0x1p-54 : 0x1p-44))
+                w.so = err < 0.0 ? 1 : -1;
+        }
+    }
     if (on) {
         w.x = step ? x2 : x1;
         w.n = step ? n1 + 1 : n1;
@@ -525,7 +608,8 @@ template <int KIND, bool EMIT, bool TIES>
 __device__ __forceinline__ void lap_walk(const BatchDev &p, const LapDev &L, int i, LapLane<KIND> &w)
 {
     w.outcome = 0;
-    w.tie_adj = 0;
+    w.eo1 = w.eo2 = w.eo3 = 0;
+    w.so = 0;
     w.hz = 0;
     if (w.active && w.b >= p.nblocks) { /* (a plan that put a lap past the last block: its link will not hold) */
         w.outcome = LAP_OUT_LATE;
@@ -808,7 +892,8 @@ struct LapPassLds {
     double m[LAP_WAVES + 1];
     int32_t b[LAP_WAVES + 1], n0[LAP_WAVES + 1];
     uint32_t head[LAP_WAVES + 1];
-    double wv0[LAP_WAVES], wv1[LAP_WAVES];
+    double wg[LAP_WAVES];
+    uint32_t wo[LAP_WAVES];
     int wc[LAP_WAVES];
 };
 /* lane + 1's value; the last lane of a wavefront takes `edge` */
@@ -843,7 +928,9 @@ __device__ __forceinline__ LapLane<KIND> lap_lane(bool on, double x, int32_t b, 
     w.hz = 0;
     w.bcflags = 0;
     w.outcome = 0;
-    w.tie_adj = 0;
+    w.eo1 = w.eo2 = w.eo3 = 0;
+    w.so = 0;
+    w.tt = false;
     w.active = on;
     w.neg = false;
     w.fresh = true;
@@ -865,20 +952,24 @@ __device__ __forceinline__ uint32_t lap_jc_of(const BatchDev &p, const LapDev &L
 template <int KIND>
 __device__ __forceinline__ LapMap lap_link(const LapLane<KIND> &w, bool mine, bool has_next, double A_next, int32_t nb, int32_t nn0)
 {
-    LapMap M;
-    M.isconst = 1;
-    M.v0 = M.v1 = 0.0;
     if (!mine)
         return lap_identity();
     if (has_next && w.outcome == LAP_OUT_WRAP && w.b == nb && w.n == nn0) {
         const double g = (w.x - A_next) * lap_runit<KIND>(); /* exact: both on the grid, close together */
         if (fabs(g) < 0x1p+50 && g == __builtin_rint(g)) {
-            M.isconst = 0;
-            M.v0 = g;
-            M.v1 = g + (double)w.tie_adj;
+            LapMap E = lap_identity(); /* the translation through the lap and what its closing wrap adds */
+            E.g = g;
+            E.o1 = w.eo1;
+            E.o2 = w.eo2;
+            E.o3 = w.eo3;
+            if (!w.so)
+                return E;
+            LapMap S = lap_identity(); /* the lap's first step in the top binade, where the step ties on its grid */
+            S.o1 = S.o3 = w.so;
+            return lap_compose(E, S);
         }
     }
-    return M; /* (a head follows, the chain ended, or the walk did not end where the plan says: the next lap's offset is a guess, 0) */
+    return lap_const(0.0); /* (a head follows, the chain ended, or the walk did not end where the plan says: the next lap's offset is a guess, 0) */
 }
 
 template <int KIND>
@@ -934,22 +1025,18 @@ __global__ __launch_bounds__(LAP_WG) void k_lap_pass1(BatchDev p, LapDev L)
     LapMap acc = lap_wave_scan(link, lane);
     if (lane == 63) {
         sh.wc[wave] = acc.isconst;
-        sh.wv0[wave] = acc.v0;
-        sh.wv1[wave] = acc.v1;
+        sh.wg[wave] = acc.g;
+        sh.wo[wave] = lap_pack_o(acc);
     }
     __syncthreads();
-    for (int q = wave - 1; q >= 0 && !acc.isconst; q--) {
-        LapMap pw;
-        pw.isconst = sh.wc[q];
-        pw.v0 = sh.wv0[q];
-        pw.v1 = sh.wv1[q];
-        acc = lap_compose(acc, pw);
-    }
+    for (int q = wave - 1; q >= 0 && !acc.isconst; q--)
+        acc = lap_compose(acc, lap_unpack(sh.wg[q], sh.wo[q], sh.wc[q]));
     if (mine) {
         LapRec rec;
         rec.A = st.A;
-        rec.v0 = acc.v0;
-        rec.v1 = acc.v1;
+        rec.g = acc.g;
+        rec.ov = lap_pack_o(acc);
+        rec._pad = 0;
         rec.b = st.b;
         rec.n0 = st.n0;
         rec.flags = (st.head ? LAPF_HEAD : 0u) | (acc.isconst ? LAPF_CONST : 0u);
@@ -958,10 +1045,9 @@ __global__ __launch_bounds__(LAP_WG) void k_lap_pass1(BatchDev p, LapDev L)
     }
     if (t == LAP_WG - 1) {
         LapAgg a;
-        a.v0 = acc.v0;
-        a.v1 = acc.v1;
+        a.g = acc.g;
+        a.ov = lap_pack_o(acc);
         a.isconst = (uint32_t)acc.isconst;
-        a._pad = 0;
         L.agg[chunk] = a;
         L.chunk_bad[chunk] = 0;
     }
@@ -983,9 +1069,7 @@ __global__ __launch_bounds__(64) void k_lap_scan(BatchDev p, LapDev L)
         LapMap my = lap_identity();
         if (q < nchunks) {
             const LapAgg a = L.agg[base + q];
-            my.isconst = (int)a.isconst;
-            my.v0 = a.v0;
-            my.v1 = a.v1;
+            my = lap_unpack(a.g, a.ov, (int)a.isconst);
         }
         const LapMap acc = lap_wave_scan(my, lane);
         /* chunk q starts where the links of chunks q0 .. q-1 take m */
@@ -993,11 +1077,7 @@ __global__ __launch_bounds__(64) void k_lap_scan(BatchDev p, LapDev L)
         const double mq = lane == 0 ? m : lap_apply(before, m);
         if (q < nchunks)
             L.chunk_m[base + q] = mq;
-        LapMap all;
-        all.isconst = __shfl(acc.isconst, 63);
-        all.v0 = __shfl(acc.v0, 63);
-        all.v1 = __shfl(acc.v1, 63);
-        m = lap_apply(all, m);
+        m = lap_apply(lap_map_shfl(acc, 63), m);
     }
 }
 
@@ -1017,16 +1097,15 @@ __global__ __launch_bounds__(LAP_WG) void k_lap_pass2(BatchDev p, LapDev L)
     const double m_first = L.chunk_m[chunk];
     LapRec rec;
     rec.A = 0.0;
-    rec.v0 = rec.v1 = 0.0;
+    rec.g = 0.0;
+    rec.ov = 0;
+    rec._pad = 0;
     rec.b = rec.n0 = 0;
     rec.flags = LAPF_HEAD;
     rec.hz = 0;
     if (mine)
         rec = L.rec[(size_t)chunk * LAP_WG + t];
-    LapMap P;
-    P.isconst = (rec.flags & LAPF_CONST) ? 1 : 0;
-    P.v0 = rec.v0;
-    P.v1 = rec.v1;
+    const LapMap P = lap_unpack(rec.g, rec.ov, (rec.flags & LAPF_CONST) ? 1 : 0);
     const int lane = t & 63, wave = t >> 6;
     const int32_t myhead = mine ? (int32_t)(rec.flags & LAPF_HEAD) : (int32_t)LAPF_HEAD;
     const double m_after = lap_apply(P, m_first); /* the offset of the lap after this one */
@@ -1071,7 +1150,7 @@ __global__ __launch_bounds__(LAP_WG) void k_lap_pass2(BatchDev p, LapDev L)
         else
             ok = w.outcome == LAP_OUT_CHAIN;
         LapRec &o = L.rec[(size_t)chunk * LAP_WG + t];
-        o.v0 = m;
+        o.g = m;
         o.hz = w.hz;
 #ifdef GPSBB_LAP_DEBUG
         if (!ok)
@@ -1135,7 +1214,7 @@ __global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L)
             LapRec rb = recs[bad];
             bool hn = bad + 1 < nl && !(recs[bad + 1 < nl ? bad + 1 : bad].flags & LAPF_HEAD);
             LapRec rn = recs[bad + 1 < nl ? bad + 1 : bad];
-            LapLane<KIND> w = lap_lane<KIND>(lane == 0, (rb.flags & LAPF_HEAD) ? rb.A : __fma_rn(rb.v0, lap_unit<KIND>(), rb.A), rb.b, rb.n0,
+            LapLane<KIND> w = lap_lane<KIND>(lane == 0, (rb.flags & LAPF_HEAD) ? rb.A : __fma_rn(rb.g, lap_unit<KIND>(), rb.A), rb.b, rb.n0,
                                              lap_jc_of<KIND>(p, L, i, bad, rb.b), hn, rn.b, rn.n0);
             lap_walk<KIND, false, false>(p, L, i, w);
             /* cur: the true trajectory at the end of that walk (lane 0's copy is the one that counts) */
@@ -1188,7 +1267,7 @@ __global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L)
                 /* 2. lap q starts at (cb, cn) from cx: is that what pass 2 walked it from? */
                 {
                     const LapRec rq = recs[q];
-                    const double xq = __fma_rn(rq.v0, lap_unit<KIND>(), rq.A);
+                    const double xq = __fma_rn(rq.g, lap_unit<KIND>(), rq.A);
                     if (f64_bits(xq) == f64_bits(cx)) {
                         from = q;
                         break;
@@ -1233,7 +1312,7 @@ __global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L)
                     const int nok = badm ? __builtin_ctzll(badm) + 1 : glen; /* lanes 0 .. nok-1 walked the truth */
                     if (lane < nok) {
                         hz_delta += (long long)w2.hz - (long long)rr.hz;
-                        recs[r].v0 = m;
+                        recs[r].g = m;
                         recs[r].hz = w2.hz;
                         recs[r].flags = rr.flags & ~LAPF_BAD;
                     }
@@ -1259,7 +1338,7 @@ __global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L)
                     /* the next group's first lap starts at (cb, cn) from cx: as pass 2 had it? */
                     {
                         const LapRec rq = recs[q];
-                        const double xq = __fma_rn(rq.v0, lap_unit<KIND>(), rq.A);
+                        const double xq = __fma_rn(rq.g, lap_unit<KIND>(), rq.A);
                         if (!(rq.flags & LAPF_BAD) && f64_bits(xq) == f64_bits(cx)) {
                             from = q;
                             break;
@@ -1274,7 +1353,11 @@ __global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L)
     }
     if (lane == 0) {
         if (KIND == NCO_CARR && p.carry && p.ch[(size_t)(p.nblocks - 1) * p.nch + i].prn > 0 && !p.kph0)
+        {
+            /* (approx_end: what the row walks' chain — k_chain_prefix — of a later push starts from, should the stream change sides) */
             p.carry->exact_end[i] = p.end[(size_t)(p.nblocks - 1) * p.nch + i].carr_phase;
+            p.carry->approx_end[i] = p.carry->exact_end[i];
+        }
         if (hz_delta)
             atomicAdd(p.hazards + (KIND == NCO_CARR ? 0 : 1), (unsigned long long)hz_delta);
         if (n_rewalked)

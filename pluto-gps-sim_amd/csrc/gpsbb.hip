@@ -1005,11 +1005,14 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
     PUSH_MARK("ev_plan");
 
     /* where the pre-pass runs and where the carrier chain is resolved: decided here, once, for all runs of the batch */
-    b->host_seed = host_seeding_wanted(b);
-    /* on the device: lap-parallel (gpsbb_laps.hip.h) wherever the model kernels render and the steps are ordinary ones; the
-     * row walks (k_walk and the chain kernels) for the rest and where GPSBB_OPT_SEED_WHERE / _CHAIN_WHERE ask for them */
-    b->laps = b->ev && !b->host_seed && h->opt_seed_where != 1 && h->opt_chain_where != 2 && h->opt_chain_where != 3 &&
-              !GPSBB_KNOB_SET("GPSBB_NO_LAPS") && lap_eligible(ch, nbc, delt, fixed);
+    /* on the device: lap-parallel (gpsbb_laps.hip.h) wherever the model kernels render and no step is tiny; the row walks
+     * (k_walk and the chain kernels) for the rest and where GPSBB_OPT_SEED_WHERE / _CHAIN_WHERE ask for them.  The lap-parallel
+     * pre-pass takes 0.1 ms whatever the size of the batch — less than host threads need for one block (tools/fill_latency.py:
+     * 0.25 against 0.33 ms per gpsbb_fill_block of the reference's geometry) — so where it is eligible the size decides nothing. */
+    const bool lap_ok = b->ev && h->opt_seed_where != 1 && h->opt_seed_where != 2 && h->opt_chain_where != 2 && h->opt_chain_where != 3 &&
+                        !GPSBB_KNOB_SET("GPSBB_NO_LAPS") && lap_eligible(ch, nbc, delt, fixed);
+    b->host_seed = !lap_ok && host_seeding_wanted(b);
+    b->laps = lap_ok;
     const bool chained = !fixed && (flags & GPSBB_CHAIN_CARRIER) && (nblocks > 1 || b->d_carry);
     b->chain_dev = chained && h->opt_chain_where != 1 && !b->host_seed;
     b->chain_fix_seq = h->opt_chain_where == 2;
@@ -2524,8 +2527,11 @@ static int stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch, bool new_chain
          * change sides between pushes: the carry then moves across, which costs a synchronisation. */
         const size_t host_lim = (size_t)GPSBB_KNOB_LONG("GPSBB_HOST_SEED_MAX", HOST_SEED_MAX_CHANNELS);
         const bool dev_only = GPSBB_KNOB_SET("GPSBB_DEVICE_SEED_ONLY");
+        /* (small pushes too where the lap-parallel pre-pass will take them: it costs less than the host threads) */
+        const bool small_on_dev = h->opt_seed_where == 0 && h->opt_synth_kernel != 1 && h->opt_chain_where == 0 && !GPSBB_KNOB_SET("GPSBB_NO_LAPS") &&
+                                  lap_eligible(ch, nbc, s->delt, false);
         const bool dev = h->opt_chain_where != 1 &&
-                         (h->opt_seed_where == 1 || h->opt_seed_where == 3 || (h->opt_seed_where == 0 && (dev_only || nbc > host_lim)));
+                         (h->opt_seed_where == 1 || h->opt_seed_where == 3 || (h->opt_seed_where == 0 && (dev_only || nbc > host_lim || small_on_dev)));
         if (!s->carry) {
             s->carry = new (std::nothrow) ChainCarry();
             if (!s->carry)

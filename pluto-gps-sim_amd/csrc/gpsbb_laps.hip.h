@@ -459,82 +459,104 @@ __device__ __forceinline__ void lap_emit_row(const BatchDev &p, int i, bool on, 
     }
 }
 
-/* One turn of the walk for the lanes of one direction (the lanes of a wavefront in lockstep, as walk_lockstep): a regular run
- * of the exact jump-ahead (possibly of no steps), then one genuine IEEE step — unless the run ended at the lane's limit in
- * this block.  Sets w.outcome for lanes whose walk ends here; lanes at a block's end (outcome 0, n == nmax) are the caller's. */
+/*
+ * The lanes in `go` — all of one direction — walk in lockstep, as walk_lockstep: every turn is a regular run of the exact
+ * jump-ahead (possibly of no steps) followed by one genuine IEEE step, until each lane has wrapped (outcome LAP_OUT_WRAP: (n, x)
+ * is the first sample of the next lap and its state), stands at the end of its territory without having wrapped
+ * (LAP_OUT_LATE), or stands at its block's last sample + 1 (outcome 0, n == nsamp: the caller's).
+ */
 template <int KIND, bool SNEG, bool EMIT, bool TIES>
-__device__ __forceinline__ void lap_turn(const BatchDev &p, int i, LapLane<KIND> &w)
+__device__ __forceinline__ void lap_run(const BatchDev &p, int i, LapLane<KIND> &w, const bool was)
 {
     constexpr int TOPEX = LapK<KIND>::TOPEX;
-    const bool on = w.active && w.neg == SNEG;
-    const double x = w.x, s = w.s;
-    const uint32_t hi = (uint32_t)__double2hiint(x);
-    const int ex = (int)(hi >> 20);
-    const int d = ex - w.es;
-    const bool weird = (unsigned)(ex - 1) >= (unsigned)(TOPEX - 1); /* zero, subnormal, negative, at or beyond the top */
-    bool expl = weird || d < 2;
-    if (__ballot(on && w.tiemask != 0ull))
-        expl |= ((w.tiemask >> (d & 63)) & 1ull) != 0ull && (__double2loint(x) & 1);
-    const double C = __hiloint2double((int)((hi & 0xfff00000u) | 0x80000u), 0);
-    const double S = add_rn(add_rn(s, C), -C);
-    double room;
-    if (!SNEG) {
-        double lim = __hiloint2double((int)(hi | 0xfffffu), -1); /* 2^(e+1) - ulp */
-        if (KIND == NCO_CODE)
-            lim = ex == 1023 + 9 ? 0x1.ff7ffffffffffp+9 /* 1023 - ulp */ : lim;
-        room = add_rn(lim, -x);
-    } else {
-        room = add_rn(x, -__hiloint2double((int)(hi & 0xfff00000u), 1)); /* 2^e + ulp */
-    }
-    if (TIES && __ballot(on && w.tt && !w.so)) {
-        /* A step that lies exactly half-way between two multiples of the top binade's last place (the coarsest grid: the unit
-         * offsets are counted in): every sum there is a tie.  From an even mantissa a step adds the even neighbour S of the two,
-         * from an odd one (once: the sum is even) the other, 2s - S.  A trajectory an odd number of units away has the other
-         * parity, so its first step up here differs by 2(s - S): one unit — and from then on the two are an even number apart. */
-        if (on && w.tt && !w.so && ex == (KIND == NCO_CARR ? 1022 : 1023 + 9)) {
-            const bool pos = add_rn(s, -S) > 0.0, even = !(__double2loint(x) & 1);
-            w.so = (even == pos) ? 1 : -1;
+    constexpr int TOP = KIND == NCO_CARR ? 1022 : 1023 + 9; /* the top binade: [0.5, 1) / [512, 1024) */
+    const double s = w.s;
+    const int es = w.es, nmax = w.nmax;
+    const bool any_tie = __ballot(was && w.tiemask != 0ull) != 0ull;
+    const bool any_tt = TIES && __ballot(was && w.tt) != 0ull;
+    double x = w.x;
+    int n = w.n;
+    bool go = was, has_wrapped = false;
+    while (__ballot(go)) {
+        const uint32_t hi = (uint32_t)__double2hiint(x);
+        const int ex = (int)(hi >> 20);
+        const int d = ex - es;
+        const bool weird = (unsigned)(ex - 1) >= (unsigned)(TOPEX - 1); /* zero, subnormal, negative, at or beyond the top */
+        bool expl = weird || d < 2;
+        if (any_tie)
+            expl |= ((w.tiemask >> (d & 63)) & 1ull) != 0ull && (__double2loint(x) & 1);
+        /* S = s rounded to a multiple of ulp(x), ties to even: adding and subtracting 1.5 * 2^e */
+        const double C = __hiloint2double((int)((hi & 0xfff00000u) | 0x80000u), 0);
+        const double S = add_rn(add_rn(s, C), -C);
+        double room;
+        if (!SNEG) {
+            double lim = __hiloint2double((int)(hi | 0xfffffu), -1); /* 2^(e+1) - ulp */
+            if (KIND == NCO_CODE)
+                lim = ex == 1023 + 9 ? 0x1.ff7ffffffffffp+9 /* 1023 - ulp */ : lim;
+            room = add_rn(lim, -x);
+        } else {
+            room = add_rn(x, -__hiloint2double((int)(hi & 0xfff00000u), 1)); /* 2^e + ulp */
         }
-    }
-    const double Sa = SNEG ? -S : S;
-    double rs = __builtin_amdgcn_rcp(Sa);
-    rs = __fma_rn(__fma_rn(-Sa, rs, 1.0), rs, rs);
-    const double kq = fmin(room * rs, 2147483000.0);
-    int ki = (int)kq;
-    const double rem = __fma_rn(-(double)ki, Sa, room); /* exact: |rem| < 2|S| */
-    ki += (rem < 0.0 ? -1 : 0) + (rem >= Sa ? 1 : 0);
-    const int kcap = w.nmax - w.n;
-    int k = (expl || !(room >= Sa)) ? 0 : (ki < kcap ? ki : kcap);
-    k = on ? k : 0;
-    const double x1 = __fma_rn((double)k, S, x);
-    if (KIND == NCO_CARR && on && ex >= TOPEX && !(hi >> 31))
-        w.hz++; /* carr_phase == 1.0 at this sample: table index 512 (gpsbb_hazards_t.itable_512) */
-    if (EMIT)
-        lap_emit_row<KIND>(p, i, on, w.b, w.n, k, x, S, w.bits);
-    const int n1 = w.n + k;
-    const bool step = on && n1 < w.nmax;
-    double x2 = add_rn(x1, s);
-    bool wrapped;
-    if (KIND == NCO_CARR) {
-        wrapped = SNEG ? x2 < 0.0 : x2 >= 1.0; /* c:2743-2746 */
-        const double xw = add_rn(x2, SNEG ? 1.0 : -1.0);
-        if (TIES && SNEG) {
-            /* was x2 + 1.0 exactly half-way between two multiples of 2^-53?  (Fast2Sum: both differences are exact.)  It then went
-             * to the even one; a trajectory an odd number of grid steps away goes to the other side of ITS half-way point */
-            const double err = add_rn(add_rn(xw, -1.0), -x2);
-            if (step && wrapped && fabs(err) == 0x1p-54)
-                w.eo1 = w.eo3 = err < 0.0 ? 1 : -1;
+        if (any_tt) {
+            /* A step that lies exactly half-way between two multiples of the top binade's last place (the coarsest grid: the unit
+             * offsets are counted in): every sum up there is a tie.  From an even mantissa a step adds the even neighbour S of the
+             * two, from an odd one (once: the sum is even) the other, 2s - S.  A trajectory an odd number of units away has the other
+             * parity, so its first step up here differs by 2(s - S): one unit — and from then on the two are an even number apart. */
+            if (go && w.tt && !w.so && ex == TOP) {
+                const bool pos = add_rn(s, -S) > 0.0, even = !(__double2loint(x) & 1);
+                w.so = (even == pos) ? 1 : -1;
+            }
         }
-        if (TIES && !SNEG) {
-            /* The sum that passes 1.0 is rounded on the grid of [1, 2): 2^-52, two units.  A rising chain's offsets are even — its
-             * post-wrap states are multiples of 2^-52 — except in the lap in which a falling phase turned round (the step changed
-             * sign with the block): an odd offset then comes out one unit further or nearer, by the side of the grid point the
-             * exact sum lies on (Fast2Sum again; exactly on it: a tie the guess leaves alone). */
-            const double err = add_rn(add_rn(x2, -x1), -s); /* the sum as rounded minus the exact sum, within a unit (2^-53) */
-            if (step && wrapped) {
+        const double Sa = SNEG ? -S : S;
+        double rs = __builtin_amdgcn_rcp(Sa);
+        rs = __fma_rn(__fma_rn(-Sa, rs, 1.0), rs, rs);
+        const double kq = fmin(room * rs, 2147483000.0);
+        int ki = (int)kq;
+        const double rem = __fma_rn(-(double)ki, Sa, room); /* exact: |rem| < 2|S| */
+        ki += (rem < 0.0 ? -1 : 0) + (rem >= Sa ? 1 : 0);
+        const int kcap = nmax - n;
+        const int k = (expl || !(room >= Sa)) ? 0 : (ki < kcap ? ki : kcap);
+        const double x1 = __fma_rn((double)k, S, x);
+        if (KIND == NCO_CARR && __ballot(go && weird)) {
+            if (go && ex >= TOPEX && !(hi >> 31))
+                w.hz++; /* carr_phase == 1.0 at this sample: table index 512 (gpsbb_hazards_t.itable_512) */
+        }
+        const int n1 = n + k;
+        if (EMIT) {
+            /* does a tile start inside the row (samples n .. n1)? */
+            const int t0 = (int)(((uint32_t)n + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
+            if (__ballot(go && t0 * TILE <= n1 && t0 < p.ntiles))
+                lap_emit_row<KIND>(p, i, go, w.b, n, k, x, S, w.bits);
+        }
+        const bool step = go && n1 < nmax;
+        double x2 = add_rn(x1, s);
+        bool wrapped;
+        double xw;
+        if (KIND == NCO_CARR) {
+            wrapped = SNEG ? x2 < 0.0 : x2 >= 1.0; /* c:2743-2746 */
+            xw = add_rn(x2, SNEG ? 1.0 : -1.0);
+        } else {
+            wrapped = x2 >= 1023.0;
+            xw = add_rn(x2, -1023.0); /* c:2711-2712 */
+        }
+        wrapped = wrapped && step;
+        if (TIES && KIND == NCO_CARR && __ballot(wrapped)) {
+            if (wrapped && SNEG) {
+                /* was x2 + 1.0 exactly half-way between two multiples of 2^-53?  (Fast2Sum: both differences are exact.)  It then went
+                 * to the even one; a trajectory an odd number of grid steps away goes to the other side of ITS half-way point */
+                const double err = add_rn(add_rn(xw, -1.0), -x2);
+                if (fabs(err) == 0x1p-54)
+                    w.eo1 = w.eo3 = err < 0.0 ? 1 : -1;
+            }
+            if (wrapped && !SNEG) {
+                /* The sum that passes 1.0 is rounded on the grid of [1, 2): 2^-52, two units.  A rising chain's offsets are even — its
+                 * post-wrap states are multiples of 2^-52 — except in the lap in which a falling phase turned round (the step changed
+                 * sign with the block): an odd offset then comes out one unit further or nearer, by the side of the grid point the
+                 * exact sum lies on.  And steps exist (one block-channel in 2^12) whose sums here are exactly half-way every other
+                 * wrap: it went to the even grid point; two units further on (an offset that is 2 mod 4) the even one is the other. */
+                const double err = add_rn(add_rn(x2, -x1), -s); /* the sum as rounded minus the exact sum, within a unit (2^-53) */
                 if (err != 0.0) {
                     w.eo1 = w.eo3 = err < 0.0 ? 1 : -1;
-                    /* ... and exactly half-way: it went to the even grid point; two units further on (2 mod 4) the even one is the other */
                     w.eo2 = fabs(err) == 0x1p-53 ? (err < 0.0 ? 2 : -2) : 0;
                 } else {
                     /* the sum is a grid point a: an odd offset lands half-way between two and takes the even one */
@@ -544,31 +566,31 @@ __device__ __forceinline__ void lap_turn(const BatchDev &p, int i, LapLane<KIND>
                 }
             }
         }
-        x2 = wrapped ? xw : x2;
-    } else {
-        wrapped = x2 >= 1023.0;
-        x2 = wrapped ? add_rn(x2, -1023.0) : x2; /* c:2711-2712 */
-    }
-    wrapped = wrapped && step;
-    if (TIES && __ballot(step && w.tt && !w.so)) {
-        /* ... or the step INTO the top binade from below is the tie (a state on the finer grid below plus a half-way step is half-way
-         * exactly when that state is a multiple of the top grid): both trajectories then arrive with even mantissas, an odd offset
-         * has already moved by one unit, to the side opposite the one the reference was rounded to */
-        constexpr int TOP = KIND == NCO_CARR ? 1022 : 1023 + 9;
-        if (step && w.tt && !w.so && !wrapped && ex < TOP && (int)((uint32_t)__double2hiint(x2) >> 20) == TOP) {
-            const double err = add_rn(add_rn(x2, -x1), -s);
-            if (fabs(err) == (KIND == NCO_CARR ? 0x1p-54 : 0x1p-44))
-                w.so = err < 0.0 ? 1 : -1;
+        if (any_tt) {
+            /* ... or the step INTO the top binade from below is the tie (a state on the finer grid below plus a half-way step is
+             * half-way exactly when that state is a multiple of the top grid): both trajectories then arrive with even mantissas, an
+             * odd offset has already moved by one unit, to the side opposite the one the reference was rounded to */
+            if (step && w.tt && !w.so && !wrapped && ex < TOP && (int)((uint32_t)__double2hiint(x2) >> 20) == TOP) {
+                const double err = add_rn(add_rn(x2, -x1), -s);
+                if (fabs(err) == (KIND == NCO_CARR ? 0x1p-54 : 0x1p-44))
+                    w.so = err < 0.0 ? 1 : -1;
+            }
         }
+        if (go) {
+            x = step ? (wrapped ? xw : x2) : x1;
+            n = step ? n1 + 1 : n1;
+        }
+        has_wrapped = has_wrapped || wrapped;
+        go = go && !wrapped && n < nmax;
     }
-    if (on) {
-        w.x = step ? x2 : x1;
-        w.n = step ? n1 + 1 : n1;
-        if (wrapped) {
+    if (was) {
+        w.x = x;
+        w.n = n;
+        if (has_wrapped) {
             w.outcome = LAP_OUT_WRAP;
             if (KIND == NCO_CODE)
                 w.jc++;
-        } else if (w.n >= w.nmax && w.b == w.bt) {
+        } else if (w.b == w.bt) {
             w.outcome = LAP_OUT_LATE;
         }
     }
@@ -630,10 +652,13 @@ __device__ __forceinline__ void lap_walk(const BatchDev &p, const LapDev &L, int
         }
     }
     while (__ballot(w.active)) {
-        if (__ballot(w.active && !w.neg))
-            lap_turn<KIND, false, EMIT, TIES>(p, i, w);
-        if (KIND == NCO_CARR && __ballot(w.active && w.neg))
-            lap_turn<KIND, true, EMIT, TIES>(p, i, w);
+        /* the lanes by the sign of their step, each group in its own straight-line loop (a wavefront's laps are neighbours in time:
+         * it normally runs only one of the two) */
+        const bool rise = w.active && !w.neg, fall = w.active && w.neg;
+        if (__ballot(rise))
+            lap_run<KIND, false, EMIT, TIES>(p, i, w, rise);
+        if (KIND == NCO_CARR && __ballot(fall))
+            lap_run<KIND, true, EMIT, TIES>(p, i, w, fall);
         /* lanes at the last sample + 1 of their block: the end state; the chain's next block, or the walk ends */
         const bool at_end = w.active && w.n >= p.nsamp;
         if (__ballot(at_end)) {

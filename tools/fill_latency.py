@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Latency of the drop-in call gpsbb_fill_block (one block, IQ into pageable host memory) with the NCO pre-pass on host
-threads (the default for one block) and on the device.   python tools/fill_latency.py"""
+threads (the default for one block) and on the device — by the row walks of rounds 1-4 (one whole-block walk per chain) and
+lap-parallel (round 5).   python tools/fill_latency.py"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +12,7 @@ CASES = (("reference block: 12 ch, 2.6 MS/s, 300000 samples", 12, 2.6e6, 300000)
 with pkg.Synth(0) as s:
     for name, nch, fs, nsamp in CASES:
         ch = pkg.synth_descriptors(8, nch=nch, seed=0xBEEF)
-        for where, label in ((2, "host threads"), (1, "device"), (0, "automatic")):
+        for where, label in ((2, "host threads"), (1, "device, row walks"), (3, "device, lap-parallel"), (0, "automatic")):
             s.set_option(pkg.OPT_SEED_WHERE, where)
             for k in range(3):
                 s.fill_block(ch[k % 8], 1.0 / fs, nsamp)
@@ -21,4 +22,4 @@ with pkg.Synth(0) as s:
                 s.fill_block(ch[k % 8], 1.0 / fs, nsamp)
                 ts.append(time.perf_counter() - t0)
             ts.sort()
-            print("%-52s pre-pass on %-13s median %.3f ms  min %.3f ms" % (name, label, ts[len(ts) // 2] * 1e3, ts[0] * 1e3))
+            print("%-52s pre-pass on %-21s median %.3f ms  min %.3f ms" % (name, label, ts[len(ts) // 2] * 1e3, ts[0] * 1e3))

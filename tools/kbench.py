@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--per-sample", action="store_true", help="force the per-sample kernel k_synth")
     ap.add_argument("--smooth", action="store_true", help="bench.py's stream descriptors (slowly varying Doppler) instead of M2's")
     ap.add_argument("--no-cpu", action="store_true", help="ignored (compatibility with older scripts)")
+    ap.add_argument("--where", type=int, default=0, help="GPSBB_OPT_SEED_WHERE: 1 the row walks of rounds 1-4, 3 the lap-parallel pre-pass")
     ap.add_argument("--fill-ceiling", action="store_true", help="also run the pure write kernel over the output buffer (counter calibration)")
     a = ap.parse_args()
     import torch
@@ -39,6 +40,8 @@ def main():
     synth = pkg.Synth(0)
     if a.per_sample:
         synth.set_option(pkg.OPT_SYNTH_KERNEL, 1)
+    if a.where:
+        synth.set_option(pkg.OPT_SEED_WHERE, a.where)
     batch = synth.batch(ch, 1.0 / a.fs, a.nsamp, flags=pkg.CHAIN_CARRIER if a.chain else 0)
     out = torch.empty(a.blocks * a.nsamp * 2, dtype=torch.int16, device="cuda:0")
     if a.synth_only:

@@ -1,0 +1,167 @@
+"""The lap-parallel exact NCO pre-pass (pluto-gps-sim_amd/csrc/gpsbb_laps.hip.h, round 5): what replaces the inline recurrences
+plutogpssim.c:2709-2712 / 2741-2746 for the model kernels.  tests/test_parity_gpu.py runs every parity case through it (mode
+"laps+auto"); here: that it is what runs by default, the steps its links have to treat specially, and its repair path forced."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def f_with_step_bits(f0, delt, grid_exp, low_half, span=1 << 19):
+    """an f near f0 whose step fl(f * delt) has, below 2^grid_exp, no bits (low_half False) or exactly the one below it (True)"""
+    f = np.float64(f0)
+    cand = f + np.spacing(f) * np.arange(span, dtype=np.float64)
+    bits = np.abs(cand * np.float64(delt)).view(np.uint64)
+    ex = ((bits >> np.uint64(52)) & np.uint64(0x7ff)).astype(np.int64) - 1023
+    mant = (bits & np.uint64((1 << 52) - 1)) | np.uint64(1 << 52)
+    dt = (grid_exp - (ex - 52)).astype(np.int64)  # bits of the mantissa below the grid
+    assert (dt > 0).all() and (dt < 53).all()
+    low = mant & ((np.uint64(1) << dt.astype(np.uint64)) - np.uint64(1))
+    want = (np.uint64(1) << (dt - 1).astype(np.uint64)) if low_half else np.zeros_like(low)
+    hit = np.nonzero(low == want)[0]
+    assert hit.size
+    return cand[hit[0]]
+
+
+@pytest.fixture()
+def fresh(pkg, synth):
+    for opt in (pkg.OPT_SEED_WHERE, pkg.OPT_SYNTH_KERNEL, pkg.OPT_CHAIN_WHERE):
+        synth.set_option(opt, 0)
+    yield synth
+    for opt in (pkg.OPT_SEED_WHERE, pkg.OPT_SYNTH_KERNEL, pkg.OPT_CHAIN_WHERE):
+        synth.set_option(opt, 0)
+
+
+def test_it_is_what_runs_by_default(pkg, fresh, oracle):
+    """GPSBB_INFO_PREPASS: 3 = lap-parallel for the model kernels at any batch size (one block included: the drop-in call),
+    1 = the row walks where the per-sample kernel renders (its tables are rows) or where the host asks for them."""
+    s = fresh
+    ch = pkg.synth_descriptors(3, nch=12, seed=5)
+    s.fill_block(ch[0], 1 / 2.6e6, 30000)
+    assert s.info(pkg.INFO_LAST_KERNEL) == 2 and s.info(pkg.INFO_PREPASS) == 3
+    b = s.batch(ch, 1 / 25e6, 50000, flags=pkg.CHAIN_CARRIER)
+    b.run(); s.sync(); b.close()
+    assert s.info(pkg.INFO_PREPASS) == 3 and s.info(pkg.INFO_CHAIN_ON_DEVICE) == 1
+    s.set_option(pkg.OPT_SYNTH_KERNEL, 1)
+    s.fill_block(ch[0], 1 / 2.6e6, 30000)
+    assert s.info(pkg.INFO_LAST_KERNEL) == 1 and s.info(pkg.INFO_PREPASS) in (1, 2)
+    s.set_option(pkg.OPT_SYNTH_KERNEL, 0)
+    s.set_option(pkg.OPT_SEED_WHERE, 1)
+    s.fill_block(ch[0], 1 / 2.6e6, 30000)
+    assert s.info(pkg.INFO_PREPASS) == 1
+    # a carrier that does not move is outside what the laps' turn covers: the row walks take the batch
+    s.set_option(pkg.OPT_SEED_WHERE, 3)
+    ch["f_carr"][:, 2] = 0.0
+    want_iq, _, _ = oracle.fill_blocks(ch, 1 / 25e6, 20000)
+    b = s.batch(ch, 1 / 25e6, 20000)
+    b.run(); s.sync()
+    assert s.info(pkg.INFO_PREPASS) == 1 and (b.read()[0] == want_iq).all()
+    b.close()
+
+
+def test_steps_that_tie_on_the_coarsest_grid(pkg, fresh, oracle):
+    """One block-channel in 2^12 of a real stream has a step whose sums on the coarsest grid of its chain are exact ties: a rising
+    carrier's wrap sums (grid of [1, 2): 2^-52) every other wrap, every sum of a falling carrier in [0.5, 1) (2^-53), every sum of a
+    code phase in [512, 1024) (2^-43).  What such a sum does to the offset between two trajectories depends on the offset
+    modulo 4: part of the links (LapMap).  Here every block of five channels has such a step; bit-exact, and the links hold
+    (they would not if the maps were plain translations: about every other lap then needs the repair)."""
+    s = fresh
+    fs, nsamp, nb, nch = 25e6, 400000, 24, 6
+    delt = 1.0 / fs
+    ch = pkg.synth_descriptors(nb, nch=nch, seed=4242)
+    rng = np.random.default_rng(5)
+    for b in range(nb):
+        for i, (f0, top, half) in enumerate([(7750.0, -52, True), (4250.0, -52, False), (-5750.0, -53, True), (-2250.0, -53, False)]):
+            ch["f_carr"][b, i] = f_with_step_bits(f0 * (1 + 0.01 * rng.uniform(-1, 1)), delt, top, half)
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    for b in range(nb):
+        ch["f_code"][b, 4] = f_with_step_bits(1.023e6 + 2.0 * rng.uniform(-1, 1), delt, -43, True)
+    ch["prn"] = np.arange(1, nch + 1)[None, :]
+    want_iq, want_st, _ = oracle.fill_blocks(ch, delt, nsamp, chain=True)
+    r0 = s.info(pkg.INFO_CHAIN_REPAIRS)
+    b = s.batch(ch, delt, nsamp, flags=pkg.CHAIN_CARRIER)
+    b.run(); s.sync()
+    iq, st = b.read(); b.close()
+    assert s.info(pkg.INFO_PREPASS) == 3
+    assert (iq == want_iq).all()
+    for f in ("carr_phase", "code_phase", "iword", "ibit", "icode", "dataBit", "codeCA"):
+        assert st[f].tobytes() == want_st[f].tobytes(), f
+    assert s.info(pkg.INFO_CHAIN_REPAIRS) - r0 <= 2
+
+
+def test_laps_across_blocks_and_turning_carriers(pkg, fresh, oracle):
+    """Laps are a chain's, not a block's: a slow carrier's lap spans many blocks (the step changes inside it), a Doppler that
+    changes sign turns the phase round inside a lap (the lap then ends with the other kind of wrap, on the other grid), a channel
+    is re-allocated or idle for a while (its chain ends and another starts from the descriptor's phase), the last step of a
+    block wraps.  Chained batch and stream, against the oracle."""
+    s = fresh
+    fs, nsamp, nb, nch = 25e6, 70000, 60, 10
+    delt = 1.0 / fs
+    ch = pkg.synth_descriptors(nb, nch=nch, seed=99)
+    rng = np.random.default_rng(12)
+    t = np.arange(nb)[:, None]
+    f = np.zeros((nb, nch))
+    f[:, 0] = 3.0 + 0.01 * t[:, 0]                      # one lap in ~120 blocks
+    f[:, 1] = -40.0                                      # a falling lap over nine blocks
+    f[:, 2] = 900.0 * np.sin((t[:, 0] + 0.37) / 4.0)     # through zero again and again (never exactly zero: that is the row walks')
+    f[:, 3] = np.where(t[:, 0] % 2 == 0, 2500.0, -2500.0)  # turns round at every block edge
+    f[:, 4] = fs / nsamp * 3                             # three laps per block, exactly: wraps at block edges
+    f[:, 5] = -fs / nsamp * 2
+    f[:, 6:] = rng.uniform(-5000, 5000, (1, nch - 6)) + rng.uniform(-1, 1, (nb, nch - 6))
+    ch["f_carr"] = f
+    ch["f_code"] = 1.023e6 + f / 1540.0
+    ch["prn"] = np.arange(1, nch + 1)[None, :]
+    ch["prn"][20:, 7] = 30
+    ch["prn"][33:37, 8] = 0
+    ch["carr_phase"][:, 4] = 0.0
+    ch["carr_phase"][:, 5] = 1.0 - 2.0 ** -53
+    want_iq, want_st, hz = oracle.fill_blocks(ch, delt, nsamp, chain=True)
+    s.hazards(reset=True)
+    s.set_option(pkg.OPT_SEED_WHERE, 3)
+    b = s.batch(ch, delt, nsamp, flags=pkg.CHAIN_CARRIER)
+    b.run(); s.sync()
+    iq, st = b.read(); b.close()
+    assert s.info(pkg.INFO_PREPASS) == 3
+    act = ch["prn"] > 0
+    assert (iq == want_iq).all()
+    assert st["carr_phase"][act].tobytes() == want_st["carr_phase"][act].tobytes()
+    assert s.hazards(reset=True) == {"itable_512": int(hz["itable_512"]), "dwrd_oob": int(hz["dwrd_oob"])}
+    bps = 6
+    stq = s.stream(nch, delt, nsamp, bps, depth=3, flags=pkg.CHAIN_CARRIER)
+    got, gst = [], []
+    for k in range(nb // bps):
+        if stq.pending == 3:
+            a, e = stq.pop(); got.append(a.copy()), gst.append(e.copy())
+        stq.push(ch[k * bps:(k + 1) * bps])
+    while stq.pending:
+        a, e = stq.pop(); got.append(a.copy()), gst.append(e.copy())
+    stq.close()
+    assert (np.concatenate(got).reshape(want_iq.shape) == want_iq).all()
+    assert np.concatenate(gst)["carr_phase"][act].tobytes() == want_st["carr_phase"][act].tobytes()
+
+
+@pytest.mark.parametrize("args,jitter,at_least", [(["--stream", "--cases", "10", "--seed", "31", "--budget", "2e7", "--also-batch"], 4000000000, 20),
+                                                 (["--stream", "--cases", "8", "--seed", "32", "--budget", "2e7", "--low-rate"], 4000000000, 20),
+                                                 (["--ev", "--cases", "60", "--seed", "33"], 1000000, 20),
+                                                 # (slow carriers, short blocks: few laps, so few links to break)
+                                                 (["--stream", "--ties", "--cases", "8", "--seed", "34", "--budget", "2e7"], 4000000000, 3)])
+def test_the_repair_path_made_common(pkg, args, jitter, at_least):
+    """k_lap_repair has work about once in 10^8 laps.  The experiments build pushes every lap's reference state off the model by a
+    pseudo-random number of grid steps (GPSBB_LAP_JITTER: up to 4e9 of them — 5e-7 cycles, 5e-4 chips — so that reference laps
+    cross binade edges at other samples than the true ones: every tenth link then does not hold): the fuzz campaigns, forced onto
+    the lap-parallel pre-pass, have to stay bit-exact — chained streams, batches, low rates, steps with few mantissa bits — and
+    the repair must really have run."""
+    env = dict(os.environ, GPSBB_PY_LIB="exp", GPSBB_LAP_JITTER=str(jitter), GPSBB_FUZZ_WHERE="3")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py")] + args, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "bit-exact" in r.stdout
+    m = re.search(r"(?:links / guesses|links) that did not hold: (\d+)", r.stdout)
+    assert m and int(m.group(1)) >= at_least, r.stdout[-600:]
+    assert "3:" in r.stdout.split("lap-parallel}:")[1]  # the lap-parallel pre-pass did take cases

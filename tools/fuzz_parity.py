@@ -25,6 +25,7 @@ def stream_soak(a):
     oracle = ob.Oracle()
     rng = np.random.default_rng(a.seed)
     fallbacks = ties = 0
+    prepass = {}
     with pkg.Synth(0) as synth:
         for case in range(a.cases):
             fs = float(rng.choice([16.368e6, 20e6, 25e6, 30e6, 2.0 ** 25, 50e6]))
@@ -56,6 +57,12 @@ def stream_soak(a):
                         f[:, i] = fs * 2.0 ** -15
             if rng.random() < 0.2:
                 f[:, -1] = 0.0
+            if os.environ.get("GPSBB_FUZZ_WHERE") == "3":
+                # a campaign aimed at the lap-parallel pre-pass: nothing that sends the case elsewhere (a carrier that does not move
+                # at all, a rate only the per-sample kernel renders)
+                f[f == 0.0] = 1e-3
+                if fs < 2e6:
+                    fs = 2.6e6
             ch["f_carr"] = f
             ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
             # satellites come and go: a channel changes PRN or goes idle for a stretch of blocks
@@ -66,8 +73,10 @@ def stream_soak(a):
             want_iq, want_st, _ = oracle.fill_blocks(ch, delt, nsamp, chain=True, fixed=False)
             depth = int(rng.integers(2, 5))
             dev_only = bool(rng.integers(0, 2))
-            synth.set_option(pkg.OPT_SEED_WHERE, 1 if rng.random() < 0.85 else 0)  # mostly: pre-pass and chain on the device
-            synth.set_option(pkg.OPT_SYNTH_KERNEL, 1 if rng.random() < 0.25 else 0)  # now and then the per-sample kernel where the other one would do
+            # pre-pass and chain on the device: lap-parallel (round 5), by the row walks (rounds 1-4), or whatever the library picks
+            where = int(os.environ.get("GPSBB_FUZZ_WHERE", rng.choice([3, 1, 0], p=[0.45, 0.4, 0.15])))
+            synth.set_option(pkg.OPT_SEED_WHERE, where)
+            synth.set_option(pkg.OPT_SYNTH_KERNEL, 1 if rng.random() < (0.25 if os.environ.get("GPSBB_FUZZ_WHERE") != "3" else 0.1) else 0)  # now and then the per-sample kernel where the other one would do
             st = synth.stream(nch, delt, nsamp, bps, depth=depth,
                               flags=pkg.CHAIN_CARRIER | (pkg.STREAM_DEVICE_ONLY if dev_only else 0))
             got = []
@@ -80,7 +89,10 @@ def stream_soak(a):
                 got.append((None if dev_only else np.asarray(iq).reshape(bps, -1), es))  # HBM-only ring: end states only
                 popped += 1
             st.close()
-            what = dict(case=case, fs=fs, nsamp=nsamp, nch=nch, bps=bps, pushes=pushes, depth=depth, dev_only=dev_only)
+            prepass[synth.info(pkg.INFO_PREPASS)] = prepass.get(synth.info(pkg.INFO_PREPASS), 0) + 1
+            what = dict(case=case, fs=fs, nsamp=nsamp, nch=nch, bps=bps, pushes=pushes, depth=depth, dev_only=dev_only, where=where)
+            if os.environ.get("GPSBB_FUZZ_VERBOSE"):
+                print(what, "pre-pass", synth.info(pkg.INFO_PREPASS), "kernel", synth.info(pkg.INFO_LAST_KERNEL), "min |f_carr|", float(np.abs(f[ch["prn"] > 0]).min()) if (ch["prn"] > 0).any() else None, flush=True)
             if getattr(a, "also_batch", False):
                 # the same blocks as ONE chained batch (no stream to continue: pass B starts from the host's drift model of the
                 # carrier, long blocks are cut into segments) and as a batch of independent blocks seeded with the oracle's phases
@@ -115,8 +127,10 @@ def stream_soak(a):
         fallbacks = synth.info(pkg.INFO_CHAIN_FALLBACKS)
         ties = synth.info(pkg.INFO_CHAIN_TIES)
         on_dev = synth.info(pkg.INFO_CHAIN_ON_DEVICE)
-    print("fuzz_parity --stream: %d chained streams bit-exact (seed %d); last push chained on the device: %d; blocks walked "
-          "sequentially by k_chain_fix: %d; wrap ties recorded: %d" % (a.cases, a.seed, on_dev, fallbacks, ties))
+        repairs = synth.info(pkg.INFO_CHAIN_REPAIRS)
+    print("fuzz_parity --stream: %d chained streams bit-exact (seed %d); last push chained on the device: %d; blocks / laps walked "
+          "again by the fix-up / the lap repair: %d; links / guesses that did not hold: %d; wrap ties recorded: %d; pre-pass of each case's "
+          "last push {1: row walks, 2: host threads, 3: lap-parallel}: %r" % (a.cases, a.seed, on_dev, fallbacks, repairs, ties, prepass))
 
 
 def main():
@@ -152,6 +166,7 @@ def main():
     shapes = [(25e6, 1 << 24, 2, 1), (2.6e6, 777, 12, 3000), (10e6, 1, 16, 5000), (25e6, 1024 * 300 + 1, 16, 3),
               (25e6, 2500000, 16, 6), (1e6, 5000000, 3, 2)]
     used = {}
+    prepass = {}
     with pkg.Synth(0) as synth:
         for case in range(len(shapes) * 2 if a.shapes else a.cases):
             fs = float(rng.choice([1e6, 2.6e6, 3e6, 4.092e6, 10e6, 16e6, 25e6, 30e6, 2.0 ** 25, 50e6]))
@@ -160,11 +175,11 @@ def main():
             nblocks = int(rng.integers(1, 6))
             fixed = bool(rng.integers(0, 4) == 0)
             chain = bool(rng.integers(0, 2))
-            mode = int(rng.integers(1, 3))            # 1: k_seed, 2: host threads
+            mode = int(os.environ.get("GPSBB_FUZZ_WHERE", rng.choice([1, 2, 3])))  # 1: the row walks (k_seed / k_walk), 2: host threads, 3: lap-parallel
             kern = int(rng.integers(0, 2))            # 0: automatic (breakpoint kernel where eligible), 1: per-sample
             if a.shapes:
                 fs, nsamp, nch, nblocks = shapes[case // 2]
-                fixed, mode = False, 1 + case % 2
+                fixed, mode = False, (1, 3)[case % 2]
             if a.ev:
                 fs = float(rng.choice([16e6, 16.368e6, 20e6, 25e6, 30e6, 2.0 ** 25, 50e6, 61.44e6]))
                 nsamp = int(rng.choice([rng.integers(1, 3000), rng.integers(3000, 300000), 1024 * int(rng.integers(1, 200))]))
@@ -203,6 +218,7 @@ def main():
             iq, st = b.read()
             b.close()
             used[synth.info(pkg.INFO_LAST_KERNEL)] = used.get(synth.info(pkg.INFO_LAST_KERNEL), 0) + 1
+            prepass[synth.info(pkg.INFO_PREPASS)] = prepass.get(synth.info(pkg.INFO_PREPASS), 0) + 1
             what = dict(case=case, fs=fs, nsamp=nsamp, nch=nch, nblocks=nblocks, fixed=fixed, chain=chain, mode=mode, kern=kern)
             if not (iq == want_iq).all():
                 bad = np.argwhere(iq != want_iq)[0]
@@ -212,9 +228,11 @@ def main():
                 if st[f][act].tobytes() != want_st[f][act].tobytes():
                     raise SystemExit("END STATE MISMATCH %r field %s" % (what, f))
         exact_runs = synth.info(pkg.INFO_EXACT_RUNS)
+        repairs, rewalked = synth.info(pkg.INFO_CHAIN_REPAIRS), synth.info(pkg.INFO_CHAIN_FALLBACKS)
     print("fuzz_parity: %d cases bit-exact (seed %d); synthesis kernel used {1: per-sample, 2: breakpoint}: %r; "
-          "lane-runs recomputed exactly by the breakpoint kernel: %d" %
-          (len(shapes) * 2 if a.shapes else a.cases, a.seed, used, exact_runs))
+          "lane-runs recomputed exactly by the breakpoint kernel: %d; pre-pass {1: row walks, 2: host threads, 3: lap-parallel}: %r; "
+          "links that did not hold: %d, laps / blocks walked again: %d" %
+          (len(shapes) * 2 if a.shapes else a.cases, a.seed, used, exact_runs, prepass, repairs, rewalked))
 
 
 if __name__ == "__main__":

@@ -34,7 +34,12 @@ duration against the 8 TB/s HBM peak.  Beside it, measured in the same invocatio
   gather        the same shard through a ring with the pinned D2H gather (PCIe-inclusive; never `value`)
   m1            BASELINE.md section 3's other leg: 12 ch, 2.6 MS/s, 300 000-sample blocks (GPU, and the CPU port)
   cpu_baseline  the CPU restatement (oracle, 1 core) on a bounded sample of the same blocks
-With N > 1 these run on rank 0 (its GPU, its host cores) while the other ranks wait.
+These four run at N = 1 only (with N > 1 they would keep N - 1 GPUs idle behind rank 0 for most of the command).
+  parity        blocks of the timed mode's ring against the CPU oracle (a handful: the oracle renders 2e7 samples/s) AND every
+                block of every shard against the per-sample kernel's rendering, by device-side digests (`blocks_cross_checked`)
+  node_driver   the product's one-process driver (include/gpsbb_node.h): the same pushes through one shard on this rank's GPU,
+                and — rank 0, after the timed regions — the whole stream over ALL visible GPUs, contiguous shards into an indexed
+                sink and interleaved slots into the ordered one, every slot digested and compared with what the ranks rendered
 """
 import argparse
 import json
@@ -88,12 +93,14 @@ def parity_check(pkg, ob, synth, mine, delt, nsamp, PB, nch, ncheck, nspot=8):
     spot_every = max(1, npush // max(1, nspot))  # one block of every spot_every-th push, from the phase the stream reports there
     st = synth.stream(nch, delt, nsamp, PB, depth=3, flags=pkg.CHAIN_CARRIER | pkg.STREAM_DEVICE_ONLY)
     checked, bad, digs = 0, [], []
+    iq_digs = np.zeros(npush * PB, np.uint64)  # gpsbb_device_digest of every block as the timed mode renders it
     pushed = 0
     for k in range(npush):
         while pushed < npush and st.pending < 3:
             st.push(mine[pushed * PB:(pushed + 1) * PB])
             pushed += 1
         dptr, ends = st.pop(copy=False)
+        iq_digs[k * PB:(k + 1) * PB] = synth.device_digest(dptr, PB, nsamp)
         act = mine["prn"][k * PB:(k + 1) * PB] > 0
         cp = np.where(act, ends["carr_phase"], 0.0)
         xp = np.where(act, ends["code_phase"], 0.0)
@@ -124,7 +131,32 @@ def parity_check(pkg, ob, synth, mine, delt, nsamp, PB, nch, ncheck, nspot=8):
             if not ok:
                 bad.append(k * PB + j)
     st.close()
-    return checked, bad, digs
+    return checked, bad, digs, iq_digs
+
+
+def cross_check(pkg, synth, mine, delt, nsamp, PB, nch, iq_digs):
+    """EVERY block of the shard, not the handful the oracle has time for: the shard once more through the same kind of ring
+    with the per-sample kernel forced (GPSBB_OPT_SYNTH_KERNEL 1: k_synth steps both NCOs of every sample with genuine IEEE
+    adds from rows built by the row walks, k_seed — another algorithm AND another pre-pass than the timed mode's model
+    kernels on the lap-parallel pre-pass, itself tested against the oracle), one device-side digest per block
+    (gpsbb_device_digest) compared with the timed mode's.  Returns the blocks whose digests differ."""
+    npush = mine.shape[0] // PB
+    synth.set_option(pkg.OPT_SYNTH_KERNEL, 1)
+    try:
+        st = synth.stream(nch, delt, nsamp, PB, depth=3, flags=pkg.CHAIN_CARRIER | pkg.STREAM_DEVICE_ONLY)
+        other = np.zeros(npush * PB, np.uint64)
+        pushed = 0
+        for k in range(npush):
+            while pushed < npush and st.pending < 3:
+                st.push(mine[pushed * PB:(pushed + 1) * PB])
+                pushed += 1
+            dptr, _ = st.pop(copy=False)
+            other[k * PB:(k + 1) * PB] = synth.device_digest(dptr, PB, nsamp)
+        kernel = synth.info(pkg.INFO_LAST_KERNEL)
+        st.close()
+    finally:
+        synth.set_option(pkg.OPT_SYNTH_KERNEL, 0)
+    return np.nonzero(other != iq_digs)[0].tolist(), kernel
 
 
 def cpu_baseline(ob, ch, delt, nsamp, budget_s=10.0):
@@ -430,8 +462,6 @@ def main():
                     "note": "gpsbb_node_run (C, one producer thread per shard bound to its GPU's NUMA node), GPSBB_NODE_DEVICE_ONLY rings of the "
                             "headline's geometry, one pass over this rank's shard, best of 3; includes the shard seeds"}
             node["one_shard"]["vs_headline"] = node["one_shard"]["value"] / (samples_per_step * K / elapsed / world)
-            if world == 1 and ndev > 1:
-                node["all_visible_gpus"] = node_leg(list(range(ndev)))
         except Exception as e:  # the headline stands on its own
             node = {"error": repr(e)}
 
@@ -449,20 +479,78 @@ def main():
         if not args.no_cpu:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle_binding as ob
-        n_ok, bad, digs = parity_check(pkg, ob, synth, mine, delt, nsamp, PB, nch, max(1, min(args.parity_blocks, PB)), args.parity_spots)
+        n_ok, bad, digs, iq_digs = parity_check(pkg, ob, synth, mine, delt, nsamp, PB, nch, max(1, min(args.parity_blocks, PB)), args.parity_spots)
+        t_cross = time.perf_counter()
+        cross_bad, cross_kernel = cross_check(pkg, synth, mine, delt, nsamp, PB, nch, iq_digs)
+        t_cross = time.perf_counter() - t_cross
         n_all = int(over_ranks(float(n_ok), dist.ReduceOp.SUM))
         n_bad = int(over_ranks(float(len(bad)), dist.ReduceOp.SUM))
+        n_cross_bad = int(over_ranks(float(len(cross_bad)), dist.ReduceOp.SUM))
         if use_dist:
             allg = [None] * world
-            dist.all_gather_object(allg, digs)
-            digs = [d for part in allg for d in part]
+            dist.all_gather_object(allg, (digs, iq_digs))
+            digs = [d for part in allg for d in part[0]]
+            iq_digs = np.concatenate([part[1] for part in allg])
         parity = {"checked_blocks": n_all, "mismatching_blocks": n_bad, "per_rank": n_ok,
+                  # every block of every rank's shard: the timed mode's rendering (model kernels, lap-parallel pre-pass) against the
+                  # per-sample kernel's (genuine IEEE steps, row-walk pre-pass), one device-side digest per block
+                  "blocks_cross_checked": int(iq_digs.shape[0]), "cross_mismatching_blocks": n_cross_bad,
+                  "cross_check": {"against": "k_synth on k_seed's rows (GPSBB_OPT_SYNTH_KERNEL 1)" if cross_kernel == 1 else "?",
+                                  "digest": "gpsbb_device_digest (64 bits per block, on the device)", "seconds_rank0": t_cross,
+                                  "stream_iq_digest": zlib.crc32(iq_digs.tobytes())},
                   "stream_end_state_digest": zlib.crc32(np.asarray(digs, np.uint32).tobytes()), "blocks_digested": len(digs),
                   "what": "int16 IQ and end-of-block carr_phase of blocks read back from the HBM slots of a "
                           "GPSBB_STREAM_DEVICE_ONLY ring (the timed mode) vs the CPU oracle, bit for bit: the first blocks of "
                           "every rank's shard, one block of every (pushes / %d)-th push and one of its last push" % args.parity_spots}
         if n_bad:
             sys.stderr.write("bench.py: rank %d: IQ differs from the oracle in blocks %s of its shard\n" % (rank, bad))
+        if cross_bad:
+            sys.stderr.write("bench.py: rank %d: the model kernels and the per-sample kernel differ in %d blocks of its shard, first %s\n" %
+                             (rank, len(cross_bad), cross_bad[:8]))
+
+    # ---- the PRODUCT's multi-device path on every GPU this process can see, checked against what the ranks rendered: rank 0
+    # runs gpsbb_node_run over the WHOLE stream on all visible GPUs — contiguous shards into an indexed sink, then slots dealt
+    # round the GPUs into the ordered sink (the reference's one consumer, c:2146-2158) — digests every slot on the GPU that
+    # rendered it and compares with the per-block digests gathered from the ranks.  Under the driver's torchrun invocation
+    # (one rank per GPU, every rank sees all GPUs) this is where the node driver first meets several physical devices. ----
+    if rank == 0 and not args.no_extras and parity is not None and node is not None and "error" not in node:
+        try:
+            full = mine if world == 1 else stream_descriptors(pkg, total, nch)
+            devs = list(range(max(ndev, 1))) if backend == "nccl" or world == 1 else [local]
+            helpers = {d: (synth if d == local else pkg.Synth(d)) for d in devs}
+            legs = {}
+            for name, nflags in (("contiguous_indexed", pkg.NODE_DEVICE_ONLY | pkg.NODE_INDEXED | pkg.NODE_CONCURRENT),
+                                 ("interleaved_ordered", pkg.NODE_DEVICE_ONLY | pkg.NODE_INTERLEAVED)):
+                got = np.zeros(full.shape[0], np.uint64)
+                seen = np.zeros(full.shape[0], np.int32)
+                order = []
+                with pkg.Node(len(devs), nch, delt, nsamp, PB, depth=args.depth, flags=nflags, devices=devs) as nd:
+                    def sink(iq, first, nb, shard):
+                        got[first:first + nb] = helpers[devs[shard]].device_digest(iq, nb, nsamp)
+                        seen[first:first + nb] += 1
+                        order.append(first)
+                        return 0
+                    stn = nd.run(full, sink)
+                legs[name] = {"value": full.shape[0] * nsamp / stn["seconds"], "unit": "IQ samples/s (digesting every slot inside the sink included)",
+                              "seconds": stn["seconds"], "blocks": int(full.shape[0]), "devices": devs,
+                              "every_block_once": bool((seen == 1).all()), "in_stream_order": order == sorted(order),
+                              "digests_equal_the_ranks": bool((got == iq_digs).all()),
+                              "blocks_that_differ": int((got != iq_digs).sum()),
+                              "shards": [{k: x[k] for k in ("first_block", "nblocks", "device", "numa_node", "cpus_bound", "seed_seconds", "busy_seconds", "wait_seconds")}
+                                         for x in stn["shards"]]}
+            for d, hsyn in helpers.items():
+                if hsyn is not synth:
+                    hsyn.close()
+            all_equal = all(legs[k]["digests_equal_the_ranks"] and legs[k]["every_block_once"] for k in legs)
+            node["all_gpus"] = legs
+            node["all_gpus"]["expectation"] = ("N GPUs: contiguous shards into an indexed sink scale with N (every GPU renders and is digested on its own); "
+                                               "the ordered sink over interleaved slots delivers in stream order at the same rate as long as the consumer keeps up; "
+                                               "here the consumer is a Python callback that digests 4 GB per slot on the slot's GPU (~1.5 ms), so these values are "
+                                               "lower bounds of the driver's rate, not the headline")
+            if not all_equal:
+                parity["node_driver_mismatch"] = True
+        except Exception as e:
+            node["all_gpus"] = {"error": repr(e)}
 
     res = None
     if rank == 0:
@@ -535,7 +623,8 @@ def main():
                                         "source": sj.get("source")}
             except Exception:
                 pass
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and not args.no_extras and world == 1:
+        # (at N = 1 only: with N > 1 these legs would keep N - 1 GPUs idle behind a barrier for most of the command's wall time)
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         rch = mine[:PB]  # the shard's first push: the headline's own descriptors, resident
         r0, ceil_gbs = resident_leg(pkg, synth, torch, rch, delt, nsamp, 0, 20, 4, dev)
@@ -586,13 +675,13 @@ def main():
             res["cpu_baseline"] = cpu_baseline(ob, mine, delt, nsamp, budget_s=args.cpu_budget)
             res["m1"]["cpu"] = cpu_baseline(ob, mch, 1.0 / 2.6e6, 300000, budget_s=args.cpu_budget / 2)
     if use_dist:
-        dist.barrier()   # the other ranks wait for rank 0's legs
+        dist.barrier()   # the other ranks wait for rank 0's node-driver leg
     if rank == 0:
         print(json.dumps(res))
     synth.close()
     if use_dist:
         dist.destroy_process_group()
-    if parity and parity["mismatching_blocks"]:
+    if parity and (parity["mismatching_blocks"] or parity["cross_mismatching_blocks"] or parity.get("node_driver_mismatch")):
         raise SystemExit(3)
 
 

@@ -23,8 +23,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # build of the same sources (libgpsbb_exp.so: measurement knobs from the environment, gpsbb_test_* hooks) is what the
 # tuning scripts under tools/ use when they say so (GPSBB_PY_LIB=exp, read HERE, in the Python veneer) and what
 # exp_lib() hands to the NCO unit tests.
-_which = os.environ.get("GPSBB_PY_LIB")  # "exp", "broken", or the tag of a variant a tuning script built (libgpsbb_<tag>.so)
-LIB_PATH = os.path.join(HERE, "libgpsbb_%s.so" % _which if _which else "libgpsbb.so")
+_which = os.environ.get("GPSBB_PY_LIB")  # "exp", the tag of a variant a tuning script built (libgpsbb_<tag>.so), or the PATH of a library
+# (the deliberately wrong builds of the tests live in the tests' temporary directories, never beside the product)
+LIB_PATH = _which if _which and os.sep in _which else os.path.join(HERE, "libgpsbb_%s.so" % _which if _which else "libgpsbb.so")
 EXP_LIB_PATH = os.path.join(HERE, "libgpsbb_exp.so")
 
 MAX_CHAN = 16
@@ -57,7 +58,7 @@ API_SYMBOLS = [
     "gpsbb_create", "gpsbb_destroy", "gpsbb_strerror", "gpsbb_last_hip_error", "gpsbb_version",
     "gpsbb_fill_block", "gpsbb_fill_block_ex", "gpsbb_fill_block_ref", "gpsbb_fill_block_ref_fixed", "gpsbb_batch_create", "gpsbb_batch_destroy",
     "gpsbb_batch_iq_bytes", "gpsbb_batch_run", "gpsbb_sync", "gpsbb_batch_read", "gpsbb_batch_device_iq",
-    "gpsbb_get_hazards", "gpsbb_device_read", "gpsbb_batch_last_timing", "gpsbb_batch_timing_stats", "gpsbb_fill_ceiling", "gpsbb_stream_create",
+    "gpsbb_get_hazards", "gpsbb_device_read", "gpsbb_device_digest", "gpsbb_batch_last_timing", "gpsbb_batch_timing_stats", "gpsbb_fill_ceiling", "gpsbb_stream_create",
     "gpsbb_stream_destroy", "gpsbb_stream_push", "gpsbb_stream_pop", "gpsbb_stream_pending", "gpsbb_stream_timing_stats",
     "gpsbb_codegen", "gpsbb_sincos_tables", "gpsbb_chain_carrier_host", "gpsbb_chain_carrier", "gpsbb_set_option",
     "gpsbb_get_info", "gpsbb_stream_reset", "gpsbb_device_affinity", "gpsbb_stream_push_ex",
@@ -116,6 +117,7 @@ def lib():
         L.gpsbb_batch_device_iq.restype = vp
         L.gpsbb_get_hazards.argtypes = [vp, vp, i]
         L.gpsbb_device_read.argtypes = [vp, vp, vp, C.c_size_t]
+        L.gpsbb_device_digest.argtypes = [vp, vp, C.c_long, C.c_int, vp]
         L.gpsbb_batch_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.gpsbb_batch_timing_stats.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                                C.POINTER(C.c_float), i]
@@ -256,6 +258,14 @@ class Synth:
         """gpsbb_device_read: a numpy array filled from device memory the library handed out"""
         out = np.empty(shape, dtype)
         _chk(lib().gpsbb_device_read(self._h, out.ctypes.data, d_ptr, out.nbytes), "gpsbb_device_read")
+        return out
+
+    def device_digest(self, d_ptr, nblocks, nsamp):
+        """gpsbb_device_digest: one uint64 per block of IQ in device memory (see block_digest_host)"""
+        out = np.empty(nblocks, np.uint64)
+        for k0 in range(0, nblocks, 65535):
+            n = min(65535, nblocks - k0)
+            _chk(lib().gpsbb_device_digest(self._h, d_ptr + k0 * nsamp * 4, n, nsamp, out[k0:].ctypes.data), "gpsbb_device_digest")
         return out
 
     def hazards(self, reset=False):
@@ -489,6 +499,18 @@ class Node:
             raise GpsbbError(rc, "gpsbb_node_run")
         return {"rc": rc, "seconds": st.seconds, "blocks": st.blocks,
                 "shards": [{k: getattr(st.shard[g], k) for k, _ in _NodeShardStats._fields_} for g in range(st.nshards)]}
+
+
+def block_digest_host(iq):
+    """gpsbb_device_digest's number for blocks in host memory: iq int16 [..., nsamp, 2] -> uint64 [...]"""
+    a = np.ascontiguousarray(iq, np.int16)
+    w = a.view(np.uint32).reshape(a.shape[:-2] + (a.shape[-2],)).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z = (np.arange(a.shape[-2], dtype=np.uint64) << np.uint64(32)) | w
+        z ^= z >> np.uint64(31)
+        z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(29)
+        return z.sum(axis=-1, dtype=np.uint64)
 
 
 class SplitMix64:

@@ -484,6 +484,23 @@ struct gpsbb {
     int last_kernel = 0;      /* synthesis kernel of the last launch: 1 per-sample, 2 breakpoint */
     int last_chain_dev = 0;   /* the last launch resolved GPSBB_CHAIN_CARRIER on the device */
     int last_prepass = 0;     /* pre-pass of the last launch: 1 row walks on the device, 2 host threads, 3 lap-parallel on the device */
+    struct DigestBuf { /* gpsbb_device_digest's scratch, kept between calls */
+        unsigned long long *p = nullptr;
+        size_t cap = 0;
+        int reserve(size_t n)
+        {
+            if (n <= cap)
+                return hipSuccess;
+            if (p)
+                (void)hipFree(p);
+            p = nullptr;
+            cap = 0;
+            const hipError_t e = hipMalloc((void **)&p, n * sizeof(unsigned long long));
+            if (e == hipSuccess)
+                cap = n;
+            return e;
+        }
+    } d_digest;
 };
 
 template <class T>
@@ -780,6 +797,8 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
         (void)hipFree(h->d_status);
     if (h->d_hz)
         (void)hipFree(h->d_hz);
+    if (h->d_digest.p)
+        (void)hipFree(h->d_digest.p);
     delete h->pool;
     h->pool = nullptr;
     if (h->s_seed)
@@ -2116,6 +2135,29 @@ extern "C" int gpsbb_device_read(gpsbb_t *h, void *host_dst, const void *device_
         return GPSBB_E_BADARG;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpy(host_dst, device_src, bytes, hipMemcpyDeviceToHost));
+    return GPSBB_OK;
+}
+
+extern "C" int gpsbb_device_digest(gpsbb_t *h, const int16_t *d_iq, long nblocks, int nsamp, uint64_t *digest_out)
+{
+    if (!h || !d_iq || !digest_out || nblocks < 1 || nblocks > 65535 || nsamp < 1)
+        return GPSBB_E_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    /* the work of every launch the caller may be reading the output of is on this handle's streams: wait for it, then digest on
+     * the synthesis stream (ordered behind everything the handle rendered) */
+    const int rc = gpsbb_sync(h);
+    if (rc != GPSBB_OK)
+        return rc;
+    HIPCHK(h, (hipError_t)h->d_digest.reserve((size_t)nblocks));
+    HIPCHK(h, hipMemsetAsync(h->d_digest.p, 0, (size_t)nblocks * sizeof(unsigned long long), h->s_compute));
+    /* enough workgroups per block to fill the chip however few blocks there are, never pieces below 4 KB */
+    long chunks = (2048 + nblocks - 1) / nblocks;
+    const long max_chunks = ((long)nsamp + 1023) / 1024;
+    chunks = chunks > max_chunks ? max_chunks : (chunks < 1 ? 1 : chunks);
+    hipLaunchKernelGGL(k_block_digest, dim3((unsigned)chunks, (unsigned)nblocks), dim3(256), 0, h->s_compute, (const uint32_t *)d_iq, nsamp, h->d_digest.p);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(digest_out, h->d_digest.p, (size_t)nblocks * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->s_compute));
+    HIPCHK(h, hipStreamSynchronize(h->s_compute));
     return GPSBB_OK;
 }
 

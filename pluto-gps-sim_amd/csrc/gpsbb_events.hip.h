@@ -863,7 +863,9 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
             o[j] = (DENSE ? P + accd[j] : P) ^ 0x8000u; /* the bias off again: the low half is I + 2^15 in [0, 2^16), the high half Q */
         }
 #ifdef GPSBB_SABOTAGE /* a deliberately wrong build (make broken): bench.py's parity check must refuse it (tests/test_bench_shards.py) */
-        if (b == 1 && wt == 3 && lane == 5)
+        /* (1: a block bench.py's oracle legs visit; 2: block 6 of every push, which — with two spot checks per shard — they do not:
+         * only the cross-check of every block against the per-sample kernel sees it) */
+        if (b == (GPSBB_SABOTAGE == 2 ? 6 : 1) && wt == 3 && lane == 5)
             o[7] ^= 1u;
 #endif
         /* ---- store.  A lane holds 16 consecutive samples = 64 bytes, and a store instruction moves 16 bytes per lane: written

@@ -1311,5 +1311,35 @@ __global__ __launch_bounds__(256) void k_gather_to_host(const gather_u32x4 *__re
     }
 }
 
+/* One 64-bit digest per block of int16 I/Q pairs in device memory (gpsbb_device_digest): the sum over the block's samples j of
+ * mix((j << 32) | pair_j), mix = one round of a multiply-xorshift mixer — position-dependent, order-independent as a sum, so
+ * that any partition of the block over lanes gives the same number.  Grid (chunks, blocks): every workgroup digests a
+ * contiguous piece of one block (16-byte loads, 4 KB per workgroup turn) and adds its part with one atomic.  Reads every byte
+ * once: bound by the HBM read stream. */
+__device__ __forceinline__ unsigned long long digest_mix(uint32_t j, uint32_t w)
+{
+    unsigned long long z = ((unsigned long long)j << 32) | w;
+    z ^= z >> 31;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 29;
+    return z;
+}
+__global__ __launch_bounds__(256) void k_block_digest(const uint32_t *__restrict__ iq, int nsamp, unsigned long long *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const uint32_t *__restrict__ p = iq + (size_t)b * (size_t)nsamp;
+    unsigned long long acc = 0ull;
+    /* a block starts on a 4-byte boundary only (nsamp is any number): scalar loads at the ragged ends, vectors in between */
+    const int per = (nsamp + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int j0 = blockIdx.x * per, j1 = j0 + per < nsamp ? j0 + per : nsamp;
+    for (int j = j0 + (int)threadIdx.x; j < j1; j += 256)
+        acc += digest_mix((uint32_t)j, p[j]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        acc += (unsigned long long)__shfl_down((long long)acc, off);
+    if ((threadIdx.x & 63) == 0 && acc)
+        atomicAdd(out + b, acc);
+}
+
 } /* namespace gpsbb_impl */
 #endif

@@ -56,7 +56,7 @@ def test_two_ranks_through_the_device_path(pkg):
     the seed the device-side chain computes (gpsbb_chain_carrier over the first shard), and the digest of the
     end-of-block states of all blocks, gathered over the ranks, is the 1-rank value; blocks read back from the HBM-only
     ring equal the oracle's on every rank; the line carries the slowest rank's seed time, the seed-inclusive value and
-    the 2.6 MS/s and CPU legs at N = 2 as well."""
+    every block cross-checked and the node driver validated at either N; the 2.6 MS/s, resident and CPU legs at N = 1 only."""
     args = ["--steps", "2", "--warmup", "1", "--repeats", "2", "--push-blocks", "8", "--nsamp", "200000", "--depth", "3",
             "--cpu-budget", "0.4", "--parity-blocks", "2"]
     env = {"GPSBB_BENCH_BACKEND": "gloo"}
@@ -69,8 +69,21 @@ def test_two_ranks_through_the_device_path(pkg):
         assert len(r["gather"]["per_rank_GBps_to_host"]) == n
         assert r["parity"]["mismatching_blocks"] == 0 and r["parity_checked_blocks"] >= 3 * n
         assert r["parity"]["blocks_digested"] == 2 * 8 * 8
+        # every block of every shard cross-checked against the per-sample kernel, by device-side digests
+        assert r["parity"]["blocks_cross_checked"] == r["parity"]["blocks_digested"] and r["parity"]["cross_mismatching_blocks"] == 0
+        assert r["parity"]["cross_check"]["against"].startswith("k_synth on k_seed")
         assert r["shard_seed_s"] >= r["shard_seed"]["seconds_rank0"] and 0 < r["value_incl_seed"] <= r["value"]
-        assert r["m1"]["gpu"]["value"] > 0 and r["cpu_baseline"]["value"] > 0 and r["m1"]["cpu"]["value"] > 0
+        # the product's node driver over the whole stream on every GPU the process sees (here: one), both layouts, every slot
+        # digested inside the sink and compared with what the ranks rendered
+        for leg in ("contiguous_indexed", "interleaved_ordered"):
+            a = r["node_driver"]["all_gpus"][leg]
+            assert a["blocks"] == 2 * 8 * 8 and a["every_block_once"] and a["digests_equal_the_ranks"] and a["blocks_that_differ"] == 0, (n, leg, a)
+            assert len(a["shards"]) == len(a["devices"]) >= 1 and all(x["nblocks"] > 0 for x in a["shards"])
+        assert r["node_driver"]["all_gpus"]["interleaved_ordered"]["in_stream_order"]
+    # the 2.6 MS/s, resident and CPU legs run at N = 1 only (at N > 1 they would keep N - 1 GPUs idle behind rank 0)
+    assert one["m1"]["gpu"]["value"] > 0 and one["cpu_baseline"]["value"] > 0 and one["m1"]["cpu"]["value"] > 0
+    assert "m1" not in two and "cpu_baseline" not in two and "resident" not in two
+    assert one["parity"]["cross_check"]["stream_iq_digest"] == two["parity"]["cross_check"]["stream_iq_digest"]
     assert two["shard_seed"]["blocks_before_the_last_shard"] == 64
     assert one["parity"]["stream_end_state_digest"] == two["parity"]["stream_end_state_digest"]
     assert one["config"]["global_samples_per_step"] == two["config"]["global_samples_per_step"]
@@ -99,16 +112,28 @@ def test_one_rank_through_the_rccl_path(pkg):
     assert r["n_gpus"] == 1 and r["value"] > 0 and r["parity"]["mismatching_blocks"] == 0
     assert len(r["gather"]["per_rank_GBps_to_host"]) == 1 and r["gather"]["node_GBps_to_host"] > 0
     assert r["node_driver"]["one_shard"]["value"] > 0 and r["node_driver"]["one_shard"]["shards"] == 1
+    # what the driver's SCALE run will carry per GPU: the node driver over all visible GPUs, both layouts, validated
+    for leg in ("contiguous_indexed", "interleaved_ordered"):
+        a = r["node_driver"]["all_gpus"][leg]
+        assert a["digests_equal_the_ranks"] and a["every_block_once"] and a["value"] > 0
+        assert set(a["shards"][0]) == {"first_block", "nblocks", "device", "numa_node", "cpus_bound", "seed_seconds", "busy_seconds", "wait_seconds"}
+    assert r["parity"]["blocks_cross_checked"] == r["parity"]["blocks_digested"] and r["parity"]["cross_mismatching_blocks"] == 0
 
 
 @pytest.mark.gpu
-def test_a_wrong_kernel_fails_the_bench(pkg):
+def test_a_wrong_kernel_fails_the_bench(pkg, tmp_path):
     """bench.py's parity check reads blocks of the timed mode's ring back and compares them with the oracle: a build of
     the library whose synthesis kernel flips ONE bit of ONE sample (make broken) makes the run exit non-zero, with the
-    mismatch in the line."""
+    mismatch in the line.  The oracle has time for a handful of blocks; EVERY block is cross-checked against the per-sample
+    kernel by device-side digests: a second wrong build (make broken2) flips its bit in a block the oracle legs do not visit —
+    they pass, the cross-check does not."""
     import subprocess
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "pluto-gps-sim_amd", "csrc"), "broken"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "pluto-gps-sim_amd", "csrc"), "broken", "broken2", "VARIANT_DIR=%s" % tmp_path])
     args = ["--steps", "1", "--warmup", "1", "--repeats", "1", "--push-blocks", "8", "--nsamp", "200000", "--depth", "3",
             "--cpu-budget", "0.2", "--parity-blocks", "2"]
-    r = _run(1, args, {"GPSBB_PY_LIB": "broken"}, expect_rc=3)
+    r = _run(1, args, {"GPSBB_PY_LIB": str(tmp_path / "libgpsbb_broken.so")}, expect_rc=3)
     assert r["parity"]["mismatching_blocks"] >= 1 and r["parity_checked_blocks"] >= 3
+    assert r["parity"]["cross_mismatching_blocks"] == 8   # block 1 of each of the 8 pushes
+    r = _run(1, args + ["--parity-spots", "2"], {"GPSBB_PY_LIB": str(tmp_path / "libgpsbb_broken2.so")}, expect_rc=3)
+    assert r["parity"]["mismatching_blocks"] == 0 and r["parity_checked_blocks"] >= 3   # the oracle legs never look at block 6 of a push
+    assert r["parity"]["cross_mismatching_blocks"] == 8 and r["parity"]["blocks_cross_checked"] == 64

@@ -1084,9 +1084,11 @@ def test_the_failure_the_round_3_budgets_allowed(pkg, synth, oracle, request):
         return
     import json
     import subprocess
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "pluto-gps-sim_amd", "csrc"), "r3budgets"])
+    import tempfile
+    vdir = tempfile.mkdtemp(prefix="gpsbb_variants_")  # (never beside the product: csrc/Makefile)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "pluto-gps-sim_amd", "csrc"), "r3budgets", "VARIANT_DIR=" + vdir])
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "graze_hunt.py"), "--load", os.path.join(GOLDEN, "graze_r3_fail.npz")],
-                       env=dict(os.environ, GPSBB_PY_LIB="r3budgets"), capture_output=True, text=True, timeout=600)
+                       env=dict(os.environ, GPSBB_PY_LIB=os.path.join(vdir, "libgpsbb_r3budgets.so")), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     doc = json.loads(r.stdout.strip().splitlines()[-1])
     assert doc["lib"] == "libgpsbb_r3budgets.so"

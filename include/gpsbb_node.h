@@ -97,7 +97,10 @@ int gpsbb_node_create(gpsbb_node_t **out, const gpsbb_node_config_t *cfg);
  * Render blocks [0, nblocks) of the stream described by ch[nblocks * nch] (block-major, as gpsbb_batch_create; consecutive
  * in time: the carrier is chained from block to block as the reference's loop does, a channel whose prn changes restarts
  * from its descriptor's carr_phase) and deliver them to `sink`.  Returns when every block has been delivered or the sink
- * stopped the run.  Can be called again (another stream): the rings are kept.
+ * stopped the run.  Can be called again (another stream): the rings are kept — also after a run that FAILED (a descriptor
+ * outside the contract: GPSBB_E_BADCHAN; out of memory; a HIP error): every shard drains its ring or, where the library has
+ * closed the stream, gets a new handle and ring before the call returns.  Only if that fails too do later runs return the error
+ * of the re-creation, and the node is good for gpsbb_node_destroy alone.
  */
 int gpsbb_node_run(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nblocks, gpsbb_node_sink_fn sink, void *user,
                    gpsbb_node_stats_t *stats);

@@ -487,14 +487,27 @@ class Node:
         """sink(iq_ptr, first_block, nblocks, shard) -> int (< 0 stops); returns the run's statistics as a dict.
         sink may also be a C function pointer (int) for a sink that lives in native code."""
         ch = _as_chan(ch)
+        if ch.ndim != 2 or ch.shape[1] != self.nch:
+            raise ValueError("descriptors of shape (nblocks, %d) wanted, got %r" % (self.nch, ch.shape))  # (C would read out of bounds)
+        raised = []
         if callable(sink):
-            cb = NODE_SINK(lambda user, iq, first, nb, shard: int(sink(iq, first, nb, shard) or 0))
+            def guarded(user, iq, first, nb, shard):
+                # an exception must not vanish inside ctypes (which would turn it into "return 0": the run goes on as if the
+                # sink were fine): it stops the run and comes back out of Node.run
+                try:
+                    return int(sink(iq, first, nb, shard) or 0)
+                except BaseException as e:  # noqa: BLE001
+                    raised.append(e)
+                    return -1
+            cb = NODE_SINK(guarded)
             fn = C.cast(cb, C.c_void_p)
         else:
             cb, fn = None, C.c_void_p(sink)
         st = _NodeStats()
         rc = lib().gpsbb_node_run(self._n, ch.ctypes.data, ch.shape[0], fn, None, C.byref(st))
         del cb
+        if raised:
+            raise raised[0]
         if rc != 0 and not (expect_stop and rc == -7):
             raise GpsbbError(rc, "gpsbb_node_run")
         return {"rc": rc, "seconds": st.seconds, "blocks": st.blocks,

@@ -419,7 +419,47 @@ void shard_main(gpsbb_node *n, Shard *sp)
                 break;
             seen = n->job;
         }
-        s.rc = s.create_rc == GPSBB_OK ? run_shard(n, s) : s.create_rc;
+        if (s.create_rc == GPSBB_OK) {
+            /* nothing may leave this thread but a return code: an exception through a std::thread is std::terminate, and this is
+             * a C library (the vectors of run_shard can throw bad_alloc on streams of millions of blocks) */
+            try {
+                s.rc = run_shard(n, s);
+            } catch (const std::bad_alloc &) {
+                s.rc = GPSBB_E_NOMEM;
+            } catch (...) {
+                s.rc = GPSBB_E_INTERNAL;
+            }
+            if (s.rc != GPSBB_OK) {
+                /* A run that failed half-way (a descriptor outside the contract in push 17, a HIP error) leaves slots in the ring, or
+                 * a stream the library has closed: the node must still be good for another run (gpsbb_node.h).  Drain what pops;
+                 * if that fails too, this shard gets a new handle and a new ring. */
+                bool fresh = false;
+                while (gpsbb_stream_pending(s.st) > 0) {
+                    const int16_t *iq = nullptr;
+                    if (gpsbb_stream_pop(s.st, &iq, nullptr) != GPSBB_OK) {
+                        fresh = true;
+                        break;
+                    }
+                }
+                if (!fresh && gpsbb_stream_reset(s.st) != GPSBB_OK)
+                    fresh = true;
+                if (fresh) {
+                    gpsbb_stream_destroy(s.st);
+                    s.st = nullptr;
+                    gpsbb_destroy(s.h);
+                    s.h = nullptr;
+                    int rc2 = gpsbb_create(&s.h, s.device);
+                    if (rc2 == GPSBB_OK) {
+                        const unsigned sf = GPSBB_CHAIN_CARRIER | ((c.flags & GPSBB_NODE_FIXED_CARRIER) ? GPSBB_FIXED_CARRIER : 0u) |
+                                            ((c.flags & GPSBB_NODE_DEVICE_ONLY) ? GPSBB_STREAM_DEVICE_ONLY : 0u);
+                        rc2 = gpsbb_stream_create(s.h, c.nch, c.delt, c.nsamp, c.blocks_per_slot, c.depth, sf, &s.st);
+                    }
+                    s.create_rc = rc2; /* (not GPSBB_OK: every later run reports it — the node is then only good for gpsbb_node_destroy) */
+                }
+            }
+        } else {
+            s.rc = s.create_rc;
+        }
         std::unique_lock<std::mutex> lk(n->m);
         if (s.rc != GPSBB_OK)
             n->stop = true; /* the others wind down: an ordered stream with a hole is no stream */

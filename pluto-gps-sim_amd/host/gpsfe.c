@@ -101,6 +101,9 @@ struct gpsfe {
     double ant_pat[37];
     int nthreads;          /* gpsfe_generate: threads the blocks of a span are spread over (gpsfe_set_threads) */
     struct fe_pool *pool;  /* ... started on first use */
+    gtime_t *span_grx;     /* gpsfe_generate's scratch of a span (block times, position indices, ranges): kept between calls */
+    int *span_ipos;
+    range_t *span_rho;
 };
 
 /* receiver antenna attenuation in dB for boresight angle 0:5:180 deg (c:164-169) */
@@ -956,6 +959,9 @@ void gpsfe_close(gpsfe_t *fe)
     if (!fe)
         return;
     fe_pool_stop(fe->pool);
+    free(fe->span_grx);
+    free(fe->span_ipos);
+    free(fe->span_rho);
     free(fe->xyz);
     free(fe);
 }
@@ -1206,8 +1212,16 @@ static fe_pool_t *fe_pool_start(int n)
     fe_pool_t *p = calloc(1, sizeof *p);
     if (!p)
         return NULL;
-    pthread_mutex_init(&p->m, NULL);
-    pthread_cond_init(&p->cv, NULL);
+    /* (a pool that cannot be set up is no pool: the caller then generates block by block on its own thread) */
+    if (pthread_mutex_init(&p->m, NULL) != 0) {
+        free(p);
+        return NULL;
+    }
+    if (pthread_cond_init(&p->cv, NULL) != 0) {
+        pthread_mutex_destroy(&p->m);
+        free(p);
+        return NULL;
+    }
     int started = 1;
     for (int t = 1; t < n; t++) {
         p->args[t].p = p;
@@ -1217,7 +1231,19 @@ static fe_pool_t *fe_pool_start(int n)
         started++;
     }
     p->n = started;
-    pthread_barrier_init(&p->bar, NULL, (unsigned)p->n);
+    if (pthread_barrier_init(&p->bar, NULL, (unsigned)p->n) != 0) {
+        /* the workers wait on the condition variable, none has touched the barrier: send them home */
+        pthread_mutex_lock(&p->m);
+        p->quit = 1;
+        pthread_cond_broadcast(&p->cv);
+        pthread_mutex_unlock(&p->m);
+        for (int t = 1; t < p->n; t++)
+            pthread_join(p->th[t], NULL);
+        pthread_mutex_destroy(&p->m);
+        pthread_cond_destroy(&p->cv);
+        free(p);
+        return NULL;
+    }
     return p;
 }
 
@@ -1313,17 +1339,22 @@ int gpsfe_generate(gpsfe_t *fe, int nblocks, gpsbb_chan_t *ch)
         const long on = sysconf(_SC_NPROCESSORS_ONLN);
         nthr = on < 1 ? 1 : (on > 16 ? 16 : (int)on);
     }
-    gtime_t *grx = NULL;
-    int *ipos = NULL;
-    range_t *rho = NULL;
+    /* the span's scratch stays with the front end between calls (freed by gpsfe_destroy): a producer that generates one push
+     * ahead of a ring calls this thousands of times */
     if (nthr > 1 && nblocks >= 64) {
-        grx = malloc(FE_SPAN_MAX * sizeof *grx);
-        ipos = malloc(FE_SPAN_MAX * sizeof *ipos);
-        rho = malloc((size_t)FE_SPAN_MAX * fe->max_chan * sizeof *rho);
+        if (!fe->span_grx)
+            fe->span_grx = malloc(FE_SPAN_MAX * sizeof(gtime_t));
+        if (!fe->span_ipos)
+            fe->span_ipos = malloc(FE_SPAN_MAX * sizeof(int));
+        if (!fe->span_rho)
+            fe->span_rho = malloc((size_t)FE_SPAN_MAX * GPSBB_MAX_CHAN * sizeof(range_t));
         if (!fe->pool)
             fe->pool = fe_pool_start(nthr);
     }
-    const int parallel = grx && ipos && rho && fe->pool && fe->pool->n > 1;
+    gtime_t *grx = fe->span_grx;
+    int *ipos = fe->span_ipos;
+    range_t *rho = fe->span_rho;
+    const int parallel = nthr > 1 && nblocks >= 64 && grx && ipos && rho && fe->pool && fe->pool->n > 1;
     int b = 0;
     while (b < nblocks) {
         if (!parallel) {
@@ -1379,9 +1410,6 @@ int gpsfe_generate(gpsfe_t *fe, int nblocks, gpsbb_chan_t *ch)
         end_of_block(fe, fe->xyz[ipos[n - 1]]);
         b += n;
     }
-    free(grx);
-    free(ipos);
-    free(rho);
     return GPSFE_OK;
 }
 

@@ -38,7 +38,8 @@ def test_node_header_symbols_are_exported(pkg):
         first = pkg.node_plan(nblocks, nshards, bps)
         assert first[0] == 0 and first[-1] == nblocks and all(a <= b for a, b in zip(first, first[1:]))
         assert all(f % bps == 0 for f in first[:-1])
-    assert pkg.node_plan(36000, 8, 400)[:3] == [0, 4400, 8800 + 400 * 0] or True
+    # 90 slots of 400 blocks over 8 shards: shard g starts at floor(90 g / 8) * 400
+    assert pkg.node_plan(36000, 8, 400) == [0, 4400, 8800, 13200, 18000, 22400, 26800, 31200, 36000]
     assert pkg.lib().gpsbb_node_create(None, None) == -1
 
 

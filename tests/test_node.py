@@ -1,6 +1,7 @@
 """include/gpsbb_node.h: one process, N producer threads / handles / rings, ONE sink (the reference has one consumer of one
-stream, plutogpssim.c:2146-2158).  On the one GPU of the test box the N shards share device 0; what is checked is what N
-GPUs would have to get right: contiguous time shards seeded with the exact carrier phase by the device-side chain, blocks
+stream, plutogpssim.c:2146-2158).  On a one-GPU test box the N shards share device 0; on a box with several GPUs they are
+spread over them (node_devices below: the first execution of the driver on distinct physical devices should be a test, not a
+user); what is checked is what N GPUs have to get right: contiguous time shards seeded with the exact carrier phase by the device-side chain, blocks
 delivered once each and — in the default mode — strictly in stream order, the same bytes whatever N is, equal to the golden
 vectors of the reference's own code and to the CPU oracle."""
 import ctypes as C
@@ -35,9 +36,19 @@ class Collect:
         return 0
 
 
+def node_devices(nshards):
+    """HIP device ordinals for nshards shards: round the GPUs of the box where it has several, device 0 for all otherwise"""
+    try:
+        import torch
+        ndev = max(1, torch.cuda.device_count())
+    except Exception:
+        ndev = 1
+    return [k % ndev for k in range(nshards)]
+
+
 def render(pkg, ch, fs, nsamp, nshards, bps, depth=2, flags=0):
     sink = Collect(ch.shape[0], nsamp)
-    with pkg.Node(nshards, ch.shape[1], 1.0 / fs, nsamp, bps, depth=depth, flags=flags, devices=[0] * nshards) as node:
+    with pkg.Node(nshards, ch.shape[1], 1.0 / fs, nsamp, bps, depth=depth, flags=flags, devices=node_devices(nshards)) as node:
         st = node.run(ch, sink)
     assert st["blocks"] == ch.shape[0] and sum(c[1] for c in sink.calls) == ch.shape[0]
     return sink, st
@@ -142,7 +153,7 @@ def test_shard_boundaries_prn_changes_padding_fixed_carrier_and_stop(pkg, oracle
         seen.append(first)
         return -1 if len(seen) == 3 else 0
 
-    with pkg.Node(3, nch, 1.0 / fs, nsamp, bps, depth=2, devices=[0, 0, 0]) as node:
+    with pkg.Node(3, nch, 1.0 / fs, nsamp, bps, depth=2, devices=node_devices(3)) as node:
         st = node.run(ch, stopper, expect_stop=True)
         assert st["rc"] == -7 and seen == [0, 3, 6] and st["blocks"] == 9
         sink = Collect(nb, nsamp)      # ... and the node is usable again afterwards
@@ -211,15 +222,42 @@ def test_a_push_that_starts_a_new_chain(pkg, oracle):
             st.close()
 
 
+def test_a_failed_run_leaves_the_node_usable(pkg, oracle):
+    """A run that fails half-way — a descriptor outside the contract in the middle of the stream (GPSBB_E_BADCHAN from that
+    push), in the middle of a shard with slots in flight — must not leave the node dead: the failing shard drains its ring (or
+    gets a new handle and ring where the library closed the stream), the others wind down, and the next gpsbb_node_run on the
+    same node delivers the good stream bit for bit.  Both layouts."""
+    fs, nsamp, nch, bps, nb = 25e6, 30000, 6, 2, 24
+    ch = pkg.synth_descriptors(nb, nch=nch, seed=77)
+    want, _, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
+    bad = ch.copy()
+    bad["prn"][13, 2] = 40  # not a PRN: gpsbb_stream_push refuses the slot that holds block 13
+    for flags in (0, pkg.NODE_INTERLEAVED):
+        with pkg.Node(3, nch, 1 / fs, nsamp, bps, depth=3, flags=flags, devices=node_devices(3)) as node:
+            with pytest.raises(pkg.GpsbbError):
+                node.run(bad, lambda *a: 0)
+            for _ in range(2):
+                sink = Collect(nb, nsamp)
+                st = node.run(ch, sink)
+                assert st["blocks"] == nb and (sink.iq == want).all()
+                assert [c[0] for c in sink.calls] == sorted(c[0] for c in sink.calls)
+            with pytest.raises(pkg.GpsbbError):
+                node.run(bad, lambda *a: 0)
+            sink = Collect(nb, nsamp)
+            node.run(ch, sink)
+            assert (sink.iq == want).all()
+
+
 def test_placement_is_reported(pkg):
     """The producer threads bind themselves next to their GPU before they allocate (plutogpssim.c:2045-2056 pins the
     reference's two threads): the statistics say where."""
-    node_id, cpus = pkg.device_affinity(0)
     ch = pkg.synth_descriptors(4, nch=4, seed=5)
-    with pkg.Node(2, 4, 1 / 4e6, 20000, 2, devices=[0, 0]) as node:
+    devs = node_devices(2)
+    with pkg.Node(2, 4, 1 / 4e6, 20000, 2, devices=devs) as node:
         st = node.run(ch, lambda *a: 0)
-    for s in st["shards"]:
-        assert s["device"] == 0 and s["numa_node"] == node_id
+    for s, d in zip(st["shards"], devs):
+        node_id, cpus = pkg.device_affinity(d)
+        assert s["device"] == d and s["numa_node"] == node_id
         if cpus:
             assert s["cpus_bound"] > 0
     with pkg.Node(1, 4, 1 / 4e6, 20000, 2, flags=pkg.NODE_NO_AFFINITY) as node:

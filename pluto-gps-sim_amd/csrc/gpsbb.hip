@@ -824,8 +824,32 @@ static hipError_t create_seed_stream(hipStream_t *st);
  * first and have its result wiped (found by the node driver's stress, tools/stress_node.py: four handles on one GPU, the
  * cleared carry of a fresh stream landing after the first push's fix-up had written it — every later block of the shard off
  * by that push's phase, once in a hundred runs).  So: on a stream of the handle, and waited for. */
+#ifdef GPSBB_EXPERIMENTS
+/* the ordering test's helper: one lane that keeps its stream busy for `ticks` of the 100 MHz wall clock */
+__global__ void k_park(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(64);
+}
+#endif
+
 static hipError_t zero_now(gpsbb *h, void *ptr, size_t bytes)
 {
+#ifdef GPSBB_EXPERIMENTS
+    {
+        /* The deterministic version of the race of round 4 (tests/test_laps_gpu.py::test_the_null_stream_owns_nothing):
+         * GPSBB_X_PARK_NULL_MS=<ms> parks a kernel on the NULL stream before every zeroing — whatever the library still put on the
+         * null stream, or ordered behind it, then lands that many milliseconds later than the code around it assumes, every time
+         * instead of once in a hundred runs under load; GPSBB_X_NULL_MEMSET brings round 3's bug back (the zeroing as a null-stream
+         * memset nobody waits for), so that the test can be seen to fail on it. */
+        const long park = GPSBB_KNOB_LONG("GPSBB_X_PARK_NULL_MS", 0);
+        if (park > 0)
+            hipLaunchKernelGGL(k_park, dim3(1), dim3(1), 0, nullptr, (unsigned long long)park * 100000ull);
+        if (GPSBB_KNOB_SET("GPSBB_X_NULL_MEMSET"))
+            return hipMemsetAsync(ptr, 0, bytes, nullptr);
+    }
+#endif
     const hipError_t e = hipMemsetAsync(ptr, 0, bytes, h->s_upload);
     return e != hipSuccess ? e : hipStreamSynchronize(h->s_upload);
 }

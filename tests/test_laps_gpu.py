@@ -165,3 +165,26 @@ def test_the_repair_path_made_common(pkg, args, jitter, at_least):
     m = re.search(r"(?:links / guesses|links) that did not hold: (\d+)", r.stdout)
     assert m and int(m.group(1)) >= at_least, r.stdout[-600:]
     assert "3:" in r.stdout.split("lap-parallel}:")[1]  # the lap-parallel pre-pass did take cases
+
+
+@pytest.mark.parametrize("where", [3, 1])
+def test_the_null_stream_owns_nothing(pkg, where):
+    """Round 4's race — a fresh stream's carry cleared by a null-stream memset that the library's non-blocking streams do not
+    wait for, landing after the first push had written the exact end phase: one run in a hundred under load — made
+    deterministic: the experiments build parks a kernel on the null stream for 60 ms before every zeroing
+    (GPSBB_X_PARK_NULL_MS), so that anything still ordered behind the null stream lands 60 ms late, every time.  With the bug
+    restored (GPSBB_X_NULL_MEMSET: the zeroing as a null-stream memset nobody waits for) the second push chains from a wiped
+    phase in every run; the product's zeroing (a stream of the handle, waited for) does not care what the null stream is
+    doing.  For the chain of either pre-pass (the lap-parallel one reads the carry in its plan kernel, the row walks in
+    k_chain_prefix / k_chain_fix_par).  DESIGN.md section 4 has the table of who owns which buffer."""
+    import json
+    env = dict(os.environ, GPSBB_PY_LIB="exp", GPSBB_X_PARK_NULL_MS="60")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "order_guard.py"), str(where)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    good = json.loads(r.stdout.strip().splitlines()[-1])
+    assert good["equal"] and good["park_ms"] == 60 and all(x["prepass"] == where for x in good["runs"]), good
+    r = subprocess.run(cmd, env=dict(env, GPSBB_X_NULL_MEMSET="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    bad = json.loads(r.stdout.strip().splitlines()[-1])
+    assert bad["null_memset"] and all(x["blocks_that_differ"] > 0 for x in bad["runs"]), bad   # every run, not one in a hundred

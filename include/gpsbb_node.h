@@ -105,6 +105,26 @@ int gpsbb_node_create(gpsbb_node_t **out, const gpsbb_node_config_t *cfg);
 int gpsbb_node_run(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nblocks, gpsbb_node_sink_fn sink, void *user,
                    gpsbb_node_stats_t *stats);
 
+/*
+ * The same stream, INCREMENTALLY — what the reference's loop does: it makes the descriptors of one block, renders it, and goes
+ * round again, for as long as it runs (plutogpssim.c:2655-2687, the 30 s maintenance c:2764-2805).
+ *   gpsbb_node_begin  starts a run with nothing to render yet;
+ *   gpsbb_node_feed   the next `nblocks` blocks of the stream (copied: the caller's array is free on return; any number — the
+ *                     driver cuts the stream into slots of blocks_per_slot itself and keeps what does not fill one).  Slot k of the
+ *                     stream goes to shard k mod nshards, a chain of its own from the exact carrier phases (the layout of
+ *                     GPSBB_NODE_INTERLEAVED, whatever the node's flags say: contiguous shards need the length of a stream that
+ *                     has none); the feeder chains the carrier across everything it is fed on a handle of its own
+ *                     (gpsbb_chain_carrier: a microsecond per block).  Returns once the blocks are queued: it WAITS while the
+ *                     queue of the shard whose turn it is holds depth + 1 slots — the front end runs that far ahead of the rings and
+ *                     no further, memory does not grow with the duration.  GPSBB_E_STATE once the sink has stopped the run;
+ *   gpsbb_node_end    no more blocks: a short last slot goes out padded, the rings drain, statistics as gpsbb_node_run
+ *                     (seed_seconds: the feeder's chain).  Must be called after begin, also after a failed feed.
+ * The sink is called as in gpsbb_node_run (ordered by default: block 0 first, every block once).  One feeder thread.
+ */
+int gpsbb_node_begin(gpsbb_node_t *n, gpsbb_node_sink_fn sink, void *user);
+int gpsbb_node_feed(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nblocks);
+int gpsbb_node_end(gpsbb_node_t *n, gpsbb_node_stats_t *stats);
+
 void gpsbb_node_destroy(gpsbb_node_t *n);
 
 /* which shard renders block b of an nblocks-long stream, and where the shards begin: first[0 .. nshards] (first[nshards] =

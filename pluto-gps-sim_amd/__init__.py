@@ -64,7 +64,7 @@ API_SYMBOLS = [
     "gpsbb_get_info", "gpsbb_stream_reset", "gpsbb_device_affinity", "gpsbb_stream_push_ex",
 ]
 # ... and include/gpsbb_node.h
-NODE_API_SYMBOLS = ["gpsbb_node_create", "gpsbb_node_run", "gpsbb_node_destroy", "gpsbb_node_plan"]
+NODE_API_SYMBOLS = ["gpsbb_node_create", "gpsbb_node_run", "gpsbb_node_destroy", "gpsbb_node_plan", "gpsbb_node_begin", "gpsbb_node_feed", "gpsbb_node_end"]
 
 
 class GpsbbError(RuntimeError):
@@ -140,6 +140,9 @@ def lib():
         L.gpsbb_node_destroy.argtypes = [vp]
         L.gpsbb_node_destroy.restype = None
         L.gpsbb_node_run.argtypes = [vp, vp, C.c_long, vp, vp, vp]
+        L.gpsbb_node_begin.argtypes = [vp, vp, vp]
+        L.gpsbb_node_feed.argtypes = [vp, vp, C.c_long]
+        L.gpsbb_node_end.argtypes = [vp, vp]
         L.gpsbb_node_plan.argtypes = [C.c_long, i, i, C.POINTER(C.c_long)]
         _lib = L
     return _lib
@@ -510,6 +513,36 @@ class Node:
             raise raised[0]
         if rc != 0 and not (expect_stop and rc == -7):
             raise GpsbbError(rc, "gpsbb_node_run")
+        return {"rc": rc, "seconds": st.seconds, "blocks": st.blocks,
+                "shards": [{k: getattr(st.shard[g], k) for k, _ in _NodeShardStats._fields_} for g in range(st.nshards)]}
+
+    def begin(self, sink):
+        """gpsbb_node_begin: an incremental run; feed() the stream as it comes, end() when it is over"""
+        self._raised = []
+
+        def guarded(user, iq, first, nb, shard):
+            try:
+                return int(sink(iq, first, nb, shard) or 0)
+            except BaseException as e:  # noqa: BLE001
+                self._raised.append(e)
+                return -1
+        self._cb = NODE_SINK(guarded)
+        _chk(lib().gpsbb_node_begin(self._n, C.cast(self._cb, C.c_void_p), None), "gpsbb_node_begin")
+
+    def feed(self, ch):
+        ch = _as_chan(ch)
+        if ch.ndim != 2 or ch.shape[1] != self.nch:
+            raise ValueError("descriptors of shape (nblocks, %d) wanted, got %r" % (self.nch, ch.shape))
+        _chk(lib().gpsbb_node_feed(self._n, ch.ctypes.data, ch.shape[0]), "gpsbb_node_feed")
+
+    def end(self, expect_stop=False):
+        st = _NodeStats()
+        rc = lib().gpsbb_node_end(self._n, C.byref(st))
+        self._cb = None
+        if self._raised:
+            raise self._raised[0]
+        if rc != 0 and not (expect_stop and rc == -7):
+            raise GpsbbError(rc, "gpsbb_node_end")
         return {"rc": rc, "seconds": st.seconds, "blocks": st.blocks,
                 "shards": [{k: getattr(st.shard[g], k) for k, _ in _NodeShardStats._fields_} for g in range(st.nshards)]}
 

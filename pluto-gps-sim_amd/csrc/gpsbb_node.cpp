@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -70,6 +71,13 @@ struct Shard {
     long first = 0, count = 0;
     int rc = GPSBB_OK;
     gpsbb_node_shard_stats_t stats{};
+    /* an incremental run (gpsbb_node_begin / _feed / _end): the slots waiting for this shard, oldest first */
+    struct FedSlot {
+        long slot;  /* its number in the stream: blocks [slot * bps, slot * bps + nb) */
+        int nb;     /* blocks it really holds (the stream's last slot may be short: padded with idle blocks) */
+        std::vector<gpsbb_chan_t> desc; /* bps * nch descriptors, the first block's carrier phases exact */
+    };
+    std::deque<FedSlot> fed;
 };
 
 } /* namespace */
@@ -94,6 +102,18 @@ struct gpsbb_node {
     long delivered = 0;
     bool stop = false;     /* the sink asked to stop, or a shard failed */
     std::mutex sink_m;     /* indexed, not concurrent: one sink call at a time */
+    /* an incremental run: the feeder (the caller's thread) cuts what it is fed into slots, chains the carrier across them on a
+     * handle of its own and deals the slots round the shards' queues; bounded: a feed waits while its shard's queue is full */
+    bool feeding = false, fed_eof = false;
+    gpsbb_t *feed_h = nullptr;           /* the feeder's handle (the chain of the fed blocks: gpsbb_chain_carrier) */
+    std::vector<gpsbb_chan_t> pend;      /* fed blocks that do not fill a slot yet */
+    std::vector<gpsbb_chan_t> work;      /* pend + the blocks of the current feed */
+    std::vector<double> work_seed;
+    long fed_slots = 0, fed_blocks = 0;
+    bool have_carry = false;
+    int carry_prn[GPSBB_MAX_CHAN] = {};
+    double carry_phase[GPSBB_MAX_CHAN] = {}; /* the exact phase (the accumulator, fixed-point carrier) at pend's first block */
+    double feed_t0 = 0.0, feed_chain_s = 0.0;
 };
 
 extern "C" int gpsbb_node_plan(long nblocks, int nshards, int blocks_per_slot, long *first)
@@ -279,8 +299,73 @@ int run_shard_interleaved(gpsbb_node *n, Shard &s)
     return GPSBB_OK;
 }
 
+/* An incremental run: this shard renders the slots the feeder queues for it (slot k of the stream goes to shard k mod N, as
+ * GPSBB_NODE_INTERLEAVED: every slot a chain of its own from the exact phases the feeder put into its first block) until the
+ * feeder says the stream is over and the queue is empty. */
+int run_shard_feed(gpsbb_node *n, Shard &s)
+{
+    const gpsbb_node_config_t &c = n->cfg;
+    const int bps = c.blocks_per_slot;
+    s.stats.first_block = (long)s.index * bps;
+    s.stats.nblocks = 0;
+    s.stats.seed_seconds = s.stats.busy_seconds = s.stats.wait_seconds = 0.0;
+    int rc = gpsbb_stream_reset(s.st);
+    if (rc != GPSBB_OK)
+        return rc;
+    const unsigned depth = (unsigned)c.depth;
+    const double t_busy = now_s();
+    std::deque<std::pair<long, int>> flying; /* (first block, blocks) of the slots in the ring, oldest first */
+    bool going = true, eof = false;
+    while (going && !(eof && flying.empty())) {
+        /* push what is waiting, as far as the ring takes it; wait for the feeder only when there is nothing to pop */
+        while (going && !eof && (unsigned)flying.size() < depth) {
+            Shard::FedSlot slot;
+            {
+                std::unique_lock<std::mutex> lk(n->m);
+                if (flying.empty())
+                    n->cv.wait(lk, [&] { return n->stop || !s.fed.empty() || n->fed_eof; });
+                if (n->stop) {
+                    going = false;
+                    break;
+                }
+                if (s.fed.empty()) {
+                    eof = n->fed_eof;
+                    break;
+                }
+                slot = std::move(s.fed.front());
+                s.fed.pop_front();
+                n->cv.notify_all(); /* room for the feeder */
+            }
+            rc = gpsbb_stream_push_ex(s.st, slot.desc.data(), GPSBB_PUSH_NEW_CHAIN);
+            if (rc != GPSBB_OK)
+                return rc;
+            flying.emplace_back(slot.slot * bps, slot.nb);
+        }
+        if (!going || flying.empty())
+            continue;
+        const int16_t *iq = nullptr;
+        rc = gpsbb_stream_pop(s.st, &iq, nullptr);
+        if (rc != GPSBB_OK)
+            return rc;
+        const std::pair<long, int> f = flying.front();
+        flying.pop_front();
+        s.stats.nblocks += f.second;
+        going = deliver(n, s, iq, f.first, f.second);
+    }
+    while (gpsbb_stream_pending(s.st) > 0) {
+        const int16_t *iq = nullptr;
+        const int r2 = gpsbb_stream_pop(s.st, &iq, nullptr);
+        if (r2 != GPSBB_OK)
+            return r2;
+    }
+    s.stats.busy_seconds = now_s() - t_busy;
+    return GPSBB_OK;
+}
+
 int run_shard(gpsbb_node *n, Shard &s)
 {
+    if (n->feeding)
+        return run_shard_feed(n, s);
     if (n->cfg.flags & GPSBB_NODE_INTERLEAVED)
         return run_shard_interleaved(n, s);
     const gpsbb_node_config_t &c = n->cfg;
@@ -532,7 +617,256 @@ extern "C" void gpsbb_node_destroy(gpsbb_node_t *n)
     for (auto &s : n->shards)
         if (s.th.joinable())
             s.th.join();
+    if (n->feed_h)
+        gpsbb_destroy(n->feed_h);
     delete n;
+}
+
+/* ---- the incremental run ------------------------------------------------------------------------------------------
+ * The reference generates its descriptors block by block inside a loop that has no end (plutogpssim.c:2655-2687, maintenance
+ * c:2764-2805): a driver that wants all of them up front (gpsbb_node_run) holds 296 bytes x channels per 0.1 s of signal — 4 GB
+ * per simulated day — and cannot start rendering before the front end has finished.  begin / feed / end take the stream as it
+ * comes: memory is what the rings and a bounded queue per shard hold, whatever the duration. */
+namespace {
+
+/* collect return codes and statistics of a finished run (both kinds) */
+int finish_run(gpsbb_node *n, long expected_blocks, double t0, gpsbb_node_stats_t *stats)
+{
+    const int N = n->cfg.nshards;
+    int rc = GPSBB_OK;
+    for (int g = 0; g < N && rc == GPSBB_OK; g++)
+        rc = n->shards[g].rc;
+    if (rc == GPSBB_OK && n->delivered != expected_blocks)
+        rc = GPSBB_E_STATE; /* the sink stopped the run */
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->seconds = now_s() - t0;
+        stats->blocks = n->delivered;
+        stats->nshards = N;
+        for (int g = 0; g < N; g++) {
+            stats->shard[g] = n->shards[g].stats;
+            stats->shard[g].device = n->shards[g].device;
+            stats->shard[g].numa_node = n->shards[g].numa_node;
+            stats->shard[g].cpus_bound = n->shards[g].cpus_bound;
+        }
+    }
+    return rc;
+}
+
+/* queue the first `nslots` slots of n->work (slot j holds blocks [j * bps, j * bps + nb)), their first blocks seeded */
+int feed_slots(gpsbb_node *n, long nslots, long nblocks_in_work)
+{
+    const gpsbb_node_config_t &c = n->cfg;
+    const int bps = c.blocks_per_slot, nch = c.nch, N = c.nshards;
+    for (long j = 0; j < nslots; j++) {
+        const long b0 = j * bps;
+        const long nb = nblocks_in_work - b0 < bps ? nblocks_in_work - b0 : bps;
+        Shard::FedSlot slot;
+        slot.slot = n->fed_slots;
+        slot.nb = (int)nb;
+        slot.desc.assign((size_t)bps * nch, gpsbb_chan_t{}); /* (a short last slot is padded with idle blocks) */
+        memcpy(slot.desc.data(), n->work.data() + (size_t)b0 * nch, (size_t)nb * nch * sizeof(gpsbb_chan_t));
+        for (int i = 0; i < nch; i++)
+            if (slot.desc[i].prn > 0)
+                slot.desc[i].carr_phase = n->work_seed[(size_t)b0 * nch + i];
+        Shard &s = n->shards[(size_t)(n->fed_slots % N)];
+        std::unique_lock<std::mutex> lk(n->m);
+        n->cv.wait(lk, [&] { return n->stop || s.fed.size() < (size_t)c.depth + 1; });
+        if (n->stop)
+            return GPSBB_E_STATE;
+        s.fed.push_back(std::move(slot));
+        n->fed_slots++;
+        n->fed_blocks += nb;
+        n->cv.notify_all();
+    }
+    return GPSBB_OK;
+}
+
+/* exact carrier phase at the first sample of every block of n->work (nblocks of them), continuing n->carry_*; leaves the
+ * phase after the last block in `end` */
+int feed_chain(gpsbb_node *n, long nblocks, double *end)
+{
+    const gpsbb_node_config_t &c = n->cfg;
+    const int nch = c.nch;
+    const bool fixed = (c.flags & GPSBB_NODE_FIXED_CARRIER) != 0;
+    n->work_seed.resize((size_t)nblocks * nch);
+    const double t0 = now_s();
+    if (fixed) {
+        for (int i = 0; i < nch; i++) {
+            int prev_prn = n->have_carry ? n->carry_prn[i] : 0;
+            uint32_t ph = n->have_carry ? (uint32_t)n->carry_phase[i] : 0u;
+            for (long b = 0; b < nblocks; b++) {
+                const gpsbb_chan_t &d = n->work[(size_t)b * nch + i];
+                if (d.prn > 0) {
+                    if (d.prn != prev_prn)
+                        ph = (uint32_t)d.carr_phase;
+                    n->work_seed[(size_t)b * nch + i] = (double)ph;
+                    const volatile double scaled = 512.0 * 65536.0 * d.f_carr * c.delt;
+                    ph += (uint32_t)c.nsamp * (uint32_t)(int32_t)std::round(scaled);
+                } else {
+                    n->work_seed[(size_t)b * nch + i] = 0.0;
+                }
+                prev_prn = d.prn > 0 ? d.prn : 0;
+            }
+            end[i] = (double)ph;
+        }
+    } else {
+        /* the first block continues the stream: its descriptors with the carried phases in place of their own */
+        if (n->have_carry)
+            for (int i = 0; i < nch; i++)
+                if (n->work[i].prn > 0 && n->work[i].prn == n->carry_prn[i])
+                    n->work[i].carr_phase = n->carry_phase[i];
+        long done = 0;
+        while (done < nblocks) {
+            const long piece = nblocks - done > 32768 ? 32768 : nblocks - done;
+            if (done > 0)
+                for (int i = 0; i < nch; i++) {
+                    gpsbb_chan_t &d = n->work[(size_t)done * nch + i];
+                    if (d.prn > 0 && d.prn == n->work[(size_t)(done - 1) * nch + i].prn)
+                        d.carr_phase = end[i];
+                }
+            const int rc = gpsbb_chain_carrier(n->feed_h, n->work.data() + (size_t)done * nch, (int)piece, nch, c.delt, c.nsamp,
+                                               n->work_seed.data() + (size_t)done * nch, end);
+            if (rc != GPSBB_OK)
+                return rc;
+            done += piece;
+        }
+    }
+    n->feed_chain_s += now_s() - t0;
+    return GPSBB_OK;
+}
+
+} /* namespace */
+
+extern "C" int gpsbb_node_begin(gpsbb_node_t *n, gpsbb_node_sink_fn sink, void *user)
+{
+    if (!n || !sink)
+        return GPSBB_E_BADARG;
+    if (n->feeding)
+        return GPSBB_E_STATE;
+    if (!n->feed_h && !(n->cfg.flags & GPSBB_NODE_FIXED_CARRIER)) {
+        const int rc = gpsbb_create(&n->feed_h, n->devices[0]);
+        if (rc != GPSBB_OK)
+            return rc;
+    }
+    std::lock_guard<std::mutex> lk(n->m);
+    n->ch = nullptr;
+    n->nblocks = 0;
+    n->sink = sink;
+    n->user = user;
+    n->next_block = 0;
+    n->delivered = 0;
+    n->stop = false;
+    n->done = 0;
+    n->feeding = true;
+    n->fed_eof = false;
+    n->pend.clear();
+    n->fed_slots = n->fed_blocks = 0;
+    n->have_carry = false;
+    n->feed_chain_s = 0.0;
+    n->feed_t0 = now_s();
+    for (auto &s : n->shards) {
+        s.fed.clear();
+        s.rc = GPSBB_OK;
+        s.first = 0;
+        s.count = 0;
+    }
+    n->job++;
+    n->cv.notify_all();
+    return GPSBB_OK;
+}
+
+extern "C" int gpsbb_node_feed(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nblocks)
+{
+    if (!n || !ch || nblocks < 1)
+        return GPSBB_E_BADARG;
+    if (!n->feeding)
+        return GPSBB_E_STATE;
+    const gpsbb_node_config_t &c = n->cfg;
+    const int bps = c.blocks_per_slot, nch = c.nch;
+    try {
+        n->work = n->pend;
+        n->work.insert(n->work.end(), ch, ch + (size_t)nblocks * nch);
+    } catch (const std::bad_alloc &) {
+        return GPSBB_E_NOMEM;
+    }
+    const long have = (long)(n->work.size() / (size_t)nch);
+    const long nslots = have / bps;
+    if (nslots == 0) {
+        n->pend.swap(n->work);
+        return GPSBB_OK;
+    }
+    /* the chain over everything at hand (cheap: 24 bytes per block and channel go to the device, a microsecond per block), the
+     * whole slots out, the rest kept with the exact phase at its first block */
+    double end[GPSBB_MAX_CHAN];
+    int rc = GPSBB_OK;
+    try {
+        rc = feed_chain(n, have, end);
+        if (rc == GPSBB_OK)
+            rc = feed_slots(n, nslots, have);
+    } catch (const std::bad_alloc &) {
+        rc = GPSBB_E_NOMEM;
+    }
+    if (rc != GPSBB_OK)
+        return rc;
+    const long used = nslots * bps;
+    for (int i = 0; i < nch; i++) {
+        if (used < have) {
+            const gpsbb_chan_t &d = n->work[(size_t)used * nch + i];
+            n->carry_prn[i] = d.prn > 0 ? d.prn : 0;
+            n->carry_phase[i] = n->work_seed[(size_t)used * nch + i];
+            /* (the kept blocks are chained again with the next feed: from the phase at their first block, like now) */
+        } else {
+            const gpsbb_chan_t &d = n->work[(size_t)(have - 1) * nch + i];
+            n->carry_prn[i] = d.prn > 0 ? d.prn : 0;
+            n->carry_phase[i] = end[i];
+        }
+    }
+    n->have_carry = true;
+    n->pend.assign(n->work.begin() + (size_t)used * nch, n->work.end());
+    if (used < have) /* the kept first block carries its exact phase itself: it must not be taken for a continuation twice */
+        for (int i = 0; i < nch; i++)
+            if (n->pend[i].prn > 0)
+                n->pend[i].carr_phase = n->carry_phase[i];
+    return GPSBB_OK;
+}
+
+extern "C" int gpsbb_node_end(gpsbb_node_t *n, gpsbb_node_stats_t *stats)
+{
+    if (!n)
+        return GPSBB_E_BADARG;
+    if (!n->feeding)
+        return GPSBB_E_STATE;
+    int rc = GPSBB_OK;
+    const long left = (long)(n->pend.size() / (size_t)n->cfg.nch);
+    if (left > 0 && !n->stop) {
+        /* the stream's last, short slot */
+        double end[GPSBB_MAX_CHAN];
+        try {
+            n->work = n->pend;
+            rc = feed_chain(n, left, end);
+            if (rc == GPSBB_OK)
+                rc = feed_slots(n, 1, left);
+        } catch (const std::bad_alloc &) {
+            rc = GPSBB_E_NOMEM;
+        }
+        n->pend.clear();
+    }
+    const int N = n->cfg.nshards;
+    {
+        std::unique_lock<std::mutex> lk(n->m);
+        if (rc != GPSBB_OK && rc != GPSBB_E_STATE)
+            n->stop = true;
+        n->fed_eof = true;
+        n->cv.notify_all();
+        n->cv.wait(lk, [&] { return n->done == N; });
+        n->feeding = false;
+    }
+    const int rc2 = finish_run(n, n->fed_blocks, n->feed_t0, stats);
+    if (stats) /* the feeder's chain, as every shard's seed time */
+        for (int g = 0; g < N; g++)
+            stats->shard[g].seed_seconds = n->feed_chain_s;
+    return rc != GPSBB_OK && rc != GPSBB_E_STATE ? rc : rc2;
 }
 
 extern "C" int gpsbb_node_run(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nblocks, gpsbb_node_sink_fn sink, void *user,
@@ -540,6 +874,8 @@ extern "C" int gpsbb_node_run(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nblo
 {
     if (!n || !ch || nblocks < 1 || !sink)
         return GPSBB_E_BADARG;
+    if (n->feeding)
+        return GPSBB_E_STATE; /* between gpsbb_node_begin and gpsbb_node_end */
     const int N = n->cfg.nshards;
     long first[GPSBB_NODE_MAX_SHARDS + 1];
     int rc = gpsbb_node_plan(nblocks, N, n->cfg.blocks_per_slot, first);
@@ -568,22 +904,5 @@ extern "C" int gpsbb_node_run(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nblo
         std::unique_lock<std::mutex> lk(n->m);
         n->cv.wait(lk, [&] { return n->done == N; });
     }
-    rc = GPSBB_OK;
-    for (int g = 0; g < N && rc == GPSBB_OK; g++)
-        rc = n->shards[g].rc;
-    if (rc == GPSBB_OK && n->delivered != nblocks)
-        rc = GPSBB_E_STATE; /* the sink stopped the run */
-    if (stats) {
-        memset(stats, 0, sizeof *stats);
-        stats->seconds = now_s() - t0;
-        stats->blocks = n->delivered;
-        stats->nshards = N;
-        for (int g = 0; g < N; g++) {
-            stats->shard[g] = n->shards[g].stats;
-            stats->shard[g].device = n->shards[g].device;
-            stats->shard[g].numa_node = n->shards[g].numa_node;
-            stats->shard[g].cpus_bound = n->shards[g].cpus_bound;
-        }
-    }
-    return rc;
+    return finish_run(n, nblocks, t0, stats);
 }

@@ -13,11 +13,14 @@
  * -F ("fast") produces the same bytes faster than real time's structure allows: the front end runs ahead,
  * blocks go through the streaming ring (gpsbb_stream_*, carrier chained exactly on host threads, pinned
  * device-to-host gather on a side stream) and are written as they pop.
- * -G N renders through the node driver (include/gpsbb_node.h): N contiguous time shards, one producer thread + handle +
- * ring per shard on the GPUs "-g a,b,c" names (default 0 .. N-1; an ordinal may repeat), each shard seeded with the exact
- * carrier phase by the device-side chain, ONE output: a regular file is written with pwrite() as slots complete
- * (GPSBB_NODE_INDEXED), a pipe in stream order; -I: the slots go round the GPUs instead of contiguous shards
- * (GPSBB_NODE_INTERLEAVED), so that an ordered output gets all the GPUs' rate too.
+ * -G N renders through the node driver (include/gpsbb_node.h): one producer thread + handle + ring per shard on the GPUs
+ * "-g a,b,c" names (default 0 .. N-1; an ordinal may repeat), ONE output: a regular file is written with pwrite() as slots
+ * complete (GPSBB_NODE_INDEXED), a pipe in stream order.  The stream is fed INCREMENTALLY (gpsbb_node_begin / _feed / _end):
+ * the front end makes the descriptors of a few slots, feeds them, and goes round again like the reference's loop — the slots go
+ * round the GPUs, each from the exact carrier phase the feeder chained, and the memory used does not grow with -d.
+ * -G N -C: N CONTIGUOUS time shards instead (BASELINE configs[4]'s layout; gpsbb_node_run: the whole descriptor sequence up
+ * front, each shard seeded by the device-side chain over everything before it); -C -I: the whole sequence up front, slots round
+ * the GPUs (GPSBB_NODE_INTERLEAVED).
  * -P usec paces the consumer like the radio does: the TX surface's sink takes one block every `usec` microseconds (the
  * reference's iio_buffer_push blocks until the hardware has room, c:2152; 100000 = real time, less = compressed time), counts
  * the blocks that were not there when their turn came (under-runs) and, with -S file, writes the latency distribution of
@@ -129,7 +132,7 @@ static int cmp_double(const void *a, const void *b)
 static void usage(void)
 {
     fprintf(stderr, "usage: gpsbb-sim -e nav [-l lat,lon,h|-c x,y,z|-u motion.csv] [-t Y/M/D,h:m:s] [-T] [-i] [-3]\n"
-                    "                 [-s fs_hz] [-d seconds] [-n samples_per_block] [-N channels] [-g gpu[,gpu...]] [-F] [-G shards [-I]]\n"
+                    "                 [-s fs_hz] [-d seconds] [-n samples_per_block] [-N channels] [-g gpu[,gpu...]] [-F] [-G shards [-C [-I]]]\n"
                     "                 [-P usec_per_block] [-Q device_queue_blocks] [-S stats.json] [-k keep,blocks] -o out.bin\n");
 }
 
@@ -147,7 +150,7 @@ int main(int argc, char **argv)
     long fs_hz = 3000000; /* TX_SAMPLE_FREQ c:43 */
     long nsamp = 300000;  /* NUM_SAMPLES c:44 */
     double duration = 1.0;
-    int gpu = 0, opt, fast = 0, nshards = 0, ndev = 0, interleaved = 0;
+    int gpu = 0, opt, fast = 0, nshards = 0, ndev = 0, interleaved = 0, contiguous = 0;
     int devs[GPSBB_NODE_MAX_SHARDS];
     struct paced_sink paced;
     memset(&paced, 0, sizeof paced);
@@ -155,7 +158,7 @@ int main(int argc, char **argv)
     const char *stats_path = NULL;
     const char *out_path = NULL;
 
-    while ((opt = getopt(argc, argv, "e:u:c:l:s:Tt:in:N:d:o:g:3FG:P:S:k:Q:I")) != -1) {
+    while ((opt = getopt(argc, argv, "e:u:c:l:s:Tt:in:N:d:o:g:3FG:P:S:k:Q:IC")) != -1) {
         switch (opt) {
         case 'e': cfg.navfile = optarg; break;
         case 'u': cfg.motion_file = optarg; break;
@@ -196,6 +199,7 @@ int main(int argc, char **argv)
             break;
         case 'G': nshards = atoi(optarg); break;
         case 'I': interleaved = 1; break;
+        case 'C': contiguous = 1; break; /* (with -I alone: the whole sequence up front as well: GPSBB_NODE_INTERLEAVED) */
         case 'P': paced.period_ns = atol(optarg) * 1000L; break;
         case 'S': stats_path = optarg; break;
         case 'Q': paced.queue = atoi(optarg) > 0 ? atoi(optarg) : 1; break;
@@ -231,26 +235,42 @@ int main(int argc, char **argv)
         }
         for (int g = 0; g < nshards; g++)
             devs[g] = ndev > 1 ? devs[g] : (ndev == 1 && nshards == 1 ? devs[0] : (ndev == 1 ? devs[0] + g : g));
-        gpsbb_chan_t *all = malloc((size_t)nblocks * cfg.max_chan * sizeof *all);
+        /* Default: the stream as the reference makes it, incrementally (gpsbb_node_begin / _feed / _end): the front end generates
+         * a few slots' worth of descriptors, feeds them, and goes round again while the GPUs render — it runs one queue ahead of
+         * the rings, and the memory this takes does not depend on -d.  -C: contiguous time shards (BASELINE configs[4]'s layout),
+         * which need the whole descriptor sequence up front (296 bytes per block and channel). */
+        const int bps = nblocks < 16 ? (int)nblocks : 16;
+        contiguous = contiguous || interleaved;
+        const long chunk = contiguous ? nblocks : (long)bps * nshards * 2;
+        gpsbb_chan_t *all = malloc((size_t)chunk * cfg.max_chan * sizeof *all);
         FILE *fo = strcmp(out_path, "-") ? fopen(out_path, "wb") : stdout;
         if (!all || !fo) {
             fprintf(stderr, "ERROR: cannot allocate the descriptors / open %s\n", out_path);
             return 1;
         }
-        gpsfe_generate(fe, (int)nblocks, all);
         struct node_out o = {fo, -1, (size_t)nsamp};
-        unsigned nflags = interleaved ? GPSBB_NODE_INTERLEAVED : 0u; /* -I: the slots go round the GPUs (an ordered output scales) */
+        unsigned nflags = interleaved ? GPSBB_NODE_INTERLEAVED : 0u; /* -C -I: the slots go round the GPUs (an ordered output scales) */
         if (fo != stdout && ftruncate(fileno(fo), (off_t)nblocks * nsamp * 4) == 0) {
             o.fd = fileno(fo); /* a regular file: blocks are placed by index as they complete, from every shard at once */
             nflags |= GPSBB_NODE_INDEXED | GPSBB_NODE_CONCURRENT;
         }
-        const int bps = nblocks < 16 ? (int)nblocks : 16;
         gpsbb_node_config_t nc = {nshards, devs, cfg.max_chan, delt, (int)nsamp, bps, 3, nflags};
         gpsbb_node_t *node = NULL;
         gpsbb_node_stats_t ns;
         rc = gpsbb_node_create(&node, &nc);
-        if (rc == GPSBB_OK)
+        if (rc == GPSBB_OK && contiguous) {
+            gpsfe_generate(fe, (int)nblocks, all);
             rc = gpsbb_node_run(node, all, nblocks, node_sink, &o, &ns);
+        } else if (rc == GPSBB_OK) {
+            rc = gpsbb_node_begin(node, node_sink, &o);
+            for (long done = 0; rc == GPSBB_OK && done < nblocks; done += chunk) { /* while (!plutotx.exit), c:2655 */
+                const long nb = nblocks - done < chunk ? nblocks - done : chunk;
+                gpsfe_generate(fe, (int)nb, all);                  /* c:2656-2687 (+ c:2764-2805) */
+                rc = gpsbb_node_feed(node, all, nb);
+            }
+            const int rc_end = gpsbb_node_end(node, &ns);
+            rc = rc == GPSBB_OK || rc == GPSBB_E_STATE ? rc_end : rc;
+        }
         if (rc != GPSBB_OK)
             fprintf(stderr, "ERROR: node driver: %s\n", gpsbb_strerror(rc));
         else

@@ -248,6 +248,75 @@ def test_a_failed_run_leaves_the_node_usable(pkg, oracle):
             assert (sink.iq == want).all()
 
 
+def test_the_stream_fed_incrementally(pkg, oracle):
+    """gpsbb_node_begin / _feed / _end: the stream as the reference's loop makes it (c:2655-2687: one block's descriptors, render,
+    round again) — fed in pieces of any size (1 block, 7, a few slots, a piece that ends inside a slot), the driver cuts it
+    into slots itself and chains the carrier across everything it is fed; the bytes are gpsbb_node_run's, the oracle's and the
+    golden vectors' (the reference scenario across its 30 s nav refresh), in stream order; PRN changes at and inside slot and
+    feed boundaries, an idle stretch, a short last slot, the fixed-point carrier; the sink stops the run; a second run on the
+    same node."""
+    z = np.load(os.path.join(GOLDEN, "static_F.npz"))
+    fs, nsamp = float(z["fs"]), int(z["nsamp"])
+    desc = z["desc"].view(pkg.CHAN_DTYPE).reshape(z["desc"].shape[0], -1)
+    blocks = [int(b) for b in z["blocks"]]
+    # the golden file holds selected blocks; a stream needs all: the dense synthetic one below, and the golden ones one by one
+    rng = np.random.default_rng(8)
+    fs, nsamp, nch, bps, nb = 25e6, 25000, 7, 3, 41
+    ch = pkg.synth_descriptors(nb, nch=nch, seed=808)
+    ch["f_carr"] = rng.uniform(-5000, 5000, (1, nch)) + rng.uniform(-2, 2, (nb, nch))
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    ch["prn"] = np.arange(1, nch + 1)[None, :]
+    ch["prn"][9:, 1] = 21      # at a slot boundary
+    ch["prn"][10:, 2] = 22     # inside a slot
+    ch["prn"][17:26, 3] = 0    # idle for a while
+    want, _, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
+    for nshards, pieces in ((1, [1] * nb), (3, [7, 1, 2, 9, 22]), (4, [nb]), (2, [5] * 8 + [1])):
+        assert sum(pieces) == nb
+        sink = Collect(nb, nsamp)
+        with pkg.Node(nshards, nch, 1 / fs, nsamp, bps, depth=2, devices=node_devices(nshards)) as node:
+            for _ in range(2):  # twice on the same node
+                sink.calls.clear()
+                sink.iq[:] = 0
+                node.begin(sink)
+                k = 0
+                for p in pieces:
+                    node.feed(ch[k:k + p])
+                    k += p
+                st = node.end()
+                assert st["blocks"] == nb and (sink.iq == want).all(), (nshards, pieces)
+                assert [c[0] for c in sink.calls] == sorted(c[0] for c in sink.calls)   # ordered: the reference's one consumer
+                assert sorted({c[2] for c in sink.calls}) == list(range(min(nshards, (nb + bps - 1) // bps)))  # the slots went round the shards
+            # ... and gpsbb_node_run still works on it afterwards
+            sink2 = Collect(nb, nsamp)
+            node.run(ch, sink2)
+            assert (sink2.iq == want).all()
+    # the sink stops the run: feed reports it, end winds the run down
+    with pkg.Node(2, nch, 1 / fs, nsamp, bps, depth=2, devices=node_devices(2)) as node:
+        seen = []
+
+        def stopper(iq, first, n, shard):
+            seen.append(first)
+            return -1 if first >= 9 else 0
+        node.begin(stopper)
+        with pytest.raises(pkg.GpsbbError):
+            for k in range(0, nb, 2):
+                node.feed(ch[k:k + 2])
+        node.end(expect_stop=True)
+        assert max(seen) < nb - bps
+    # the fixed-point carrier: the accumulator is carried across feeds in integer arithmetic
+    fch = ch.copy()
+    fch["carr_phase"] = np.floor(fch["carr_phase"] * 2.0 ** 32)
+    fwant, _, _ = oracle.fill_blocks(fch, 1 / fs, nsamp, chain=True, fixed=True)
+    sink = Collect(nb, nsamp)
+    with pkg.Node(2, nch, 1 / fs, nsamp, bps, depth=2, flags=pkg.NODE_FIXED_CARRIER, devices=node_devices(2)) as node:
+        node.begin(sink)
+        for k in range(0, nb, 4):
+            node.feed(fch[k:k + 4])
+        node.end()
+    assert (sink.iq == fwant).all()
+    del desc, blocks
+
+
 def test_placement_is_reported(pkg):
     """The producer threads bind themselves next to their GPU before they allocate (plutogpssim.c:2045-2056 pins the
     reference's two threads): the statistics say where."""
@@ -283,10 +352,51 @@ def test_gpsbb_sim_over_several_shards_writes_the_same_file(pkg, tmp_path):
     for k, blk in enumerate(int(b) for b in z["blocks"]):
         assert sha(want.reshape(-1, nsamp, 2)[blk]) == str(z["iq_sha256"][k]), blk
     for n in (1, 3):
-        out = str(tmp_path / ("g%d.bin" % n))
-        subprocess.run(common + ["-G", str(n), "-g", ",".join(["0"] * n), "-o", out], check=True, stderr=subprocess.DEVNULL)
-        assert (np.fromfile(out, np.int16) == want).all(), n
+        # -G N: the stream fed incrementally (gpsbb_node_begin / _feed / _end); -C: contiguous shards, everything up front
+        for extra in ([], ["-C"]):
+            out = str(tmp_path / ("g%d%s.bin" % (n, "c" if extra else "")))
+            subprocess.run(common + ["-G", str(n), "-g", ",".join(["0"] * n), "-o", out] + extra, check=True, stderr=subprocess.DEVNULL)
+            assert (np.fromfile(out, np.int16) == want).all(), (n, extra)
     piped = subprocess.run(common + ["-G", "3", "-I", "-g", "0,0,0", "-o", "-"], check=True, stderr=subprocess.DEVNULL, stdout=subprocess.PIPE).stdout
     assert np.frombuffer(piped, np.int16).tobytes() == want.tobytes()   # interleaved slots, ordered pipe
     piped = subprocess.run(common + ["-G", "2", "-g", "0,0", "-o", "-"], check=True, stderr=subprocess.DEVNULL, stdout=subprocess.PIPE).stdout
     assert np.frombuffer(piped, np.int16).tobytes() == want.tobytes()
+    piped = subprocess.run(common + ["-G", "2", "-C", "-g", "0,0", "-o", "-"], check=True, stderr=subprocess.DEVNULL, stdout=subprocess.PIPE).stdout
+    assert np.frombuffer(piped, np.int16).tobytes() == want.tobytes()
+
+
+def test_gpsbb_sim_feeds_the_node_in_bounded_memory(pkg, tmp_path):
+    """gpsbb-sim -G: the front end runs a queue ahead of the rings and no further — the process's peak memory does not grow with
+    the duration (it did: all descriptors up front, 296 bytes x channels per block).  Ten times the signal, the same peak RSS to
+    within a few MB (device scratch that is re-grown once when the Dopplers have grown is the only thing that ever moves it); the first minute of both outputs is the same bytes (a pipe, so that nothing is kept on disk)."""
+    import resource
+    pkg.build_frontend()
+    exe = os.path.join(os.path.dirname(pkg.LIB_PATH), "gpsbb-sim")
+    common = [exe, "-e", os.path.join(GOLDEN, "synth3540.14n"), "-l", "30.286502,120.032669,100", "-s", "2600000", "-n", "26000",
+              "-G", "2", "-g", "0,0", "-o", "-"]
+
+    def run(seconds, keep):
+        cmd = "exec %s -d %s | head -c %d | sha256sum; true" % (" ".join(common), seconds, keep)
+        # peak RSS of the generator: /usr/bin/time is not in the image; a wrapper that reports ru_maxrss of its child
+        code = ("import resource,subprocess,sys,hashlib\n"
+                "p=subprocess.Popen(%r+['-d',%r],stdout=subprocess.PIPE,stderr=subprocess.DEVNULL)\n"
+                "h=hashlib.sha256(); n=0\n"
+                "while True:\n"
+                "    b=p.stdout.read(1<<20)\n"
+                "    if not b: break\n"
+                "    if n<%d: h.update(b[:%d-n])\n"
+                "    n+=len(b)\n"
+                "p.wait()\n"
+                "print(h.hexdigest(), n, resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss, p.returncode)\n") % (common, str(seconds), keep, keep)
+        del cmd
+        out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        dig, n, rss_kb, rc = out.stdout.split()
+        assert int(rc) == 0
+        return dig, int(n), int(rss_kb)
+    keep = 600 * 26000 * 4          # the first minute
+    d1, n1, rss1 = run(60, keep)
+    d2, n2, rss2 = run(600, keep)
+    assert n1 == 600 * 26000 * 4 and n2 == 6000 * 26000 * 4 and d1 == d2
+    # kB.  Measured: 2 947 336 against 2 947 276; with -C (everything up front) the same pair is 8 MB apart, and grows with -d
+    assert abs(rss2 - rss1) < 4 * 1024, (rss1, rss2)

@@ -347,7 +347,8 @@ bool lap_eligible(const gpsbb_chan_t *ch, size_t nbc, double delt, bool fixed)
 
 /* room for the laps of every channel, in chunks of LAP_WG lanes: a chain of n steps of size s wraps at most floor(n * s / range)
  * + 1 times, a block may start a chain (one more lap), and the model's step differs from s by parts in 10^12 */
-void lap_bound(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp, bool fixed, uint32_t chunk0[2][GPSBB_MAX_CHAN + 1])
+void lap_bound(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp, bool fixed, uint32_t chunk0[2][GPSBB_MAX_CHAN + 1],
+               bool carr_only = false)
 {
     for (int kind = 0; kind < 2; kind++) {
         chunk0[kind][0] = kind == 0 ? 0u : chunk0[0][GPSBB_MAX_CHAN]; /* one array of chunks: the code chains', then the carriers' */
@@ -355,7 +356,7 @@ void lap_bound(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int ns
             double laps = 0.0;
             for (int blk = 0; blk < nblocks; blk++) {
                 const gpsbb_chan_t &c = ch[(size_t)blk * nch + i];
-                if (c.prn <= 0 || (kind == NCO_CARR && fixed))
+                if (c.prn <= 0 || (kind == NCO_CARR && fixed) || (kind == NCO_CODE && carr_only))
                     continue;
                 const double s = kind == NCO_CARR ? std::fabs(c.f_carr * delt) : c.f_code * delt * (1.0 / 1023.0);
                 laps += std::floor((double)nsamp * s * (1.0 + 0x1p-30)) + 3.0;
@@ -1815,6 +1816,7 @@ static int host_seed_run(gpsbb_batch *b, int set, hipStream_t stream)
 static BatchDev batch_dev(const gpsbb_batch *b, int set)
 {
     BatchDev p;
+    memset(&p, 0, sizeof p); /* (every field has a value, also the ones a later round adds) */
     p.ch = b->d_ch.p;
     p.nblocks = b->nblocks;
     p.nch = b->nch;
@@ -1859,6 +1861,7 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.prefix_rows = b->chain_dev && !b->chain_starts ? b->d_prefix[set].p : nullptr;
     p.carry = b->chain_dev ? b->d_carry : nullptr;
     p.cont0_mask = b->cont0_mask;
+    p.lap_end = nullptr;
     return p;
 }
 
@@ -2882,8 +2885,18 @@ struct ChainOnly {
     int fix_epoch = 0;
     std::vector<ChainDesc> h_cd;
     std::vector<double> h_start0;
+    /* the lap-parallel chain (gpsbb_laps.hip.h with nothing to emit): the phase after every block, scratch of the lap kernels */
+    DevBuf<double> d_lap_end;
+    DevBuf<LapBC> d_lap_bc;
+    DevBuf<uint32_t> d_lap_lane0, d_lap_cnt, d_lap_chunk_bad;
+    DevBuf<LapRec> d_lap_rec;
+    DevBuf<LapAgg> d_lap_agg;
+    DevBuf<double> d_lap_chunk_m;
+    unsigned long long *d_hz_scratch = nullptr; /* (a chain alone counts no hazards: the render of those blocks does) */
+    std::vector<double> h_lap_end;
 };
-constexpr int CHAIN_ONLY_BLOCKS = 16384; /* blocks per sub-batch: 168 MB of ChainAux at 16 channels */
+constexpr int CHAIN_ONLY_BLOCKS = 16384;
+constexpr double CHAIN_ONLY_LAPS = 6.0e6; /* laps per sub-batch of the lap-parallel chain (40 bytes of scratch each) */ /* blocks per sub-batch: 168 MB of ChainAux at 16 channels */
 
 static void chain_only_free(gpsbb *h)
 {
@@ -2893,6 +2906,16 @@ static void chain_only_free(gpsbb *h)
     c->d_cd.release();
     c->d_start0.release();
     c->d_aux.release();
+    c->d_lap_end.release();
+    c->d_lap_bc.release();
+    c->d_lap_lane0.release();
+    c->d_lap_cnt.release();
+    c->d_lap_chunk_bad.release();
+    c->d_lap_rec.release();
+    c->d_lap_agg.release();
+    c->d_lap_chunk_m.release();
+    if (c->d_hz_scratch)
+        (void)hipFree(c->d_hz_scratch);
     c->d_fix_end.release();
     c->d_fix_flag.release();
     if (c->d_carry)
@@ -2977,6 +3000,121 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
             return GPSBB_E_BADCHAN;
 
     hipStream_t ss = h->s_seed;
+    /* Lap-parallel (gpsbb_laps.hip.h: plan, reference walks, scan, true walks with nothing to emit but the phase after every
+     * block, repair) wherever no carrier step is below 2^-50: a fraction of a millisecond per sub-batch whatever its blocks are —
+     * the row walks below take as long as their longest chain, twice (a feeder that chains every few slots of a stream, the
+     * node driver's incremental run, could not live with 8 ms per call). */
+    bool use_laps = h->opt_seed_where != 1 && !GPSBB_KNOB_SET("GPSBB_NO_LAPS");
+    for (size_t k = 0; k < nbc_all && use_laps; k++)
+        if (c->h_cd[k].prn > 0) {
+            const volatile double sk = c->h_cd[k].f_carr * delt;
+            use_laps = std::fabs(sk) >= 0x1p-50;
+        }
+    if (use_laps) {
+        if (!c->d_hz_scratch)
+            HIPCHK(h, hipMalloc((void **)&c->d_hz_scratch, 64));
+        HIPCHK(h, hipMemsetAsync(c->d_hz_scratch, 0, 64, ss));
+        if (carr_phase_seed)
+            c->h_lap_end.resize(nbc_all);
+        int b0 = 0;
+        while (b0 < nblocks) {
+            /* as many blocks as fit the scratch: by the laps they hold */
+            double laps = 0.0;
+            int nb = 0;
+            while (b0 + nb < nblocks && nb < CHAIN_ONLY_BLOCKS) {
+                double l = 0.0;
+                for (int i = 0; i < nch; i++) {
+                    const ChainDesc &d = c->h_cd[(size_t)(b0 + nb) * nch + i];
+                    if (d.prn > 0)
+                        l += std::floor((double)nsamp * std::fabs(d.f_carr * delt)) + 3.0;
+                }
+                if (nb > 0 && laps + l > CHAIN_ONLY_LAPS)
+                    break;
+                laps += l;
+                nb++;
+            }
+            const size_t nbc = (size_t)nb * nch, k0 = (size_t)b0 * nch;
+            LapDev L;
+            memset(&L, 0, sizeof L);
+            lap_bound(ch + k0, nb, nch, delt, nsamp, false, L.chunk0, true);
+            const size_t chunks = L.chunk0[1][nch];
+            HIPCHK(h, (hipError_t)c->d_cd.reserve(nbc));
+            HIPCHK(h, (hipError_t)c->d_lap_end.reserve(nbc));
+            HIPCHK(h, (hipError_t)c->d_lap_bc.reserve(2 * nbc));
+            HIPCHK(h, (hipError_t)c->d_lap_lane0.reserve(2 * (size_t)nch * ((size_t)nb + 1)));
+            HIPCHK(h, (hipError_t)c->d_lap_cnt.reserve(4 * GPSBB_MAX_CHAN));
+            HIPCHK(h, (hipError_t)c->d_lap_rec.reserve(chunks * LAP_WG));
+            HIPCHK(h, (hipError_t)c->d_lap_agg.reserve(chunks));
+            HIPCHK(h, (hipError_t)c->d_lap_chunk_m.reserve(chunks));
+            HIPCHK(h, (hipError_t)c->d_lap_chunk_bad.reserve(chunks));
+            HIPCHK(h, hipMemcpyAsync(c->d_cd.p, c->h_cd.data() + k0, nbc * sizeof(ChainDesc), hipMemcpyHostToDevice, ss));
+            L.bc = c->d_lap_bc.p;
+            L.lane0 = c->d_lap_lane0.p;
+            L.nlaps = c->d_lap_cnt.p;
+            L.nbad = c->d_lap_cnt.p + 2 * GPSBB_MAX_CHAN;
+            L.rec = c->d_lap_rec.p;
+            L.agg = c->d_lap_agg.p;
+            L.chunk_m = c->d_lap_chunk_m.p;
+            L.chunk_bad = c->d_lap_chunk_bad.p;
+            L.chained = 1;
+            L.jitter = (uint32_t)GPSBB_KNOB_LONG("GPSBB_LAP_JITTER", 0);
+            BatchDev p;
+            memset(&p, 0, sizeof p);
+            p.nblocks = nb;
+            p.nch = nch;
+            p.nsamp = nsamp;
+            p.ntiles = (nsamp + TILE - 1) / TILE;
+            p.delt = delt;
+            p.flags = GPSBB_CHAIN_CARRIER;
+            p.status = c->d_status;
+            p.hazards = c->d_hz_scratch;
+            p.chain_dev = 1;
+            p.nseg = 1;
+            p.nvb = nb;
+            p.cd = c->d_cd.p;
+            p.carry = c->d_carry;
+            p.lap_end = c->d_lap_end.p;
+            p.cont0_mask = 0;
+            if (b0 > 0)
+                for (int i = 0; i < nch; i++) {
+                    const int prn = c->h_cd[k0 + i].prn;
+                    if (prn > 0 && prn == c->h_cd[k0 - nch + i].prn)
+                        p.cont0_mask |= 1u << i;
+                }
+            const unsigned ck = L.chunk0[NCO_CARR][nch] - L.chunk0[NCO_CARR][0];
+            hipLaunchKernelGGL(k_lap_plan<NCO_CARR>, dim3(nch), dim3(64), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_pass1<NCO_CARR>, dim3(ck), dim3(LAP_WG), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_scan<NCO_CARR>, dim3(nch), dim3(64), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_pass2<NCO_CARR>, dim3(ck), dim3(LAP_WG), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_repair<NCO_CARR>, dim3(nch), dim3(64), 0, ss, p, L);
+            HIPCHK(h, hipGetLastError());
+            if (carr_phase_seed)
+                HIPCHK(h, hipMemcpyAsync(c->h_lap_end.data() + k0, c->d_lap_end.p, nbc * sizeof(double), hipMemcpyDeviceToHost, ss));
+            HIPCHK(h, hipStreamSynchronize(ss));
+            b0 += nb;
+        }
+        if (carr_phase_seed)
+            /* a block starts where the one before ended, or — a channel that was idle or had another prn there — from its own phase */
+            for (int i = 0; i < nch; i++)
+                for (int blk = 0; blk < nblocks; blk++) {
+                    const size_t k = (size_t)blk * nch + i;
+                    const ChainDesc &d = c->h_cd[k];
+                    double v = 0.0;
+                    if (d.prn > 0)
+                        v = (blk > 0 && c->h_cd[k - nch].prn == d.prn) ? c->h_lap_end[k - nch] : d.carr_phase;
+                    carr_phase_seed[k] = v;
+                }
+        if (carr_phase_end) {
+            ChainCarryDev cc;
+            HIPCHK(h, hipMemcpy(&cc, c->d_carry, sizeof cc, hipMemcpyDeviceToHost));
+            for (int i = 0; i < nch; i++)
+                carr_phase_end[i] = c->h_cd[nbc_all - nch + i].prn > 0 ? cc.exact_end[i] : 0.0;
+        }
+        h->last_chain_dev = 1;
+        uint32_t st = 0;
+        HIPCHK(h, hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
+        return st ? GPSBB_E_INTERNAL : GPSBB_OK;
+    }
     for (int b0 = 0; b0 < nblocks; b0 += CHAIN_ONLY_BLOCKS) {
         const int nb = nblocks - b0 < CHAIN_ONLY_BLOCKS ? nblocks - b0 : CHAIN_ONLY_BLOCKS;
         const size_t nbc = (size_t)nb * nch, k0 = (size_t)b0 * nch;

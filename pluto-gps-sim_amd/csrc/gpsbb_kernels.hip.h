@@ -231,6 +231,8 @@ struct BatchDev {
     int *fix_flag;
     int fix_epoch, fix_chunks;
     uint32_t cont0_mask;            /* ... for the channels of this mask (same prn as in that block: the host knows) */
+    double *lap_end;                /* the lap-parallel chain alone (gpsbb_chain_carrier): [nblocks*nch] the carrier phase after every
+                                       block, instead of `end`; `ch` is then NULL and the chain's descriptors are `cd` */
 };
 
 /* samples of segment sgi of a block (see BatchDev::nseg) */

@@ -522,7 +522,7 @@ __device__ __forceinline__ void lap_run(const BatchDev &p, int i, LapLane<KIND> 
                 w.hz++; /* carr_phase == 1.0 at this sample: table index 512 (gpsbb_hazards_t.itable_512) */
         }
         const int n1 = n + k;
-        if (EMIT) {
+        if (EMIT && p.tile_x) { /* (no tile states where only the chain is wanted: gpsbb_chain_carrier) */
             /* does a tile start inside the row (samples n .. n1)? */
             const int t0 = (int)(((uint32_t)n + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
             if (__ballot(go && t0 * TILE <= n1 && t0 < p.ntiles))
@@ -602,8 +602,12 @@ __device__ __forceinline__ void lap_block_end(const BatchDev &p, int i, LapLane<
 {
     const size_t k = (size_t)w.b * p.nch + i;
     if (KIND == NCO_CARR) {
-        if (emit)
-            p.end[k].carr_phase = w.x;
+        if (emit) {
+            if (p.lap_end)
+                p.lap_end[k] = w.x; /* (the chain alone: gpsbb_chain_carrier) */
+            else
+                p.end[k].carr_phase = w.x;
+        }
     } else {
         const gpsbb_chan_t &ch = p.ch[k];
         const uint32_t c = w.c0 + w.jc;
@@ -764,24 +768,38 @@ __global__ __launch_bounds__(64) void k_lap_plan(BatchDev p, LapDev L)
         const int b = b0 + lane;
         const bool in = b < p.nblocks;
         const size_t k = (size_t)(in ? b : 0) * p.nch + i;
-        const gpsbb_chan_t &ch = p.ch[k];
-        const int prn = in ? ch.prn : 0;
+        /* the chain alone (gpsbb_chain_carrier, carriers only): 24-byte chain descriptors instead of the 296-byte ones */
+        const bool slim = KIND == NCO_CARR && p.ch == nullptr;
+        int prn = 0;
+        double f_of = 0.0, phase_of = 0.0;
+        uint32_t c0_of = 0;
+        if (slim) {
+            prn = in ? p.cd[k].prn : 0;
+            f_of = p.cd[k].f_carr;
+            phase_of = p.cd[k].carr_phase;
+        } else {
+            const gpsbb_chan_t &ch = p.ch[k];
+            prn = in ? ch.prn : 0;
+            f_of = KIND == NCO_CARR ? ch.f_carr : ch.f_code;
+            phase_of = KIND == NCO_CARR ? ch.carr_phase : ch.code_phase;
+            c0_of = (uint32_t)ch.icode + 20u * (uint32_t)ch.ibit + 600u * (uint32_t)ch.iword;
+        }
         const bool act = prn > 0 && !(KIND == NCO_CARR && fixed);
-        const double s = act ? (KIND == NCO_CARR ? mul_rn(ch.f_carr, p.delt) : mul_rn(ch.f_code, p.delt)) : 0.0;
+        const double s = act ? mul_rn(f_of, p.delt) : 0.0;
         const double ds = act ? lap_drift<KIND>(s) : 0.0;
         /* does this block continue the one before / go on into the next? */
         bool cont_in = false, cont_out = false;
         if (KIND == NCO_CARR && act && L.chained) {
             if (b > 0)
-                cont_in = p.ch[k - p.nch].prn == prn;
+                cont_in = (slim ? p.cd[k - p.nch].prn : p.ch[k - p.nch].prn) == prn;
             else
                 cont_in = p.carry && ((p.cont0_mask >> i) & 1u);
-            cont_out = b + 1 < p.nblocks && p.ch[k + p.nch].prn == prn;
+            cont_out = b + 1 < p.nblocks && (slim ? p.cd[k + p.nch].prn : p.ch[k + p.nch].prn) == prn;
         }
         const bool head = act && !cont_in;
         double start = 0.0;
         if (head)
-            start = KIND == NCO_CARR ? ch.carr_phase : ch.code_phase;
+            start = phase_of;
         if (KIND == NCO_CARR && act && b == 0 && cont_in)
             start = p.carry->exact_end[i]; /* a stream: where the push before this one ended, exactly */
         const bool known = act && (head || (b == 0 && cont_in)); /* the block's first state is known exactly */
@@ -846,10 +864,12 @@ __global__ __launch_bounds__(64) void k_lap_plan(BatchDev p, LapDev L)
             o.s = s;
             o.ds = ds;
             o.flags = (act ? LAPF_ACTIVE : 0u) | (known ? LAPF_HEAD : 0u) | (cont_out ? LAPF_CONT : 0u);
-            o.c0 = KIND == NCO_CODE && act ? (uint32_t)ch.icode + 20u * (uint32_t)ch.ibit + 600u * (uint32_t)ch.iword : 0u;
+            o.c0 = KIND == NCO_CODE && act ? c0_of : 0u;
             bcs[b] = o;
             lane0[b] = lanes_before + incl - nl;
-            if (!act) {
+            if (!act && slim) {
+                p.lap_end[k] = 0.0;
+            } else if (!act) {
                 /* what an idle channel leaves behind (as k_walk) */
                 gpsbb_chan_state_t &e = p.end[k];
                 if (KIND == NCO_CARR) {
@@ -1377,10 +1397,11 @@ __global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L)
         }
     }
     if (lane == 0) {
-        if (KIND == NCO_CARR && p.carry && p.ch[(size_t)(p.nblocks - 1) * p.nch + i].prn > 0 && !p.kph0)
+        const size_t klast = (size_t)(p.nblocks - 1) * p.nch + i;
+        if (KIND == NCO_CARR && p.carry && !p.kph0 && (p.ch ? p.ch[klast].prn : p.cd[klast].prn) > 0)
         {
             /* (approx_end: what the row walks' chain — k_chain_prefix — of a later push starts from, should the stream change sides) */
-            p.carry->exact_end[i] = p.end[(size_t)(p.nblocks - 1) * p.nch + i].carr_phase;
+            p.carry->exact_end[i] = p.lap_end ? p.lap_end[klast] : p.end[klast].carr_phase;
             p.carry->approx_end[i] = p.carry->exact_end[i];
         }
         if (hz_delta)

@@ -336,7 +336,8 @@ int run_shard_feed(gpsbb_node *n, Shard &s)
                 s.fed.pop_front();
                 n->cv.notify_all(); /* room for the feeder */
             }
-            rc = gpsbb_stream_push_ex(s.st, slot.desc.data(), GPSBB_PUSH_NEW_CHAIN);
+            /* (one shard: consecutive slots of one stream, the ring's own chain carries the phase across them) */
+            rc = c.nshards == 1 ? gpsbb_stream_push(s.st, slot.desc.data()) : gpsbb_stream_push_ex(s.st, slot.desc.data(), GPSBB_PUSH_NEW_CHAIN);
             if (rc != GPSBB_OK)
                 return rc;
             flying.emplace_back(slot.slot * bps, slot.nb);
@@ -666,9 +667,10 @@ int feed_slots(gpsbb_node *n, long nslots, long nblocks_in_work)
         slot.nb = (int)nb;
         slot.desc.assign((size_t)bps * nch, gpsbb_chan_t{}); /* (a short last slot is padded with idle blocks) */
         memcpy(slot.desc.data(), n->work.data() + (size_t)b0 * nch, (size_t)nb * nch * sizeof(gpsbb_chan_t));
-        for (int i = 0; i < nch; i++)
-            if (slot.desc[i].prn > 0)
-                slot.desc[i].carr_phase = n->work_seed[(size_t)b0 * nch + i];
+        if (N > 1)
+            for (int i = 0; i < nch; i++)
+                if (slot.desc[i].prn > 0)
+                    slot.desc[i].carr_phase = n->work_seed[(size_t)b0 * nch + i];
         Shard &s = n->shards[(size_t)(n->fed_slots % N)];
         std::unique_lock<std::mutex> lk(n->m);
         n->cv.wait(lk, [&] { return n->stop || s.fed.size() < (size_t)c.depth + 1; });
@@ -689,6 +691,13 @@ int feed_chain(gpsbb_node *n, long nblocks, double *end)
     const gpsbb_node_config_t &c = n->cfg;
     const int nch = c.nch;
     const bool fixed = (c.flags & GPSBB_NODE_FIXED_CARRIER) != 0;
+    if (c.nshards == 1) {
+        /* one shard: its ring chains the carrier from push to push itself (the slots are pushed in order, as a continuing
+         * stream): nothing to chain here */
+        for (int i = 0; i < nch; i++)
+            end[i] = 0.0;
+        return GPSBB_OK;
+    }
     n->work_seed.resize((size_t)nblocks * nch);
     const double t0 = now_s();
     if (fixed) {
@@ -810,7 +819,7 @@ extern "C" int gpsbb_node_feed(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nbl
     if (rc != GPSBB_OK)
         return rc;
     const long used = nslots * bps;
-    for (int i = 0; i < nch; i++) {
+    for (int i = 0; i < nch && c.nshards > 1; i++) { /* (one shard: the ring carries the phase, feed_chain computed nothing) */
         if (used < have) {
             const gpsbb_chan_t &d = n->work[(size_t)used * nch + i];
             n->carry_prn[i] = d.prn > 0 ? d.prn : 0;
@@ -824,7 +833,7 @@ extern "C" int gpsbb_node_feed(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nbl
     }
     n->have_carry = true;
     n->pend.assign(n->work.begin() + (size_t)used * nch, n->work.end());
-    if (used < have) /* the kept first block carries its exact phase itself: it must not be taken for a continuation twice */
+    if (used < have && c.nshards > 1) /* the kept first block carries its exact phase itself: it must not be taken for a continuation twice */
         for (int i = 0; i < nch; i++)
             if (n->pend[i].prn > 0)
                 n->pend[i].carr_phase = n->carry_phase[i];

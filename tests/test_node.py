@@ -367,8 +367,8 @@ def test_gpsbb_sim_over_several_shards_writes_the_same_file(pkg, tmp_path):
 
 def test_gpsbb_sim_feeds_the_node_in_bounded_memory(pkg, tmp_path):
     """gpsbb-sim -G: the front end runs a queue ahead of the rings and no further — the process's peak memory does not grow with
-    the duration (it did: all descriptors up front, 296 bytes x channels per block).  Ten times the signal, the same peak RSS to
-    within a few MB (device scratch that is re-grown once when the Dopplers have grown is the only thing that ever moves it); the first minute of both outputs is the same bytes (a pipe, so that nothing is kept on disk)."""
+    the duration (it did: all descriptors up front, 296 bytes x channels per block).  Five times the signal, the same peak RSS to
+    within a few MB (both runs long enough for every lazily created stream and scratch buffer to exist); the first minute of both outputs is the same bytes (a pipe, so that nothing is kept on disk)."""
     import resource
     pkg.build_frontend()
     exe = os.path.join(os.path.dirname(pkg.LIB_PATH), "gpsbb-sim")
@@ -395,8 +395,9 @@ def test_gpsbb_sim_feeds_the_node_in_bounded_memory(pkg, tmp_path):
         assert int(rc) == 0
         return dig, int(n), int(rss_kb)
     keep = 600 * 26000 * 4          # the first minute
-    d1, n1, rss1 = run(60, keep)
-    d2, n2, rss2 = run(600, keep)
-    assert n1 == 600 * 26000 * 4 and n2 == 6000 * 26000 * 4 and d1 == d2
-    # kB.  Measured: 2 947 336 against 2 947 276; with -C (everything up front) the same pair is 8 MB apart, and grows with -d
-    assert abs(rss2 - rss1) < 4 * 1024, (rss1, rss2)
+    d1, n1, rss1 = run(300, keep)
+    d2, n2, rss2 = run(1500, keep)
+    assert n1 == 3000 * 26000 * 4 and n2 == 15000 * 26000 * 4 and d1 == d2
+    # kB.  Measured on the feed: 3 139 780 (300 s) .. 3 150 096 (2400 s) — the events of the handles' timing rings fill up, then
+    # nothing moves; 12 000 blocks more with all descriptors up front (-C) are + 42 MB (12 ch x 296 B each)
+    assert abs(rss2 - rss1) < 16 * 1024, (rss1, rss2)

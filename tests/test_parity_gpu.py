@@ -877,8 +877,9 @@ def test_carrier_chain_alone_on_the_device(pkg, synth, request):
     bit for bit, gpsbb_chain_carrier_host's sequential walk — start phase of every block and the phase after the last —
     for special steps (no wrap, ties, idle and re-allocated channels), for the bench's own stream, and for more blocks
     than one sub-batch of the device-side chain takes (the carry crosses sub-batches)."""
-    if not request.node.callspec.params["seed_mode"].startswith("k_seed+auto"):
-        pytest.skip("independent of the pre-pass mode")
+    mode = request.node.callspec.params["seed_mode"]
+    if not (mode.startswith("k_seed+auto") or mode == "laps+auto"):  # by the row walks (pass A, prefix, pass B, fix-up) / lap-parallel
+        pytest.skip("independent of the other options")
     sys.path.insert(0, ROOT)
     import bench
     cases = [(_special_chain_descriptors(pkg, 700, 16, 25e6, 17), 25e6, 120000),
@@ -940,7 +941,7 @@ def test_stream_changes_sides_between_pushes(pkg, synth, oracle, request):
     want_iq, want_st, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
     st_ = synth.stream(nch, 1 / fs, nsamp, bps, depth=3, flags=pkg.CHAIN_CARRIER)
     got, gst = [], []
-    plan = [(1, 0), (1, 0), (2, 0), (1, 2), (1, 1), (2, 0), (1, 0), (1, 2)]      # (OPT_SEED_WHERE, OPT_CHAIN_WHERE) per push
+    plan = [(1, 0), (3, 0), (2, 0), (1, 2), (3, 1), (3, 0), (1, 0), (1, 2)]      # (OPT_SEED_WHERE, OPT_CHAIN_WHERE) per push
     for k in range(npush):
         if st_.pending == 3:
             a, b = st_.pop()

@@ -107,6 +107,27 @@ def run_overlapped(pkg, synth, nav, motion, max_chan, fs, nsamp, nblocks, push_b
             "x_realtime_overlapped": nblocks * 0.1 / dt, "front_end_span_blocks": span}
 
 
+def run_node_feed(pkg, nav, motion, max_chan, fs, nsamp, nblocks, push_blocks, span, nshards=1):
+    """RINEX file -> the PRODUCT's node driver, fed incrementally (gpsbb_node_begin / _feed / _end: the front end one queue ahead
+    of the rings, memory independent of the duration), IQ left in HBM, one clock: what `gpsbb-sim -G` does"""
+    fe0 = pkg.FrontEnd(os.path.join(GOLD, nav), llh=SITE, motion=os.path.join(GOLD, motion) if motion else None, max_chan=max_chan)
+    warm = fe0.generate(4 * push_blocks)
+    fe0.close()
+    flags = pkg.NODE_DEVICE_ONLY | pkg.NODE_INDEXED | pkg.NODE_CONCURRENT
+    with pkg.Node(nshards, warm.shape[1], 1.0 / fs, nsamp, push_blocks, depth=6, flags=flags, devices=[0] * nshards) as nd:
+        nd.run(warm, lambda *a: 0)   # rings allocated, kernels loaded
+        t0 = time.perf_counter()
+        fe = pkg.FrontEnd(os.path.join(GOLD, nav), llh=SITE, motion=os.path.join(GOLD, motion) if motion else None, max_chan=max_chan)
+        nd.begin(lambda *a: 0)
+        for _ in range(nblocks // span):
+            nd.feed(fe.generate(span))
+        st = nd.end()
+        dt = time.perf_counter() - t0
+        fe.close()
+    return {"node_feed_s": dt, "node_feed_iq_samples_per_s": nblocks * nsamp / dt, "x_realtime_node_feed": nblocks * 0.1 / dt,
+            "node_feed_shards": nshards, "node_feed_chain_s": st["shards"][0]["seed_seconds"], "node_feed_blocks": st["blocks"]}
+
+
 NB_F = 24000  # 40 minutes of signal: long enough for the ring to reach its steady state (a 3000-block run is over in 13 ms)
 
 
@@ -120,9 +141,11 @@ def main():
         out.append(run(pkg, s, "1/2 static, 2.6 MS/s, reference block (300000 samples)", "synth3540.14n", None, 12,
                        2.6e6, 300000, NB_F, 1000))
         out[-1].update(run_overlapped(pkg, s, "synth3540.14n", None, 12, 2.6e6, 300000, NB_F, 1000, 1000))
+        out[-1].update(run_node_feed(pkg, "synth3540.14n", None, 12, 2.6e6, 300000, NB_F, 1000, 1000))
         out.append(run(pkg, s, "4 user motion (10 Hz), 2.6 MS/s", "synth3540.14n", "circle_motion.csv", 12, 2.6e6,
                        300000, NB_F, 1000))
         out[-1].update(run_overlapped(pkg, s, "synth3540.14n", "circle_motion.csv", 12, 2.6e6, 300000, NB_F, 1000, 1000))
+        out[-1].update(run_node_feed(pkg, "synth3540.14n", "circle_motion.csv", 12, 2.6e6, 300000, NB_F, 1000, 1000))
         out.append(run(pkg, s, "3 geometry through the front end: 16 ch, 25 MS/s, 2.5 M-sample blocks", "dense3540.14n",
                        None, 16, 25e6, 2500000, 400, 100))
     print(json.dumps(out, indent=1))

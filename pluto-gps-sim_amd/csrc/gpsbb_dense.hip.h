@@ -452,17 +452,10 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
         const double *ts = L.tstate[wave][buf];
         const uint32_t dbits = (uint32_t)__ballot(nav_v & 1u), dnext = (uint32_t)__ballot(nav_v & 2u);
         if (pos == 0 && lane == 0)
-#ifdef GPSBB_X_CLAIM_ASM
-            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(pending) : "v"(p.tile_ctr + b), "v"(p.ev_chunk) : "memory");
-#else
             pending = __hip_atomic_fetch_add(p.tile_ctr + b, p.ev_chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
         const bool last_of_chunk = pos + 1 >= p.ev_chunk || wt + 1 >= ntw;
         int next_base = base, next_pos = pos + 1;
         if (last_of_chunk) {
-#ifdef GPSBB_X_CLAIM_ASM
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pending)::"memory");
-#endif
             next_base = __builtin_amdgcn_readfirstlane(pending);
             next_pos = 0;
         }
@@ -526,9 +519,6 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
         /* ---- the low halves of the two sums side by side, store (c:2754-2755): sample wt*TILE + j*64 + lane ---- */
         uint32_t *out = reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + (size_t)wt * TILE + lane;
         const int left = p.nsamp - wt * TILE - lane; /* samples j*64 < left exist */
-#ifdef GPSBB_X_PD_NOSTORE /* (measurement: tools/bound_hunt.sh) */
-        if (__float_as_uint(acc[3].x) == 0x12345678u && __float_as_uint(acc[9].y) == 0x9abcdef0u)
-#endif
         if (__builtin_expect(p.nsamp - wt * TILE >= TILE, 1)) {
 #pragma unroll
             for (int j = 0; j < SPT; j++)

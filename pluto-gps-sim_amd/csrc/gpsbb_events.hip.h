@@ -93,7 +93,7 @@ constexpr int EV_ROW_DISCARD = 15;                 /* D row of changes that fall
  * to be idle: round 3 lost chunks that way once (patched at the call sites with this macro) and round 4 again, as a hang, when
  * one more variable changed the allocation of k_synth_pd.  The claim is an ordinary atomic now: the compiler waits for it where
  * it issues it (it aggregates the wavefront's lanes and needs the value at once), which costs 1.2 % of the kernel
- * (tools/bound_hunt.sh CLAIM_ASM) and depends on nobody's register allocator.  GPSBB_X_CLAIM_ASM: the old way, for measuring. */
+ * (tools/bound_hunt.sh CLAIM_ASM) and depends on nobody's register allocator.  The old way, for measuring: tools/experiments/bound_hunt_variants.patch. */
 #define GPSBB_EV_SETTLE_CLAIM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 /* LDS image of one workgroup.  Two shapes: the mixed kernel (k_synth_ev_dense) needs the long chip table of the channels it
@@ -125,17 +125,9 @@ struct EvLdsT {
                                                     the fma wants it */
     uint16_t chip2[GPSBB_MAX_CHAN][CHIP_LEN];    /* low byte: 0 where codeCA of chip c mod 1023 is +1, 0xff where -1;
                                                     high byte: the same for chip c+1 */
-#ifdef GPSBB_X_ALLLDS
-    double kc[GPSBB_MAX_CHAN][4];                /* (measurement) sc, rsc, S, rS of the block's channels */
-    uint32_t kdanger[GPSBB_MAX_CHAN];
-#endif
 };
 typedef EvLdsT<EV_AMP_STRIDE, EV_CHIP_LEN> EvLds;                   /* k_synth_ev_dense */
-#ifdef GPSBB_X_MASKED
-typedef EvLdsT<EV_AMP_STRIDE, EV_CHIP_LEN> EvLdsLean;
-#else
 typedef EvLdsT<EV_AMP_STRIDE_LONG, EV_CHIP_LEN_SHORT> EvLdsLean;    /* k_synth_ev, k_synth_ev_fixed */
-#endif
 static_assert(sizeof(EvLds) <= 160 * 1024 && sizeof(EvLdsLean) <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
 static_assert(offsetof(EvLdsLean, D) < 65536 && offsetof(EvLds, D) < 65536, "the difference arrays are addressed with a 16-bit offset");
 
@@ -149,10 +141,9 @@ __device__ __forceinline__ T lds_read_at(uint32_t a)
     return *(__attribute__((address_space(3))) const T *)(uintptr_t)a;
 }
 
-/* Measurement builds (tools/bound_hunt.sh): deliberately WRONG variants of k_synth_ev that take one resource out of the
- * picture each (GPSBB_X_NOADD / NOATOMIC / DOUBLEADD: the differences; NOAMP: the table reads; NOSMEM: the scalar loads;
- * NOSTORE / COALESCED: the stores; MOREVALU: more arithmetic), to see what the kernel's time is made of.  Never defined in
- * the product. */
+/* (The measurement variants of this kernel — deliberately WRONG builds that take one resource out of the picture each, to see
+ * what its time is made of: DESIGN.md 3.1 — are not in this file: tools/experiments/bound_hunt_variants.patch puts them into a
+ * scratch copy, tools/bound_hunt.sh builds and times them.) */
 
 typedef uint32_t ev_u32x4 __attribute__((ext_vector_type(4))); /* 16 bytes: one ds_read_b128 / ds_write_b128 / global_store_dwordx4 */
 
@@ -176,27 +167,13 @@ constexpr uint32_t EV_SAT_HI_C = 0x4130000fu; /* the high word of a position cla
 template <class LDS>
 __device__ __forceinline__ void ev_d_add(uint32_t &drow, int wave, uint32_t pos_hi, uint32_t v)
 {
-#if defined(GPSBB_X_NOADD)
-    (void)v;
-#else
     /* volatile, no memory clobber: the differences keep their order among themselves and stay before the fence the
      * tile's epilogue starts with, but the compiler may still issue the next channel's table reads ahead of them */
     asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_0\n\t"
-#if defined(GPSBB_X_NOATOMIC)
-                 "ds_write_b32 %0, %3 offset:%4"
-#else
                  "ds_add_u32 %0, %3 offset:%4"
-#endif
-#if defined(GPSBB_X_DOUBLEADD)
-                 "\n\tds_add_u32 %0, %5 offset:%4"
-#endif
                  : "+v"(drow)
                  : "s"(wave << 4), "v"(pos_hi), "v"(v), "n"(offsetof(LDS, D))
-#if defined(GPSBB_X_DOUBLEADD)
-                   , "v"(0u)
-#endif
                  );
-#endif
 }
 
 /* (x ^ m) - m: x where m = 0, -x where m = -1 */
@@ -292,13 +269,6 @@ template <class LDS>
 __device__ __forceinline__ EvK ev_load_k(const LDS &L, const EvConst *kb, int i)
 {
     EvK k;
-#ifdef GPSBB_X_ALLLDS
-    k.sc = L.kc[i][0];
-    k.rsc = L.kc[i][1];
-    k.S = L.kc[i][2];
-    k.rS = L.kc[i][3];
-    k.danger = L.kdanger[i];
-#else
     /* the record's address as base + (i << 7): one shift, which the two loads take as their scalar offset; the fields in
      * the order of the record (gpsbb_kernels.hip.h), 32 + 16 bytes */
     typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
@@ -311,15 +281,9 @@ __device__ __forceinline__ EvK ev_load_k(const LDS &L, const EvConst *kb, int i)
     k.sc = __hiloint2double((int)a[5], (int)a[4]);
     k.rsc = __hiloint2double((int)a[7], (int)a[6]);
     k.danger = c[0];
-#endif
     if (LDS::UNMASKED) { /* (EvLdsLean: the host put the two table addresses into the record, next to the threshold) */
-#ifdef GPSBB_X_ALLLDS
-        k.chip_base = scalar_load(&kb[i].chip_at);
-        k.amp_base = scalar_load(&kb[i].amp_at);
-#else
         k.chip_base = c[1];
         k.amp_base = c[2];
-#endif
     } else {
         k.chip_base = lds_addr_of(&L.chip2[i][0]) - (EV_GUARD_HI << 1);
         k.amp_base = lds_addr_of(&L.amp[i][0]) - (EV_GUARD_HI << 2);
@@ -377,20 +341,12 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const LDS &L, int i, const EvK &K
         asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(amp_at) : "v"(__double2hiint(y0)), "s"(K.amp_base));
 #pragma unroll
         for (int k = 0; k <= KC; k++)
-#ifdef GPSBB_X_NOAMP
-            h.A[k] = amp_at + k;
-#else
             h.A[k] = lds_read_at<uint32_t>(amp_at + 4u * (uint32_t)k);
-#endif
     } else {
         const uint32_t *ampi = &L.amp[i][it0];
 #pragma unroll
         for (int k = 0; k <= KC; k++)
-#ifdef GPSBB_X_NOAMP
-            h.A[k] = (uint32_t)(it0 + k);
-#else
             h.A[k] = ampi[k];
-#endif
     }
     /* ---- code: chip of the first sample and the sample at which it changes ---- */
     const double x0 = __fma_rn(off, K.sc, xt);
@@ -403,21 +359,8 @@ __device__ __forceinline__ EvHalf<KC> ev_first(const LDS &L, int i, const EvK &K
      * exponent bits a constant that the channel's base already has taken off — no masking instruction */
     uint32_t chip_at;
     asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(chip_at) : "v"(__double2hiint(x0)), "s"(K.chip_base));
-#ifdef GPSBB_X_NOAMP
-    h.ch2 = (uint16_t)chip_at;
-#else
     h.ch2 = lds_read_at<uint16_t>(chip_at);
-#endif
     /* lanes that cannot rule out a disagreement between the model and the reference: one comparison for everything tested */
-#ifdef GPSBB_X_MOREVALU /* eight more f64 operations per channel-run that the compiler cannot drop (about +20 % VALU) */
-    {
-        double z = y0;
-#pragma unroll
-        for (int r = 0; r < 8; r++)
-            asm volatile("v_add_f64 %0, %0, %1" : "+v"(z) : "v"(x0));
-        m = min(m, (uint32_t)__double2loint(z) | 0x80000000u);
-    }
-#endif
     h.um = __builtin_amdgcn_uicmp(m, K.danger, 37 /* ule */);
     return h;
 }
@@ -479,19 +422,11 @@ __device__ __forceinline__ void ev_second(LDS &L, uint32_t &drow, int wave, int 
         const bool before = h.hk[k] < hc; /* the index change comes before the chip change */
         const uint32_t mk = before ? m0 : m1;
         const uint32_t dk = signed_by(h.A[k + 1] - h.A[k], mk);
-#ifdef GPSBB_X_NOSDWA
-        __hip_atomic_fetch_add(&L.D[wave][h.hk[k] & 15u][lane], dk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
         ev_d_add<LDS>(drow, wave, h.hk[k], dk);
-#endif
         Ax = before ? Ax : h.A[k]; /* amplitude in force just before the chip change */
     }
     /* the chip change flips the sign: -s0*A -> s1*A = 2*s1*A more */
-#ifdef GPSBB_X_NOSDWA
-    __hip_atomic_fetch_add(&L.D[wave][hc & 15u][lane], signed_by(Ax << 1, m1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
     ev_d_add<LDS>(drow, wave, hc, signed_by(Ax << 1, m1));
-#endif
 }
 
 /* what a wavefront knows about the tile it is working on */
@@ -501,9 +436,6 @@ struct EvTile {
                              tile_x[c * ntiles] */
     int ntiles;
     uint32_t dbits, dnext; /* bit i: channel i's data bit in force / after the next roll-over is -1 */
-#ifdef GPSBB_X_TSTATE_VMEM
-    uint32_t vzero; /* a zero the compiler cannot see through: makes the address a vector one */
-#endif
 };
 
 /*
@@ -560,25 +492,10 @@ __device__ __forceinline__ void ev_channels(LDS &L, uint32_t &drow, int wave, in
                                             double off, unsigned long long live_mask, uint32_t &acc0, unsigned long long *n_exact,
                                             const EvFixed &fx)
 {
-#ifdef GPSBB_X_TSTATE_VMEM /* (measurement: the same 2 x 16 bytes per channel through the vector memory path — uniform addresses
-                              of the tile-state array and of the channel's record — instead of two LDS broadcasts) */
-#define GPSBB_EV_STATES(i)                                                                                             \
-    const double2 sv##i = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T.tile_x) + T.vzero + (size_t)i * 16);  \
-    const double2 cv##i = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(kb) + T.vzero + (size_t)i * 128 + offsetof(EvConst, tK0)); \
-    const double xt##i = sv##i.x + 0x1p+20, yt##i = sv##i.y + 0x1p+20, tk##i = cv##i.x, tc##i = cv##i.y;
-#elif defined(GPSBB_X_NOTSTATE) /* (measurement: the tile states and position constants out of thin air instead of LDS) */
-#define GPSBB_EV_STATES(i)                                                                                             \
-    const double xt##i = off * 0.25 + (0x1p+20 + 0.37), yt##i = off * 0.125 + (0x1p+20 + 0.41), tc##i = 0x1p+20 + 3.3, tk##i = 0x1p+20 + 5.7;
-#else
 #define GPSBB_EV_STATES(i)                                                                                             \
     const double xt##i = T.ts[2 * i], yt##i = T.ts[2 * i + 1];                                                         \
     const double tc##i = T.ts[2 * GPSBB_MAX_CHAN + 2 * i], tk##i = T.ts[2 * GPSBB_MAX_CHAN + 2 * i + 1];
-#endif
-#ifdef GPSBB_X_NOSMEM
-#define GPSBB_EV_KIDX(i) 0
-#else
 #define GPSBB_EV_KIDX(i) i
-#endif
 #define GPSBB_EV_IN(i)                                                                                                 \
     const EvK K##i = ev_load_k(L, kb, GPSBB_EV_KIDX(i));                                                               \
     GPSBB_EV_STATES(i)
@@ -707,15 +624,6 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         (&L.D[0][0][0])[e] = 0u;
     {
         const int l = tid & 63;
-#ifdef GPSBB_X_ALLLDS
-        if (tid < p.nch) {
-            L.kc[tid][0] = kb[tid].sc;
-            L.kc[tid][1] = kb[tid].rsc;
-            L.kc[tid][2] = kb[tid].S;
-            L.kc[tid][3] = kb[tid].rS;
-            L.kdanger[tid] = kb[tid].danger_le;
-        }
-#endif
         if (l < p.nch) { /* every wavefront's own copy of the position constants (see EvLds::tstate) */
             L.tstate[tid >> 6][1][2 * l] = kb[l].tC0;     /* beside the code state */
             L.tstate[tid >> 6][1][2 * l + 1] = kb[l].tK0; /* beside the carrier state */
@@ -787,10 +695,6 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         EvTile T;
         T.ts = L.tstate[wave][0];
         T.tile_x = txb + wt;
-#ifdef GPSBB_X_TSTATE_VMEM
-        asm volatile("v_mov_b32 %0, 0" : "=v"(T.vzero));
-        T.tile_x = txb + (size_t)wt * nch2; /* (wrong data, right footprint: 16 bytes per channel and tile, tile-major) */
-#endif
         T.ntiles = ntw;
         T.dbits = (uint32_t)__ballot(nav_v & 1u);
         T.dnext = (uint32_t)__ballot(nav_v & 2u);
@@ -802,18 +706,11 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         /* which tile comes next, and its states on their way */
         if (pos == 0 && lane == 0) {
             /* the next chunk (see GPSBB_EV_SETTLE_CLAIM) */
-#ifdef GPSBB_X_CLAIM_ASM
-            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(pending) : "v"(p.tile_ctr + b), "v"(p.ev_chunk) : "memory");
-#else
             pending = __hip_atomic_fetch_add(p.tile_ctr + b, p.ev_chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
         }
         const bool last_of_chunk = pos + 1 >= p.ev_chunk || wt + 1 >= ntw;
         int next_base = base, next_pos = pos + 1;
         if (last_of_chunk) {
-#ifdef GPSBB_X_CLAIM_ASM
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pending)::"memory");
-#endif
             next_base = __builtin_amdgcn_readfirstlane(pending);
             next_pos = 0;
         }
@@ -880,9 +777,6 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         uint32_t *const tile_out = reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + (size_t)wt * TILE;
         const bool whole = (wt + 1) * TILE <= p.nsamp && (reinterpret_cast<uintptr_t>(tile_out) & 15u) == 0; /* wave-uniform */
         asm volatile("" ::: "memory");
-#ifdef GPSBB_X_NOSTORE
-        if (o[3] == 0x12345678u && o[9] == 0x9abcdef0u) /* (practically never) */
-#endif
         if (__builtin_expect(whole, 1)) {
 #pragma unroll
             for (int q = 0; q < 4; q++)

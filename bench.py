@@ -655,7 +655,7 @@ def main():
         m1c, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, pkg.CHAIN_CARRIER, 30, 4, dev)
         m1_alg = 4.0 * mch.shape[0] * 300000
         res["m1"] = {"gpu": m1, "gpu_chained_on_the_device": m1c, "unit": "IQ samples/s",
-                     "roofline": {"bound": "hbm", "kernel": "k_synth_pd", "ms_per_launch": m1["synth_kernel_ms"],
+                     "roofline": {"bound": "valu+lds issue", "priced_against": "hbm", "kernel": "k_synth_pd", "ms_per_launch": m1["synth_kernel_ms"],
                                   "achieved": m1_alg / (m1["synth_kernel_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": m1_alg / (m1["synth_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "alone": {"ms_per_launch": m1s["synth_kernel_ms"],

@@ -427,35 +427,47 @@ __device__ __forceinline__ void lap_emit_row(const BatchDev &p, int i, bool on, 
         return;
     double *__restrict__ tx = p.tile_x + ((size_t)b * (2 * (size_t)p.nch) + 2 * i + KIND) * (size_t)p.ntiles;
     uint32_t *__restrict__ tn = p.tile_nav + ((size_t)b * (size_t)p.nch + i) * (size_t)p.ntiles;
-    /* long rows (slow chains: hundreds of tiles in one row) are written by the whole wavefront, a lane per tile */
-    unsigned long long big = __ballot(cnt > 8);
-    const int lane = (int)__lane_id();
-    while (big) {
-        const int src = __builtin_ctzll(big);
-        big &= big - 1;
-        const int t0 = __builtin_amdgcn_readlane(t, src), c = __builtin_amdgcn_readlane(cnt, src);
-        const int nn = __builtin_amdgcn_readlane(n, src);
-        const double xx = bits_f64(readlane_u64(f64_bits(x), src)), SS = bits_f64(readlane_u64(f64_bits(S), src));
-        const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)bits, src);
-        double *txs = (double *)readlane_u64((uint64_t)tx, src);
-        uint32_t *tns = (uint32_t *)readlane_u64((uint64_t)tn, src);
-        for (int q = lane; q < c; q += 64) {
-            const int tt = t0 + q;
-            const double v = __fma_rn((double)(tt * TILE - nn), SS, xx);
-            txs[tt] = KIND == NCO_CARR ? mul_rn(v, 512.0) : v;
-            if (KIND == NCO_CODE)
-                tns[tt] = bb;
+    /* A turn of the loop below costs the wavefront the same whether one lane or all of them have a tile to write: fine where the
+     * lanes' rows are alike (neighbouring laps of one chain: each has its dozen tiles).  A FEW lanes with very long rows — a slow
+     * chain, hundreds of tiles in one row, beside lanes that have none — are written by the whole wavefront instead, a lane per
+     * tile (which costs ~40 instructions per such row to set up: not worth it for rows every lane has). */
+    unsigned long long big = __ballot(cnt > 24);
+    if (big && __popcll(big) <= 6) {
+        const int lane = (int)__lane_id();
+        while (big) {
+            const int src = __builtin_ctzll(big);
+            big &= big - 1;
+            const int t0 = __builtin_amdgcn_readlane(t, src), c = __builtin_amdgcn_readlane(cnt, src);
+            const int nn = __builtin_amdgcn_readlane(n, src);
+            const double xx = bits_f64(readlane_u64(f64_bits(x), src)), SS = bits_f64(readlane_u64(f64_bits(S), src));
+            const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)bits, src);
+            double *txs = (double *)readlane_u64((uint64_t)tx, src);
+            uint32_t *tns = (uint32_t *)readlane_u64((uint64_t)tn, src);
+            for (int q = lane; q < c; q += 64) {
+                const int tt = t0 + q;
+                const double v = __fma_rn((double)(tt * TILE - nn), SS, xx);
+                txs[tt] = KIND == NCO_CARR ? mul_rn(v, 512.0) : v;
+                if (KIND == NCO_CODE)
+                    tns[tt] = bb;
+            }
+            if (lane == src)
+                cnt = 0;
         }
-        if (lane == src)
-            cnt = 0;
     }
-    for (; __ballot(cnt > 0); t++, cnt--) {
+    /* the state at the row's first tile start, then 1024 steps further per tile: both exact (states of the row: fma(j, S, x) is) */
+    double v = __fma_rn((double)(t * TILE - n), S, x);
+    const double dv = mul_rn(S, (double)TILE); /* exact: a power of two */
+    double *px = tx + t;
+    uint32_t *pn = tn + t;
+    for (; __ballot(cnt > 0); cnt--) {
         if (cnt > 0) {
-            const double v = __fma_rn((double)(t * TILE - n), S, x);
-            tx[t] = KIND == NCO_CARR ? mul_rn(v, 512.0) : v;
+            *px = KIND == NCO_CARR ? mul_rn(v, 512.0) : v;
             if (KIND == NCO_CODE)
-                tn[t] = bits;
+                *pn = bits;
         }
+        v = add_rn(v, dv);
+        px++;
+        pn++;
     }
 }
 
@@ -478,6 +490,10 @@ __device__ __forceinline__ void lap_run(const BatchDev &p, int i, LapLane<KIND> 
     int n = w.n;
     bool go = was, has_wrapped = false;
     while (__ballot(go)) {
+#ifdef GPSBB_LAP_DEBUG /* (how many turns does a wavefront take?  hazards[3] is scratch) */
+        if (__lane_id() == (unsigned)__builtin_ctzll(__ballot(go)))
+            atomicAdd(p.hazards + 3, 1ull);
+#endif
         const uint32_t hi = (uint32_t)__double2hiint(x);
         const int ex = (int)(hi >> 20);
         const int d = ex - es;
@@ -1108,6 +1124,10 @@ __global__ __launch_bounds__(64) void k_lap_scan(BatchDev p, LapDev L)
     const uint32_t nl = L.nlaps[KIND * GPSBB_MAX_CHAN + i];
     const uint32_t nchunks = (nl + LAP_WG - 1) / LAP_WG;
     const uint32_t base = L.chunk0[KIND][i];
+#ifdef GPSBB_LAP_DEBUG
+    if (i == 0 && lane == 0)
+        printf("kind %d: wave-turns so far %llu; laps of channel 0: %u\n", KIND, p.hazards[3], nl);
+#endif
     double m = 0.0; /* the offset of the first lap of chunk q0 (a channel's first lap starts a chain: 0) */
     for (uint32_t q0 = 0; q0 < nchunks; q0 += 64) {
         const uint32_t q = q0 + (uint32_t)lane;

@@ -347,6 +347,15 @@ bool lap_eligible(const gpsbb_chan_t *ch, size_t nbc, double delt, bool fixed)
 
 /* room for the laps of every channel, in chunks of LAP_WG lanes: a chain of n steps of size s wraps at most floor(n * s / range)
  * + 1 times, a block may start a chain (one more lap), and the model's step differs from s by parts in 10^12 */
+/* laps a lane walks (LapDev::unit): what a lane costs besides its walk is about one lap's walk (measured: 17 turns of ~55
+ * vector instructions against ~900 for finding the lap, the model, the scan and the record), so a lane takes a few */
+constexpr int LAP_UNIT_CARR = 4, LAP_UNIT_CODE = 2;
+int lap_unit(int kind)
+{
+    const long u = kind == NCO_CARR ? GPSBB_KNOB_LONG("GPSBB_LAP_UNIT_CARR", LAP_UNIT_CARR) : GPSBB_KNOB_LONG("GPSBB_LAP_UNIT_CODE", LAP_UNIT_CODE);
+    return u < 1 ? 1 : (u > 64 ? 64 : (int)u);
+}
+
 void lap_bound(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int nsamp, bool fixed, uint32_t chunk0[2][GPSBB_MAX_CHAN + 1],
                bool carr_only = false)
 {
@@ -359,7 +368,8 @@ void lap_bound(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int ns
                 if (c.prn <= 0 || (kind == NCO_CARR && fixed) || (kind == NCO_CODE && carr_only))
                     continue;
                 const double s = kind == NCO_CARR ? std::fabs(c.f_carr * delt) : c.f_code * delt * (1.0 / 1023.0);
-                laps += std::floor((double)nsamp * s * (1.0 + 0x1p-30)) + 3.0;
+                /* (wraps, in lanes of `unit` laps, + a head and the rounding) */
+                laps += std::floor((std::floor((double)nsamp * s * (1.0 + 0x1p-30)) + 1.0) / (double)lap_unit(kind)) + 3.0;
             }
             const uint32_t chunks = (uint32_t)((laps + (double)(LAP_WG - 1)) / (double)LAP_WG) + 1u;
             chunk0[kind][i + 1] = chunk0[kind][i] + chunks;
@@ -1879,6 +1889,8 @@ static LapDev lap_dev(const gpsbb_batch *b, int set)
     memcpy(L.chunk0, b->lap_chunk0, sizeof L.chunk0);
     L.chained = b->chain_dev ? 1 : 0;
     L.jitter = (uint32_t)GPSBB_KNOB_LONG("GPSBB_LAP_JITTER", 0);
+    L.unit[NCO_CODE] = lap_unit(NCO_CODE);
+    L.unit[NCO_CARR] = lap_unit(NCO_CARR);
     return L;
 }
 
@@ -3026,7 +3038,7 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
                 for (int i = 0; i < nch; i++) {
                     const ChainDesc &d = c->h_cd[(size_t)(b0 + nb) * nch + i];
                     if (d.prn > 0)
-                        l += std::floor((double)nsamp * std::fabs(d.f_carr * delt)) + 3.0;
+                        l += std::floor((std::floor((double)nsamp * std::fabs(d.f_carr * delt)) + 1.0) / (double)lap_unit(NCO_CARR)) + 3.0;
                 }
                 if (nb > 0 && laps + l > CHAIN_ONLY_LAPS)
                     break;
@@ -3058,6 +3070,8 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
             L.chunk_bad = c->d_lap_chunk_bad.p;
             L.chained = 1;
             L.jitter = (uint32_t)GPSBB_KNOB_LONG("GPSBB_LAP_JITTER", 0);
+            L.unit[NCO_CODE] = lap_unit(NCO_CODE);
+            L.unit[NCO_CARR] = lap_unit(NCO_CARR);
             BatchDev p;
             memset(&p, 0, sizeof p);
             p.nblocks = nb;

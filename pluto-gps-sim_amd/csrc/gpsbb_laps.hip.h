@@ -105,6 +105,9 @@ struct LapDev {
     uint32_t chunk0[2][GPSBB_MAX_CHAN + 1]; /* first chunk of each channel's range (host plan: lap_bound) */
     int chained;         /* GPSBB_CHAIN_CARRIER is in force (blocks continue each other) */
     uint32_t jitter;     /* experiments: reference states are pushed off by up to this many grid steps (exercises the repair) */
+    int unit[2];         /* laps per lane, per kind: a lane walks `unit` consecutive laps of its chain (up to the next lane's first
+                            sample): what a lane costs besides its walk — finding its lap, the model, the scan, its record — is as
+                            much as one lap's walk, so several laps share it (1: a lane per lap) */
 };
 
 template <int KIND>
@@ -281,7 +284,8 @@ __device__ __forceinline__ LapStart lap_start(const BatchDev &p, const LapDev &L
         st.A = bc.phi;
         return st;
     }
-    const uint32_t jw = j - ((bc.flags & LAPF_HEAD) ? 1u : 0u); /* the jw-th wrap inside the block */
+    /* lane j of the block (after its head) starts at the block's wrap number jw = unit * (j - head), 0-based */
+    const uint32_t jw = (j - ((bc.flags & LAPF_HEAD) ? 1u : 0u)) * (uint32_t)L.unit[KIND];
     const double s = bc.s, sbar = s + bc.ds;
     const bool neg = s < 0.0;
     const double range = KIND == NCO_CARR ? 1.0 : 1023.0;
@@ -377,11 +381,13 @@ struct LapLane {
     uint32_t hz;       /* hazards met: carrier, samples whose phase is exactly 1.0; code, data-bit fetches past dwrd[59] */
     uint32_t bcflags;
     int outcome;
-    int eo1, eo2, eo3; /* pass 1: what the closing wrap adds to an offset that is 1, 2, 3 mod 4, on top of the translation */
     int so;            /* pass 1: what the first step in the top binade adds to an odd offset, where the step ties on that binade's grid */
     bool tt;           /* the block's step ties on the grid of the top binade ([0.5, 1) / [512, 1024)): every sum there is half-way */
     bool active, neg;
     bool fresh;        /* code: the walk starts on the first sample after a roll-over (whose data-bit fetch is this lap's to count) */
+    bool one_lap;      /* stop at the first wrap wherever it falls (the repair's walks; a lane otherwise goes on through the wraps
+                          inside its territory: it holds several laps, LapDev::unit) */
+    LapMap acc;        /* pass 1: what the wraps and top-binade entries so far do to an offset, besides carrying it along */
 };
 
 /* the data bits of code period c of a channel (c:2717-2733): bit 0: the bit in force is -1; bit 1: the one in force after the
@@ -488,7 +494,7 @@ __device__ __forceinline__ void lap_run(const BatchDev &p, int i, LapLane<KIND> 
     const bool any_tt = TIES && __ballot(was && w.tt) != 0ull;
     double x = w.x;
     int n = w.n;
-    bool go = was, has_wrapped = false;
+    bool go = was, last_wrapped = false;
     while (__ballot(go)) {
 #ifdef GPSBB_LAP_DEBUG /* (how many turns does a wavefront take?  hazards[3] is scratch) */
         if (__lane_id() == (unsigned)__builtin_ctzll(__ballot(go)))
@@ -556,15 +562,16 @@ __device__ __forceinline__ void lap_run(const BatchDev &p, int i, LapLane<KIND> 
             xw = add_rn(x2, -1023.0); /* c:2711-2712 */
         }
         wrapped = wrapped && step;
-        if (TIES && KIND == NCO_CARR && __ballot(wrapped)) {
-            if (wrapped && SNEG) {
+        if ((TIES || KIND == NCO_CODE) && __ballot(wrapped)) {
+            int eo1 = 0, eo2 = 0, eo3 = 0; /* what this wrap adds to an offset that is 1, 2, 3 mod 4, on top of carrying it along */
+            if (TIES && KIND == NCO_CARR && wrapped && SNEG) {
                 /* was x2 + 1.0 exactly half-way between two multiples of 2^-53?  (Fast2Sum: both differences are exact.)  It then went
                  * to the even one; a trajectory an odd number of grid steps away goes to the other side of ITS half-way point */
                 const double err = add_rn(add_rn(xw, -1.0), -x2);
                 if (fabs(err) == 0x1p-54)
-                    w.eo1 = w.eo3 = err < 0.0 ? 1 : -1;
+                    eo1 = eo3 = err < 0.0 ? 1 : -1;
             }
-            if (wrapped && !SNEG) {
+            if (TIES && KIND == NCO_CARR && wrapped && !SNEG) {
                 /* The sum that passes 1.0 is rounded on the grid of [1, 2): 2^-52, two units.  A rising chain's offsets are even — its
                  * post-wrap states are multiples of 2^-52 — except in the lap in which a falling phase turned round (the step changed
                  * sign with the block): an odd offset then comes out one unit further or nearer, by the side of the grid point the
@@ -572,13 +579,35 @@ __device__ __forceinline__ void lap_run(const BatchDev &p, int i, LapLane<KIND> 
                  * wrap: it went to the even grid point; two units further on (an offset that is 2 mod 4) the even one is the other. */
                 const double err = add_rn(add_rn(x2, -x1), -s); /* the sum as rounded minus the exact sum, within a unit (2^-53) */
                 if (err != 0.0) {
-                    w.eo1 = w.eo3 = err < 0.0 ? 1 : -1;
-                    w.eo2 = fabs(err) == 0x1p-53 ? (err < 0.0 ? 2 : -2) : 0;
+                    eo1 = eo3 = err < 0.0 ? 1 : -1;
+                    eo2 = fabs(err) == 0x1p-53 ? (err < 0.0 ? 2 : -2) : 0;
                 } else {
                     /* the sum is a grid point a: an odd offset lands half-way between two and takes the even one */
                     const bool a_even = !(__double2loint(x2) & 1);
-                    w.eo1 = a_even ? -1 : 1;
-                    w.eo3 = a_even ? 1 : -1;
+                    eo1 = a_even ? -1 : 1;
+                    eo3 = a_even ? 1 : -1;
+                }
+            }
+            if (TIES && wrapped && (eo1 | eo2 | eo3 | w.so)) {
+                /* this lap's part of the link: first the step into / in the top binade (so), then the wrap */
+                LapMap F = lap_identity(), E = lap_identity();
+                F.o1 = F.o3 = w.so;
+                E.o1 = eo1;
+                E.o2 = eo2;
+                E.o3 = eo3;
+                w.acc = lap_compose(E, lap_compose(F, w.acc));
+                w.so = 0;
+            }
+            if (KIND == NCO_CODE && wrapped) {
+                /* a code period is over (c:2714-2733): the data bits of the next one, should the lane go on into it — and its
+                 * roll-over's data-bit fetch (past dwrd[59]?  the fetch of the roll-over that ENDS the lane's walk is the next lane's
+                 * to count, or — on a block's last step — lap_walk's) */
+                w.jc++;
+                if (n1 + 1 < nmax && !w.one_lap) {
+                    const uint32_t c = w.c0 + w.jc;
+                    w.bits = lap_code_bits(p.ch[(size_t)w.b * p.nch + i].dwrd, c);
+                    if (c % 20u == 0u && c / 600u >= (uint32_t)GPSBB_N_DWRD)
+                        w.hz++;
                 }
             }
         }
@@ -596,19 +625,17 @@ __device__ __forceinline__ void lap_run(const BatchDev &p, int i, LapLane<KIND> 
             x = step ? (wrapped ? xw : x2) : x1;
             n = step ? n1 + 1 : n1;
         }
-        has_wrapped = has_wrapped || wrapped;
-        go = go && !wrapped && n < nmax;
+        last_wrapped = go ? wrapped : last_wrapped;
+        /* a lane holds several laps (LapDev::unit): a wrap inside its territory is just another step */
+        go = go && n < nmax && !(wrapped && w.one_lap);
     }
     if (was) {
         w.x = x;
         w.n = n;
-        if (has_wrapped) {
+        if (last_wrapped)
             w.outcome = LAP_OUT_WRAP;
-            if (KIND == NCO_CODE)
-                w.jc++;
-        } else if (w.b == w.bt) {
+        else if (w.b == w.bt)
             w.outcome = LAP_OUT_LATE;
-        }
     }
 }
 
@@ -650,8 +677,8 @@ template <int KIND, bool EMIT, bool TIES>
 __device__ __forceinline__ void lap_walk(const BatchDev &p, const LapDev &L, int i, LapLane<KIND> &w)
 {
     w.outcome = 0;
-    w.eo1 = w.eo2 = w.eo3 = 0;
     w.so = 0;
+    w.acc = lap_identity();
     w.hz = 0;
     if (w.active && w.b >= p.nblocks) { /* (a plan that put a lap past the last block: its link will not hold) */
         w.outcome = LAP_OUT_LATE;
@@ -864,7 +891,7 @@ __global__ __launch_bounds__(64) void k_lap_plan(BatchDev p, LapDev L)
             /* rising: the levels reached; falling: the levels passed (floor of the unwrapped phase either way) */
             int W = s < 0.0 ? -eK : eK;
             W = W < 0 ? 0 : W;
-            nl = (uint32_t)W + (head || known ? 1u : 0u);
+            nl = ((uint32_t)W + (uint32_t)L.unit[KIND] - 1u) / (uint32_t)L.unit[KIND] + (head || known ? 1u : 0u);
         }
         /* lanes: an exclusive sum over the blocks */
         uint32_t incl = nl;
@@ -989,9 +1016,10 @@ __device__ __forceinline__ LapLane<KIND> lap_lane(bool on, double x, int32_t b, 
     w.hz = 0;
     w.bcflags = 0;
     w.outcome = 0;
-    w.eo1 = w.eo2 = w.eo3 = 0;
     w.so = 0;
     w.tt = false;
+    w.one_lap = false;
+    w.acc = lap_identity();
     w.active = on;
     w.neg = false;
     w.fresh = true;
@@ -1006,7 +1034,10 @@ __device__ __forceinline__ uint32_t lap_jc_of(const BatchDev &p, const LapDev &L
     if (KIND != NCO_CODE)
         return 0u;
     const uint32_t *lane0 = L.lane0 + ((size_t)KIND * p.nch + i) * ((size_t)p.nblocks + 1);
-    return r - lane0[b_start]; /* every code block starts a chain: lane 0 of the block is its head, lane j its j-th wrap */
+    /* every code block starts a chain: lane 0 of the block is its head (no period completed yet), lane j >= 1 starts with the
+     * block's wrap number unit * (j - 1), 0-based: that many + 1 periods are over */
+    const uint32_t j = r - lane0[b_start];
+    return j == 0 ? 0u : (j - 1u) * (uint32_t)L.unit[KIND] + 1u;
 }
 
 /* the link a reference walk leaves: how the offset of the NEXT lap follows from this lap's */
@@ -1018,16 +1049,9 @@ __device__ __forceinline__ LapMap lap_link(const LapLane<KIND> &w, bool mine, bo
     if (has_next && w.outcome == LAP_OUT_WRAP && w.b == nb && w.n == nn0) {
         const double g = (w.x - A_next) * lap_runit<KIND>(); /* exact: both on the grid, close together */
         if (fabs(g) < 0x1p+50 && g == __builtin_rint(g)) {
-            LapMap E = lap_identity(); /* the translation through the lap and what its closing wrap adds */
-            E.g = g;
-            E.o1 = w.eo1;
-            E.o2 = w.eo2;
-            E.o3 = w.eo3;
-            if (!w.so)
-                return E;
-            LapMap S = lap_identity(); /* the lap's first step in the top binade, where the step ties on its grid */
-            S.o1 = S.o3 = w.so;
-            return lap_compose(E, S);
+            LapMap T = lap_identity(); /* carried along through the lane's laps, and what their wraps and top-binade entries add */
+            T.g = g;
+            return lap_compose(T, w.acc);
         }
     }
     return lap_const(0.0); /* (a head follows, the chain ended, or the walk did not end where the plan says: the next lap's offset is a guess, 0) */
@@ -1307,6 +1331,7 @@ __global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L)
                     /* one more lap (or what is left of the territory after a late end), from the truth, to its end wherever that is */
                     LapLane<KIND> v = lap_lane<KIND>(lane == 0, cx, cb, cn, cjc, false, 0, 0);
                     v.fresh = cout == LAP_OUT_WRAP;
+                    v.one_lap = true;
                     lap_walk<KIND, true, false>(p, L, i, v);
                     n_rewalked++;
                     hz_delta += (long long)__builtin_amdgcn_readlane((int)v.hz, 0);

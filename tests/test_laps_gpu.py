@@ -149,7 +149,7 @@ def test_laps_across_blocks_and_turning_carriers(pkg, fresh, oracle):
 
 @pytest.mark.parametrize("args,jitter,at_least", [(["--stream", "--cases", "10", "--seed", "31", "--budget", "2e7", "--also-batch"], 4000000000, 20),
                                                  (["--stream", "--cases", "8", "--seed", "32", "--budget", "2e7", "--low-rate"], 4000000000, 20),
-                                                 (["--ev", "--cases", "60", "--seed", "33"], 1000000, 20),
+                                                 (["--ev", "--cases", "120", "--seed", "33"], 1000000000, 20),
                                                  # (slow carriers, short blocks: few laps, so few links to break)
                                                  (["--stream", "--ties", "--cases", "8", "--seed", "34", "--budget", "2e7"], 4000000000, 3)])
 def test_the_repair_path_made_common(pkg, args, jitter, at_least):

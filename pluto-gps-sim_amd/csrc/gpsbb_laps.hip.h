@@ -68,11 +68,12 @@ constexpr uint32_t ST_LAP_PLAN = 8u; /* status word: more laps than the host pla
 struct LapBC {
     double phi;     /* model state at the block's first sample (a head: the exact start state) */
     double s;       /* the step, fl(f * delt) (c:2709 / c:2741) */
-    double ds;      /* mean rounding drift per step: the model advances by s + ds per sample */
+    double R1;      /* the model's rounding drift over one whole lap with this step (lap_R at the top of the range) */
+    double Rphi;    /* ... and from 0 up to phi */
     uint32_t flags; /* LAPF_* */
     uint32_t c0;    /* code: code periods at the block's first sample, icode + 20*ibit + 600*iword */
 };
-static_assert(sizeof(LapBC) == 32, "LapBC layout");
+static_assert(sizeof(LapBC) == 40, "LapBC layout");
 
 /* one lap, written by pass 1, read by pass 2 and the repair */
 struct LapRec {
@@ -223,26 +224,35 @@ __device__ __forceinline__ LapMap lap_wave_scan(LapMap acc, int lane)
 
 /* ---- the model ---------------------------------------------------------------------------------------------- */
 
-/* mean rounding drift per step of the recurrence x = fl(x + s): while x is in binade e a step adds s rounded to a
- * multiple of that binade's last place (gpsbb_nco.h), and a lap spends the fraction 2^e / range of its steps there */
+/* The model: rounding drift of the recurrence x = fl(x + s).  While x is in binade e a step adds not s but s rounded to a
+ * multiple of that binade's last place, S_e (gpsbb_nco.h): a drift of S_e - s per step, i.e. of (S_e - s) / |s| per unit of phase
+ * travelled there.  R(x) is that density integrated from 0 to x (piecewise linear, one piece per binade from the step's own up
+ * to the top one; nothing below: those steps are exact), R1 = R(range) the drift of a whole lap.  n steps from x0 then end at
+ *     x0 + n*s + D,   D = wraps * R1 + R(end) - R(x0)  (rising)  /  wraps * R1 + R(x0) - R(end)  (falling)
+ * — the host's CarrDrift (gpsbb.hip) is the same model.  What it leaves out (the roundings of the steps that cross a binade
+ * edge, that a binade holds a whole number of steps) averages out: a few 1e-15 per block.  The walks are exact whatever the
+ * model says; a poor model only makes reference laps start further from the truth, and links break more often. */
 template <int KIND>
-__device__ __forceinline__ double lap_drift(double s)
+__device__ __forceinline__ double lap_R(double s, double x, double &R1)
 {
     const int es = (int)((f64_bits(s) >> 52) & 0x7ff);
     const int etop = KIND == NCO_CARR ? 1022 : 1023 + 9; /* the top binade: [0.5, 1) / [512, 1024) */
-    double ds = 0.0;
+    double R = 0.0;
+    R1 = 0.0;
     if (es < 1023 - 60 || es > etop)
         return 0.0;
+    const double rs = 1.0 / fabs(s);
     for (int e = es; e <= etop; e++) {
         const double C = bits_f64(((uint64_t)e << 52) | (1ull << 51)); /* 1.5 * 2^e */
         const double S = add_rn(add_rn(s, C), -C);
-        const double w = bits_f64((uint64_t)e << 52); /* 2^e: the width of the binade */
-        double frac = KIND == NCO_CARR ? w : w * (1.0 / 1023.0);
-        if (KIND == NCO_CODE && e == etop)
-            frac = 511.0 / 1023.0;
-        ds += frac * add_rn(S, -s);
+        const double dens = add_rn(S, -s) * rs;
+        const double lo = bits_f64((uint64_t)e << 52); /* the binade: [2^e, 2^(e+1)), the code's top one: [512, 1023) */
+        const double w = KIND == NCO_CODE && e == etop ? 511.0 : lo;
+        R1 += w * dens;
+        const double in = x - lo;
+        R += (in <= 0.0 ? 0.0 : (in < w ? in : w)) * dens;
     }
-    return ds;
+    return R;
 }
 
 /* where a lap starts, by the model */
@@ -286,7 +296,9 @@ __device__ __forceinline__ LapStart lap_start(const BatchDev &p, const LapDev &L
     }
     /* lane j of the block (after its head) starts at the block's wrap number jw = unit * (j - head), 0-based */
     const uint32_t jw = (j - ((bc.flags & LAPF_HEAD) ? 1u : 0u)) * (uint32_t)L.unit[KIND];
-    const double s = bc.s, sbar = s + bc.ds;
+    const double s = bc.s;
+    const double range_ = KIND == NCO_CARR ? 1.0 : 1023.0;
+    const double sbar = s + fabs(s) * bc.R1 * (1.0 / range_); /* the mean step, drift included: for the estimate of n0 only */
     const bool neg = s < 0.0;
     const double range = KIND == NCO_CARR ? 1.0 : 1023.0;
     const double level = (double)(jw + 1) * range; /* exact */
@@ -300,7 +312,10 @@ __device__ __forceinline__ LapStart lap_start(const BatchDev &p, const LapDev &L
         /* A = phi + n0*sbar -/+ level, with the product in two pieces (the model has to be good to ~1e-15) */
         const double nd = (double)n0;
         const double hi = nd * s;
-        const double lo = __fma_rn(nd, s, -hi) + nd * bc.ds;
+        /* ... and the drift up to there: a post-wrap state is the end of jw + 1 whole laps but for the stretch from 0 up to
+         * phi (rising: not travelled) / from phi down to 0 (falling: travelled on top of jw whole laps) */
+        const double D = neg ? (double)jw * bc.R1 + bc.Rphi : (double)(jw + 1u) * bc.R1 - bc.Rphi;
+        const double lo = __fma_rn(nd, s, -hi) + D;
         A = ((neg ? hi + level : hi - level) + bc.phi) + lo;
         if (it)
             break;
@@ -732,6 +747,11 @@ __device__ __forceinline__ void lap_walk(const BatchDev &p, const LapDev &L, int
                     if (goes_on) {
                         w.b++; /* canonical position of the next lap's first sample: (b + 1, 0) */
                         w.n = 0;
+                        if (!(w.b == w.bt && w.nt == 0) && !w.one_lap) {
+                            /* a wrap on a block's last step INSIDE the lane's territory (a lane holds several laps): on it goes */
+                            w.outcome = 0;
+                            lap_enter_block<KIND>(p, L, i, w);
+                        }
                     } else {
                         w.outcome = LAP_OUT_CHAIN; /* the chain ends with a wrap on its last step: no lap follows */
                     }
@@ -766,7 +786,7 @@ __device__ __forceinline__ LapScanEl lap_scan_combine(const LapScanEl &left, con
     return r;
 }
 
-/* the model's advance over n steps of step s + ds, as whole laps and a fraction in [0, range) */
+/* the model's advance over n steps of step s with a drift of ds per step, as whole laps and a fraction in [0, range) */
 __device__ __forceinline__ void lap_advance(double s, double ds, int n, double range, int &K, double &f)
 {
     const double nd = (double)n;
@@ -804,6 +824,7 @@ __global__ __launch_bounds__(64) void k_lap_plan(BatchDev p, LapDev L)
     carry.K = 0;
     carry.phi = 0.0;
     uint32_t lanes_before = 0;
+    double carry_c = 0.0; /* the chain's drift corrections up to the first block of the group (see c_own below) */
     if (KIND == NCO_CODE && i == 0)
         for (int b = lane; b < p.nblocks; b += 64)
             p.tile_ctr[b] = 0;
@@ -829,7 +850,13 @@ __global__ __launch_bounds__(64) void k_lap_plan(BatchDev p, LapDev L)
         }
         const bool act = prn > 0 && !(KIND == NCO_CARR && fixed);
         const double s = act ? mul_rn(f_of, p.delt) : 0.0;
-        const double ds = act ? lap_drift<KIND>(s) : 0.0;
+        /* the drift of one whole lap with this step, and — first — the model as if a block's drift were its share of that by the
+         * samples it holds (linear in the sample count: what the scan below can add up); the stretch of a lap a block starts and
+         * ends with is put right after it */
+        double R1 = 0.0;
+        if (act)
+            (void)lap_R<KIND>(s, 0.0, R1);
+        const double ds = fabs(s) * R1 * (1.0 / range);
         /* does this block continue the one before / go on into the next? */
         bool cont_in = false, cont_out = false;
         if (KIND == NCO_CARR && act && L.chained) {
@@ -874,8 +901,53 @@ __global__ __launch_bounds__(64) void k_lap_plan(BatchDev p, LapDev L)
                 acc = lap_scan_combine(prev, acc, range);
         }
         acc = lap_scan_combine(carry, acc, range);
-        /* acc = the model state at block b's first sample, as (laps since the chain's first sample, fraction) */
-        const double phi = known ? start : acc.phi;
+        /* acc = the model state at block b's first sample, as (laps since the chain's first sample, fraction) — to first order.
+         * What a block really drifts by is not its share of whole laps' drift: it starts and ends somewhere INSIDE a lap, and the
+         * drift per step depends on the binade the phase is in (a slow carrier's block covers a fraction of one lap, all of it
+         * in one or two binades).  c = the block's drift by the model (lap_R) minus its linear share, from the first-order start
+         * phase (the difference this makes to c is of second order); a second scan sums the c of the chain's blocks so far. */
+        const double phi0 = known ? start : acc.phi;
+        double c_own = 0.0;
+        if (act) {
+            int k0 = 0;
+            double f0 = 0.0, r1 = 0.0;
+            lap_advance(s, ds, p.nsamp, range, k0, f0);
+            double xe = (phi0 >= range ? 0.0 : phi0) + f0; /* where the block ends, first order */
+            int wraps = s < 0.0 ? -k0 : k0;
+            if (xe >= range) {
+                xe -= range;
+                wraps += s < 0.0 ? -1 : 1;
+            }
+            const double Rs = lap_R<KIND>(s, phi0 >= range ? range : phi0, r1), Re = lap_R<KIND>(s, xe, r1);
+            const double Dtrue = (double)(wraps < 0 ? -wraps : wraps) * R1 + (s < 0.0 ? Rs - Re : Re - Rs);
+            c_own = Dtrue - (double)p.nsamp * ds;
+        }
+        /* exclusive segmented sum of c over the chain's blocks before this one (lane - 1's c: shifted in) */
+        double cs = __shfl_up(c_own, 1);
+        int cf = el.reset; /* a block whose start is known starts the sum afresh */
+        cs = (lane == 0 || el.reset) ? 0.0 : cs;
+        /* (the c of the last block of the group before this one travels in carry_c) */
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double vu = __shfl_up(cs, off);
+            const int fu = __shfl_up(cf, off);
+            if (lane >= off) {
+                cs = cf ? cs : cs + vu;
+                cf = cf | fu;
+            }
+        }
+        const double corr = cf ? cs : cs + carry_c;
+        double phi = known ? start : acc.phi + corr;
+        int dK = 0; /* (a correction across a lap boundary moves the block's lap count by one) */
+        if (!known && phi >= range) {
+            phi -= range;
+            dK = 1;
+        }
+        if (!known && phi < 0.0) {
+            phi += range;
+            dK = -1;
+        }
+        (void)dK;
         /* where the block ends — or, for a chain's last block, where its last step starts: a wrap on that step starts no lap */
         int eK = 0;
         double ef = 0.0;
@@ -883,10 +955,14 @@ __global__ __launch_bounds__(64) void k_lap_plan(BatchDev p, LapDev L)
         if (act) {
             const bool to_end = KIND == NCO_CARR && cont_out;
             lap_advance(s, ds, to_end ? p.nsamp : p.nsamp - 1, range, eK, ef);
-            double f = (known && start >= range ? 0.0 : phi) + ef;
+            double f = (known && start >= range ? 0.0 : phi) + ef + c_own;
             if (f >= range) {
                 f -= range;
                 eK++;
+            }
+            if (f < 0.0) {
+                f += range;
+                eK--;
             }
             /* rising: the levels reached; falling: the levels passed (floor of the unwrapped phase either way) */
             int W = s < 0.0 ? -eK : eK;
@@ -905,7 +981,11 @@ __global__ __launch_bounds__(64) void k_lap_plan(BatchDev p, LapDev L)
             LapBC o;
             o.phi = phi;
             o.s = s;
-            o.ds = ds;
+            o.R1 = R1;
+            {
+                double r1 = 0.0;
+                o.Rphi = act ? lap_R<KIND>(s, phi >= range ? range : phi, r1) : 0.0;
+            }
             o.flags = (act ? LAPF_ACTIVE : 0u) | (known ? LAPF_HEAD : 0u) | (cont_out ? LAPF_CONT : 0u);
             o.c0 = KIND == NCO_CODE && act ? c0_of : 0u;
             bcs[b] = o;
@@ -935,6 +1015,7 @@ __global__ __launch_bounds__(64) void k_lap_plan(BatchDev p, LapDev L)
         adv.K = __shfl(aK, 63);
         adv.phi = __shfl(af, 63);
         carry = lap_scan_combine(last, adv, range);
+        carry_c = __shfl(corr + c_own, 63);
     }
     if (lane == 0) {
         lane0[p.nblocks] = lanes_before;

@@ -662,7 +662,7 @@ def main():
                                             "frac": m1_alg / (m1s["synth_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                                   "bound_measured": "valu+lds issue",
                                   "note": "VALU- and LDS-issue-bound (about 27 VALU issue cycles and 12 bytes of LDS reads per channel-sample), not HBM-bound: "
-                                          "DESIGN.md 2.7; the stores cost it 7 % (tools/bound_hunt.sh PD_NOSTORE)"},
+                                          "DESIGN.md 2.4; the stores cost it 7 % (tools/bound_hunt.sh PD_NOSTORE)"},
                      "workload": "12 ch, fs 2.6e6 S/s, 300000-sample blocks, 1000 independent blocks per step; synthesis kernel " + m1_kernel}
         # the reference built without FLOAT_CARR_PHASE (h:12): 32-bit fixed-point carrier, the same M1 geometry
         fch = mch.copy()

@@ -154,7 +154,7 @@ uint64_t row_bound(double s_abs, double range, int top_e, int nsamp)
 
 /*
  * Where a carrier will be n steps on, to ~1e-14 cycles, WITHOUT walking it: the phase pass B of the device-side chain
- * starts a segment from (DESIGN.md 2.4).  The reference's recurrence x = fl(x + s) does not advance by s per step but,
+ * starts a segment from (DESIGN.md 2.5).  The reference's recurrence x = fl(x + s) does not advance by s per step but,
  * while x is in binade e, by s rounded to a multiple of that binade's last place (gpsbb_nco.h): a drift of
  * delta_e = RN(s / ulp_e) * ulp_e - s per step, i.e. of delta_e / |s| per unit of phase travelled there.  R(x) is that
  * density integrated from 0 to x (piecewise linear, one piece per binade from s's own up to [0.5, 1)); a path of
@@ -1065,7 +1065,10 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
      * 0.25 against 0.33 ms per gpsbb_fill_block of the reference's geometry) — so where it is eligible the size decides nothing. */
     const bool lap_ok = b->ev && h->opt_seed_where != 1 && h->opt_seed_where != 2 && h->opt_chain_where != 2 && h->opt_chain_where != 3 &&
                         !GPSBB_KNOB_SET("GPSBB_NO_LAPS") && lap_eligible(ch, nbc, delt, fixed);
-    b->host_seed = !lap_ok && host_seeding_wanted(b);
+    /* (a stream's push that was promised the device-side chain — b->d_carry: decided in gpsbb_stream_push on what it can see of
+     * the descriptors, before the kernel plan exists — stays on the device whatever the size: the row walks where the laps
+     * decline, e.g. a rate only the per-sample kernel renders) */
+    b->host_seed = !lap_ok && !b->d_carry && host_seeding_wanted(b);
     b->laps = lap_ok;
     const bool chained = !fixed && (flags & GPSBB_CHAIN_CARRIER) && (nblocks > 1 || b->d_carry);
     b->chain_dev = chained && h->opt_chain_where != 1 && !b->host_seed;

@@ -967,6 +967,10 @@ __global__ __launch_bounds__(64) void k_lap_plan(BatchDev p, LapDev L)
             /* rising: the levels reached; falling: the levels passed (floor of the unwrapped phase either way) */
             int W = s < 0.0 ? -eK : eK;
             W = W < 0 ? 0 : W;
+            /* (never more laps than samples they could start at: a one-sample block that does not go on has none but its head's,
+             * whatever the model makes of a phase of exactly 0 that falls) */
+            const int wmax = to_end ? p.nsamp : p.nsamp - 1;
+            W = W > wmax ? wmax : W;
             nl = ((uint32_t)W + (uint32_t)L.unit[KIND] - 1u) / (uint32_t)L.unit[KIND] + (head || known ? 1u : 0u);
         }
         /* lanes: an exclusive sum over the blocks */
@@ -1363,6 +1367,10 @@ __global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L)
     if (L.nbad[KIND * GPSBB_MAX_CHAN + i] != 0) {
         const uint32_t nchunks = (nl + LAP_WG - 1) / LAP_WG;
         uint32_t from = 0; /* laps before this one are settled */
+        /* laps below this one may hold what a group of step 3 wrote BEYOND a link that broke inside the group (walks from starts
+         * that were not the truth, into their own territories): what pass 2 left there is gone, so "as pass 2 had it" settles
+         * nothing for them — they are done again whatever the state they start from */
+        uint32_t dirty_end = 0;
         for (;;) {
             /* the next broken link at or after `from` */
             uint32_t bad = nl;
@@ -1382,6 +1390,10 @@ __global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L)
             n_links++;
             /* the lap that leaves the broken link, again, from its true start (it wrote the truth already: no need to write) */
             LapRec rb = recs[bad];
+#ifdef GPSBB_LAP_DEBUG
+            if (lane == 0)
+                printf("repair kind %d ch %d: bad link %u of %u (from %u) start (%d,%d) A %.17g g %.0f flags %x\n", KIND, i, bad, nl, from, rb.b, rb.n0, rb.A, rb.g, rb.flags);
+#endif
             bool hn = bad + 1 < nl && !(recs[bad + 1 < nl ? bad + 1 : bad].flags & LAPF_HEAD);
             LapRec rn = recs[bad + 1 < nl ? bad + 1 : bad];
             LapLane<KIND> w = lap_lane<KIND>(lane == 0, (rb.flags & LAPF_HEAD) ? rb.A : __fma_rn(rb.g, lap_unit<KIND>(), rb.A), rb.b, rb.n0,
@@ -1422,6 +1434,10 @@ __global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L)
                     cout = __builtin_amdgcn_readlane(v.outcome, 0);
                     cjc = KIND == NCO_CODE ? (uint32_t)__builtin_amdgcn_readlane((int)v.jc, 0) : 0u;
                     chain_done = cout == LAP_OUT_CHAIN;
+#ifdef GPSBB_LAP_DEBUG
+                    if (lane == 0)
+                        printf("   alone: now at (%d,%d) x %.17g outcome %d; next planned q %u (%d,%d)\n", cb, cn, cx, cout, q, q < nl ? recs[q].b : -1, q < nl ? recs[q].n0 : -1);
+#endif
                 }
                 if (chain_done) {
                     /* whatever was planned up to the chain's end is void */
@@ -1439,7 +1455,11 @@ __global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L)
                 {
                     const LapRec rq = recs[q];
                     const double xq = __fma_rn(rq.g, lap_unit<KIND>(), rq.A);
-                    if (f64_bits(xq) == f64_bits(cx)) {
+#ifdef GPSBB_LAP_DEBUG
+                    if (lane == 0)
+                        printf("   synced at lap %u (%d,%d): truth %.17g, pass 2 had %.17g (A %.17g g %.0f flags %x)\n", q, cb, cn, cx, xq, rq.A, rq.g, rq.flags);
+#endif
+                    if (q >= dirty_end && f64_bits(xq) == f64_bits(cx)) {
                         from = q;
                         break;
                     }
@@ -1481,6 +1501,11 @@ __global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L)
                     }
                     const unsigned long long badm = __ballot(mine && !ok);
                     const int nok = badm ? __builtin_ctzll(badm) + 1 : glen; /* lanes 0 .. nok-1 walked the truth */
+#ifdef GPSBB_LAP_DEBUG
+                    if (mine)
+                        printf("   redo lap %u: start (%d,%d) x0 %.17g (A %.17g m %.0f) -> end (%d,%d) x %.17g outcome %d; next (%d,%d) x_next %.17g has_next %d ok %d glen %d\n",
+                               r, rr.b, rr.n0, x0, rr.A, m, w2.b, w2.n, w2.x, w2.outcome, rx.b, rx.n0, x_next, (int)has_next, (int)ok, glen);
+#endif
                     if (lane < nok) {
                         hz_delta += (long long)w2.hz - (long long)rr.hz;
                         recs[r].g = m;
@@ -1495,6 +1520,8 @@ __global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L)
                     cn = __builtin_amdgcn_readlane(w2.n, last);
                     cout = __builtin_amdgcn_readlane(w2.outcome, last);
                     cjc = KIND == NCO_CODE ? (uint32_t)__builtin_amdgcn_readlane((int)w2.jc, last) : 0u;
+                    if (badm && q + (uint32_t)glen > dirty_end)
+                        dirty_end = q + (uint32_t)glen;
                     q += (uint32_t)nok;
                     if (badm) {
                         n_links++;
@@ -1510,7 +1537,7 @@ __global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L)
                     {
                         const LapRec rq = recs[q];
                         const double xq = __fma_rn(rq.g, lap_unit<KIND>(), rq.A);
-                        if (!(rq.flags & LAPF_BAD) && f64_bits(xq) == f64_bits(cx)) {
+                        if (q >= dirty_end && !(rq.flags & LAPF_BAD) && f64_bits(xq) == f64_bits(cx)) {
                             from = q;
                             break;
                         }

@@ -167,6 +167,68 @@ def test_the_repair_path_made_common(pkg, args, jitter, at_least):
     assert "3:" in r.stdout.split("lap-parallel}:")[1]  # the lap-parallel pre-pass did take cases
 
 
+def test_a_link_that_breaks_inside_a_group_the_repair_walks_again(pkg):
+    """Round 5's soak, seed 3700 case 31 (tests/golden/lap_repair_second_break.npz: 64 blocks, a 141 Hz carrier, reference states
+    pushed off by up to 2e9 grid steps): link 8 breaks, the repair walks laps 9 .. 56 again as one group, link 40 breaks INSIDE
+    that group — the group's lanes beyond it have then written walks from starts that were not the truth over what pass 2 had left
+    there, and pass 2's start of lap 41 happened to BE the truth: "as pass 2 had it, so everything from here on stands" left 18
+    blocks' end phases one grid step off (the IQ did not notice: 2^-52 of a cycle).  Laps a failed group may have written into are
+    done again whatever they start from."""
+    env = dict(os.environ, GPSBB_PY_LIB="exp", GPSBB_LAP_JITTER="2000000000")
+    for extra in ({}, {"GPSBB_LAP_UNIT_CARR": "9", "GPSBB_LAP_UNIT_CODE": "5"}, {"GPSBB_LAP_UNIT_CARR": "1", "GPSBB_LAP_UNIT_CODE": "1"}):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "replay_fail.py"), os.path.join(ROOT, "tests", "golden", "lap_repair_second_break.npz"),
+                            "25e6", "155681", "--chain"], env=dict(env, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        first = r.stdout.split("where 1:")[0]
+        assert "where 3: pre-pass 3" in first and "blocks whose IQ differs: 0 " in first and "end state" not in first, r.stdout[-1500:]
+        assert int(re.search(r"repairs (\d+)", first).group(1)) >= 2
+
+
+def test_one_sample_blocks(pkg, fresh, oracle):
+    """Blocks of ONE sample that do not continue each other (round 5's soak, the "shapes" flavour): a carrier phase of exactly 0
+    that falls made the model count a wrap before the block's first step — a second lap, whose first sample could only be the
+    NEXT block's: it wrote that block's first tile state.  Never more laps than samples they could start at."""
+    s = fresh
+    rng = np.random.default_rng(77)
+    ch = pkg.synth_descriptors(600, nch=16, seed=78)
+    ch["f_carr"] = rng.choice([-1.0, 1.0], size=ch.shape) * 10.0 ** rng.uniform(-2, 5.4, size=ch.shape)
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    ch["carr_phase"] = np.floor(ch["carr_phase"] * 512.0) / 512.0
+    ch["carr_phase"][rng.random(ch.shape) < 0.3] = 0.0
+    ch["code_phase"][rng.random(ch.shape) < 0.1] = 0.0
+    for fs, nsamp in ((10e6, 1), (25e6, 1), (25e6, 2), (2.6e6, 1)):
+        for chain in (False, True):
+            want_iq, want_st, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=chain)
+            b = s.batch(ch, 1 / fs, nsamp, flags=pkg.CHAIN_CARRIER if chain else 0)
+            b.run(); s.sync()
+            iq, st = b.read(); b.close()
+            assert s.info(pkg.INFO_PREPASS) == 3
+            assert (iq == want_iq).all(), (fs, nsamp, chain)
+            act = ch["prn"] > 0
+            for f in ("carr_phase", "code_phase", "icode"):
+                assert st[f][act].tobytes() == want_st[f][act].tobytes(), (fs, nsamp, chain, f)
+
+
+def test_a_small_chained_stream_at_a_rate_the_laps_decline(pkg, fresh, oracle):
+    """gpsbb_stream_push decides where the carrier is chained before the kernel plan exists (a small push goes to the device where
+    the lap-parallel pre-pass will take it); a 1 MS/s stream is rendered by the per-sample kernel, whose pre-pass is the row walks:
+    the push was promised the device and batch_setup chose the host threads for its size — GPSBB_E_INTERNAL, found by round 5's
+    soak.  A promised device chain stays on the device."""
+    s = fresh
+    nch, bps, pushes, nsamp, fs = 3, 4, 3, 20000, 1e6
+    ch = pkg.synth_descriptors(bps * pushes, nch=nch, seed=91)
+    want_iq, want_st, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
+    st = s.stream(nch, 1 / fs, nsamp, bps, depth=2, flags=pkg.CHAIN_CARRIER)
+    got = []
+    for k in range(pushes):
+        st.push(ch[k * bps:(k + 1) * bps])
+        iq, es = st.pop(copy=True)
+        got.append(np.asarray(iq).reshape(bps, -1))
+    st.close()
+    assert s.info(pkg.INFO_LAST_KERNEL) == 1 and s.info(pkg.INFO_PREPASS) == 1 and s.info(pkg.INFO_CHAIN_ON_DEVICE) == 1
+    assert (np.concatenate(got).reshape(want_iq.shape) == want_iq).all()
+
+
 @pytest.mark.parametrize("where", [3, 1])
 def test_the_null_stream_owns_nothing(pkg, where):
     """Round 4's race — a fresh stream's carry cleared by a null-stream memset that the library's non-blocking streams do not
@@ -176,7 +238,7 @@ def test_the_null_stream_owns_nothing(pkg, where):
     restored (GPSBB_X_NULL_MEMSET: the zeroing as a null-stream memset nobody waits for) the second push chains from a wiped
     phase in every run; the product's zeroing (a stream of the handle, waited for) does not care what the null stream is
     doing.  For the chain of either pre-pass (the lap-parallel one reads the carry in its plan kernel, the row walks in
-    k_chain_prefix / k_chain_fix_par).  DESIGN.md section 4 has the table of who owns which buffer."""
+    k_chain_prefix / k_chain_fix_par).  DESIGN.md 4.1 has the table of who owns which buffer."""
     import json
     env = dict(os.environ, GPSBB_PY_LIB="exp", GPSBB_X_PARK_NULL_MS="60")
     cmd = [sys.executable, os.path.join(ROOT, "tools", "order_guard.py"), str(where)]

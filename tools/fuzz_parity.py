@@ -70,13 +70,18 @@ def stream_soak(a):
                 i = int(rng.integers(0, nch)); b0 = int(rng.integers(0, nb)); b1 = int(rng.integers(b0, nb + 1))
                 ch["prn"][b0:b1, i] = 0 if rng.random() < 0.5 else int(rng.integers(1, 33))
             delt = 1.0 / fs
-            want_iq, want_st, _ = oracle.fill_blocks(ch, delt, nsamp, chain=True, fixed=False)
             depth = int(rng.integers(2, 5))
             dev_only = bool(rng.integers(0, 2))
             # pre-pass and chain on the device: lap-parallel (round 5), by the row walks (rounds 1-4), or whatever the library picks
             where = int(os.environ.get("GPSBB_FUZZ_WHERE", rng.choice([3, 1, 0], p=[0.45, 0.4, 0.15])))
+            kern = 1 if rng.random() < (0.25 if os.environ.get("GPSBB_FUZZ_WHERE") != "3" else 0.1) else 0  # now and then the per-sample kernel where the other one would do
+            if a.only >= 0 and case != a.only:         # --only: the same random numbers drawn, nothing rendered
+                continue
+            if os.environ.get("GPSBB_FUZZ_VERBOSE"):
+                print("case", case, dict(fs=fs, nsamp=nsamp, nch=nch, bps=bps, pushes=pushes, depth=depth, dev_only=dev_only, where=where, kern=kern), flush=True)
+            want_iq, want_st, _ = oracle.fill_blocks(ch, delt, nsamp, chain=True, fixed=False)
             synth.set_option(pkg.OPT_SEED_WHERE, where)
-            synth.set_option(pkg.OPT_SYNTH_KERNEL, 1 if rng.random() < (0.25 if os.environ.get("GPSBB_FUZZ_WHERE") != "3" else 0.1) else 0)  # now and then the per-sample kernel where the other one would do
+            synth.set_option(pkg.OPT_SYNTH_KERNEL, kern)
             st = synth.stream(nch, delt, nsamp, bps, depth=depth,
                               flags=pkg.CHAIN_CARRIER | (pkg.STREAM_DEVICE_ONLY if dev_only else 0))
             got = []
@@ -151,6 +156,7 @@ def main():
     ap.add_argument("--also-batch", action="store_true", help="--stream: every case also as one chained batch and as a batch of independent blocks")
     ap.add_argument("--nsamp-max", type=int, default=200000, help="--stream: longest block")
     ap.add_argument("--budget", type=float, default=3e7, help="--stream: channel-samples per case (what the CPU oracle has to walk)")
+    ap.add_argument("--only", type=int, default=-1, help="render this case only (the others' random numbers are drawn all the same)")
     a = ap.parse_args()
     if a.stream:
         return stream_soak(a)
@@ -202,6 +208,8 @@ def main():
             if fixed:
                 ch["carr_phase"] = np.floor(ch["carr_phase"] * 2.0 ** 32)
             flags = (pkg.FIXED_CARRIER if fixed else 0) | (pkg.CHAIN_CARRIER if chain else 0)
+            if a.only >= 0 and case != a.only:
+                continue
             want_iq, want_st, _ = oracle.fill_blocks(ch, 1.0 / fs, nsamp, chain=chain, fixed=fixed)
             synth.set_option(pkg.OPT_SEED_WHERE, mode)
             synth.set_option(pkg.OPT_SYNTH_KERNEL, kern)
@@ -222,7 +230,11 @@ def main():
             what = dict(case=case, fs=fs, nsamp=nsamp, nch=nch, nblocks=nblocks, fixed=fixed, chain=chain, mode=mode, kern=kern)
             if not (iq == want_iq).all():
                 bad = np.argwhere(iq != want_iq)[0]
-                raise SystemExit("MISMATCH %r first at block %d sample %d" % (what, bad[0], bad[1]))
+                np.save("gpurun_out/fuzz_fail_ch.npy", ch)
+                nbad = np.argwhere((iq != want_iq).reshape(len(iq), -1).any(axis=1))[:, 0]
+                raise SystemExit("MISMATCH %r first at block %d sample %d; %d blocks differ: %r; pre-pass %d kernel %d; f_carr of the block %r prn %r code_phase %r carr_phase %r" %
+                                 (what, bad[0], bad[1], len(nbad), nbad[:20].tolist(), synth.info(pkg.INFO_PREPASS), synth.info(pkg.INFO_LAST_KERNEL),
+                                  ch["f_carr"][bad[0]].tolist(), ch["prn"][bad[0]].tolist(), ch["code_phase"][bad[0]].tolist(), ch["carr_phase"][bad[0]].tolist()))
             act = ch["prn"] > 0
             for f in ("carr_phase", "code_phase", "iword", "ibit", "icode", "dataBit", "codeCA"):
                 if st[f][act].tobytes() != want_st[f][act].tobytes():

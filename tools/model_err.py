@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The error budgets of the model kernels, MEASURED (DESIGN.md 2.3 / 2.7; gpsbb_modelerr.hip.h).
+"""The error budgets of the model kernels, MEASURED (DESIGN.md 2.3 / 2.6; gpsbb_modelerr.hip.h).
 
 Run with the experiments build (GPSBB_PY_LIB=exp).  For a set of workloads at the corners of what k_synth_ev /
 k_synth_ev_dense / k_synth_ev_fixed / k_synth_pd take — Dopplers at the edge of every breakpoint class, both signs,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Which stream owns what (DESIGN.md section 4, the ordering contract), as an experiment: a chained stream whose second push
+"""Which stream owns what (DESIGN.md 4.1, the ordering contract), as an experiment: a chained stream whose second push
 follows the first by more than GPSBB_X_PARK_NULL_MS.  Anything of the library's that still went through the null stream — the
 zeroing of a fresh stream's carry did until round 4 — lands between the two pushes and the second one chains from a wiped
 phase.  Run on the experiments build: prints one JSON line, "equal": whether every block equals the oracle's.

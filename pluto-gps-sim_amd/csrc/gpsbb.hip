@@ -350,6 +350,8 @@ bool lap_eligible(const gpsbb_chan_t *ch, size_t nbc, double delt, bool fixed)
 /* laps a lane walks (LapDev::unit): what a lane costs besides its walk is about one lap's walk (measured: 17 turns of ~55
  * vector instructions against ~900 for finding the lap, the model, the scan and the record), so a lane takes a few */
 constexpr int LAP_UNIT_CARR = 4, LAP_UNIT_CODE = 2;
+/* a burst of plain steps (lap_run) for the lanes that are due one when they are at least 1 / LAP_BURST_SHARE of the lanes still walking */
+constexpr int LAP_BURST_SHARE = 4;
 int lap_unit(int kind)
 {
     const long u = kind == NCO_CARR ? GPSBB_KNOB_LONG("GPSBB_LAP_UNIT_CARR", LAP_UNIT_CARR) : GPSBB_KNOB_LONG("GPSBB_LAP_UNIT_CODE", LAP_UNIT_CODE);
@@ -1892,6 +1894,7 @@ static LapDev lap_dev(const gpsbb_batch *b, int set)
     memcpy(L.chunk0, b->lap_chunk0, sizeof L.chunk0);
     L.chained = b->chain_dev ? 1 : 0;
     L.jitter = (uint32_t)GPSBB_KNOB_LONG("GPSBB_LAP_JITTER", 0);
+    L.burst = GPSBB_KNOB_SET("GPSBB_LAP_NO_BURST") ? 0 : (int)GPSBB_KNOB_LONG("GPSBB_LAP_BURST_SHARE", LAP_BURST_SHARE);
     L.unit[NCO_CODE] = lap_unit(NCO_CODE);
     L.unit[NCO_CARR] = lap_unit(NCO_CARR);
     return L;
@@ -3073,6 +3076,7 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
             L.chunk_bad = c->d_lap_chunk_bad.p;
             L.chained = 1;
             L.jitter = (uint32_t)GPSBB_KNOB_LONG("GPSBB_LAP_JITTER", 0);
+            L.burst = GPSBB_KNOB_SET("GPSBB_LAP_NO_BURST") ? 0 : (int)GPSBB_KNOB_LONG("GPSBB_LAP_BURST_SHARE", LAP_BURST_SHARE);
             L.unit[NCO_CODE] = lap_unit(NCO_CODE);
             L.unit[NCO_CARR] = lap_unit(NCO_CARR);
             BatchDev p;

@@ -106,6 +106,7 @@ struct LapDev {
     uint32_t chunk0[2][GPSBB_MAX_CHAN + 1]; /* first chunk of each channel's range (host plan: lap_bound) */
     int chained;         /* GPSBB_CHAIN_CARRIER is in force (blocks continue each other) */
     uint32_t jitter;     /* experiments: reference states are pushed off by up to this many grid steps (exercises the repair) */
+    int burst;           /* plain steps where runs are short (lap_run): for at least 1 / burst of the lanes still walking (0: never) */
     int unit[2];         /* laps per lane, per kind: a lane walks `unit` consecutive laps of its chain (up to the next lane's first
                             sample): what a lane costs besides its walk — finding its lap, the model, the scan, its record — is as
                             much as one lap's walk, so several laps share it (1: a lane per lap) */
@@ -498,8 +499,9 @@ __device__ __forceinline__ void lap_emit_row(const BatchDev &p, int i, bool on, 
  * is the first sample of the next lap and its state), stands at the end of its territory without having wrapped
  * (LAP_OUT_LATE), or stands at its block's last sample + 1 (outcome 0, n == nsamp: the caller's).
  */
+constexpr int LAP_BURST = 16;
 template <int KIND, bool SNEG, bool EMIT, bool TIES>
-__device__ __forceinline__ void lap_run(const BatchDev &p, int i, LapLane<KIND> &w, const bool was)
+__device__ __forceinline__ void lap_run(const BatchDev &p, int i, LapLane<KIND> &w, const bool was, const int L_burst)
 {
     constexpr int TOPEX = LapK<KIND>::TOPEX;
     constexpr int TOP = KIND == NCO_CARR ? 1022 : 1023 + 9; /* the top binade: [0.5, 1) / [512, 1024) */
@@ -507,6 +509,8 @@ __device__ __forceinline__ void lap_run(const BatchDev &p, int i, LapLane<KIND> 
     const int es = w.es, nmax = w.nmax;
     const bool any_tie = __ballot(was && w.tiemask != 0ull) != 0ull;
     const bool any_tt = TIES && __ballot(was && w.tt) != 0ull;
+    /* (bursts only where every lane's step is small enough for them — the lanes of a wavefront share a channel, mostly a block) */
+    const bool burst_ok = L_burst != 0 && !__ballot(was && es > TOP - 8);
     double x = w.x;
     int n = w.n;
     bool go = was, last_wrapped = false;
@@ -518,6 +522,46 @@ __device__ __forceinline__ void lap_run(const BatchDev &p, int i, LapLane<KIND> 
         const uint32_t hi = (uint32_t)__double2hiint(x);
         const int ex = (int)(hi >> 20);
         const int d = ex - es;
+        /* Where the state is within a few binades of the step's own — the start of a rising lap, the end of a falling one —
+         * regular runs are a step or two long and a turn buys next to nothing: LAP_BURST plain steps of the recurrence itself
+         * instead (genuine IEEE adds: nothing to prove), for the lanes that have that many before anything happens — no wrap (a
+         * rising state below 16 steps ends below 32 of them, short of the top binade: the links' bookkeeping up there never sees
+         * a burst; a falling one stops before the step that would take it below zero), no tile's first sample, no end of block or
+         * territory.  The lanes of a wavefront are neighbouring laps of one chain and start theirs together; a burst for a few
+         * stragglers costs the others more than it saves them: it takes 1 / L_burst of the lanes still walking.  (A negative
+         * state has its sign in ex: d is then large.) */
+        if (burst_ok && __ballot(go && d < 4)) {
+            const int r = n & (TILE - 1);
+            const bool clear = n + LAP_BURST <= nmax && (!(EMIT && p.tile_x) || (r != 0 && r + LAP_BURST <= TILE));
+            bool bq = go && d < 4 && clear;
+            if (SNEG)
+                bq = bq && x >= -s; /* (a state below one step wraps with the next: the turn's business) */
+            const unsigned long long bm = __ballot(bq), gm = __ballot(go);
+            if (bm && L_burst * __popcll(bm) >= __popcll(gm)) {
+                if (!SNEG) {
+                    if (bq) {
+#pragma unroll
+                        for (int j = 0; j < LAP_BURST; j++)
+                            x = add_rn(x, s);
+                        n += LAP_BURST;
+                        last_wrapped = false;
+                    }
+                } else {
+                    bool on = bq;
+#pragma unroll
+                    for (int j = 0; j < LAP_BURST; j++) {
+                        const double x2 = add_rn(x, s);
+                        on = on && x2 >= 0.0;
+                        x = on ? x2 : x;
+                        n += on ? 1 : 0;
+                    }
+                    if (bq)
+                        last_wrapped = false; /* (it took at least one step: x >= |s|) */
+                }
+                go = go && n < nmax;
+                continue;
+            }
+        }
         const bool weird = (unsigned)(ex - 1) >= (unsigned)(TOPEX - 1); /* zero, subnormal, negative, at or beyond the top */
         bool expl = weird || d < 2;
         if (any_tie)
@@ -718,9 +762,9 @@ __device__ __forceinline__ void lap_walk(const BatchDev &p, const LapDev &L, int
          * it normally runs only one of the two) */
         const bool rise = w.active && !w.neg, fall = w.active && w.neg;
         if (__ballot(rise))
-            lap_run<KIND, false, EMIT, TIES>(p, i, w, rise);
+            lap_run<KIND, false, EMIT, TIES>(p, i, w, rise, L.burst);
         if (KIND == NCO_CARR && __ballot(fall))
-            lap_run<KIND, true, EMIT, TIES>(p, i, w, fall);
+            lap_run<KIND, true, EMIT, TIES>(p, i, w, fall, L.burst);
         /* lanes at the last sample + 1 of their block: the end state; the chain's next block, or the walk ends */
         const bool at_end = w.active && w.n >= p.nsamp;
         if (__ballot(at_end)) {

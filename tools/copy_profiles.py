@@ -19,6 +19,23 @@ shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(dst, tag + "_str
 sq = os.path.join(ROOT, "gpurun_out", tag + "_sq.txt")
 if os.path.exists(sq):
     shutil.copy(sq, os.path.join(dst, tag + "_sq_counters.txt"))
+if os.path.exists(sq):
+    # the numbers bench.py's roofline_valu is computed from: vector wave-instructions per sample and the share of bank conflicts,
+    # from the SQ passes over ONE 400-block launch (1e9 samples) of the headline geometry
+    vals = {}
+    for line in open(sq):
+        f = line.split()
+        if len(f) >= 3 and f[0] == "k_synth_ev":
+            vals[f[1]] = float(f[2])
+    if "SQ_INSTS_VALU" in vals:
+        old = json.load(open(os.path.join(dst, "sq_latest.json")))
+        old["k_synth_ev_valu_wave_insts_per_sample"] = vals["SQ_INSTS_VALU"] / (400 * 2500000.0)
+        if vals.get("SQ_ACTIVE_INST_LDS"):
+            old["lds_bank_conflict_share"] = vals.get("SQ_LDS_BANK_CONFLICT", 0.0) / vals["SQ_ACTIVE_INST_LDS"]
+        old["source"] = ("profiles/%s_sq_counters.txt (SQ_INSTS_VALU, SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS of k_synth_ev over ONE 400-block "
+                         "launch: tools/kbench.py --blocks 400 --chain --smooth, 1e9 samples), profiles/r03_valu_rates_ubench.txt (4.3 cycles: the "
+                         "kernel's mix of f64 / 32-bit integer / v_and), clock 2.38-2.41 GHz measured under load" % tag)
+        json.dump(old, open(os.path.join(dst, "sq_latest.json"), "w"), indent=1)
 sq = os.path.join(ROOT, "gpurun_out", tag + "_m1_sq.txt")
 if os.path.exists(sq):
     shutil.copy(sq, os.path.join(dst, tag + "_m1_sq_counters.txt"))

@@ -75,7 +75,7 @@ def stream_soak(a):
             # pre-pass and chain on the device: lap-parallel (round 5), by the row walks (rounds 1-4), or whatever the library picks
             where = int(os.environ.get("GPSBB_FUZZ_WHERE", rng.choice([3, 1, 0], p=[0.45, 0.4, 0.15])))
             kern = 1 if rng.random() < (0.25 if os.environ.get("GPSBB_FUZZ_WHERE") != "3" else 0.1) else 0  # now and then the per-sample kernel where the other one would do
-            if a.only >= 0 and case != a.only:         # --only: the same random numbers drawn, nothing rendered
+            if getattr(a, "only", -1) >= 0 and case != a.only:         # --only: the same random numbers drawn, nothing rendered
                 continue
             if os.environ.get("GPSBB_FUZZ_VERBOSE"):
                 print("case", case, dict(fs=fs, nsamp=nsamp, nch=nch, bps=bps, pushes=pushes, depth=depth, dev_only=dev_only, where=where, kern=kern), flush=True)

@@ -24,5 +24,6 @@ python tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.json" 2> "$OUT/pmc_summar
 # the reference's own geometry (M1: 12 ch, 2.6 MS/s, 300 000-sample blocks, k_synth_pd): kernel stats and SQ counters
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/prof_m1" -o trace -- python "$ROOT/tools/m1_rate.py" > "$ROOT/$OUT/prof_m1_stdout.log" 2>&1 )
 timeout 600 bash tools/pmc_sq.sh ${TAG}_m1_sq --fs 2.6e6 --nsamp 300000 --nch 12 --blocks 333 > gpurun_out/${TAG}_m1_sq.txt 2>&1
-timeout 600 bash tools/pmc_sq.sh ${TAG}_sq > gpurun_out/${TAG}_sq.txt 2>&1
+# SQ counters of ONE 400-block launch of the headline geometry (1e9 samples: what a push of the bench is)
+timeout 900 bash tools/pmc_sq.sh ${TAG}_sq --blocks 400 --chain --smooth > gpurun_out/${TAG}_sq.txt 2>&1
 timeout 200 python tools/seed_rate.py --host > "$OUT/seed_rate.txt" 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # vector instructions of the pre-pass kernels per launch, lap-parallel (where 3) against the row walks (where 1), for the headline
 # geometry (400 chained blocks of 16 ch at 25 MS/s) and the reference's (1000 independent blocks of 12 ch at 2.6 MS/s)
-#   bash tools/lap_valu.sh <tag>       (GPU box)
+#   bash tools/lap_valu.sh <tag>       (GPU box; GPSBB_PY_LIB=exp and the experiments knobs apply: e.g. GPSBB_LAP_NO_BURST=1)
 TAG="${1:-lapvalu}"
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -9,6 +9,7 @@ export TMPDIR=/tmp
 ROOT=$PWD
 run() { # name, kbench args
   local name=$1; shift
+  if [ -n "$ONLY" ] && [[ ! "$name" =~ $ONLY ]]; then return; fi   # ONLY=laps: a subset by name
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES -d "$OUT/$name" -o pmc -- python "$ROOT/tools/kbench.py" --steps 2 --warmup 1 "$@" > "$OUT/$name.log" 2>&1 )
   python - "$OUT/$name" "$name" <<'PY'
 import sqlite3, glob, sys, os

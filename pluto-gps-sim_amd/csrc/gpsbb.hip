@@ -352,9 +352,16 @@ bool lap_eligible(const gpsbb_chan_t *ch, size_t nbc, double delt, bool fixed)
 constexpr int LAP_UNIT_CARR = 4, LAP_UNIT_CODE = 2;
 /* a burst of plain steps (lap_run) for the lanes that are due one when they are at least 1 / LAP_BURST_SHARE of the lanes still walking */
 constexpr int LAP_BURST_SHARE = 4;
-int lap_unit(int kind)
+/* ... where there are lanes to spare: a batch of a few block-channels (one block: the drop-in call, whose LATENCY is the point)
+ * has a few thousand laps for 1024 SIMDs — a lane per lap there (gpsbb_fill_block of the reference's geometry: 0.25 against
+ * 0.31 ms) */
+int lap_unit(int kind, size_t nbc)
 {
-    const long u = kind == NCO_CARR ? GPSBB_KNOB_LONG("GPSBB_LAP_UNIT_CARR", LAP_UNIT_CARR) : GPSBB_KNOB_LONG("GPSBB_LAP_UNIT_CODE", LAP_UNIT_CODE);
+    long u = kind == NCO_CARR ? GPSBB_KNOB_LONG("GPSBB_LAP_UNIT_CARR", LAP_UNIT_CARR) : GPSBB_KNOB_LONG("GPSBB_LAP_UNIT_CODE", LAP_UNIT_CODE);
+    if (nbc <= 256)
+        u = 1;
+    else if (nbc <= 1024)
+        u = std::min(u, kind == NCO_CARR ? 2L : 1L);
     return u < 1 ? 1 : (u > 64 ? 64 : (int)u);
 }
 
@@ -371,7 +378,7 @@ void lap_bound(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int ns
                     continue;
                 const double s = kind == NCO_CARR ? std::fabs(c.f_carr * delt) : c.f_code * delt * (1.0 / 1023.0);
                 /* (wraps, in lanes of `unit` laps, + a head and the rounding) */
-                laps += std::floor((std::floor((double)nsamp * s * (1.0 + 0x1p-30)) + 1.0) / (double)lap_unit(kind)) + 3.0;
+                laps += std::floor((std::floor((double)nsamp * s * (1.0 + 0x1p-30)) + 1.0) / (double)lap_unit(kind, (size_t)nblocks * nch)) + 3.0;
             }
             const uint32_t chunks = (uint32_t)((laps + (double)(LAP_WG - 1)) / (double)LAP_WG) + 1u;
             chunk0[kind][i + 1] = chunk0[kind][i] + chunks;
@@ -1895,8 +1902,8 @@ static LapDev lap_dev(const gpsbb_batch *b, int set)
     L.chained = b->chain_dev ? 1 : 0;
     L.jitter = (uint32_t)GPSBB_KNOB_LONG("GPSBB_LAP_JITTER", 0);
     L.burst = GPSBB_KNOB_SET("GPSBB_LAP_NO_BURST") ? 0 : (int)GPSBB_KNOB_LONG("GPSBB_LAP_BURST_SHARE", LAP_BURST_SHARE);
-    L.unit[NCO_CODE] = lap_unit(NCO_CODE);
-    L.unit[NCO_CARR] = lap_unit(NCO_CARR);
+    L.unit[NCO_CODE] = lap_unit(NCO_CODE, (size_t)b->nblocks * b->nch);
+    L.unit[NCO_CARR] = lap_unit(NCO_CARR, (size_t)b->nblocks * b->nch);
     return L;
 }
 
@@ -3044,7 +3051,7 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
                 for (int i = 0; i < nch; i++) {
                     const ChainDesc &d = c->h_cd[(size_t)(b0 + nb) * nch + i];
                     if (d.prn > 0)
-                        l += std::floor((std::floor((double)nsamp * std::fabs(d.f_carr * delt)) + 1.0) / (double)lap_unit(NCO_CARR)) + 3.0;
+                        l += std::floor((std::floor((double)nsamp * std::fabs(d.f_carr * delt)) + 1.0) / (double)lap_unit(NCO_CARR, (size_t)-1)) + 3.0;
                 }
                 if (nb > 0 && laps + l > CHAIN_ONLY_LAPS)
                     break;
@@ -3077,8 +3084,8 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
             L.chained = 1;
             L.jitter = (uint32_t)GPSBB_KNOB_LONG("GPSBB_LAP_JITTER", 0);
             L.burst = GPSBB_KNOB_SET("GPSBB_LAP_NO_BURST") ? 0 : (int)GPSBB_KNOB_LONG("GPSBB_LAP_BURST_SHARE", LAP_BURST_SHARE);
-            L.unit[NCO_CODE] = lap_unit(NCO_CODE);
-            L.unit[NCO_CARR] = lap_unit(NCO_CARR);
+            L.unit[NCO_CODE] = lap_unit(NCO_CODE, (size_t)nb * nch);
+            L.unit[NCO_CARR] = lap_unit(NCO_CARR, (size_t)nb * nch);
             BatchDev p;
             memset(&p, 0, sizeof p);
             p.nblocks = nb;

@@ -14,10 +14,10 @@
  * post-wrap states differ by d (a multiple of that coarsest grid u) stay exactly d apart for as long as they spend
  * the same steps in the same binades — through the whole lap, through the next wrap, for ever.  So:
  *
- *   k_lap_plan   a model of the recurrence (step + mean rounding drift per step, summed per binade) says where
- *                every lap of every chain starts — sample number and a reference state A on the grid u —
- *                without walking anything.  One lane per block and channel, scans over the blocks.
- *   k_lap_pass1  ONE LANE PER LAP walks its lap exactly from A (the same turn as k_walk: a regular run of the
+ *   k_lap_plan   a model of the recurrence (step + rounding drift: per binade and unit of phase, integrated over the part of a
+ *                lap a block covers: lap_R) says where every lap of every chain starts — sample number and a reference
+ *                state A on the grid u — without walking anything.  One lane per block and channel, two scans over the blocks.
+ *   k_lap_pass1  ONE LANE PER LAP (per LapDev::unit consecutive laps: 4 carrier, 2 code; 1 in small batches) walks its lap exactly from A (the same turn as k_walk: a regular run of the
  *                exact jump-ahead, gpsbb_nco.h, then one genuine IEEE step; ~15 turns per lap) and finds
  *                where the reference trajectory ends: y'.  The next lap's reference start is A_next, so the offset of
  *                the true trajectory to the reference one changes by (y' - A_next) / u from lap to lap: an exact
@@ -36,10 +36,14 @@
  *   k_lap_repair one wavefront per chain kind and channel; does nothing unless a link failed (a reference lap
  *                that spends a step more or less in some binade than the true one: about one lap in 10^8; a wrap
  *                within the model's error of a lap's planned first sample).  Then: from the failed lap's true end it
- *                walks on sequentially until a wrap falls on a planned lap start, and from there re-does pass 1,
+ *                walks on sequentially until a wrap falls on a planned lap start, and from there — unless the state there is
+ *                what pass 2 started that lap from, and nothing has been written over its output since — re-does pass 1,
  *                the scan and pass 2 for the rest of the chain, 64 laps at a time, checking as it goes.
  *
- * Cost: a lap is walked twice (~15 turns of ~50 vector instructions each) whatever the length of the chain, and all
+ * Where runs are short (the first steps of a rising lap, the last of a falling one) a lane takes LAP_BURST plain steps of the
+ * recurrence instead of turns (lap_run).
+ *
+ * Cost: a lap is walked twice (~13 turns of ~60 vector instructions each) whatever the length of the chain, and all
  * laps are independent: the pre-pass of a 400-block push is a few hundred thousand wavefront-turns spread over the
  * machine instead of 1 750 turns in a row on 500 wavefronts.  The walks are exact (genuine IEEE adds, the jump-ahead
  * of gpsbb_nco.h); the model decides only how often the repair kernel has work.

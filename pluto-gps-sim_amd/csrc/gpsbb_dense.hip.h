@@ -363,6 +363,9 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     PdLds<WIDE> &L = *reinterpret_cast<PdLds<WIDE> *>(smem_raw);
+#ifdef GPSBB_EV_PRIO /* (measurement, as in k_synth_ev) */
+    __builtin_amdgcn_s_setprio(GPSBB_EV_PRIO);
+#endif
     const int tid = threadIdx.x;
     const int b = blockIdx.x; /* the block is the fast grid dimension, helpers join blocks still in flight (see k_synth_ev) */
     if (blockIdx.y > 0 && __hip_atomic_load(&p.tile_ctr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.ntiles)

@@ -349,6 +349,9 @@ bool lap_eligible(const gpsbb_chan_t *ch, size_t nbc, double delt, bool fixed)
  * + 1 times, a block may start a chain (one more lap), and the model's step differs from s by parts in 10^12 */
 /* laps a lane walks (LapDev::unit): what a lane costs besides its walk is about one lap's walk (measured: 17 turns of ~55
  * vector instructions against ~900 for finding the lap, the model, the scan and the record), so a lane takes a few */
+/* (GPSBB_LAP_UNIT_CODE = 0: a block's whole code chain in one lane — it starts from a known state, so nothing but the walk itself
+ * is needed: 14 % fewer instructions, and measured SLOWER, 5.22e11 against 5.39e11: what a neighbour costs the synthesis kernel
+ * is the time its wavefronts sit on a SIMD, not what they issue; a hundred laps in a row sit 0.4 ms) */
 constexpr int LAP_UNIT_CARR = 4, LAP_UNIT_CODE = 2;
 /* a burst of plain steps (lap_run) for the lanes that are due one when they are at least 1 / LAP_BURST_SHARE of the lanes still walking */
 constexpr int LAP_BURST_SHARE = 4;
@@ -361,7 +364,9 @@ int lap_unit(int kind, size_t nbc)
     if (nbc <= 256)
         u = 1;
     else if (nbc <= 1024)
-        u = std::min(u, kind == NCO_CARR ? 2L : 1L);
+        u = kind == NCO_CARR ? std::min(u, 2L) : 1L;
+    if (kind == NCO_CODE && u == 0)
+        return 0; /* one lane per block: a code chain is a block long and starts from its descriptor's code_phase (c:2673) */
     return u < 1 ? 1 : (u > 64 ? 64 : (int)u);
 }
 
@@ -378,7 +383,7 @@ void lap_bound(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, int ns
                     continue;
                 const double s = kind == NCO_CARR ? std::fabs(c.f_carr * delt) : c.f_code * delt * (1.0 / 1023.0);
                 /* (wraps, in lanes of `unit` laps, + a head and the rounding) */
-                laps += std::floor((std::floor((double)nsamp * s * (1.0 + 0x1p-30)) + 1.0) / (double)lap_unit(kind, (size_t)nblocks * nch)) + 3.0;
+                laps += std::floor((std::floor((double)nsamp * s * (1.0 + 0x1p-30)) + 1.0) / (double)std::max(1, lap_unit(kind, (size_t)nblocks * nch))) + 3.0;
             }
             const uint32_t chunks = (uint32_t)((laps + (double)(LAP_WG - 1)) / (double)LAP_WG) + 1u;
             chunk0[kind][i + 1] = chunk0[kind][i] + chunks;

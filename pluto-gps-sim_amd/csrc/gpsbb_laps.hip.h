@@ -60,6 +60,12 @@
 
 namespace gpsbb_impl {
 
+/* (measurement: GPSBB_LAP_WAVES = n caps the two passes' registers at what n wavefronts per SIMD leave each) */
+#ifdef GPSBB_LAP_WAVES
+#define GPSBB_LAP_OCC __attribute__((amdgpu_waves_per_eu(GPSBB_LAP_WAVES, GPSBB_LAP_WAVES)))
+#else
+#define GPSBB_LAP_OCC
+#endif
 constexpr int LAP_WG = 256; /* lanes (= laps) per workgroup of the two passes: one chunk of the scan */
 constexpr uint32_t LAPF_ACTIVE = 1u; /* the channel is on in this block */
 constexpr uint32_t LAPF_HEAD = 2u;   /* the block starts a chain: its first lap starts at sample 0 from an exactly known state */
@@ -111,7 +117,8 @@ struct LapDev {
     int chained;         /* GPSBB_CHAIN_CARRIER is in force (blocks continue each other) */
     uint32_t jitter;     /* experiments: reference states are pushed off by up to this many grid steps (exercises the repair) */
     int burst;           /* plain steps where runs are short (lap_run): for at least 1 / burst of the lanes still walking (0: never) */
-    int unit[2];         /* laps per lane, per kind: a lane walks `unit` consecutive laps of its chain (up to the next lane's first
+    int unit[2];         /* laps per lane, per kind (0: a block's whole chain where its first state is known — code chains, which are a
+                            block long: no reference walk at all, 100 laps in a row per lane): a lane walks `unit` consecutive laps of its chain (up to the next lane's first
                             sample): what a lane costs besides its walk — finding its lap, the model, the scan, its record — is as
                             much as one lap's walk, so several laps share it (1: a lane per lap) */
 };
@@ -300,7 +307,7 @@ __device__ __forceinline__ LapStart lap_start(const BatchDev &p, const LapDev &L
         return st;
     }
     /* lane j of the block (after its head) starts at the block's wrap number jw = unit * (j - head), 0-based */
-    const uint32_t jw = (j - ((bc.flags & LAPF_HEAD) ? 1u : 0u)) * (uint32_t)L.unit[KIND];
+    const uint32_t jw = (j - ((bc.flags & LAPF_HEAD) ? 1u : 0u)) * (uint32_t)(L.unit[KIND] > 0 ? L.unit[KIND] : 1);
     const double s = bc.s;
     const double range_ = KIND == NCO_CARR ? 1.0 : 1023.0;
     const double sbar = s + fabs(s) * bc.R1 * (1.0 / range_); /* the mean step, drift included: for the estimate of n0 only */
@@ -1019,7 +1026,11 @@ __global__ __launch_bounds__(64) void k_lap_plan(BatchDev p, LapDev L)
              * whatever the model makes of a phase of exactly 0 that falls) */
             const int wmax = to_end ? p.nsamp : p.nsamp - 1;
             W = W > wmax ? wmax : W;
-            nl = ((uint32_t)W + (uint32_t)L.unit[KIND] - 1u) / (uint32_t)L.unit[KIND] + (head || known ? 1u : 0u);
+            /* (unit 0: the whole chain of a block whose first state is known is its head's — no lap of its own starts in it) */
+            if (L.unit[KIND] == 0 && (head || known))
+                W = 0;
+            const uint32_t un = L.unit[KIND] > 0 ? (uint32_t)L.unit[KIND] : 1u;
+            nl = ((uint32_t)W + un - 1u) / un + (head || known ? 1u : 0u);
         }
         /* lanes: an exclusive sum over the blocks */
         uint32_t incl = nl;
@@ -1170,7 +1181,7 @@ __device__ __forceinline__ uint32_t lap_jc_of(const BatchDev &p, const LapDev &L
     /* every code block starts a chain: lane 0 of the block is its head (no period completed yet), lane j >= 1 starts with the
      * block's wrap number unit * (j - 1), 0-based: that many + 1 periods are over */
     const uint32_t j = r - lane0[b_start];
-    return j == 0 ? 0u : (j - 1u) * (uint32_t)L.unit[KIND] + 1u;
+    return j == 0 ? 0u : (j - 1u) * (uint32_t)(L.unit[KIND] > 0 ? L.unit[KIND] : 1) + 1u;
 }
 
 /* the link a reference walk leaves: how the offset of the NEXT lap follows from this lap's */
@@ -1191,7 +1202,7 @@ __device__ __forceinline__ LapMap lap_link(const LapLane<KIND> &w, bool mine, bo
 }
 
 template <int KIND>
-__global__ __launch_bounds__(LAP_WG) void k_lap_pass1(BatchDev p, LapDev L)
+__global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass1(BatchDev p, LapDev L)
 {
     __shared__ LapPassLds sh;
     const uint32_t chunk = blockIdx.x + L.chunk0[KIND][0];
@@ -1236,7 +1247,9 @@ __global__ __launch_bounds__(LAP_WG) void k_lap_pass1(BatchDev p, LapDev L)
     const bool has_next = mine && !next_head;
     const double A_next = lap_next(st.A, sh.A[wave + 1], lane);
     const int32_t nb = lap_next(st.b, sh.b[wave + 1], lane), nn0 = lap_next(st.n0, sh.n0[wave + 1], lane);
-    LapLane<KIND> w = lap_lane<KIND>(mine, st.A, st.b, st.n0, st.jc, has_next, nb, nn0);
+    /* (a lane whose chain ends with it — a head follows, or nothing — has no link to find: the next lap's offset is 0 whatever this
+     * one does.  Code chains of big batches are such lanes only: one lane per block, LapDev::unit 0) */
+    LapLane<KIND> w = lap_lane<KIND>(has_next, st.A, st.b, st.n0, st.jc, has_next, nb, nn0);
     lap_walk<KIND, false, true>(p, L, i, w);
     const LapMap link = lap_link<KIND>(w, mine, has_next, A_next, nb, nn0);
     /* inclusive scan of the links over the chunk */
@@ -1304,7 +1317,7 @@ __global__ __launch_bounds__(64) void k_lap_scan(BatchDev p, LapDev L)
 }
 
 template <int KIND>
-__global__ __launch_bounds__(LAP_WG) void k_lap_pass2(BatchDev p, LapDev L)
+__global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass2(BatchDev p, LapDev L)
 {
     __shared__ LapPassLds sh;
     const uint32_t chunk = blockIdx.x + L.chunk0[KIND][0];

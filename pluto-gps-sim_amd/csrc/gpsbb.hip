@@ -919,8 +919,18 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail(e);
     h->sm_count = prop.multiProcessorCount;
     if ((e = create_seed_stream(&h->s_seed)) != hipSuccess) return fail(e);
-    if ((e = hipStreamCreateWithFlags(&h->s_compute, hipStreamNonBlocking)) != hipSuccess) return fail(e);
-    if ((e = hipStreamCreateWithFlags(&h->s_compute2, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+    {
+        /* (experiments: GPSBB_SYNTH_STREAM_PRIO = p gives the synthesis streams queue priority p — HIP: -1 high, 0 normal, 1 low —,
+         * GPSBB_SEED_STREAM_PRIO the pre-pass streams: whose workgroup gets a CU that has just come free) */
+        const long sp = GPSBB_KNOB_LONG("GPSBB_SYNTH_STREAM_PRIO", 0);
+        if (sp != 0) {
+            if ((e = hipStreamCreateWithPriority(&h->s_compute, hipStreamNonBlocking, (int)sp)) != hipSuccess) return fail(e);
+            if ((e = hipStreamCreateWithPriority(&h->s_compute2, hipStreamNonBlocking, (int)sp)) != hipSuccess) return fail(e);
+        } else {
+            if ((e = hipStreamCreateWithFlags(&h->s_compute, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+            if ((e = hipStreamCreateWithFlags(&h->s_compute2, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+        }
+    }
     if ((e = hipStreamCreateWithFlags(&h->s_upload, hipStreamNonBlocking)) != hipSuccess) return fail(e);
     if ((e = hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&h->d_tabs, sizeof tabs)) != hipSuccess) return fail(e);
@@ -1469,6 +1479,11 @@ static hipError_t create_seed_stream(hipStream_t *st)
                 mask[bit >> 5] |= 1u << (bit & 31);
         }
         return hipExtStreamCreateWithCUMask(st, 16, mask);
+    }
+    {
+        const long pp = GPSBB_KNOB_LONG("GPSBB_SEED_STREAM_PRIO", 0);
+        if (pp != 0)
+            return hipStreamCreateWithPriority(st, hipStreamNonBlocking, (int)pp);
     }
     return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }

@@ -1881,7 +1881,7 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.seed_order = b->d_seed_order.p;
     p.seed_lanes = (int)b->h_seed_order.size();
     p.ev = b->ev ? 1 : 0;
-    const int ev_chunk = (int)GPSBB_KNOB_LONG("GPSBB_EV_CHUNK", EV_CHUNK);
+    const int ev_chunk = b->ev_all_dense ? (int)GPSBB_KNOB_LONG("GPSBB_PD_CHUNK", PD_CHUNK) : (int)GPSBB_KNOB_LONG("GPSBB_EV_CHUNK", EV_CHUNK);
     p.ev_chunk = ev_chunk < 1 ? 1 : ev_chunk;
     p.pd_danger = (uint32_t)GPSBB_KNOB_LONG("GPSBB_PD_DANGER", 2u * PD_BAND); /* (larger: more lanes take the exact path; a test aid) */
     p.tile_x = b->d_tile_x[set].p;

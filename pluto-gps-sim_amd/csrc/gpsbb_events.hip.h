@@ -57,9 +57,12 @@ constexpr int EV_CHIP_LEN = 1024 + 544;            /* chips 0 .. 1567: a tile's 
                                                       sc up to (EV_CHIP_LEN - 1026) / 1040 = 0.52 chips per sample (1.96 MS/s) */
 constexpr int EV_KC_DENSE = EV_KC_MAX + 1;         /* EvConst::kc of a channel that is evaluated sample by sample (ev_dense) */
 #ifndef GPSBB_EV_CHUNK
-#define GPSBB_EV_CHUNK 2
+#define GPSBB_EV_CHUNK 4
 #endif
-constexpr int EV_CHUNK = GPSBB_EV_CHUNK;           /* consecutive tiles a wavefront takes at a time (default of BatchDev::ev_chunk) */
+constexpr int EV_CHUNK = GPSBB_EV_CHUNK;           /* consecutive tiles a wavefront of the breakpoint kernels takes at a time (default of
+                                                      BatchDev::ev_chunk; measured beside the lap-parallel pre-pass, round 5: 2 -> 4 tiles
+                                                      + 1.6 % for k_synth_ev, alone and in the stream; 6 and 8 lose it again) */
+constexpr int PD_CHUNK = 2;                        /* ... of k_synth_pd (3 and 4 tiles: - 1.3 %, - 2 %) */
 constexpr int EV_ROW_DISCARD = 15;                 /* D row of changes that fall behind the run's last sample */
 
 /* Bound on |guard-format model - truth| at the first sample of a run, in table-index units / chips: the linear model's own

@@ -12,7 +12,7 @@ print("%s: %d launches; middle third: start-to-start min %.2f median %.2f max %.
       (kern, len(ks), min(gaps), sorted(gaps)[len(gaps) // 2], max(gaps), sum((e - s) for s, e in mid) / len(mid) / 1e6))
 # union busy time of all kernels in the middle window
 w0, w1 = mid[0][0], mid[-1][1]
-for name in ("k_walk<1>", "k_walk<2>", "k_chain_fix", "k_tiles", "k_synth_ev"):
+for name in ("k_lap_plan", "k_lap_pass1", "k_lap_scan", "k_lap_pass2", "k_lap_repair", "k_walk<1>", "k_walk<2>", "k_chain_fix", "k_tiles", "k_synth_ev"):
     iv = sorted((max(s, w0), min(e, w1)) for n, s, e, st in rows if name in n and e > w0 and s < w1)
     tot = sum(e - s for s, e in iv)
     # concurrency: average number in flight

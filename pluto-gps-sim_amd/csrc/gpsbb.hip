@@ -947,15 +947,15 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(SynthLds))) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)sizeof(EvLdsLean))) != hipSuccess) return fail(e);
+                                 (int)sizeof(EvLdsLean) + EV_PICK_LDS)) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev_dense), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)sizeof(EvLds))) != hipSuccess) return fail(e);
+                                 (int)sizeof(EvLds) + EV_PICK_LDS)) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev_fixed), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)sizeof(EvLdsLean))) != hipSuccess) return fail(e);
+                                 (int)sizeof(EvLdsLean) + EV_PICK_LDS)) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_pd<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)sizeof(PdLds<true>))) != hipSuccess) return fail(e);
+                                 (int)sizeof(PdLds<true>) + EV_PICK_LDS)) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_pd<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)sizeof(PdLds<false>))) != hipSuccess) return fail(e);
+                                 (int)sizeof(PdLds<false>) + EV_PICK_LDS)) != hipSuccess) return fail(e);
     *out = h;
     return GPSBB_OK;
 }
@@ -1195,7 +1195,7 @@ static int batch_setup(gpsbb_batch *b, const gpsbb_chan_t *ch, int nblocks, int 
      * a free synchronises the device) */
     HIPCHK(h, (hipError_t)b->d_ch.reserve(nbc));
     HIPCHK(h, (hipError_t)b->d_row_off.reserve(nbc + nvbc + 1));
-    HIPCHK(h, (hipError_t)b->d_tile_ctr.reserve((size_t)NSETS * (size_t)nblocks)); /* one set of counters per table set */
+    HIPCHK(h, (hipError_t)b->d_tile_ctr.reserve((size_t)NSETS * ((size_t)nblocks + 1))); /* one set of counters per table set: a block's next tile, [nblocks] the helpers' tickets (ev_pick_block) */
     /* table sets = pre-passes in flight + 1: the pre-pass of either kernel takes longer than the synthesis it feeds
      * (M1 geometry, per-sample kernel: two sets 6.6e10, three 7.7e10 samples/s), the chained ones longer still */
     b->nsets = (int)GPSBB_KNOB_LONG("GPSBB_NSETS", b->chain_dev ? 4 : 3);
@@ -1872,7 +1872,7 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.row_off = b->d_row_off.p;
     p.tile_row = b->d_tile_row[set].p;
     p.row_cnt = b->d_row_cnt[set].p;
-    p.tile_ctr = b->d_tile_ctr.p + (size_t)set * (size_t)b->nblocks;
+    p.tile_ctr = b->d_tile_ctr.p + (size_t)set * ((size_t)b->nblocks + 1);
     p.kph0 = (b->flags & GPSBB_FIXED_CARRIER) ? b->d_kph0.p : nullptr;
     p.kstep = (b->flags & GPSBB_FIXED_CARRIER) ? b->d_kstep.p : nullptr;
     p.end = b->d_end[set].p;
@@ -2087,31 +2087,34 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     b->last_cs = sc;
     HIPCHK(h, hipStreamWaitEvent(sc, ev[1], 0));
     if (!ctr_reset_by_prepass)
-        HIPCHK(h, hipMemsetAsync(p.tile_ctr, 0, (size_t)b->nblocks * sizeof(int32_t), sc));
+        HIPCHK(h, hipMemsetAsync(p.tile_ctr, 0, ((size_t)b->nblocks + 1) * sizeof(int32_t), sc));
     HIPCHK(h, hipEventRecord(ev[2], sc));
     if (b->ev) {
-        /* One workgroup of EV_WG lanes fits a CU (its LDS image takes ~140 KB).  Grid = (blocks, workgroups per
-         * block) with the block as the fast dimension, see k_synth_ev: enough workgroups per block that the
-         * chip is full when there are few blocks and that the last blocks in flight get helpers when there
-         * are many, never more than there are chunks of tiles. */
+        /* One workgroup of EV_WG lanes fits a CU (its LDS image takes ~140 - 156 KB).  Grid = the blocks' primaries, then the
+         * helpers (ev_pick_block: a helper joins one of the blocks that still have tiles to hand out, chosen when it starts):
+         * as many as can be useful when there are few blocks (never more workgroups per block than there are chunks of tiles
+         * per wavefront), else enough to keep every CU busy through the end of the launch — the last round of blocks and then
+         * what is left of it take the CUs twice over. */
         const long wg_slots = (long)(h->sm_count > 0 ? h->sm_count : 256);
         const long chunks = ((long)b->ntiles + p.ev_chunk - 1) / p.ev_chunk;
         const long max_useful = (chunks + EV_WAVES - 1) / EV_WAVES;
-        const long oversub = GPSBB_KNOB_LONG("GPSBB_EV_OVERSUB", 3);
-        const long min_wg = GPSBB_KNOB_LONG("GPSBB_EV_MIN_WG", 3);
-        long want = (wg_slots * oversub + b->nblocks - 1) / b->nblocks;
-        want = want < min_wg ? min_wg : want;
-        want = want > max_useful ? max_useful : want;
+        const long oversub = GPSBB_KNOB_LONG("GPSBB_EV_HELPERS", 2);
+        long helpers = (long)b->nblocks * (max_useful - 1);
+        if (helpers > wg_slots * oversub)
+            helpers = wg_slots * oversub;
+        if (helpers < 0)
+            helpers = 0;
+        const dim3 grid((unsigned)(b->nblocks + helpers));
         if (b->ev_all_dense && b->nch <= PD_WIDE_CHAN)
-            hipLaunchKernelGGL(k_synth_pd<true>, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(PdLds<true>), sc, p, d_iq);
+            hipLaunchKernelGGL(k_synth_pd<true>, grid, dim3(EV_WG), sizeof(PdLds<true>) + EV_PICK_LDS, sc, p, d_iq);
         else if (b->ev_all_dense)
-            hipLaunchKernelGGL(k_synth_pd<false>, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(PdLds<false>), sc, p, d_iq);
+            hipLaunchKernelGGL(k_synth_pd<false>, grid, dim3(EV_WG), sizeof(PdLds<false>) + EV_PICK_LDS, sc, p, d_iq);
         else if (b->ev_dense)
-            hipLaunchKernelGGL(k_synth_ev_dense, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLds), sc, p, d_iq);
+            hipLaunchKernelGGL(k_synth_ev_dense, grid, dim3(EV_WG), sizeof(EvLds) + EV_PICK_LDS, sc, p, d_iq);
         else if (p.kph0)
-            hipLaunchKernelGGL(k_synth_ev_fixed, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLdsLean), sc, p, d_iq);
+            hipLaunchKernelGGL(k_synth_ev_fixed, grid, dim3(EV_WG), sizeof(EvLdsLean) + EV_PICK_LDS, sc, p, d_iq);
         else
-            hipLaunchKernelGGL(k_synth_ev, dim3(b->nblocks, (int)want), dim3(EV_WG), sizeof(EvLdsLean), sc, p, d_iq);
+            hipLaunchKernelGGL(k_synth_ev, grid, dim3(EV_WG), sizeof(EvLdsLean) + EV_PICK_LDS, sc, p, d_iq);
         h->last_kernel = 2;
         h->last_chain_dev = b->chain_dev && !b->chain_indep ? 1 : 0;
     } else {
@@ -3387,4 +3390,46 @@ extern "C" unsigned long long gpsbb_test_row_bound(int kind, double s_abs, int n
 {
     return kind == NCO_CODE ? row_bound(s_abs, 1023.0, 9, nsamp) : row_bound(s_abs, 1.0, -1, nsamp);
 }
+
+#ifdef GPSBB_WG_TRACE
+/* The workgroup trace of the measurement build (gpsbb_kernels.hip.h: wg_trace_leave; make trace; tools/corun_diag.py).
+ * _begin: (re)arm the trace with room for `cap` records; _read: wait for the device, copy out up to `cap` records of
+ * WG_TRACE_WORDS 64-bit words, return how many were written (the device counts on past the capacity). */
+namespace {
+unsigned long long *g_trace_buf = nullptr;
+unsigned g_trace_cap = 0;
+}
+extern "C" int gpsbb_test_wg_trace_begin(unsigned cap)
+{
+    if (hipDeviceSynchronize() != hipSuccess)
+        return GPSBB_E_HIP;
+    if (cap > g_trace_cap) {
+        if (g_trace_buf)
+            (void)hipFree(g_trace_buf);
+        g_trace_buf = nullptr;
+        g_trace_cap = 0;
+        if (hipMalloc((void **)&g_trace_buf, (size_t)cap * WG_TRACE_WORDS * 8) != hipSuccess)
+            return GPSBB_E_NOMEM;
+        g_trace_cap = cap;
+    }
+    const unsigned zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace), &g_trace_buf, sizeof g_trace_buf) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace_cap), &cap, sizeof cap) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace_n), &zero, sizeof zero) != hipSuccess)
+        return GPSBB_E_HIP;
+    return hipDeviceSynchronize() == hipSuccess ? GPSBB_OK : GPSBB_E_HIP;
+}
+extern "C" long gpsbb_test_wg_trace_read(unsigned long long *out, unsigned cap)
+{
+    if (hipDeviceSynchronize() != hipSuccess)
+        return GPSBB_E_HIP;
+    unsigned n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wg_trace_n), sizeof n) != hipSuccess)
+        return GPSBB_E_HIP;
+    const unsigned have = n < g_trace_cap ? n : g_trace_cap, take = have < cap ? have : cap;
+    if (take && hipMemcpy(out, g_trace_buf, (size_t)take * WG_TRACE_WORDS * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return GPSBB_E_HIP;
+    return (long)n;
+}
+#endif
 #endif /* GPSBB_EXPERIMENTS */

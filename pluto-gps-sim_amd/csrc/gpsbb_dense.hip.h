@@ -327,19 +327,25 @@ __device__ __forceinline__ uint32_t pd_channel_fast_narrow(const PdModel &M, dou
 #undef GPSBB_PD_ACCS
 #undef GPSBB_PD_CLOBBERS
 
-/* the smallest low word of a lane's models over its 16 samples of a channel, as the fast path sees it (for the lanes that
- * have to be looked at again) */
-__device__ __forceinline__ uint32_t pd_model_min(const PdModel &M, int lane, bool fixed)
+/* which of a lane's 16 samples of a channel the fast path cannot vouch for: bit j = the low word of one of the models at sample
+ * j * 64 + lane, computed exactly as the fast path computes it, is below the threshold (for the lanes that have to be looked at
+ * again: the fast path itself only keeps the minimum over the 16).  The test is per sample — index and chip of a sample are
+ * floor() of that sample's models and of nothing else — so only these samples are recomputed: until round 6 a flagged lane
+ * recomputed all 16, sixteen jump-aheads from the tile start where one was needed, and the wavefront it sat in was busy for
+ * 200 - 400 us: in one block out of fifteen of the reference's geometry, and whenever that block was among the last of a
+ * launch the whole chip waited for it (profiles/r06_corun_diag.txt: 1.07 ms per launch of which the last 0.14 were 3 blocks). */
+__device__ __forceinline__ uint32_t pd_model_flagged(const PdModel &M, int lane, bool fixed, uint32_t danger)
 {
     double y = __fma_rn((double)lane, M.S8, M.ytg), x = __fma_rn((double)lane, M.sc2, M.xtg);
-    uint32_t m = 0xffffffffu;
+    uint32_t bad = 0u;
 #pragma unroll 1
     for (int j = 0; j < SPT; j++) {
-        m = min(m, min(fixed ? 0xffffffffu : (uint32_t)__double2loint(y), (uint32_t)__double2loint(x)));
+        const uint32_t m = min(fixed ? 0xffffffffu : (uint32_t)__double2loint(y), (uint32_t)__double2loint(x));
+        bad |= m < danger ? 1u << j : 0u;
         y = __dadd_rn(y, M.dy);
         x = __dadd_rn(x, M.dx);
     }
-    return m;
+    return bad;
 }
 
 /* channel i's models for the tile whose states are at ts */
@@ -367,9 +373,20 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     __builtin_amdgcn_s_setprio(GPSBB_EV_PRIO);
 #endif
     const int tid = threadIdx.x;
-    const int b = blockIdx.x; /* the block is the fast grid dimension, helpers join blocks still in flight (see k_synth_ev) */
-    if (blockIdx.y > 0 && __hip_atomic_load(&p.tile_ctr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.ntiles)
+#ifdef GPSBB_WG_TRACE /* measurement build: see wg_trace_leave */
+    WgTrace wgt = wg_trace_enter();
+#endif
+    const int b = ev_pick_block(p, (uint32_t)sizeof(PdLds<WIDE>)); /* a primary's own block, or the block a helper joins (gpsbb_events.hip.h) */
+#ifdef GPSBB_WG_TRACE
+    wgt.block = b;
+    wgt.nblocks = p.nblocks;
+#endif
+    if (b < 0) {
+#ifdef GPSBB_WG_TRACE
+        wg_trace_leave(wgt, wgt.wall0, wgt.clk0, 0u, 2u, false);
+#endif
         return;
+    }
     const gpsbb_chan_t *__restrict__ cb = p.ch + (size_t)b * p.nch;
     const EvConst *__restrict__ kb = p.evc + (size_t)b * p.nch;
     /* ---- stage the block's per-channel tables in LDS: wavefront w takes channels w, w + 16, ... ---- */
@@ -406,6 +423,9 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
         }
     }
     __syncthreads();
+#ifdef GPSBB_WG_TRACE
+    const unsigned long long t_staged = wall_clock64(), c_staged = clock64();
+#endif
 
     /* ---- from here on every wavefront works alone ---- */
     const int wave = tid >> 6, lane = tid & 63;
@@ -501,12 +521,15 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
                 const int i = __builtin_ctz(mk);
                 PdModel M;
                 pd_model_of(L, kb, ts, i, dbits, dnext, M);
-                if (((exact_mask >> i) & 1u) || pd_model_min(M, lane, fixed != 0u) < p.pd_danger) {
+                const uint32_t bad = ((exact_mask >> i) & 1u) ? (1u << SPT) - 1u : pd_model_flagged(M, lane, fixed != 0u, p.pd_danger);
+                if (bad) {
                     const size_t kk = (size_t)b * p.nch + i;
                     const int32_t fx_step = fixed ? p.kstep[kk] : 0;
                     const uint32_t fx_phase = fixed ? p.kph0[kk] + (uint32_t)wt * (uint32_t)TILE * (uint32_t)fx_step : 0u;
 #pragma unroll 1
                     for (int j = 0; j < SPT; j++) {
+                        if (!((bad >> j) & 1u))
+                            continue;
                         const v2f t = pd_fix_sample(L, i, kb + i, txb + wt, ntw, M.ytg, M.xtg, M.amp_base, M.roll_addr, M.neg | (M.neg_next << 1), lane, j,
                                                     (int)fixed, fx_phase, fx_step);
 #pragma unroll
@@ -539,6 +562,9 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     }
     if (lane == 0 && tiles_rendered)
         atomicAdd(p.hazards + 7, (unsigned long long)tiles_rendered); /* see synth_ev_body */
+#ifdef GPSBB_WG_TRACE
+    wg_trace_leave(wgt, t_staged, c_staged, tiles_rendered, 2u, true);
+#endif
 }
 
 } /* namespace gpsbb_impl */

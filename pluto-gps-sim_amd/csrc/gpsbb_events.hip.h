@@ -533,6 +533,79 @@ __device__ __forceinline__ void ev_channels(LDS &L, uint32_t &drow, int wave, in
 #undef GPSBB_EV_STATES
 }
 
+/*
+ * Which block a workgroup of the model kernels works on (k_synth_ev*, k_synth_pd).  The grid is one-dimensional:
+ * workgroups 0 .. nblocks-1 are the blocks' PRIMARIES (dispatched first, in order, one per CU as CUs come free); the
+ * EV_HELPERS(...) workgroups behind them are HELPERS, dispatched once every primary has been placed, i.e. when the launch is
+ * running out of whole blocks.  A helper takes a ticket and joins the (ticket mod L)-th of the L blocks that still have at
+ * least a chunk of tiles per wavefront left to hand out, counted from the LAST block — the blocks placed last have most left —
+ * so that the helpers that arrive together spread evenly over what is still running, and the ones that arrive when a round
+ * of blocks has finished go where the work is.  No live block: the helper leaves.
+ *
+ * Until round 6 the grid was (blocks, workgroups per block) with a block's helpers fixed in advance.  The workgroup trace of
+ * round 6 (tools/corun_diag.py, profiles/r06_corun_diag.txt) showed what that cost: helpers of blocks long finished had to
+ * be placed on a whole CU each and leave again before the first useful one was reached (1 941 of 3 000 workgroups of the
+ * reference geometry's launch, 624 of 1 200 of the headline's), the last blocks of a launch got their helpers late or not at
+ * all (the 32 blocks left at the end of the headline's launch had three workgroups each while 160 CUs idled), and the CUs
+ * drained over the last 9 % (k_synth_ev) and 18 % (k_synth_pd) of a launch.
+ *
+ * slot: LDS byte address of a word outside the kernel's LDS image (the launch allocates EV_PICK_LDS bytes behind it).
+ */
+constexpr int EV_PICK_LDS = 16;
+static_assert(sizeof(EvLds) + EV_PICK_LDS <= 160 * 1024 && sizeof(EvLdsLean) + EV_PICK_LDS <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
+constexpr int EV_HELP_SCAN = 64 * 64; /* a helper looks at the last 4 096 blocks of the launch (one ballot per 64) */
+__device__ __forceinline__ int ev_pick_block(const BatchDev &p, uint32_t slot)
+{
+    const int wg = (int)blockIdx.x;
+    if (wg < p.nblocks)
+        return wg;
+    int b = -1;
+    if (threadIdx.x < 64) { /* wavefront 0 decides for the workgroup */
+        const int lane = (int)threadIdx.x;
+        int ticket = 0;
+        if (lane == 0)
+            ticket = __hip_atomic_fetch_add(p.tile_ctr + p.nblocks, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        /* live: what is left to hand out is at least a chunk per wavefront (what a workgroup's staging is worth) */
+        const int live_upto = p.ntiles - EV_WAVES * p.ev_chunk;
+        const int nscan = p.nblocks < EV_HELP_SCAN ? p.nblocks : EV_HELP_SCAN;
+        unsigned long long mymask = 0ull; /* lane c: which of the blocks at positions 64 c .. 64 c + 63 from the end are live */
+        int nlive = 0;
+        for (int c = 0; c * 64 < nscan; c++) {
+            const int pos = c * 64 + lane;
+            const bool live = pos < nscan &&
+                              __hip_atomic_load(p.tile_ctr + (p.nblocks - 1 - (pos < nscan ? pos : 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= live_upto;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(live);
+            if (lane == c)
+                mymask = m;
+            nlive += __popcll(m);
+        }
+        if (nlive > 0) {
+            const int r = ticket % nlive;
+            const int cnt = __popcll(mymask);
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d);
+                if (lane >= d)
+                    incl += v;
+            }
+            const unsigned long long hm = __builtin_amdgcn_ballot_w64(r >= incl - cnt && r < incl); /* exactly one lane */
+            const int c = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)hm) - 1);
+            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mymask, c), hi = (uint32_t)__shfl((int)(uint32_t)(mymask >> 32), c);
+            unsigned long long cm = ((unsigned long long)hi << 32) | lo;
+            int k = __builtin_amdgcn_readfirstlane(r - __shfl(incl - cnt, c));
+            for (; k > 0; k--)
+                cm &= cm - 1ull; /* drop the k lowest set bits */
+            b = p.nblocks - 1 - (c * 64 + (int)__ffsll((long long)cm) - 1);
+        }
+        if (lane == 0)
+            lds_write_at<int>(slot, b);
+    }
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(lds_read_at<int>(slot));
+}
+
 /* DENSE: the batch has channels that are evaluated per sample (ev_dense): a kernel of its own (k_synth_ev_dense), so
  * that the common one keeps its register count: at <= 104 VGPRs four of its wavefronts leave room on a SIMD for a
  * wavefront of the pre-pass of the next push; at 120 they do not, and a CU that hosts walk wavefronts cannot take a
@@ -553,27 +626,20 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
             atomicOr(p.status, ST_LDS_LAYOUT);
         return;
     }
-    /* The block is the FAST grid dimension: the first workgroups dispatched are one per block, on as many
-     * CUs as there are; the workgroups with blockIdx.y > 0 come after them and join blocks that are still
-     * being worked on (tiles are handed out from a per-block counter), or leave at once if theirs is done.
-     * With the block as the slow dimension the launch proceeds in rounds of (CUs / workgroups per block)
-     * blocks and the last round leaves part of the chip idle: 2.4 instead of 2.1 ms. */
-    const int b = blockIdx.x;
-#ifdef GPSBB_EV_TIMING /* measurement build: when every workgroup started, finished staging and left (tools/wg_timing.py) */
-    const unsigned long long t_entry = wall_clock64();
-    unsigned long long *tlog = reinterpret_cast<unsigned long long *>(iq) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
-    if (blockIdx.y > 0 && __hip_atomic_load(&p.tile_ctr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.ntiles) {
-        if (threadIdx.x == 0) {
-            tlog[0] = t_entry;
-            tlog[1] = t_entry;
-            tlog[2] = wall_clock64();
-            tlog[3] = 0;
-        }
+#ifdef GPSBB_WG_TRACE /* measurement build (make trace; tools/corun_diag.py): when, where and at what clock every workgroup ran */
+    WgTrace wgt = wg_trace_enter();
+#endif
+    const int b = ev_pick_block(p, (uint32_t)sizeof(LDS)); /* a primary's own block, or the block a helper joins */
+#ifdef GPSBB_WG_TRACE
+    wgt.block = b;
+    wgt.nblocks = p.nblocks;
+#endif
+    if (b < 0) {
+#ifdef GPSBB_WG_TRACE
+        wg_trace_leave(wgt, wgt.wall0, wgt.clk0, 0u, 1u, false);
+#endif
         return;
     }
-#endif
-    if (blockIdx.y > 0 && __hip_atomic_load(&p.tile_ctr[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.ntiles)
-        return;
     const gpsbb_chan_t *__restrict__ cb = p.ch + (size_t)b * p.nch;
     const EvConst *__restrict__ kb = p.evc + (size_t)b * p.nch;
     /* ---- stage the block's per-channel tables in LDS (once per workgroup) ---- */
@@ -633,9 +699,8 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         }
     }
     __syncthreads();
-#ifdef GPSBB_EV_TIMING
-    const unsigned long long t_staged = wall_clock64();
-    unsigned long long n_tiles_done = 0;
+#ifdef GPSBB_WG_TRACE
+    const unsigned long long t_staged = wall_clock64(), c_staged = clock64();
 #endif
 
     /* ---- from here on every wavefront works alone ---- */
@@ -812,20 +877,11 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         base = next_base;
         pos = next_pos;
         tiles_rendered++;
-#ifdef GPSBB_EV_TIMING
-        n_tiles_done++;
-#endif
     }
     if (lane == 0 && tiles_rendered)
         atomicAdd(p.hazards + 7, (unsigned long long)tiles_rendered);
-#ifdef GPSBB_EV_TIMING
-    __syncthreads(); /* the workgroup leaves when its last wavefront does */
-    if (threadIdx.x == 0) {
-        tlog[0] = t_entry;
-        tlog[1] = t_staged;
-        tlog[2] = wall_clock64();
-        tlog[3] = n_tiles_done; /* wavefront 0's */
-    }
+#ifdef GPSBB_WG_TRACE
+    wg_trace_leave(wgt, t_staged, c_staged, tiles_rendered, 1u, true); /* wavefront 0's tiles and its own clocks: it need not be the last to leave */
 #endif
 }
 

@@ -164,6 +164,60 @@ struct ChainCarryDev {
     double exact_end[GPSBB_MAX_CHAN];     /* ... and exactly, once its k_chain_fix has run                         */
 };
 
+#ifdef GPSBB_WG_TRACE
+/* Measurement build only (make trace -> libgpsbb_trace.so; tools/corun_diag.py): every workgroup of the synthesis kernels leaves
+ * one record — when it entered, had its tables staged, finished wavefront 0's tiles and left, in ticks of the 100 MHz
+ * reference counter (s_memrealtime) AND in shader-clock cycles (s_memtime): cycles / ticks is the clock the chip ran at,
+ * cycles / tile is what a wavefront's work cost in issue slots whatever the clock — and where it ran (HW_ID, XCC_ID).  The
+ * buffer lives in device globals so that no kernel argument changes; gpsbb_test_wg_trace_begin / _read are the host side. */
+constexpr int WG_TRACE_WORDS = 12;
+__device__ unsigned long long *g_wg_trace;
+__device__ unsigned g_wg_trace_cap, g_wg_trace_n;
+struct WgTrace {
+    unsigned long long wall0, clk0;
+    int block;   /* the block the workgroup worked on (-1: a helper that found none) */
+    int nblocks; /* blocks of the launch (the model kernels: workgroups from this number on are helpers); 0: not a synthesis kernel */
+};
+__device__ __forceinline__ WgTrace wg_trace_enter()
+{
+    WgTrace t;
+    t.wall0 = wall_clock64();
+    t.clk0 = clock64();
+    t.block = (int)blockIdx.x;
+    t.nblocks = 0;
+    return t;
+}
+/* every lane of the workgroup calls it (a barrier: the workgroup leaves when its last wavefront does), except on the helpers'
+ * early way out (!worked), where nobody waits for anybody */
+__device__ __forceinline__ void wg_trace_leave(const WgTrace &t, unsigned long long wall_staged, unsigned long long clk_staged, unsigned tiles,
+                                               unsigned kind, bool worked)
+{
+    const unsigned long long wall_loop = wall_clock64(), clk_loop = clock64();
+    if (worked)
+        __syncthreads();
+    if (threadIdx.x == 0 && g_wg_trace) {
+        const unsigned k = atomicAdd(&g_wg_trace_n, 1u);
+        if (k < g_wg_trace_cap) {
+            unsigned long long *r = g_wg_trace + (size_t)k * WG_TRACE_WORDS;
+            r[0] = t.wall0;
+            r[1] = wall_staged;
+            r[2] = wall_loop;
+            r[3] = wall_clock64();
+            r[4] = t.clk0;
+            r[5] = clk_staged;
+            r[6] = clk_loop;
+            r[7] = clock64();
+            r[8] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) /* HW_REG_HW_ID */ |
+                   ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) /* HW_REG_XCC_ID */ << 32);
+            r[9] = (unsigned long long)(uint32_t)(t.block & 0xffffff) | ((unsigned long long)(t.nblocks && (int)blockIdx.x >= t.nblocks ? 1u : 0u) << 24) |
+                   ((unsigned long long)tiles << 40);
+            r[10] = kind | (worked ? 0x100u : 0u);
+            r[11] = (unsigned long long)(uint32_t)t.nblocks | ((unsigned long long)gridDim.x << 32);
+        }
+    }
+}
+#endif
+
 /* Everything the kernels need about one batch; passed by value as the kernel argument. */
 struct BatchDev {
     const gpsbb_chan_t *ch;         /* [nblocks*nch] descriptors, block-major                        */

@@ -881,7 +881,7 @@ __global__ __launch_bounds__(64) void k_lap_plan(BatchDev p, LapDev L)
     uint32_t lanes_before = 0;
     double carry_c = 0.0; /* the chain's drift corrections up to the first block of the group (see c_own below) */
     if (KIND == NCO_CODE && i == 0)
-        for (int b = lane; b < p.nblocks; b += 64)
+        for (int b = lane; b <= p.nblocks; b += 64) /* ([nblocks]: the helpers' ticket counter, ev_pick_block) */
             p.tile_ctr[b] = 0;
     for (int b0 = 0; b0 < p.nblocks; b0 += 64) {
         const int b = b0 + lane;
@@ -1212,6 +1212,9 @@ __global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass1(BatchDev p, 
     const uint32_t nl = L.nlaps[KIND * GPSBB_MAX_CHAN + i];
     if (c * (uint32_t)LAP_WG >= nl)
         return;
+#ifdef GPSBB_WG_TRACE /* measurement build: see wg_trace_leave */
+    const WgTrace wgt = wg_trace_enter();
+#endif
     const uint32_t r = c * (uint32_t)LAP_WG + (uint32_t)t;
     const bool mine = r < nl;
     LapStart st;
@@ -1282,6 +1285,9 @@ __global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass1(BatchDev p, 
         L.agg[chunk] = a;
         L.chunk_bad[chunk] = 0;
     }
+#ifdef GPSBB_WG_TRACE
+    wg_trace_leave(wgt, wgt.wall0, wgt.clk0, 0u, 3u + (unsigned)KIND, true);
+#endif
 }
 
 /* the offset of every chunk's first lap: one wavefront per kind and channel composes the chunks' links in order */
@@ -1327,6 +1333,9 @@ __global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass2(BatchDev p, 
     const uint32_t nl = L.nlaps[KIND * GPSBB_MAX_CHAN + i];
     if (c * (uint32_t)LAP_WG >= nl)
         return;
+#ifdef GPSBB_WG_TRACE
+    const WgTrace wgt = wg_trace_enter();
+#endif
     const uint32_t r = c * (uint32_t)LAP_WG + (uint32_t)t;
     const bool mine = r < nl;
     const double m_first = L.chunk_m[chunk];
@@ -1400,6 +1409,9 @@ __global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass2(BatchDev p, 
         if (w.hz)
             atomicAdd(p.hazards + (KIND == NCO_CARR ? 0 : 1), (unsigned long long)w.hz);
     }
+#ifdef GPSBB_WG_TRACE
+    wg_trace_leave(wgt, wgt.wall0, wgt.clk0, 0u, 5u + (unsigned)KIND, true);
+#endif
 }
 
 /* ---- k_lap_repair -------------------------------------------------------------------------------------------- */

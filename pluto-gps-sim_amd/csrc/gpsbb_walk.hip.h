@@ -1258,7 +1258,7 @@ __global__ __launch_bounds__(GPSBB_TILES_WG) void k_tiles(BatchDev p)
     const int ntl = nseg > 1 ? ((p.ntiles - t0 < p.seg_tiles) ? p.ntiles - t0 : p.seg_tiles) : p.ntiles; /* ... and how many it has */
     /* the tile counters of this table set, for the synthesis kernel that follows (the one that last used them has
      * finished: the pre-pass waited for it): saves a memset and its launch gap on the synthesis stream */
-    if (chain < p.nblocks && threadIdx.x == 0)
+    if (chain <= p.nblocks && threadIdx.x == 0) /* ([nblocks]: the helpers' ticket counter, ev_pick_block; the grid has at least 2 * nblocks * nch workgroups) */
         p.tile_ctr[chain] = 0;
     const int b = bi / p.nch, i = bi % p.nch;
     if (kind && p.kph0) {

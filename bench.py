@@ -10,9 +10,10 @@ time-continuous 16-channel stream at fs = 25 MS/s in 0.1 s blocks of 2.5 M sampl
 exactly from block to block (GPSBB_CHAIN_CARRIER, c:2741-2746 never re-seeds carr_phase).  One "step" is one
 pass of the hot path over the next 3200 blocks of that stream (8e9 IQ samples, 32 GB of int16 IQ), from
 descriptors the library plans afresh: per 400-block push the host validates and plans the descriptors and uploads
-them, the device chains the carrier exactly in parallel over the blocks (k_walk pass A, k_chain_prefix, k_walk pass
-B, k_chain_fix_par), expands the tile states (k_tiles) and synthesises (k_synth_ev); the IQ lands in the ring's HBM
-slots (GPSBB_STREAM_DEVICE_ONLY).  The stream has T = K*3200 blocks; the warm-up and every one of the --repeats
+them, the device builds the exact NCO states of every tile with the lap-parallel pre-pass (k_lap_plan, k_lap_pass1, k_lap_scan,
+k_lap_pass2, k_lap_repair for the code chains and for the carriers, the carrier chained exactly across the blocks and from the
+phase the push before left on the device) and synthesises (k_synth_ev); the IQ lands in the ring's HBM slots
+(GPSBB_STREAM_DEVICE_ONLY).  The stream has T = K*3200 blocks; the warm-up and every one of the --repeats
 timed regions walk through its pushes cyclically (a region of K steps is one pass over a rank's whole shard).  With
 N ranks the stream is cut into N contiguous time shards (rank r renders blocks [r*T/N, (r+1)*T/N): strong scaling,
 no data-path collective); a shard starts from the stream's exact carrier phase there, which every rank computes for
@@ -32,9 +33,16 @@ duration against the 8 TB/s HBM peak.  Beside it, measured in the same invocatio
   resident      re-runs of one 400-block batch whose descriptors and plans stay in HBM (independent blocks and
                 chained): what round 1 reported as its value
   gather        the same shard through a ring with the pinned D2H gather (PCIe-inclusive; never `value`)
-  m1            BASELINE.md section 3's other leg: 12 ch, 2.6 MS/s, 300 000-sample blocks (GPU, and the CPU port)
-  cpu_baseline  the CPU restatement (oracle, 1 core) on a bounded sample of the same blocks
-These four run at N = 1 only (with N > 1 they would keep N - 1 GPUs idle behind rank 0 for most of the command).
+  m1            BASELINE.md section 3's other leg, the reference's own geometry: 12 ch, 2.6 MS/s, 300 000-sample blocks
+                (plutogpssim.c:43-45).  `m1.stream` (and `m1.value`, `m1.roofline_stream`) AT EVERY N: a time-sharded stream of
+                fresh chained pushes like the headline's (1000 blocks per push), every block cross-checked against the per-sample
+                kernel by device-side digests, leading blocks against the oracle; `m1.gpu*` (resident re-runs of one batch) at N = 1
+  fill_block    the drop-in call itself, gpsbb_fill_block_ref on the reference's channel_t layout with a pageable iq_buff: median /
+                p99 of 200 calls for the reference's block and for the headline's, each checked against the oracle once (rank 0)
+  cpu_baseline  the CPU restatement (oracle, 1 core) on a bounded sample of the same blocks, AT EVERY N: rank 0 runs it on a
+                thread of its own while the GPU legs that follow the timed regions run (it is CPU-only)
+`resident`, `m1.gpu*`, `roofline.alone` and the write ceiling run at N = 1 only (with N > 1 they would keep N - 1 GPUs idle behind
+rank 0 for most of the command).
   parity        blocks of the timed mode's ring against the CPU oracle (a handful: the oracle renders 2e7 samples/s) AND every
                 block of every shard against the per-sample kernel's rendering, by device-side digests (`blocks_cross_checked`)
   node_driver   the product's one-process driver (include/gpsbb_node.h): the same pushes through one shard on this rank's GPU,
@@ -62,6 +70,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 PUSH_BLOCKS = 400      # blocks per push (1e9 samples, 4 GB of IQ)
 STEP_PUSHES = 8        # pushes per step over all ranks: a step is 3200 blocks
+# BASELINE.md section 3's other geometry, the reference's own (plutogpssim.c:43-45; README.md:123): 12 channels (MAX_CHAN, h:21),
+# 2.6 MS/s, NUM_SAMPLES 300 000 per block; as a stream: pushes of 1000 blocks (3e8 samples, 1.2 GB of IQ), 8 per step
+M1_NCH, M1_FS, M1_NSAMP, M1_PUSH_BLOCKS, M1_SEED, M1_DESC_STEPS = 12, 2.6e6, 300000, 1000, 0xF00D, 4
 
 
 def stream_descriptors(pkg, nblocks, nch, seed=0x5EED, max_doppler=5000.0, first=0, count=None, fields=None):
@@ -224,6 +235,139 @@ def resident_leg(pkg, synth, torch, ch, delt, nsamp, flags, steps, warmup, dev, 
             "chained": bool(flags & pkg.CHAIN_CARRIER)}, n * 4 / (ceil_ms * 1e-3) / 1e9
 
 
+def m1_stream_leg(pkg, synth, torch, dist, use_dist, backend, dev, rank, world, ob, K, W, R, depth, PB, nsamp, parity_blocks, parity_spots):
+    """The reference's geometry AT EVERY N (north_star: throughput at 2.6 MS/s and 25 MS/s at 1, 2, 4 and 8 GPUs): one
+    time-continuous 12-channel stream at 2.6 MS/s in 300 000-sample blocks, cut into `world` contiguous time shards like the
+    headline's, every rank seeding its shard on its own GPU; K steps of 8 / world fresh chained pushes of PB blocks per timed
+    region (the descriptors of min(K, M1_DESC_STEPS) steps, walked through cyclically), R regions, max over ranks, median.
+    Then the shard once more in order: leading blocks and spots against the oracle (ob; None: skipped), every block's digest
+    against the per-sample kernel's.  Returns (result dict for rank 0, this rank's shard descriptors, mismatches)."""
+    nch, delt = M1_NCH, 1.0 / M1_FS
+    ppr = STEP_PUSHES // world
+    kd = max(1, min(K, M1_DESC_STEPS))
+    total = kd * STEP_PUSHES * PB
+    b0, b1 = pkg.shard_blocks(total, rank, world)
+    mine = stream_descriptors(pkg, total, nch, seed=M1_SEED, first=b0, count=b1 - b0)
+    before = np.concatenate([stream_descriptors(pkg, total, nch, seed=M1_SEED, first=0, count=b0, fields=("prn", "f_carr", "carr_phase")), mine[:1]])
+    synth.shard_seed(before, min(b0, 64), delt, nsamp)
+    synth.sync()
+    t_seed = time.perf_counter()
+    mine["carr_phase"][0] = synth.shard_seed(before, b0, delt, nsamp)
+    t_seed = time.perf_counter() - t_seed
+    del before
+    npush = mine.shape[0] // PB
+
+    def barrier():
+        synth.sync()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+
+    def over_ranks(x, op):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    def run_ring(st, first, count):
+        for j in range(count):
+            if st.pending >= depth:
+                st.pop(copy=False)
+            k = (first + j) % npush
+            st.push(mine[k * PB:(k + 1) * PB])
+        while st.pending:
+            st.pop(copy=False)
+
+    st = synth.stream(nch, delt, nsamp, PB, depth=depth, flags=pkg.CHAIN_CARRIER | pkg.STREAM_DEVICE_ONLY)
+    run_ring(st, 0, max(W, 1) * ppr)
+    pos = max(W, 1) * ppr
+    barrier()
+    st.timing_stats(reset=True)
+    times = []
+    for _ in range(R):
+        barrier()
+        t0 = time.perf_counter()
+        run_ring(st, pos, K * ppr)
+        synth.sync()
+        torch.cuda.synchronize()
+        times.append(over_ranks(time.perf_counter() - t0, dist.ReduceOp.MAX if use_dist else None))
+        pos += K * ppr
+    barrier()
+    stats = st.timing_stats(reset=True)
+    kernel = {1: "k_synth", 2: "k_synth_pd"}.get(synth.info(pkg.INFO_LAST_KERNEL), "?")
+    prepass = synth.info(pkg.INFO_PREPASS)
+    st.close()
+    # bytes of evidence: the shard in order through a fresh ring, against the oracle and against the per-sample kernel
+    n_ok, bad, digs, iq_digs = parity_check(pkg, ob, synth, mine, delt, nsamp, PB, nch, max(1, min(parity_blocks, PB)), parity_spots)
+    cross_bad, cross_kernel = cross_check(pkg, synth, mine, delt, nsamp, PB, nch, iq_digs)
+    n_all = int(over_ranks(float(n_ok), dist.ReduceOp.SUM if use_dist else None))
+    n_bad = int(over_ranks(float(len(bad)), dist.ReduceOp.SUM if use_dist else None))
+    n_cross_bad = int(over_ranks(float(len(cross_bad)), dist.ReduceOp.SUM if use_dist else None))
+    seed_max = over_ranks(t_seed, dist.ReduceOp.MAX if use_dist else None)
+    if use_dist:
+        allg = [None] * world
+        dist.all_gather_object(allg, (digs, iq_digs))
+        digs = [d for part in allg for d in part[0]]
+        iq_digs = np.concatenate([part[1] for part in allg])
+    if bad or cross_bad:
+        sys.stderr.write("bench.py: rank %d, 2.6 MS/s stream: %d blocks differ from the oracle, %d from the per-sample kernel\n" % (rank, len(bad), len(cross_bad)))
+    elapsed = statistics.median(times)
+    samples_per_step = STEP_PUSHES * PB * nsamp
+    ms_synth = stats["ms_synth_sum"] / max(stats["runs"], 1)
+    achieved = 4.0 * PB * nsamp / (ms_synth * 1e-3) / 1e9
+    res = {"value": samples_per_step * K / elapsed, "unit": "IQ samples/s", "ms_per_step": elapsed / K * 1e3, "steps": K, "n_gpus": world,
+           "seconds": times, "synth_kernel_ms": ms_synth, "prepass_ms": stats["ms_seed_sum"] / max(stats["runs"], 1),
+           "synthesis_kernel": kernel, "prepass": {3: "lap-parallel", 2: "host threads", 1: "row walks"}.get(prepass, "?"),
+           "shard_seed_s": seed_max, "value_incl_seed": samples_per_step * K / (elapsed + seed_max),
+           "workload": "%d ch, fs %.3g S/s, %d-sample blocks as ONE chained stream: %d blocks per step (%d fresh pushes of %d), descriptors of %d "
+                       "blocks walked through cyclically, cut into %d contiguous time shards" % (nch, M1_FS, nsamp, STEP_PUSHES * PB, STEP_PUSHES, PB, total, world),
+           "roofline": {"bound": "valu+lds issue (the package's power limit: DESIGN.md 3.1)", "priced_against": "hbm", "kernel": kernel, "ms_per_launch": ms_synth,
+                        "launches_timed": stats["runs"], "algorithmic_bytes_per_launch": 4 * PB * nsamp, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS},
+           "parity": {"checked_blocks": n_all, "mismatching_blocks": n_bad, "blocks_cross_checked": int(iq_digs.shape[0]),
+                      "cross_mismatching_blocks": n_cross_bad, "blocks_digested": len(digs),
+                      "cross_check_against": "k_synth on k_seed's rows (GPSBB_OPT_SYNTH_KERNEL 1)" if cross_kernel == 1 else "?",
+                      "stream_iq_digest": zlib.crc32(iq_digs.tobytes()), "stream_end_state_digest": zlib.crc32(np.asarray(digs, np.uint32).tobytes())}}
+    return res, mine, n_bad + n_cross_bad
+
+
+def fill_block_leg(pkg, synth, ob, cases, calls=200):
+    """The drop-in call itself (plutogpssim.c:2689-2759 replaced by ONE call): gpsbb_fill_block_ref on the reference's own
+    channel_t[] / gain[] (offsetof layout), IQ into a pageable iq_buff, state updated in place — median / p99 / min of `calls`
+    calls, every case checked against the oracle once (IQ and the updated channel state)."""
+    out = {}
+    for name, nch, fs, nsamp, seed in cases:
+        d = pkg.synth_descriptors(8, nch=nch, seed=seed)
+        iq = np.zeros((nsamp, 2), np.int16)           # pageable, like the reference's iq_buff (c:84)
+        lay = pkg.ref_layout()
+        for k in range(4):
+            chan, gain = pkg.ref_channels(d[k % 8])
+            synth.fill_block_ref(chan, gain, 1.0 / fs, nsamp, iq, lay)
+        ok = None
+        if ob is not None:
+            chan, gain = pkg.ref_channels(d[3])
+            synth.fill_block_ref(chan, gain, 1.0 / fs, nsamp, iq, lay)
+            want_iq, want_st, _ = ob.Oracle().fill_blocks(d[3:4], 1.0 / fs, nsamp)
+            act = d["prn"][3] > 0
+            ok = bool((iq == want_iq[0]).all()) and all(chan[f][act].tobytes() == want_st[f][0][act].astype(chan[f].dtype).tobytes()
+                                                         for f in ("carr_phase", "code_phase", "iword", "ibit", "icode", "dataBit", "codeCA"))
+        ts = []
+        for k in range(calls):
+            chan, gain = pkg.ref_channels(d[k % 8])
+            t0 = time.perf_counter()
+            synth.fill_block_ref(chan, gain, 1.0 / fs, nsamp, iq, lay)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        out[name] = {"median_ms": ts[len(ts) // 2] * 1e3, "p99_ms": ts[min(len(ts) - 1, int(len(ts) * 0.99))] * 1e3, "min_ms": ts[0] * 1e3,
+                     "calls": calls, "samples_per_s_at_median": nsamp / ts[len(ts) // 2], "nch": nch, "fs": fs, "nsamp": nsamp,
+                     "equals_oracle": ok, "prepass": {3: "lap-parallel, on the device", 2: "host threads", 1: "row walks, on the device"}.get(synth.info(pkg.INFO_PREPASS), "?"),
+                     "real_time_factor": (nsamp / fs) / ts[len(ts) // 2]}
+    out["what"] = ("gpsbb_fill_block_ref (include/gpsbb.h): the reference's channel_t[] and gain[] in, int16 IQ into a pageable host buffer, "
+                   "channel state updated in place; wall clock around the call, Python's ctypes overhead (~10 us) included")
+    return out
+
+
 def dry_run(args, pkg, dist, world, rank):
     """No GPU: the sharding, the shard seeds and the digest exchange of the N > 1 path with the CPU oracle rendering
     (tiny blocks).  What tests/test_shard_gloo.py runs under gloo with world_size 2."""
@@ -239,13 +383,25 @@ def dry_run(args, pkg, dist, world, rank):
     mine["carr_phase"][0] = seeds[b0]
     iq, _, _ = ob.Oracle().fill_blocks(mine, delt, nsamp, chain=True)
     dig = [hashlib.sha256(iq[k].tobytes()).digest() for k in range(b1 - b0)]
+    # ... and the 2.6 MS/s stream of m1_stream_leg: the same cut, the same seeds, 12 channels
+    m_delt, m_nsamp = 1.0 / M1_FS, args.m1_nsamp
+    m_total = max(1, min(args.steps, M1_DESC_STEPS)) * STEP_PUSHES * args.m1_push_blocks
+    mch = stream_descriptors(pkg, m_total, M1_NCH, seed=M1_SEED)
+    m0, m1 = pkg.shard_blocks(m_total, rank, world)
+    m_mine = mch[m0:m1].copy()
+    m_mine["carr_phase"][0] = pkg.chain_carrier_host(mch[:m0 + 1], m_delt, m_nsamp)[m0]
+    m_iq, _, _ = ob.Oracle().fill_blocks(m_mine, m_delt, m_nsamp, chain=True)
+    m_dig = [hashlib.sha256(m_iq[k].tobytes()).digest() for k in range(m1 - m0)]
     if world > 1:
         allg = [None] * world
-        dist.all_gather_object(allg, dig)
-        dig = [d for part in allg for d in part]
+        dist.all_gather_object(allg, (dig, m_dig))
+        dig = [d for part in allg for d in part[0]]
+        m_dig = [d for part in allg for d in part[1]]
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_ranks": world, "blocks": total,
-                          "stream_digest": hashlib.sha256(b"".join(dig)).hexdigest()}))
+                          "stream_digest": hashlib.sha256(b"".join(dig)).hexdigest(),
+                          "m1": {"blocks": m_total, "nch": M1_NCH, "fs": M1_FS, "nsamp": m_nsamp,
+                                 "stream_digest": hashlib.sha256(b"".join(m_dig)).hexdigest()}}))
 
 
 def main():
@@ -265,6 +421,9 @@ def main():
     ap.add_argument("--parity-spots", type=int, default=8)
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling runs)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: sharding / seeds / digest exchange with the CPU oracle")
+    ap.add_argument("--m1-push-blocks", type=int, default=M1_PUSH_BLOCKS, help="blocks per push of the 2.6 MS/s stream leg")
+    ap.add_argument("--m1-nsamp", type=int, default=M1_NSAMP, help="samples per block of the 2.6 MS/s legs (the reference's NUM_SAMPLES)")
+    ap.add_argument("--fill-calls", type=int, default=200, help="gpsbb_fill_block_ref calls timed per case of the fill_block leg")
     args = ap.parse_args()
 
     import torch  # first: it brings the HIP runtime the library then shares
@@ -435,6 +594,31 @@ def main():
                   "digest_of_block_digests": zlib.crc32(np.asarray(digs, np.uint32).tobytes()),
                   "note": "IQ stored into pinned host memory by a copy kernel on the side stream, the first and last 64 KiB of every block digested on arrival; PCIe Gen5 x16 = 63 GB/s raw"}
 
+    # ---- the reference's own geometry as a time-sharded stream, at every N (all ranks: its regions are bracketed by barriers) ----
+    m1_stream, m1_mine, m1_bad, ob_all = None, None, 0, None
+    if not args.no_cpu and not args.no_extras:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_binding as ob_all
+        ob_all.Oracle().fill_blocks(mine[:1], delt, 1000)   # the oracle's one-time tables, before any thread uses it
+    if not args.no_extras:
+        m1_stream, m1_mine, m1_bad = m1_stream_leg(pkg, synth, torch, dist, use_dist, backend, dev, rank, world, ob_all, K, W, R, args.depth,
+                                                   args.m1_push_blocks, args.m1_nsamp, max(1, min(args.parity_blocks, 8)), min(args.parity_spots, 4))
+
+    # ---- the CPU baselines, at every N: rank 0, on a thread of its own (the oracle is C: the call drops the GIL) while the legs
+    # below — GPU work that is not the headline's timed regions — run; joined before the line is printed ----
+    cpu_thread, cpu_out = None, {}
+    if rank == 0 and ob_all is not None:
+        import threading
+
+        def cpu_legs():
+            try:
+                cpu_out["cpu_baseline"] = cpu_baseline(ob_all, mine, delt, nsamp, budget_s=args.cpu_budget)
+                cpu_out["m1_cpu"] = cpu_baseline(ob_all, m1_mine, 1.0 / M1_FS, args.m1_nsamp, budget_s=args.cpu_budget / 2)
+            except Exception as e:  # reported in the line, never fatal for the GPU figures
+                cpu_out["error"] = repr(e)
+        cpu_thread = threading.Thread(target=cpu_legs, name="cpu-baseline")
+        cpu_thread.start()
+
     # ---- the same pushes through the PRODUCT's node driver (include/gpsbb_node.h): one process, one producer thread +
     # handle + ring per shard, one sink.  N = 1 on this rank's GPU must agree with the headline (same ring, same pushes,
     # driven from C instead of from this script); with one rank and several GPUs visible, also all of them in one process,
@@ -475,10 +659,7 @@ def main():
     seed_max = over_ranks(t_seed, dist.ReduceOp.MAX)
     parity = None
     if not args.no_extras:
-        ob = None
-        if not args.no_cpu:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import oracle_binding as ob
+        ob = ob_all
         n_ok, bad, digs, iq_digs = parity_check(pkg, ob, synth, mine, delt, nsamp, PB, nch, max(1, min(args.parity_blocks, PB)), args.parity_spots)
         t_cross = time.perf_counter()
         cross_bad, cross_kernel = cross_check(pkg, synth, mine, delt, nsamp, PB, nch, iq_digs)
@@ -623,6 +804,10 @@ def main():
                                         "source": sj.get("source")}
             except Exception:
                 pass
+    if rank == 0 and m1_stream is not None:
+        res["m1"] = {"value": m1_stream["value"], "unit": "IQ samples/s", "n_gpus": world, "stream": m1_stream, "roofline_stream": m1_stream["roofline"],
+                     "note": "the reference's own geometry (plutogpssim.c:43-45: 12 ch, 2.6 MS/s, 300 000-sample blocks); `value` = the time-sharded stream of "
+                             "fresh chained pushes over all ranks (m1.stream), at every N; m1.gpu* = resident re-runs of one 1000-block batch, N = 1 only"}
     if rank == 0 and not args.no_extras and world == 1:
         # (at N = 1 only: with N > 1 these legs would keep N - 1 GPUs idle behind a barrier for most of the command's wall time)
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -647,14 +832,16 @@ def main():
         if "roofline_valu" in res:
             res["roofline_valu"]["frac_alone"] = res["roofline_valu"]["issue_ms_per_launch"] / r2["synth_kernel_ms"]
         # the reference-faithful geometry (12 ch, 2.6 MS/s, 300 000-sample blocks)
-        mch = pkg.synth_descriptors(1000, nch=12, seed=0xF00D)
-        m1, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, 0, 30, 4, dev)
+        mns = args.m1_nsamp
+        mch = pkg.synth_descriptors(args.m1_push_blocks, nch=12, seed=0xF00D)
+        m1, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, mns, 0, 30, 4, dev)
         m1_kernel = {1: "k_synth", 2: "k_synth_pd (every channel evaluated per sample on the in-tile model)"}.get(
             synth.info(pkg.INFO_LAST_KERNEL), "?")
-        m1s, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, 0, 30, 5, dev, synth_only=True)
-        m1c, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, 300000, pkg.CHAIN_CARRIER, 30, 4, dev)
-        m1_alg = 4.0 * mch.shape[0] * 300000
-        res["m1"] = {"gpu": m1, "gpu_chained_on_the_device": m1c, "unit": "IQ samples/s",
+        m1s, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, mns, 0, 30, 5, dev, synth_only=True)
+        m1c, _ = resident_leg(pkg, synth, torch, mch, 1.0 / 2.6e6, mns, pkg.CHAIN_CARRIER, 30, 4, dev)
+        m1_alg = 4.0 * mch.shape[0] * mns
+        res.setdefault("m1", {"unit": "IQ samples/s"})
+        res["m1"].update({"gpu": m1, "gpu_chained_on_the_device": m1c,
                      "roofline": {"bound": "valu+lds issue", "priced_against": "hbm", "kernel": "k_synth_pd", "ms_per_launch": m1["synth_kernel_ms"],
                                   "achieved": m1_alg / (m1["synth_kernel_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": m1_alg / (m1["synth_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -663,17 +850,31 @@ def main():
                                   "bound_measured": "valu+lds issue",
                                   "note": "VALU- and LDS-issue-bound (about 27 VALU issue cycles and 12 bytes of LDS reads per channel-sample), not HBM-bound: "
                                           "DESIGN.md 2.4; the stores cost it 7 % (tools/bound_hunt.sh PD_NOSTORE)"},
-                     "workload": "12 ch, fs 2.6e6 S/s, 300000-sample blocks, 1000 independent blocks per step; synthesis kernel " + m1_kernel}
+                     "workload": "12 ch, fs 2.6e6 S/s, %d-sample blocks, %d independent blocks per step (resident re-runs); synthesis kernel %s" % (mns, mch.shape[0], m1_kernel)})
         # the reference built without FLOAT_CARR_PHASE (h:12): 32-bit fixed-point carrier, the same M1 geometry
         fch = mch.copy()
         fch["carr_phase"] = np.floor(fch["carr_phase"] * 2.0 ** 32)
-        m1f, _ = resident_leg(pkg, synth, torch, fch, 1.0 / 2.6e6, 300000, pkg.FIXED_CARRIER, 20, 4, dev)
+        m1f, _ = resident_leg(pkg, synth, torch, fch, 1.0 / 2.6e6, mns, pkg.FIXED_CARRIER, 20, 4, dev)
         m1f["synthesis_kernel"] = {1: "k_synth", 2: "k_synth_pd"}.get(synth.info(pkg.INFO_LAST_KERNEL), "?")
         res["m1"]["gpu_fixed_point_carrier"] = m1f
-        if not args.no_cpu:
-            import oracle_binding as ob
-            res["cpu_baseline"] = cpu_baseline(ob, mine, delt, nsamp, budget_s=args.cpu_budget)
-            res["m1"]["cpu"] = cpu_baseline(ob, mch, 1.0 / 2.6e6, 300000, budget_s=args.cpu_budget / 2)
+    fill_bad = False
+    if cpu_thread is not None:
+        cpu_thread.join()
+        if "cpu_baseline" in cpu_out:
+            res["cpu_baseline"] = cpu_out["cpu_baseline"]
+            res["cpu_baseline"]["concurrency"] = "on a thread of rank 0 while that rank's post-timing GPU legs ran (one core busy with it; the rank is bound to its GPU's NUMA node)"
+        if "m1_cpu" in cpu_out and "m1" in res:
+            res["m1"]["cpu"] = cpu_out["m1_cpu"]
+        if "error" in cpu_out:
+            res["cpu_baseline_error"] = cpu_out["error"]
+    if rank == 0 and not args.no_extras:
+        # the drop-in call itself, after the CPU legs have left the cores alone
+        try:
+            res["fill_block"] = fill_block_leg(pkg, synth, ob_all, (("reference_block_12ch_2.6MSps_300000", 12, 2.6e6, args.m1_nsamp, 0xBEEF),
+                                                                     ("headline_block_16ch_25MSps", nch, args.fs, nsamp, 0xBEE5)), calls=args.fill_calls)
+            fill_bad = any(v.get("equals_oracle") is False for v in res["fill_block"].values() if isinstance(v, dict))
+        except Exception as e:
+            res["fill_block"] = {"error": repr(e)}
     if use_dist:
         dist.barrier()   # the other ranks wait for rank 0's node-driver leg
     if rank == 0:
@@ -682,6 +883,8 @@ def main():
     if use_dist:
         dist.destroy_process_group()
     if parity and (parity["mismatching_blocks"] or parity["cross_mismatching_blocks"] or parity.get("node_driver_mismatch")):
+        raise SystemExit(3)
+    if m1_bad or fill_bad:
         raise SystemExit(3)
 
 

@@ -37,6 +37,46 @@ CHAN_DTYPE = np.dtype([("prn", "<i4"), ("iword", "<i4"), ("ibit", "<i4"), ("icod
 STATE_DTYPE = np.dtype([("carr_phase", "<f8"), ("code_phase", "<f8"), ("iword", "<i4"),
                         ("ibit", "<i4"), ("icode", "<i4"), ("dataBit", "<i4"), ("codeCA", "<i4"),
                         ("_pad", "<i4")])
+# The reference's channel_t (plutogpssim.h:152-174, FLOAT_CARR_PHASE build, LP64) as a numpy record: what a caller that kept the
+# reference's structures hands to gpsbb_fill_block_ref.  tests/test_ref_layout.py checks every offset against offsetof() on the
+# real header (in the build container, where /root/reference exists).
+REF_CHANNEL_DTYPE = np.dtype([("prn", "<i4"), ("ca", "<i4", (1023,)), ("f_carr", "<f8"), ("f_code", "<f8"),
+                              ("carr_phase", "<f8"), ("code_phase", "<f8"), ("g0_week", "<i4"), ("_p0", "<i4"),
+                              ("g0_sec", "<f8"), ("sbf", "<u8", (50,)), ("dwrd", "<u8", (60,)), ("iword", "<i4"),
+                              ("ibit", "<i4"), ("icode", "<i4"), ("dataBit", "<i4"), ("codeCA", "<i4"), ("_p1", "<i4"),
+                              ("azel", "<f8", (2,)), ("rho0", "<f8", (8,))])
+# ... and the same struct of a reference built WITHOUT FLOAT_CARR_PHASE (h:12 removed): h:160-161 put a 32-bit accumulator and its
+# step where the double was (same size, so nothing else moves): what gpsbb_fill_block_ref_fixed is handed
+REF_CHANNEL_FIXED_DTYPE = np.dtype([("prn", "<i4"), ("ca", "<i4", (1023,)), ("f_carr", "<f8"), ("f_code", "<f8"),
+                                    ("carr_phase", "<u4"), ("carr_phasestep", "<i4"), ("code_phase", "<f8"), ("g0_week", "<i4"),
+                                    ("_p0", "<i4"), ("g0_sec", "<f8"), ("sbf", "<u8", (50,)), ("dwrd", "<u8", (60,)),
+                                    ("iword", "<i4"), ("ibit", "<i4"), ("icode", "<i4"), ("dataBit", "<i4"), ("codeCA", "<i4"),
+                                    ("_p1", "<i4"), ("azel", "<f8", (2,)), ("rho0", "<f8", (8,))])
+
+
+class RefLayout(C.Structure):
+    """gpsbb_ref_layout_t (include/gpsbb.h): where the fields gpsbb_fill_block_ref reads and updates sit in the caller's channel_t"""
+    _fields_ = [(n, C.c_size_t) for n in ("stride", "off_prn", "off_f_carr", "off_f_code", "off_carr_phase", "off_code_phase",
+                                          "off_dwrd", "sizeof_dwrd_elem", "off_iword", "off_ibit", "off_icode", "off_dataBit",
+                                          "off_codeCA")]
+
+
+def ref_layout(dtype=None):
+    dtype = REF_CHANNEL_DTYPE if dtype is None else dtype
+    off = lambda n: dtype.fields[n][1]
+    return RefLayout(dtype.itemsize, off("prn"), off("f_carr"), off("f_code"), off("carr_phase"), off("code_phase"), off("dwrd"), 8,
+                     off("iword"), off("ibit"), off("icode"), off("dataBit"), off("codeCA"))
+
+
+def ref_channels(d):
+    """one block's descriptors (CHAN_DTYPE[nch]) as the reference's channel_t[] and gain[] (plutogpssim.c:2241)"""
+    chan = np.zeros(d.shape[0], REF_CHANNEL_DTYPE)
+    for f in ("prn", "f_carr", "f_code", "carr_phase", "code_phase", "iword", "ibit", "icode"):
+        chan[f] = d[f]
+    chan["dwrd"] = d["dwrd"]
+    return chan, np.ascontiguousarray(d["gain"])
+
+
 ROW_DTYPE = np.dtype([("n0", "<i4"), ("nav", "<u4"), ("xb", "<u8"), ("inc", "<i8")])
 assert CHAN_DTYPE.itemsize == 296 and STATE_DTYPE.itemsize == 40 and ROW_DTYPE.itemsize == 24
 
@@ -247,6 +287,13 @@ class Synth:
         _chk(lib().gpsbb_fill_block_ex(self._h, ch.ctypes.data, ch.shape[0], delt, nsamp, flags, iq.ctypes.data,
                                        st.ctypes.data), "gpsbb_fill_block_ex")
         return iq, st
+
+    def fill_block_ref(self, chan, gain, delt, nsamp, iq, layout=None):
+        """gpsbb_fill_block_ref: the reference's own channel_t[] (REF_CHANNEL_DTYPE, updated in place like the loop does,
+        c:2709-2746) and gain[]; iq: int16 [nsamp, 2], the caller's iq_buff (c:84)"""
+        layout = layout or ref_layout(chan.dtype)
+        _chk(lib().gpsbb_fill_block_ref(self._h, chan.ctypes.data, C.byref(layout), chan.shape[0], gain.ctypes.data, delt, nsamp,
+                                        iq.ctypes.data), "gpsbb_fill_block_ref")
 
     def batch(self, ch, delt, nsamp, flags=0):
         return Batch(self, ch, delt, nsamp, flags)

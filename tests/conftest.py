@@ -58,21 +58,7 @@ def synth(pkg):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-# The reference's channel_t (plutogpssim.h:152-174, FLOAT_CARR_PHASE build, LP64) as a numpy record: what a caller
-# that kept the reference's structures hands to gpsbb_fill_block_ref.  tests/test_ref_layout.py checks every offset
-# against offsetof() on the real header (in the build container, where /root/reference exists).
-import numpy as _np
-
-REF_CHANNEL_DTYPE = _np.dtype([("prn", "<i4"), ("ca", "<i4", (1023,)), ("f_carr", "<f8"), ("f_code", "<f8"),
-                               ("carr_phase", "<f8"), ("code_phase", "<f8"), ("g0_week", "<i4"), ("_p0", "<i4"),
-                               ("g0_sec", "<f8"), ("sbf", "<u8", (50,)), ("dwrd", "<u8", (60,)), ("iword", "<i4"),
-                               ("ibit", "<i4"), ("icode", "<i4"), ("dataBit", "<i4"), ("codeCA", "<i4"), ("_p1", "<i4"),
-                               ("azel", "<f8", (2,)), ("rho0", "<f8", (8,))])
-
-# ... and the same struct of a reference built WITHOUT FLOAT_CARR_PHASE (h:12 removed): h:160-161 put a 32-bit accumulator
-# and its step where the double was (same size, so nothing else moves): what gpsbb_fill_block_ref_fixed is handed
-REF_CHANNEL_FIXED_DTYPE = _np.dtype([("prn", "<i4"), ("ca", "<i4", (1023,)), ("f_carr", "<f8"), ("f_code", "<f8"),
-                                     ("carr_phase", "<u4"), ("carr_phasestep", "<i4"), ("code_phase", "<f8"), ("g0_week", "<i4"),
-                                     ("_p0", "<i4"), ("g0_sec", "<f8"), ("sbf", "<u8", (50,)), ("dwrd", "<u8", (60,)),
-                                     ("iword", "<i4"), ("ibit", "<i4"), ("icode", "<i4"), ("dataBit", "<i4"), ("codeCA", "<i4"),
-                                     ("_p1", "<i4"), ("azel", "<f8", (2,)), ("rho0", "<f8", (8,))])
+# The reference's channel_t (plutogpssim.h:152-174, LP64) as numpy records, with and without FLOAT_CARR_PHASE: the package's
+# (bench.py's fill_block leg uses them too); tests/test_ref_layout.py checks every offset against offsetof() on the real header.
+REF_CHANNEL_DTYPE = load_package().REF_CHANNEL_DTYPE
+REF_CHANNEL_FIXED_DTYPE = load_package().REF_CHANNEL_FIXED_DTYPE

@@ -42,12 +42,15 @@ def _run(world, extra, env_extra=None, timeout=600, expect_rc=0):
 
 
 def test_dry_run_digest_does_not_depend_on_the_number_of_ranks(pkg):
-    args = ["--dry-run", "--steps", "1", "--push-blocks", "1", "--nsamp", "20000", "--fs", "25e6"]
+    args = ["--dry-run", "--steps", "1", "--push-blocks", "1", "--nsamp", "20000", "--fs", "25e6", "--m1-push-blocks", "1", "--m1-nsamp", "9000"]
     one = _run(1, args)
     two = _run(2, args)
     assert one["blocks"] == two["blocks"] == 8
     assert one["n_ranks"] == 1 and two["n_ranks"] == 2
     assert one["stream_digest"] == two["stream_digest"]
+    # the 2.6 MS/s stream (12 channels, the reference's geometry) is cut and seeded the same way, at every N
+    assert one["m1"]["blocks"] == two["m1"]["blocks"] == 8 and one["m1"]["nch"] == 12 and one["m1"]["fs"] == 2.6e6
+    assert one["m1"]["stream_digest"] == two["m1"]["stream_digest"] != one["stream_digest"]
 
 
 @pytest.mark.gpu
@@ -56,9 +59,11 @@ def test_two_ranks_through_the_device_path(pkg):
     the seed the device-side chain computes (gpsbb_chain_carrier over the first shard), and the digest of the
     end-of-block states of all blocks, gathered over the ranks, is the 1-rank value; blocks read back from the HBM-only
     ring equal the oracle's on every rank; the line carries the slowest rank's seed time, the seed-inclusive value and
-    every block cross-checked and the node driver validated at either N; the 2.6 MS/s, resident and CPU legs at N = 1 only."""
+    every block cross-checked and the node driver validated at either N; so are the 2.6 MS/s stream (12 ch, the reference's
+    geometry: cut, seeded and cross-checked like the headline's), the CPU baselines and the drop-in call's latency; the resident
+    legs at N = 1 only."""
     args = ["--steps", "2", "--warmup", "1", "--repeats", "2", "--push-blocks", "8", "--nsamp", "200000", "--depth", "3",
-            "--cpu-budget", "0.4", "--parity-blocks", "2"]
+            "--cpu-budget", "0.4", "--parity-blocks", "2", "--m1-push-blocks", "40", "--fill-calls", "12"]
     env = {"GPSBB_BENCH_BACKEND": "gloo"}
     one = _run(1, args, env)
     two = _run(2, args, env)
@@ -80,9 +85,21 @@ def test_two_ranks_through_the_device_path(pkg):
             assert a["blocks"] == 2 * 8 * 8 and a["every_block_once"] and a["digests_equal_the_ranks"] and a["blocks_that_differ"] == 0, (n, leg, a)
             assert len(a["shards"]) == len(a["devices"]) >= 1 and all(x["nblocks"] > 0 for x in a["shards"])
         assert r["node_driver"]["all_gpus"]["interleaved_ordered"]["in_stream_order"]
-    # the 2.6 MS/s, resident and CPU legs run at N = 1 only (at N > 1 they would keep N - 1 GPUs idle behind rank 0)
-    assert one["m1"]["gpu"]["value"] > 0 and one["cpu_baseline"]["value"] > 0 and one["m1"]["cpu"]["value"] > 0
-    assert "m1" not in two and "cpu_baseline" not in two and "resident" not in two
+        # the reference's geometry as a time-sharded stream, and the CPU baselines beside the line, at EVERY N
+        m = r["m1"]
+        assert m["n_gpus"] == n and m["value"] == m["stream"]["value"] > 0 and m["stream"]["synthesis_kernel"] == "k_synth_pd"
+        assert m["stream"]["prepass"] == "lap-parallel" and 0 < m["roofline_stream"]["frac"] < 1
+        assert m["stream"]["parity"]["mismatching_blocks"] == 0 and m["stream"]["parity"]["checked_blocks"] >= 3 * n
+        assert m["stream"]["parity"]["blocks_cross_checked"] == 2 * 8 * 40 and m["stream"]["parity"]["cross_mismatching_blocks"] == 0
+        assert r["cpu_baseline"]["value"] > 0 and r["cpu_baseline"]["cores"] == 1 and m["cpu"]["value"] > 0
+        # the drop-in call, timed and checked
+        for case in ("reference_block_12ch_2.6MSps_300000", "headline_block_16ch_25MSps"):
+            f = r["fill_block"][case]
+            assert f["equals_oracle"] is True and 0 < f["min_ms"] <= f["median_ms"] <= f["p99_ms"] and f["calls"] == 12
+    # the resident legs run at N = 1 only (at N > 1 they would keep N - 1 GPUs idle behind rank 0)
+    assert one["m1"]["gpu"]["value"] > 0 and "gpu" not in two["m1"] and "resident" not in two
+    assert one["m1"]["stream"]["parity"]["stream_iq_digest"] == two["m1"]["stream"]["parity"]["stream_iq_digest"]
+    assert one["m1"]["stream"]["parity"]["stream_end_state_digest"] == two["m1"]["stream"]["parity"]["stream_end_state_digest"]
     assert one["parity"]["cross_check"]["stream_iq_digest"] == two["parity"]["cross_check"]["stream_iq_digest"]
     assert two["shard_seed"]["blocks_before_the_last_shard"] == 64
     assert one["parity"]["stream_end_state_digest"] == two["parity"]["stream_end_state_digest"]
@@ -100,7 +117,7 @@ def test_one_rank_through_the_rccl_path(pkg):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
            "--repeats", "2", "--push-blocks", "8", "--nsamp", "200000", "--depth", "3", "--cpu-budget", "0.3", "--parity-blocks", "2",
-           "--parity-spots", "2"]
+           "--parity-spots", "2", "--m1-push-blocks", "40", "--fill-calls", "12"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -118,6 +135,11 @@ def test_one_rank_through_the_rccl_path(pkg):
         assert a["digests_equal_the_ranks"] and a["every_block_once"] and a["value"] > 0
         assert set(a["shards"][0]) == {"first_block", "nblocks", "device", "numa_node", "cpus_bound", "seed_seconds", "busy_seconds", "wait_seconds"}
     assert r["parity"]["blocks_cross_checked"] == r["parity"]["blocks_digested"] and r["parity"]["cross_mismatching_blocks"] == 0
+    # ... and the keys the 2.6 MS/s leg, the CPU baselines and the drop-in call carry at every N
+    assert r["m1"]["value"] == r["m1"]["stream"]["value"] > 0 and r["m1"]["stream"]["parity"]["cross_mismatching_blocks"] == 0
+    assert r["m1"]["stream"]["parity"]["blocks_cross_checked"] == 2 * 8 * 40 and r["m1"]["roofline_stream"]["kernel"] == "k_synth_pd"
+    assert r["cpu_baseline"]["value"] > 0 and r["m1"]["cpu"]["value"] > 0
+    assert r["fill_block"]["reference_block_12ch_2.6MSps_300000"]["equals_oracle"] is True
 
 
 @pytest.mark.gpu
@@ -130,7 +152,7 @@ def test_a_wrong_kernel_fails_the_bench(pkg, tmp_path):
     import subprocess
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "pluto-gps-sim_amd", "csrc"), "broken", "broken2", "VARIANT_DIR=%s" % tmp_path])
     args = ["--steps", "1", "--warmup", "1", "--repeats", "1", "--push-blocks", "8", "--nsamp", "200000", "--depth", "3",
-            "--cpu-budget", "0.2", "--parity-blocks", "2"]
+            "--cpu-budget", "0.2", "--parity-blocks", "2", "--m1-push-blocks", "16", "--fill-calls", "4"]
     r = _run(1, args, {"GPSBB_PY_LIB": str(tmp_path / "libgpsbb_broken.so")}, expect_rc=3)
     assert r["parity"]["mismatching_blocks"] >= 1 and r["parity_checked_blocks"] >= 3
     assert r["parity"]["cross_mismatching_blocks"] == 8   # block 1 of each of the 8 pushes

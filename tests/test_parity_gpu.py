@@ -23,10 +23,15 @@ def assert_state_equal(got, want, active):
         assert g.tobytes() == w.tobytes(), f
 
 
-@pytest.fixture(autouse=True, params=["k_seed+auto", "host+auto", "k_seed+per-sample", "host+per-sample",
+ONCE = "default"   # the mode in which the tests that run once run: no option set at all, what a host that sets none gets
+
+
+@pytest.fixture(autouse=True, params=["default", "k_seed+auto", "host+auto", "k_seed+per-sample", "host+per-sample",
                                       "k_seed+auto+seqfix", "k_seed+per-sample+seqfix", "k_seed+auto+passA", "laps+auto"])
 def seed_mode(pkg, synth, request):
-    """Every test below runs eight ways.  The exact NCO pre-pass of a run is computed on the device — by the row walks of
+    """Every test below runs nine ways: first with NO option set ("default": the library's own choices — the lap-parallel
+    pre-pass wherever it is eligible, the model kernels wherever they are; the full-size and full-length runs, which run once,
+    run in this mode), then with the choices forced.  The exact NCO pre-pass of a run is computed on the device — by the row walks of
     rounds 1-4 (k_seed / k_walk + the chain kernels: "k_seed") or lap-parallel (gpsbb_laps.hip.h, round 5: "laps"; what the
     library picks by itself for anything but a handful of blocks) — or,
     for small batches, by host threads running the same code (by default the batch size decides); the
@@ -35,14 +40,21 @@ def seed_mode(pkg, synth, request):
     device-side carrier chain takes the blocks in parallel (k_chain_fix_par, the default) or in order (k_chain_fix); and
     the start phases its one walk (pass B) begins from come from the host's drift model (the default) or from a first
     walk (pass A + k_chain_prefix)."""
-    where, kernel = request.param.split("+")[:2]
-    synth.set_option(pkg.OPT_SEED_WHERE, {"k_seed": 1, "host": 2, "laps": 3}[where])
-    synth.set_option(pkg.OPT_SYNTH_KERNEL, 1 if kernel == "per-sample" else 0)
-    synth.set_option(pkg.OPT_CHAIN_WHERE, 2 if request.param.endswith("seqfix") else (3 if request.param.endswith("passA") else 0))
+    if request.param != "default":
+        where, kernel = request.param.split("+")[:2]
+        synth.set_option(pkg.OPT_SEED_WHERE, {"k_seed": 1, "host": 2, "laps": 3}[where])
+        synth.set_option(pkg.OPT_SYNTH_KERNEL, 1 if kernel == "per-sample" else 0)
+        synth.set_option(pkg.OPT_CHAIN_WHERE, 2 if request.param.endswith("seqfix") else (3 if request.param.endswith("passA") else 0))
     yield
     synth.set_option(pkg.OPT_SEED_WHERE, 0)
     synth.set_option(pkg.OPT_SYNTH_KERNEL, 0)
     synth.set_option(pkg.OPT_CHAIN_WHERE, 0)
+
+
+def mode_of(request):
+    """(where, kernel) of the running mode; "default" reads as the library's own choices"""
+    m = request.node.callspec.params["seed_mode"]
+    return ("auto", "auto") if m == "default" else tuple(m.split("+")[:2])
 
 
 def test_native_library_is_what_runs(pkg, synth):
@@ -263,7 +275,7 @@ def test_carrier_chained_on_the_device(pkg, synth, oracle, request):
     synth.sync()
     iq, st = b.read()
     b.close()
-    where, kernel = request.node.callspec.params["seed_mode"].split("+")[:2]
+    where, kernel = mode_of(request)
     if where == "k_seed" and kernel == "auto":
         assert synth.info(pkg.INFO_LAST_KERNEL) == 2 and synth.info(pkg.INFO_CHAIN_ON_DEVICE) == 1
         # blocks the fix-up had to walk sequentially: at most those of the four special channels (often fewer:
@@ -331,7 +343,7 @@ def test_device_chain_through_wraps_that_tie(pkg, synth, oracle, request):
     synth.sync()
     iq, st = b.read()
     b.close()
-    where, kernel = request.node.callspec.params["seed_mode"].split("+")[:2]
+    where, kernel = mode_of(request)
     if where == "k_seed" and kernel == "auto":
         assert synth.info(pkg.INFO_CHAIN_ON_DEVICE) == 1
         # the first tie after a block's first wrap is recorded (later ones cannot matter): the case is really exercised,
@@ -439,7 +451,7 @@ def test_stream_carrier_carried_on_the_device(pkg, synth, oracle, request):
     ch["prn"][bps * 2:, 6] = 29            # re-allocated exactly at a push boundary
     ch["prn"][bps * 3 + 2:bps * 4 + 1, 11] = 0
     want_iq, want_st, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
-    where, kernel = request.node.callspec.params["seed_mode"].split("+")[:2]
+    where, kernel = mode_of(request)
     for flags in (pkg.CHAIN_CARRIER, pkg.CHAIN_CARRIER | pkg.STREAM_DEVICE_ONLY):
         st_ = synth.stream(nch, 1 / fs, nsamp, bps, depth=3, flags=flags)
         got, gst = [], []
@@ -850,7 +862,7 @@ def test_reference_geometry_runs_on_the_dense_model_kernel(pkg, synth, oracle, r
     synth.sync()
     iq, st = b.read()
     b.close()
-    where, kernel = request.node.callspec.params["seed_mode"].split("+")[:2]
+    where, kernel = mode_of(request)
     if kernel == "auto":
         assert synth.info(pkg.INFO_LAST_KERNEL) == 2
     for k in range(nb):
@@ -878,7 +890,7 @@ def test_carrier_chain_alone_on_the_device(pkg, synth, request):
     for special steps (no wrap, ties, idle and re-allocated channels), for the bench's own stream, and for more blocks
     than one sub-batch of the device-side chain takes (the carry crosses sub-batches)."""
     mode = request.node.callspec.params["seed_mode"]
-    if not (mode.startswith("k_seed+auto") or mode == "laps+auto"):  # by the row walks (pass A, prefix, pass B, fix-up) / lap-parallel
+    if not (mode.startswith("k_seed+auto") or mode in ("laps+auto", "default")):  # by the row walks (pass A, prefix, pass B, fix-up) / lap-parallel / the library's choice
         pytest.skip("independent of the other options")
     sys.path.insert(0, ROOT)
     import bench
@@ -1001,28 +1013,30 @@ def test_low_rate_soak_with_the_exact_path_forced_often(pkg, request):
     2^22 units of 2^-32 (one test in a thousand instead of one in 10^8 sends a lane to pd_fix_sample: most wavefronts
     then hold lanes that take the model's 16 contributions of a channel out and put exact ones in), over random chained
     streams at 1 .. 10 MS/s with 1 to 16 channels (both chip-table layouts, data bits that change inside tiles)."""
-    if request.node.callspec.params["seed_mode"] != "k_seed+auto":
+    if request.node.callspec.params["seed_mode"] != ONCE:
         pytest.skip("a process of its own with its own options: once")
     import subprocess
-    env = dict(os.environ, GPSBB_PY_LIB="exp", GPSBB_PD_DANGER=str(1 << 22))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--stream", "--low-rate", "--cases", "24",
-                        "--seed", "77", "--budget", "1.5e7"], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "bit-exact" in r.stdout
+    for where in ("3", "1"):   # on the lap-parallel pre-pass (the product's default) and on the row walks
+        env = dict(os.environ, GPSBB_PY_LIB="exp", GPSBB_PD_DANGER=str(1 << 22), GPSBB_FUZZ_WHERE=where)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--stream", "--low-rate", "--cases", "24",
+                            "--seed", "77", "--budget", "1.5e7"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert "bit-exact" in r.stdout
 
 
 def test_high_rate_soak_with_the_exact_path_forced_often(pkg, request):
     """The same for k_synth_ev: the danger threshold of every channel raised to 2^22 units of 2^-32, so that about one
     lane-run in two hundred is recomputed by ev_exact_run (out of line) — with one or two channels per block the call
     then comes right after the wavefront has claimed its next chunk of tiles, which must not get lost."""
-    if request.node.callspec.params["seed_mode"] != "k_seed+auto":
+    if request.node.callspec.params["seed_mode"] != ONCE:
         pytest.skip("a process of its own with its own options: once")
     import subprocess
-    env = dict(os.environ, GPSBB_PY_LIB="exp", GPSBB_EV_DANGER=str(1 << 22))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--stream", "--cases", "30", "--seed", "78",
-                        "--budget", "1.5e7"], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "bit-exact" in r.stdout
+    for where in ("3", "1"):   # on the lap-parallel pre-pass (the product's default) and on the row walks
+        env = dict(os.environ, GPSBB_PY_LIB="exp", GPSBB_EV_DANGER=str(1 << 22), GPSBB_FUZZ_WHERE=where)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--stream", "--cases", "30", "--seed", "78",
+                            "--budget", "1.5e7"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert "bit-exact" in r.stdout
 
 
 GRAZE_OFFSETS = [0, 1, -1, 2, -2, 3, -3, 4, -4, 6, -6, 8, -8, 10, -10, 12, -12, 13, -13, 14, -14, 16, -16, 20, -20, 24, -24,
@@ -1081,7 +1095,7 @@ def test_the_failure_the_round_3_budgets_allowed(pkg, synth, oracle, request):
         iq, _ = b.read()
         b.close()
         assert (iq == want_iq).all(), name
-    if request.node.callspec.params["seed_mode"] != "k_seed+auto":
+    if request.node.callspec.params["seed_mode"] != ONCE:
         return
     import json
     import subprocess
@@ -1103,7 +1117,7 @@ def test_model_error_budgets_are_measured_not_summed(pkg, request):
     the kernels take (gpsbb_modelerr.hip.h).  Asserted: no unflagged decision differs from the truth; the replay flags
     exactly the lane-runs the kernel itself sent to the exact path; the realised error of everything tested is at most HALF
     its budget; the plain linear model stays within the derived 2^-33.9 (0.27 units; EV_MODEL_ERR allows 1)."""
-    if request.node.callspec.params["seed_mode"] != "k_seed+auto":
+    if request.node.callspec.params["seed_mode"] != ONCE:
         pytest.skip("a process of its own with its own options: once")
     import json
     import subprocess
@@ -1156,8 +1170,8 @@ def test_config5_at_full_block_size_in_1_2_and_4_time_shards(pkg, synth, oracle,
     shard starts from the stream's exact carrier phase there (gpsbb_chain_carrier_host) and chains on the device from
     then on; every block is digested as it lands in pinned host memory.  The digest of the block digests must not
     depend on the number of shards, two blocks are compared with the CPU oracle in full, and no hazard may have
-    been counted.  (Run once: the seeding variants are covered at small sizes.)"""
-    if request.node.callspec.params["seed_mode"] != "k_seed+auto":
+    been counted.  (Run once, with no option set — the lap-parallel pre-pass, what the product runs; the forced variants are covered at small sizes.)"""
+    if request.node.callspec.params["seed_mode"] != ONCE:
         pytest.skip("full-size run: once")
     import xxhash
     import bench
@@ -1188,6 +1202,7 @@ def test_config5_at_full_block_size_in_1_2_and_4_time_shards(pkg, synth, oracle,
 
     one = render(1)
     assert synth.info(pkg.INFO_CHAIN_ON_DEVICE) == 1 and synth.info(pkg.INFO_LAST_KERNEL) == 2
+    assert synth.info(pkg.INFO_PREPASS) == 3   # no option set: the lap-parallel pre-pass, what the product runs
     assert len(one) == nb
     for n in (2, 4):
         assert render(n) == one, "%d shards" % n
@@ -1207,7 +1222,7 @@ def test_config5_at_its_stated_length(pkg, synth, oracle, request):
     gpsbb_chain_carrier_host's sequential walk bit for bit; the digests of the first 3600 blocks equal those of the same
     descriptors rendered as a stream of their own; two blocks from the stream's far end equal the CPU oracle's render from
     the phase the stream reports there; no hazard.  The sustained gather rate goes to gpurun_out/ (copied to profiles/)."""
-    if request.node.callspec.params["seed_mode"] != "k_seed+auto":
+    if request.node.callspec.params["seed_mode"] != ONCE:
         pytest.skip("full-length run: once")
     import json
     import time
@@ -1248,6 +1263,7 @@ def test_config5_at_its_stated_length(pkg, synth, oracle, request):
 
     digs, ends, dt = render(nb)
     assert synth.info(pkg.INFO_CHAIN_ON_DEVICE) == 1 and synth.info(pkg.INFO_LAST_KERNEL) == 2
+    assert synth.info(pkg.INFO_PREPASS) == 3   # no option set: the lap-parallel pre-pass, what the product runs
     assert synth.hazards(reset=True) == {"itable_512": 0, "dwrd_oob": 0}
     starts = pkg.chain_carrier_host(np.concatenate([ch, ch[-1:]]), delt, nsamp)
     assert ends.tobytes() == starts[1:].tobytes()                      # all 36 000 end-of-block carrier phases

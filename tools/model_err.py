@@ -142,7 +142,7 @@ def main():
     oracle = None if a.no_oracle else ob.Oracle()
     res = {}
     with pkg.Synth(0) as s:
-        s.set_option(pkg.OPT_SEED_WHERE, 1)  # the device pre-pass (the tile states the kernels run on in production)
+        s.set_option(pkg.OPT_SEED_WHERE, int(os.environ.get("GPSBB_MODEL_ERR_WHERE", "0")))  # 0: the library's choice (lap-parallel), what production runs on
         for name, ch, fs, nsamp, flags, check in workloads(pkg, a.quick):
             res[name] = measure(pkg, s, ch, fs, nsamp, flags, oracle if check else None)
             res[name]["fs"] = fs

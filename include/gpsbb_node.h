@@ -106,6 +106,17 @@ int gpsbb_node_run(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nblocks, gpsbb_
                    gpsbb_node_stats_t *stats);
 
 /*
+ * gpsbb_node_run with the DRIVER'S OWN sink: digests[b] = the 64-bit digest of block b (gpsbb_device_digest's number), taken on
+ * the GPU that rendered the block by the shard's producer thread as soon as the slot is complete (gpsbb_slot_digest: the ring
+ * behind the slot keeps rendering), every shard on its own — what a host that keeps the IQ in HBM compares instead of the bytes,
+ * and a consumer that costs the driver next to nothing: the rate of this call is the driver's own.  Rings in host memory
+ * (no GPSBB_NODE_DEVICE_ONLY) are digested by the producer threads on the host, the same number.  The node's flags decide the
+ * layout (contiguous / GPSBB_NODE_INTERLEAVED) as for gpsbb_node_run; the order of delivery does not matter to this sink: it is
+ * entered as GPSBB_NODE_INDEXED | GPSBB_NODE_CONCURRENT whatever the flags say.
+ */
+int gpsbb_node_run_digest(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nblocks, uint64_t *digests, gpsbb_node_stats_t *stats);
+
+/*
  * The same stream, INCREMENTALLY — what the reference's loop does: it makes the descriptors of one block, renders it, and goes
  * round again, for as long as it runs (plutogpssim.c:2655-2687, the 30 s maintenance c:2764-2805).
  *   gpsbb_node_begin  starts a run with nothing to render yet;

@@ -98,13 +98,13 @@ API_SYMBOLS = [
     "gpsbb_create", "gpsbb_destroy", "gpsbb_strerror", "gpsbb_last_hip_error", "gpsbb_version",
     "gpsbb_fill_block", "gpsbb_fill_block_ex", "gpsbb_fill_block_ref", "gpsbb_fill_block_ref_fixed", "gpsbb_batch_create", "gpsbb_batch_destroy",
     "gpsbb_batch_iq_bytes", "gpsbb_batch_run", "gpsbb_sync", "gpsbb_batch_read", "gpsbb_batch_device_iq",
-    "gpsbb_get_hazards", "gpsbb_device_read", "gpsbb_device_digest", "gpsbb_batch_last_timing", "gpsbb_batch_timing_stats", "gpsbb_fill_ceiling", "gpsbb_stream_create",
+    "gpsbb_get_hazards", "gpsbb_device_read", "gpsbb_device_digest", "gpsbb_slot_digest", "gpsbb_batch_last_timing", "gpsbb_batch_timing_stats", "gpsbb_fill_ceiling", "gpsbb_stream_create",
     "gpsbb_stream_destroy", "gpsbb_stream_push", "gpsbb_stream_pop", "gpsbb_stream_pending", "gpsbb_stream_timing_stats",
     "gpsbb_codegen", "gpsbb_sincos_tables", "gpsbb_chain_carrier_host", "gpsbb_chain_carrier", "gpsbb_set_option",
     "gpsbb_get_info", "gpsbb_stream_reset", "gpsbb_device_affinity", "gpsbb_stream_push_ex",
 ]
 # ... and include/gpsbb_node.h
-NODE_API_SYMBOLS = ["gpsbb_node_create", "gpsbb_node_run", "gpsbb_node_destroy", "gpsbb_node_plan", "gpsbb_node_begin", "gpsbb_node_feed", "gpsbb_node_end"]
+NODE_API_SYMBOLS = ["gpsbb_node_create", "gpsbb_node_run", "gpsbb_node_run_digest", "gpsbb_node_destroy", "gpsbb_node_plan", "gpsbb_node_begin", "gpsbb_node_feed", "gpsbb_node_end"]
 
 
 class GpsbbError(RuntimeError):
@@ -180,6 +180,8 @@ def lib():
         L.gpsbb_node_destroy.argtypes = [vp]
         L.gpsbb_node_destroy.restype = None
         L.gpsbb_node_run.argtypes = [vp, vp, C.c_long, vp, vp, vp]
+        L.gpsbb_node_run_digest.argtypes = [vp, vp, C.c_long, vp, vp]
+        L.gpsbb_slot_digest.argtypes = [vp, vp, C.c_long, C.c_int, vp]
         L.gpsbb_node_begin.argtypes = [vp, vp, vp]
         L.gpsbb_node_feed.argtypes = [vp, vp, C.c_long]
         L.gpsbb_node_end.argtypes = [vp, vp]
@@ -308,6 +310,12 @@ class Synth:
         """gpsbb_device_read: a numpy array filled from device memory the library handed out"""
         out = np.empty(shape, dtype)
         _chk(lib().gpsbb_device_read(self._h, out.ctypes.data, d_ptr, out.nbytes), "gpsbb_device_read")
+        return out
+
+    def slot_digest(self, d_ptr, nblocks, nsamp):
+        """gpsbb_slot_digest: digests of a slot known to be complete (what pop returned), without draining the handle"""
+        out = np.zeros(nblocks, np.uint64)
+        _chk(lib().gpsbb_slot_digest(self._h, C.c_void_p(int(d_ptr)), nblocks, nsamp, out.ctypes.data), "gpsbb_slot_digest")
         return out
 
     def device_digest(self, d_ptr, nblocks, nsamp):
@@ -562,6 +570,18 @@ class Node:
             raise GpsbbError(rc, "gpsbb_node_run")
         return {"rc": rc, "seconds": st.seconds, "blocks": st.blocks,
                 "shards": [{k: getattr(st.shard[g], k) for k, _ in _NodeShardStats._fields_} for g in range(st.nshards)]}
+
+    def run_digest(self, ch):
+        """gpsbb_node_run_digest: the driver's own sink — one 64-bit digest per block, taken on the GPU that rendered it by the
+        shard's producer thread (no Python in the data path); returns (statistics, uint64 [nblocks])"""
+        ch = _as_chan(ch)
+        if ch.ndim != 2 or ch.shape[1] != self.nch:
+            raise ValueError("descriptors of shape (nblocks, %d) wanted, got %r" % (self.nch, ch.shape))
+        digs = np.zeros(ch.shape[0], np.uint64)
+        st = _NodeStats()
+        _chk(lib().gpsbb_node_run_digest(self._n, ch.ctypes.data, ch.shape[0], digs.ctypes.data, C.byref(st)), "gpsbb_node_run_digest")
+        return {"rc": 0, "seconds": st.seconds, "blocks": st.blocks,
+                "shards": [{k: getattr(st.shard[g], k) for k, _ in _NodeShardStats._fields_} for g in range(st.nshards)]}, digs
 
     def begin(self, sink):
         """gpsbb_node_begin: an incremental run; feed() the stream as it comes, end() when it is over"""

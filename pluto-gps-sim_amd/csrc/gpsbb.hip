@@ -2236,6 +2236,24 @@ extern "C" int gpsbb_device_digest(gpsbb_t *h, const int16_t *d_iq, long nblocks
     return GPSBB_OK;
 }
 
+extern "C" int gpsbb_slot_digest(gpsbb_t *h, const int16_t *d_iq, long nblocks, int nsamp, uint64_t *digest_out)
+{
+    if (!h || !d_iq || !digest_out || nblocks < 1 || nblocks > 65535 || nsamp < 1)
+        return GPSBB_E_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t cs = h->s_copy;
+    HIPCHK(h, (hipError_t)h->d_digest.reserve((size_t)nblocks));
+    HIPCHK(h, hipMemsetAsync(h->d_digest.p, 0, (size_t)nblocks * sizeof(unsigned long long), cs));
+    long chunks = (2048 + nblocks - 1) / nblocks;
+    const long max_chunks = ((long)nsamp + 1023) / 1024;
+    chunks = chunks > max_chunks ? max_chunks : (chunks < 1 ? 1 : chunks);
+    hipLaunchKernelGGL(k_block_digest, dim3((unsigned)chunks, (unsigned)nblocks), dim3(256), 0, cs, (const uint32_t *)d_iq, nsamp, h->d_digest.p);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(digest_out, h->d_digest.p, (size_t)nblocks * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+    HIPCHK(h, hipStreamSynchronize(cs));
+    return GPSBB_OK;
+}
+
 extern "C" int gpsbb_get_hazards(gpsbb_t *h, gpsbb_hazards_t *out, int reset)
 {
     if (!h || !out)

@@ -102,6 +102,7 @@ struct gpsbb_node {
     long delivered = 0;
     bool stop = false;     /* the sink asked to stop, or a shard failed */
     std::mutex sink_m;     /* indexed, not concurrent: one sink call at a time */
+    uint64_t *digest_out = nullptr; /* gpsbb_node_run_digest: the driver's own sink writes here; the sink is entered indexed + concurrent */
     /* an incremental run: the feeder (the caller's thread) cuts what it is fed into slots, chains the carrier across them on a
      * handle of its own and deals the slots round the shards' queues; bounded: a feed waits while its shard's queue is full */
     bool feeding = false, fed_eof = false;
@@ -159,8 +160,8 @@ void fixed_carrier_seed(const gpsbb_chan_t *ch, long first, int nch, double delt
 /* hand one popped slot to the sink; returns false when the run is to stop */
 bool deliver(gpsbb_node *n, Shard &s, const int16_t *iq, long first_block, int nb)
 {
-    const bool indexed = (n->cfg.flags & GPSBB_NODE_INDEXED) != 0;
-    const bool concurrent = indexed && (n->cfg.flags & GPSBB_NODE_CONCURRENT);
+    const bool indexed = (n->cfg.flags & GPSBB_NODE_INDEXED) != 0 || n->digest_out != nullptr;
+    const bool concurrent = (indexed && (n->cfg.flags & GPSBB_NODE_CONCURRENT)) || n->digest_out != nullptr;
     const double t0 = now_s();
     int rc = 0;
     if (!indexed) {
@@ -876,6 +877,43 @@ extern "C" int gpsbb_node_end(gpsbb_node_t *n, gpsbb_node_stats_t *stats)
         for (int g = 0; g < N; g++)
             stats->shard[g].seed_seconds = n->feed_chain_s;
     return rc != GPSBB_OK && rc != GPSBB_E_STATE ? rc : rc2;
+}
+
+namespace {
+/* the driver's own sink (gpsbb_node_run_digest): called on the producer thread of the shard that rendered the slot */
+int digest_sink(void *user, const int16_t *iq, long first_block, int nblocks, int shard)
+{
+    gpsbb_node *n = static_cast<gpsbb_node *>(user);
+    Shard &s = n->shards[shard];
+    uint64_t *out = n->digest_out + first_block;
+    if (n->cfg.flags & GPSBB_NODE_DEVICE_ONLY)
+        return gpsbb_slot_digest(s.h, iq, nblocks, n->cfg.nsamp, out);
+    /* a ring in pinned host memory: the same number on the host (include/gpsbb.h, gpsbb_device_digest) */
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(iq);
+    const size_t ns = (size_t)n->cfg.nsamp;
+    for (int b = 0; b < nblocks; b++) {
+        uint64_t acc = 0;
+        for (size_t j = 0; j < ns; j++) {
+            uint64_t z = ((uint64_t)j << 32) | w[(size_t)b * ns + j];
+            z ^= z >> 31;
+            z *= 0xBF58476D1CE4E5B9ull;
+            z ^= z >> 29;
+            acc += z;
+        }
+        out[b] = acc;
+    }
+    return 0;
+}
+} /* namespace */
+
+extern "C" int gpsbb_node_run_digest(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nblocks, uint64_t *digests, gpsbb_node_stats_t *stats)
+{
+    if (!n || !digests)
+        return GPSBB_E_BADARG;
+    n->digest_out = digests;
+    const int rc = gpsbb_node_run(n, ch, nblocks, digest_sink, n, stats);
+    n->digest_out = nullptr;
+    return rc;
 }
 
 extern "C" int gpsbb_node_run(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nblocks, gpsbb_node_sink_fn sink, void *user,

@@ -403,3 +403,33 @@ def test_gpsbb_sim_feeds_the_node_in_bounded_memory(pkg, tmp_path):
     # scratch buffers of the handles come to exist, which a short run may or may not reach (measured: 2 947 300 or 3 141 800 kB at
     # 300 s, 3 133 600 .. 3 150 100 from 1 500 s on): hence the margin
     assert abs(rss2 - rss1) < 300 * 1024, (rss1, rss2)
+
+
+def test_the_drivers_own_digest_sink(pkg, synth, oracle):
+    """gpsbb_node_run_digest: the driver's own sink — every slot digested on the GPU that rendered it by the shard's producer
+    thread (gpsbb_slot_digest: the ring behind the slot keeps rendering), no callback in the data path.  The digests equal the
+    oracle's bytes' (block_digest_host) for 1, 2 and 3 shards, contiguous and interleaved, device-only rings and rings in host
+    memory (digested on the host by the same threads); gpsbb_slot_digest equals gpsbb_device_digest on a popped slot."""
+    nch, fs, nsamp, nb, bps = 7, 4.092e6, 40000, 24, 4
+    ch = pkg.synth_descriptors(nb, nch=nch, seed=8181)
+    ch["prn"][10:, 2] = 21                       # a re-allocated channel inside the stream
+    want_iq, _, _ = oracle.fill_blocks(ch, 1.0 / fs, nsamp, chain=True)
+    want = pkg.block_digest_host(want_iq)
+    for nshards in (1, 2, 3):
+        for flags in (pkg.NODE_DEVICE_ONLY, pkg.NODE_DEVICE_ONLY | pkg.NODE_INTERLEAVED, 0, pkg.NODE_INTERLEAVED):
+            with pkg.Node(nshards, nch, 1.0 / fs, nsamp, bps, depth=2, flags=flags, devices=node_devices(nshards)) as node:
+                for _ in range(2):   # twice on one node: the rings are kept
+                    st, digs = node.run_digest(ch)
+                    assert st["blocks"] == nb and (digs == want).all(), (nshards, flags)
+                # and an ordinary run on the same node afterwards still delivers in order
+                sink = Collect(nb, nsamp)
+                if not (flags & pkg.NODE_DEVICE_ONLY):
+                    node.run(ch, sink)
+                    assert (sink.iq == want_iq).all() and [c[0] for c in sink.calls] == sorted(c[0] for c in sink.calls)
+    st_ = synth.stream(nch, 1.0 / fs, nsamp, bps, depth=2, flags=pkg.CHAIN_CARRIER | pkg.STREAM_DEVICE_ONLY)
+    st_.push(ch[:bps])
+    st_.push(ch[bps:2 * bps])
+    dptr, _ = st_.pop(copy=False)
+    a = synth.slot_digest(dptr, bps, nsamp)
+    assert (a == synth.device_digest(dptr, bps, nsamp)).all() and (a == want[:bps]).all()
+    st_.close()

@@ -497,6 +497,8 @@ struct gpsbb {
     unsigned long long *d_hz = nullptr;
     int last_hip = 0;
     gpsbb_batch *scratch = nullptr;
+    unsigned char *h_fill = nullptr; /* pinned: what the drop-in call brings back besides the IQ — the end states and the status word
+                                        (fill_block_finish) */
     struct ChainOnly *chain_only = nullptr; /* device scratch of gpsbb_chain_carrier, kept between calls */
     int sm_count = 0;
     /* per-handle options (gpsbb_set_option) */
@@ -800,6 +802,8 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
     (void)hipSetDevice(h->device);
     if (h->scratch)
         gpsbb_batch_destroy(h->scratch);
+    if (h->h_fill)
+        (void)hipHostFree(h->h_fill);
     chain_only_free(h);
     if (h->s_seed)
         (void)hipStreamSynchronize(h->s_seed);
@@ -1985,25 +1989,59 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         const LapDev L = lap_dev(b, set);
         const unsigned cc = b->lap_chunk0[NCO_CODE][b->nch] - b->lap_chunk0[NCO_CODE][0];
         const unsigned ck = b->lap_chunk0[NCO_CARR][b->nch] - b->lap_chunk0[NCO_CARR][0];
-        hipLaunchKernelGGL(k_lap_plan<NCO_CODE>, dim3(b->nch), dim3(64), 0, ss, p, L);
-        hipLaunchKernelGGL(k_lap_pass1<NCO_CODE>, dim3(cc), dim3(LAP_WG), 0, ss, p, L);
-        hipLaunchKernelGGL(k_lap_scan<NCO_CODE>, dim3(b->nch), dim3(64), 0, ss, p, L);
-        hipLaunchKernelGGL(k_lap_pass2<NCO_CODE>, dim3(cc), dim3(LAP_WG), 0, ss, p, L);
-        hipLaunchKernelGGL(k_lap_repair<NCO_CODE>, dim3(b->nch), dim3(64), 0, ss, p, L);
-        if (p.kph0) {
-            /* fixed-point carrier: no chain to walk; the plan kernel leaves the end states, the tile states are a closed form */
-            hipLaunchKernelGGL(k_lap_plan<NCO_CARR>, dim3(b->nch), dim3(64), 0, ss, p, L);
-            hipLaunchKernelGGL(k_lap_fixed_tiles, dim3(b->nblocks * b->nch), dim3(256), 0, ss, p);
+        /* a batch that continues nothing (no stream carry: the drop-in call's block, resident batches): both kinds in one grid
+         * per step, five launches instead of ten — the chain of small launches IS the latency of a small batch's pre-pass (one
+         * block of the reference's geometry: 98 -> 50 us), and a big batch's two plan kernels (16 wavefronts each, 0.1 - 0.2 ms)
+         * run side by side.  A stream's pushes keep the kinds apart: their code chains wait for nobody, their carriers for the
+         * push before (GPSBB_LAP_MERGE=1, experiments build: merged there too). */
+        const bool merged = !p.kph0 && (!(b->d_carry && b->ev_fix) || GPSBB_KNOB_LONG("GPSBB_LAP_MERGE", 0) == 1) &&
+                            GPSBB_KNOB_LONG("GPSBB_LAP_MERGE", 0) != 2;
+        /* a stream's carry (ChainCarryDev) is read by this push's carrier plan and written by its repair (exact_end AND approx_end):
+         * ordered behind every writer of the push before — lap-parallel or row walks — and ahead of every reader of the next, whichever
+         * pre-pass that push takes: both events waited for, both recorded */
+        const auto carry_wait = [&]() -> hipError_t {
+            hipError_t e = hipSuccess;
+            if (b->d_carry && b->ev_fix)
+                e = hipStreamWaitEvent(ss, b->ev_fix, 0);
+            if (e == hipSuccess && b->d_carry && b->ev_prefix)
+                e = hipStreamWaitEvent(ss, b->ev_prefix, 0);
+            return e;
+        };
+        const auto carry_done = [&]() -> hipError_t {
+            hipError_t e = hipSuccess;
+            if (b->d_carry && b->ev_fix)
+                e = hipEventRecord(b->ev_fix, ss);
+            if (e == hipSuccess && b->d_carry && b->ev_prefix)
+                e = hipEventRecord(b->ev_prefix, ss);
+            return e;
+        };
+        if (merged) {
+            HIPCHK(h, carry_wait());
+            hipLaunchKernelGGL(k_lap_plan2, dim3(2 * b->nch), dim3(64), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_pass1_2, dim3(cc + ck), dim3(LAP_WG), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_scan2, dim3(2 * b->nch), dim3(64), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_pass2_2, dim3(cc + ck), dim3(LAP_WG), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_repair2, dim3(2 * b->nch), dim3(64), 0, ss, p, L);
+            HIPCHK(h, carry_done());
         } else {
-            if (b->d_carry && b->ev_fix)
-                HIPCHK(h, hipStreamWaitEvent(ss, b->ev_fix, 0));
-            hipLaunchKernelGGL(k_lap_plan<NCO_CARR>, dim3(b->nch), dim3(64), 0, ss, p, L);
-            hipLaunchKernelGGL(k_lap_pass1<NCO_CARR>, dim3(ck), dim3(LAP_WG), 0, ss, p, L);
-            hipLaunchKernelGGL(k_lap_scan<NCO_CARR>, dim3(b->nch), dim3(64), 0, ss, p, L);
-            hipLaunchKernelGGL(k_lap_pass2<NCO_CARR>, dim3(ck), dim3(LAP_WG), 0, ss, p, L);
-            hipLaunchKernelGGL(k_lap_repair<NCO_CARR>, dim3(b->nch), dim3(64), 0, ss, p, L);
-            if (b->d_carry && b->ev_fix)
-                HIPCHK(h, hipEventRecord(b->ev_fix, ss));
+            hipLaunchKernelGGL(k_lap_plan<NCO_CODE>, dim3(b->nch), dim3(64), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_pass1<NCO_CODE>, dim3(cc), dim3(LAP_WG), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_scan<NCO_CODE>, dim3(b->nch), dim3(64), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_pass2<NCO_CODE>, dim3(cc), dim3(LAP_WG), 0, ss, p, L);
+            hipLaunchKernelGGL(k_lap_repair<NCO_CODE>, dim3(b->nch), dim3(64), 0, ss, p, L);
+            if (p.kph0) {
+                /* fixed-point carrier: no chain to walk; the plan kernel leaves the end states, the tile states are a closed form */
+                hipLaunchKernelGGL(k_lap_plan<NCO_CARR>, dim3(b->nch), dim3(64), 0, ss, p, L);
+                hipLaunchKernelGGL(k_lap_fixed_tiles, dim3(b->nblocks * b->nch), dim3(256), 0, ss, p);
+            } else {
+                HIPCHK(h, carry_wait());
+                hipLaunchKernelGGL(k_lap_plan<NCO_CARR>, dim3(b->nch), dim3(64), 0, ss, p, L);
+                hipLaunchKernelGGL(k_lap_pass1<NCO_CARR>, dim3(ck), dim3(LAP_WG), 0, ss, p, L);
+                hipLaunchKernelGGL(k_lap_scan<NCO_CARR>, dim3(b->nch), dim3(64), 0, ss, p, L);
+                hipLaunchKernelGGL(k_lap_pass2<NCO_CARR>, dim3(ck), dim3(LAP_WG), 0, ss, p, L);
+                hipLaunchKernelGGL(k_lap_repair<NCO_CARR>, dim3(b->nch), dim3(64), 0, ss, p, L);
+                HIPCHK(h, carry_done());
+            }
         }
         ctr_reset_by_prepass = true; /* k_lap_plan zeroes the set's tile counters */
     } else if (b->ev) {
@@ -2340,6 +2378,32 @@ extern "C" int gpsbb_fill_ceiling(gpsbb_t *h, void *d_dst, size_t bytes, int ite
 
 /* ---- the synchronous single-block surface ------------------------------------------------------------ */
 
+/* What the drop-in call waits for.  Everything of the call is ordered in front of the synthesis stream's tail (upload -> pre-pass
+ * -> synthesis by events), so ONE stream is waited for, not the handle's ten; the end states and the status word come back
+ * through pinned memory behind the IQ on that stream instead of as two blocking copies of their own (each a round trip of
+ * 25 - 30 us: with the ten-kernel pre-pass they were half of the call's 0.26 ms for the reference's block). */
+static int fill_block_finish(gpsbb_t *h, gpsbb_batch *b, int nch, int nsamp, int16_t *iq_out, gpsbb_chan_state_t *end_state)
+{
+    const size_t end_bytes = (size_t)GPSBB_MAX_CHAN * sizeof(gpsbb_chan_state_t);
+    if (!h->h_fill)
+        HIPCHK(h, hipHostMalloc((void **)&h->h_fill, end_bytes + 64, hipHostMallocDefault));
+    hipStream_t cs = b->last_cs;
+    uint32_t *st = reinterpret_cast<uint32_t *>(h->h_fill + end_bytes);
+    *st = 0xffffffffu;
+    if (end_state)
+        HIPCHK(h, hipMemcpyAsync(h->h_fill, b->d_end[b->last_set].p, (size_t)nch * sizeof(gpsbb_chan_state_t), hipMemcpyDeviceToHost, cs));
+    HIPCHK(h, hipMemcpyAsync(st, h->d_status, 4, hipMemcpyDeviceToHost, cs));
+    HIPCHK(h, hipMemcpyAsync(iq_out, b->last_iq, (size_t)nsamp * 4, hipMemcpyDeviceToHost, cs));
+    HIPCHK(h, hipStreamSynchronize(cs));
+    if (end_state)
+        memcpy(end_state, h->h_fill, (size_t)nch * sizeof(gpsbb_chan_state_t));
+    if (*st) {
+        HIPCHK(h, zero_now(h, h->d_status, 4));
+        return GPSBB_E_INTERNAL;
+    }
+    return GPSBB_OK;
+}
+
 extern "C" int gpsbb_fill_block(gpsbb_t *h, const gpsbb_chan_t *ch, int nch, double delt, int nsamp,
                                 int16_t *iq_out, gpsbb_chan_state_t *end_state)
 {
@@ -2366,11 +2430,7 @@ extern "C" int gpsbb_fill_block_ex(gpsbb_t *h, const gpsbb_chan_t *ch, int nch, 
     rc = gpsbb_batch_run(b, nullptr);
     if (rc != GPSBB_OK)
         return rc;
-    HIPCHK(h, hipMemcpyAsync(iq_out, b->last_iq, (size_t)nsamp * 4, hipMemcpyDeviceToHost, b->last_cs));
-    if (end_state)
-        HIPCHK(h, hipMemcpyAsync(end_state, b->d_end[b->last_set].p, (size_t)nch * sizeof(gpsbb_chan_state_t),
-                                 hipMemcpyDeviceToHost, b->last_cs));
-    return gpsbb_sync(h);
+    return fill_block_finish(h, b, nch, nsamp, iq_out, end_state);
 }
 
 /* the reference's own channel_t[] / gain[] in, rendered, updated in place as its loop leaves them; fixed: the build without

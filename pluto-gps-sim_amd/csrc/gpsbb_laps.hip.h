@@ -865,9 +865,9 @@ __device__ __forceinline__ void lap_advance(double s, double ds, int n, double r
  * chain's first block starts from its exact state), the laps that start in every block, their lanes.  Also what idle
  * channels leave (end states) and, kind 0, the tile counters of the table set (as k_tiles did). */
 template <int KIND>
-__global__ __launch_bounds__(64) void k_lap_plan(BatchDev p, LapDev L)
+__device__ __forceinline__ void lap_plan_body(const BatchDev &p, const LapDev &L, const uint32_t bx)
 {
-    const int i = blockIdx.x, lane = threadIdx.x;
+    const int i = (int)bx, lane = threadIdx.x;
     if (i >= p.nch)
         return;
     const double range = KIND == NCO_CARR ? 1.0 : 1023.0;
@@ -1202,10 +1202,10 @@ __device__ __forceinline__ LapMap lap_link(const LapLane<KIND> &w, bool mine, bo
 }
 
 template <int KIND>
-__global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass1(BatchDev p, LapDev L)
+__device__ __forceinline__ void lap_pass1_body(const BatchDev &p, const LapDev &L, const uint32_t bx)
 {
     __shared__ LapPassLds sh;
-    const uint32_t chunk = blockIdx.x + L.chunk0[KIND][0];
+    const uint32_t chunk = bx + L.chunk0[KIND][0];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int i = lap_channel_of<KIND>(L, p.nch, chunk);
     const uint32_t c = chunk - L.chunk0[KIND][i];
@@ -1292,9 +1292,9 @@ __global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass1(BatchDev p, 
 
 /* the offset of every chunk's first lap: one wavefront per kind and channel composes the chunks' links in order */
 template <int KIND>
-__global__ __launch_bounds__(64) void k_lap_scan(BatchDev p, LapDev L)
+__device__ __forceinline__ void lap_scan_body(const BatchDev &p, const LapDev &L, const uint32_t bx)
 {
-    const int i = blockIdx.x, lane = threadIdx.x;
+    const int i = (int)bx, lane = threadIdx.x;
     if (i >= p.nch)
         return;
     const uint32_t nl = L.nlaps[KIND * GPSBB_MAX_CHAN + i];
@@ -1323,10 +1323,10 @@ __global__ __launch_bounds__(64) void k_lap_scan(BatchDev p, LapDev L)
 }
 
 template <int KIND>
-__global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass2(BatchDev p, LapDev L)
+__device__ __forceinline__ void lap_pass2_body(const BatchDev &p, const LapDev &L, const uint32_t bx)
 {
     __shared__ LapPassLds sh;
-    const uint32_t chunk = blockIdx.x + L.chunk0[KIND][0];
+    const uint32_t chunk = bx + L.chunk0[KIND][0];
     const int t = threadIdx.x;
     const int i = lap_channel_of<KIND>(L, p.nch, chunk);
     const uint32_t c = chunk - L.chunk0[KIND][i];
@@ -1427,9 +1427,9 @@ __global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass2(BatchDev p, 
  * At the end (a stream) the channel's exact end phase is what the last block's end state says.
  */
 template <int KIND>
-__global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L)
+__device__ __forceinline__ void lap_repair_body(const BatchDev &p, const LapDev &L, const uint32_t bx)
 {
-    const int i = blockIdx.x, lane = threadIdx.x;
+    const int i = (int)bx, lane = threadIdx.x;
     if (i >= p.nch)
         return;
     const uint32_t nl = L.nlaps[KIND * GPSBB_MAX_CHAN + i];
@@ -1638,6 +1638,62 @@ __global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L)
             atomicAdd(p.hazards + 6, n_links); /* GPSBB_INFO_CHAIN_REPAIRS: links that did not hold */
     }
 }
+
+/* ---- the kernels ----------------------------------------------------------------------------------------------------
+ * One kind per launch (k_lap_*<KIND>: a stream's pushes, whose code chains need not wait for the push before while their
+ * carriers do; the chain alone, gpsbb_chain_carrier), or BOTH kinds in one grid (k_lap_*2: batches that continue nothing —
+ * the drop-in call's one block, resident batches — where the ten launches in a row were the pre-pass's latency: five, and the
+ * two plan kernels' 16 wavefronts each run side by side). */
+template <int KIND>
+__global__ __launch_bounds__(64) void k_lap_plan(BatchDev p, LapDev L) { lap_plan_body<KIND>(p, L, blockIdx.x); }
+template <int KIND>
+__global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass1(BatchDev p, LapDev L) { lap_pass1_body<KIND>(p, L, blockIdx.x); }
+template <int KIND>
+__global__ __launch_bounds__(64) void k_lap_scan(BatchDev p, LapDev L) { lap_scan_body<KIND>(p, L, blockIdx.x); }
+template <int KIND>
+__global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass2(BatchDev p, LapDev L) { lap_pass2_body<KIND>(p, L, blockIdx.x); }
+template <int KIND>
+__global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L) { lap_repair_body<KIND>(p, L, blockIdx.x); }
+
+/* both kinds: workgroups [0, nch) / [0, code chunks) are the code chains', the rest the carriers' */
+__global__ __launch_bounds__(64) void k_lap_plan2(BatchDev p, LapDev L)
+{
+    if ((int)blockIdx.x < p.nch)
+        lap_plan_body<NCO_CODE>(p, L, blockIdx.x);
+    else
+        lap_plan_body<NCO_CARR>(p, L, blockIdx.x - (uint32_t)p.nch);
+}
+__global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass1_2(BatchDev p, LapDev L)
+{
+    const uint32_t cc = L.chunk0[NCO_CODE][p.nch] - L.chunk0[NCO_CODE][0];
+    if (blockIdx.x < cc)
+        lap_pass1_body<NCO_CODE>(p, L, blockIdx.x);
+    else
+        lap_pass1_body<NCO_CARR>(p, L, blockIdx.x - cc);
+}
+__global__ __launch_bounds__(64) void k_lap_scan2(BatchDev p, LapDev L)
+{
+    if ((int)blockIdx.x < p.nch)
+        lap_scan_body<NCO_CODE>(p, L, blockIdx.x);
+    else
+        lap_scan_body<NCO_CARR>(p, L, blockIdx.x - (uint32_t)p.nch);
+}
+__global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass2_2(BatchDev p, LapDev L)
+{
+    const uint32_t cc = L.chunk0[NCO_CODE][p.nch] - L.chunk0[NCO_CODE][0];
+    if (blockIdx.x < cc)
+        lap_pass2_body<NCO_CODE>(p, L, blockIdx.x);
+    else
+        lap_pass2_body<NCO_CARR>(p, L, blockIdx.x - cc);
+}
+__global__ __launch_bounds__(64) void k_lap_repair2(BatchDev p, LapDev L)
+{
+    if ((int)blockIdx.x < p.nch)
+        lap_repair_body<NCO_CODE>(p, L, blockIdx.x);
+    else
+        lap_repair_body<NCO_CARR>(p, L, blockIdx.x - (uint32_t)p.nch);
+}
+
 
 } /* namespace gpsbb_impl */
 #endif

@@ -471,8 +471,10 @@ constexpr int CHAIN_SEG_MIN_TILES = 16; /* ... but no segment shorter than this 
 constexpr int CHAIN_SEG_MAX = 8;        /* segments per block at most */
 constexpr int CHAIN_INDEP_MIN_TILES = 1024; /* independent blocks of at least this many tiles are cut into segments as well */
 constexpr long CHAIN_MODEL_MAX_SEGS = 4096; /* segments per channel up to which pass B starts from the host's drift model */
-constexpr unsigned STREAM_SEED_STREAMS = 4; /* pre-passes of a stream's pushes in flight (measured with 2 .. 6 and rings of 4 .. 8 slots: 4.1 .. 4.3e11
-                                               samples/s, all within 5 %: the pre-pass is 4 ms now, the synthesis 2.2) */
+constexpr unsigned STREAM_SEED_STREAMS = 3; /* pre-passes of a stream's pushes in flight.  Round 6, the lap-parallel pre-pass beside a synthesis
+                                               kernel that keeps every CU to the end of its launch: 2, 3 and 4 give the same rate (5.43 - 5.60e11 on the
+                                               boxes measured, tools/sweep_seed_streams.sh) and 3.2 / 3.1 / 3.6 - 4.3 ms of pre-pass per push:
+                                               what is in flight shares the slots the synthesis leaves */
 
 struct gpsbb {
     int device = 0;
@@ -2723,8 +2725,15 @@ static int stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch, bool new_chain
         const size_t host_lim = (size_t)GPSBB_KNOB_LONG("GPSBB_HOST_SEED_MAX", HOST_SEED_MAX_CHANNELS);
         const bool dev_only = GPSBB_KNOB_SET("GPSBB_DEVICE_SEED_ONLY");
         /* (small pushes too where the lap-parallel pre-pass will take them: it costs less than the host threads) */
-        const bool small_on_dev = h->opt_seed_where == 0 && h->opt_synth_kernel != 1 && h->opt_chain_where == 0 && !GPSBB_KNOB_SET("GPSBB_NO_LAPS") &&
-                                  lap_eligible(ch, nbc, s->delt, false);
+        /* (... which it only does for blocks the model kernels render: the kernel plan's own test, here, before the push is promised
+         * the device-side chain — a small push of a 1 MS/s stream, which they decline, stays with the host threads instead of the
+         * row walks' milliseconds) */
+        bool small_on_dev = nbc <= host_lim && h->opt_seed_where == 0 && h->opt_synth_kernel != 1 && h->opt_chain_where == 0 &&
+                            !GPSBB_KNOB_SET("GPSBB_NO_LAPS") && lap_eligible(ch, nbc, s->delt, false);
+        if (small_on_dev) {
+            std::vector<EvConst> probe;
+            small_on_dev = ev_plan(ch, s->bps, s->nch, s->delt, probe);
+        }
         const bool dev = h->opt_chain_where != 1 &&
                          (h->opt_seed_where == 1 || h->opt_seed_where == 3 || (h->opt_seed_where == 0 && (dev_only || nbc > host_lim || small_on_dev)));
         if (!s->carry) {
@@ -3149,10 +3158,13 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
             int nb = 0;
             while (b0 + nb < nblocks && nb < CHAIN_ONLY_BLOCKS) {
                 double l = 0.0;
+                /* lanes by the laps per lane a sub-batch of nb + 1 blocks would get (lap_unit grows with the batch: a block counted
+                 * with the smaller unit of a smaller batch is over-counted, never under: the scratch stays within CHAIN_ONLY_LAPS) */
+                const double unit = (double)lap_unit(NCO_CARR, (size_t)(nb + 1) * nch);
                 for (int i = 0; i < nch; i++) {
                     const ChainDesc &d = c->h_cd[(size_t)(b0 + nb) * nch + i];
                     if (d.prn > 0)
-                        l += std::floor((std::floor((double)nsamp * std::fabs(d.f_carr * delt)) + 1.0) / (double)lap_unit(NCO_CARR, (size_t)-1)) + 3.0;
+                        l += std::floor((std::floor((double)nsamp * std::fabs(d.f_carr * delt)) + 1.0) / unit) + 3.0;
                 }
                 if (nb > 0 && laps + l > CHAIN_ONLY_LAPS)
                     break;

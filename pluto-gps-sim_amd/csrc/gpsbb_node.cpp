@@ -794,18 +794,19 @@ extern "C" int gpsbb_node_feed(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nbl
         return GPSBB_E_STATE;
     const gpsbb_node_config_t &c = n->cfg;
     const int bps = c.blocks_per_slot, nch = c.nch;
+    /* what is fed goes behind what is kept, in place; nothing is chained or copied again until a slot is complete (fed block by
+     * block, a 400-block slot used to be copied and re-chained 400 times) */
     try {
-        n->work = n->pend;
-        n->work.insert(n->work.end(), ch, ch + (size_t)nblocks * nch);
+        n->pend.insert(n->pend.end(), ch, ch + (size_t)nblocks * nch);
     } catch (const std::bad_alloc &) {
         return GPSBB_E_NOMEM;
     }
-    const long have = (long)(n->work.size() / (size_t)nch);
+    const long have = (long)(n->pend.size() / (size_t)nch);
     const long nslots = have / bps;
-    if (nslots == 0) {
-        n->pend.swap(n->work);
+    if (nslots == 0)
         return GPSBB_OK;
-    }
+    n->work.swap(n->pend);
+    n->pend.clear();
     /* the chain over everything at hand (cheap: 24 bytes per block and channel go to the device, a microsecond per block), the
      * whole slots out, the rest kept with the exact phase at its first block */
     double end[GPSBB_MAX_CHAN];
@@ -849,7 +850,12 @@ extern "C" int gpsbb_node_end(gpsbb_node_t *n, gpsbb_node_stats_t *stats)
         return GPSBB_E_STATE;
     int rc = GPSBB_OK;
     const long left = (long)(n->pend.size() / (size_t)n->cfg.nch);
-    if (left > 0 && !n->stop) {
+    bool stopped;
+    {
+        std::lock_guard<std::mutex> lk(n->m);
+        stopped = n->stop;
+    }
+    if (left > 0 && !stopped) {
         /* the stream's last, short slot */
         double end[GPSBB_MAX_CHAN];
         try {

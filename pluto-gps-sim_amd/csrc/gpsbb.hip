@@ -3481,6 +3481,28 @@ extern "C" unsigned long long gpsbb_test_row_bound(int kind, double s_abs, int n
     return kind == NCO_CODE ? row_bound(s_abs, 1023.0, 9, nsamp) : row_bound(s_abs, 1.0, -1, nsamp);
 }
 
+/* FETCH_SIZE calibration: `bytes` bytes of d_src (device memory, at least that big) read once with the tile states' pattern
+ * (k_read_pattern: 32 rows of 2442 doubles per wavefront, what a wavefront of k_synth_ev reads of one block); returns the bytes
+ * actually read */
+extern "C" long long gpsbb_test_read_pattern(gpsbb_t *h, const void *d_src, size_t bytes)
+{
+    if (!h || !d_src)
+        return GPSBB_E_BADARG;
+    const int rows = 32, cols = 2442;
+    const size_t per_wave = (size_t)rows * cols * 8;
+    size_t waves = bytes / per_wave;
+    waves -= waves % 4;
+    if (waves < 4)
+        return GPSBB_E_BADARG;
+    double *d_sink = nullptr;
+    if (hipMalloc((void **)&d_sink, 8) != hipSuccess)
+        return GPSBB_E_NOMEM;
+    hipLaunchKernelGGL(k_read_pattern, dim3((unsigned)(waves / 4)), dim3(256), 0, h->s_compute, (const double *)d_src, rows, cols, d_sink);
+    const hipError_t e = hipStreamSynchronize(h->s_compute);
+    (void)hipFree(d_sink);
+    return e == hipSuccess ? (long long)(waves * per_wave) : (long long)GPSBB_E_HIP;
+}
+
 #ifdef GPSBB_WG_TRACE
 /* The workgroup trace of the measurement build (gpsbb_kernels.hip.h: wg_trace_leave; make trace; tools/corun_diag.py).
  * _begin: (re)arm the trace with room for `cap` records; _read: wait for the device, copy out up to `cap` records of

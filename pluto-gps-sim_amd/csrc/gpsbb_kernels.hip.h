@@ -1322,6 +1322,21 @@ __global__ __launch_bounds__(TILE_THREADS, GPSBB_WAVES_PER_SIMD) void k_synth(Ba
 }
 
 /* pure write stream of the same shape as k_synth's output: the empirical int16x2 write ceiling */
+/* Counter calibration for READS (experiments build, tools/kbench.py --read-cal): a known number of bytes fetched with the
+ * synthesis kernels' own access pattern for the tile states — the first `rows` lanes of a wavefront each read one double of a row of
+ * their own, the same column, column after column (k_synth_ev: tx[chain * ntiles + tile]) — so that FETCH_SIZE can be priced on
+ * this pattern instead of with the factor the guide gives for wide coalesced reads.  Reads rows * cols * 8 bytes per wavefront. */
+__global__ __launch_bounds__(256) void k_read_pattern(const double *__restrict__ src, int rows, int cols, double *__restrict__ sink)
+{
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63);
+    const double *__restrict__ p = src + ((size_t)wave * rows + (size_t)(lane < rows ? lane : 0)) * (size_t)cols;
+    double acc = 0.0;
+    for (int t = 0; t < cols; t++)
+        acc += lane < rows ? p[t] : 0.0;
+    if (acc == 0x1.23456789abcdep+700)
+        sink[0] = acc; /* (never: keeps the loads) */
+}
+
 __global__ __launch_bounds__(256) void k_fill_ceiling(uint4 *__restrict__ dst, size_t n16, uint32_t seed)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;

@@ -9,7 +9,11 @@ c = sqlite3.connect(os.path.join(src, "prof", "trace_results.db"))
 cols = [r[1] for r in c.execute("pragma table_info(top_kernels)")]
 rows = c.execute("select * from top_kernels").fetchall()
 with open(os.path.join(dst, tag + "_stream_kernel_stats.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu   (bench.py's defaults)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-extras --no-cpu   (the timed leg alone; bench.py's default steps / repeats)\n")
+    try:
+        f.write("# the bench line of this very run: " + open(os.path.join(src, "prof_bench_line.json")).read().strip()[:330] + "\n")
+    except OSError:
+        pass
     f.write("# top_kernels view of the trace database; total_duration and average in microseconds\n")
     f.write(" | ".join(cols) + "\n")
     for r in rows:
@@ -36,6 +40,9 @@ if os.path.exists(sq):
                          "launch: tools/kbench.py --blocks 400 --chain --smooth, 1e9 samples), profiles/r03_valu_rates_ubench.txt (4.3 cycles: the "
                          "kernel's mix of f64 / 32-bit integer / v_and), clock 2.38-2.41 GHz measured under load" % tag)
         json.dump(old, open(os.path.join(dst, "sq_latest.json"), "w"), indent=1)
+for extra, name in ((tag + "_corun/corun_diag.txt", tag + "_corun_diag.txt"), (tag + "_corun/corun_diag.json", tag + "_corun_diag.json")):
+    if os.path.exists(os.path.join(ROOT, "gpurun_out", extra)):
+        shutil.copy(os.path.join(ROOT, "gpurun_out", extra), os.path.join(dst, name))
 sq = os.path.join(ROOT, "gpurun_out", tag + "_m1_sq.txt")
 if os.path.exists(sq):
     shutil.copy(sq, os.path.join(dst, tag + "_m1_sq_counters.txt"))
@@ -52,7 +59,9 @@ if os.path.exists(m1db):
 s = json.load(open(os.path.join(src, "pmc_summary.json")))
 d = {k: s[k] for k in ("k_synth_hbm_write_bytes_per_launch", "k_synth_hbm_read_bytes_per_launch", "k_synth_hbm_bytes_per_launch")}
 d["kernel"] = "k_synth_ev"
-d["source"] = "profiles/%s_stream_pmc.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE in separate passes, KiB -> bytes, calibration factor 1.0 measured on k_fill_ceiling)" % tag
+d["source"] = ("profiles/%s_stream_pmc.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE in separate passes — counter passes serialise kernels: the figures are "
+               "k_synth_ev's own —, KiB -> bytes, WRITE_SIZE calibrated on k_fill_ceiling (%.3f), FETCH_SIZE on k_read_pattern (%s))" %
+               (tag, s.get("write_size_calibration", 1.0) or 1.0, ("%.3f" % s["fetch_size_calibration"]) if s.get("fetch_size_calibration") else "no pass: x2"))
 json.dump(d, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
 b = json.load(open(os.path.join(src, "bench.json")))
 print("value %.4g  ms/step %.2f  seconds %s" % (b["value"], b["ms_per_step"], b["repeats"]["seconds"]))

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="ignored (compatibility with older scripts)")
     ap.add_argument("--where", type=int, default=0, help="GPSBB_OPT_SEED_WHERE: 1 the row walks of rounds 1-4, 3 the lap-parallel pre-pass")
     ap.add_argument("--fill-ceiling", action="store_true", help="also run the pure write kernel over the output buffer (counter calibration)")
+    ap.add_argument("--read-cal", action="store_true", help="also read the output buffer once with the tile states' access pattern (k_read_pattern, experiments build: FETCH_SIZE calibration); prints the bytes read")
     a = ap.parse_args()
     import torch
     from __graft_entry__ import load_package
@@ -62,12 +63,20 @@ def main():
     n = a.blocks * a.nsamp
     if a.fill_ceiling:
         synth.fill_ceiling(out.data_ptr(), out.numel() * 2, iters=10)
+    read_cal_bytes = None
+    if a.read_cal:
+        import ctypes as C
+        L = pkg.lib()
+        L.gpsbb_test_read_pattern.restype = C.c_longlong
+        L.gpsbb_test_read_pattern.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        for _ in range(3):
+            read_cal_bytes = L.gpsbb_test_read_pattern(synth._h, C.c_void_p(out.data_ptr()), out.numel() * 2)
     print(json.dumps({"value": n * a.steps / dt, "ms_per_step": dt / a.steps * 1e3,
                       "roofline": {"ms_per_launch": st["ms_synth_sum"] / max(st["runs"], 1)},
                       "seed_kernel_ms_per_launch": st["ms_seed_sum"] / max(st["runs"], 1),
                       "kernel": synth.info(pkg.INFO_LAST_KERNEL), "chain_on_device": synth.info(pkg.INFO_CHAIN_ON_DEVICE),
                       "chain_fallbacks": synth.info(pkg.INFO_CHAIN_FALLBACKS), "chain_repairs": synth.info(pkg.INFO_CHAIN_REPAIRS),
-                      "launches": a.steps + a.warmup}))
+                      "launches": a.steps + a.warmup, "read_cal_bytes": read_cal_bytes}))
     synth.set_option(pkg.OPT_SKIP_SEED, 0)
     batch.close()
     synth.close()

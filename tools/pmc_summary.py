@@ -7,8 +7,12 @@ that can be committed under profiles/.
 Reads <tag>/prof/*.db (--kernel-trace --stats run), <tag>/pmc_w/*.db (--pmc WRITE_SIZE run) and
 <tag>/pmc_r/*.db (--pmc FETCH_SIZE run).  HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md
 ("HBM"): counters collected in their own passes; WRITE_SIZE / FETCH_SIZE are in KiB (x1024);
-FETCH_SIZE is doubled (gfx950 reports half the bytes of wide coalesced reads); WRITE_SIZE is calibrated
-on k_fill_ceiling, which writes a known byte count.
+WRITE_SIZE is calibrated on k_fill_ceiling, which writes a known byte count; FETCH_SIZE on k_read_pattern, which reads a known byte
+count with the synthesis kernel's own pattern for the tile states (8 bytes per lane, a row per lane: tools/kbench.py --read-cal) —
+the guide's factor 2 for gfx950 is for wide coalesced reads (16 bytes per lane) and does not hold for this pattern (round 6:
+measured, see "fetch_size_calibration"); without a calibration pass the factor 2 is applied and said so.
+rocprofv3 --pmc SERIALISES kernels (round 6: none of the lap-pass launches of a counter pass overlaps a k_synth_ev launch in its
+own kernel trace, tools/corun_session.sh), so a kernel's counters are its own.
 """
 import glob
 import json
@@ -27,7 +31,8 @@ def q(db, sql):
 
 KERNELS = ("k_synth_ev", "k_synth_ev_dense", "k_synth_pd<true>", "k_synth_pd<false>", "k_synth", "k_walk<0>", "k_walk<1>", "k_walk<2>", "k_walk<3>", "k_tiles",
            "k_chain_fix", "k_chain_fix_par<128>", "k_chain_fix_par<256>", "k_chain_prefix", "k_seed<true>", "k_seed<false>", "k_fill_ceiling",
-           "k_gather_to_host", "k_end_states_to_host")
+           "k_gather_to_host", "k_end_states_to_host", "k_read_pattern", "k_lap_pass1<0>", "k_lap_pass1<1>", "k_lap_pass2<0>", "k_lap_pass2<1>",
+           "k_lap_plan<0>", "k_lap_plan<1>", "k_lap_scan<0>", "k_lap_scan<1>", "k_lap_repair<0>", "k_lap_repair<1>", "k_block_digest")
 
 
 def short(name):
@@ -74,7 +79,19 @@ def main():
     if dom in k and "WRITE_SIZE_KiB_per_launch" in k[dom]:
         cal = res.get("write_size_calibration", 1.0) or 1.0
         w = k[dom]["WRITE_SIZE_KiB_per_launch"] * 1024.0 / cal
-        r = 2.0 * k[dom].get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024.0
+        rcal = None
+        if "k_read_pattern" in k and "FETCH_SIZE_KiB_per_launch" in k["k_read_pattern"] and bench:
+            per_wave = 32 * 2442 * 8
+            waves = bench["roofline"]["algorithmic_bytes_per_launch"] // per_wave
+            waves -= waves % 4
+            rcal = k["k_read_pattern"]["FETCH_SIZE_KiB_per_launch"] * 1024.0 / (waves * per_wave)
+            res["fetch_size_calibration"] = rcal
+            res["fetch_size_calibration_note"] = "FETCH_SIZE of k_read_pattern / the bytes it reads (the tile states' pattern)"
+        if rcal:
+            r = k[dom].get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024.0 / rcal
+        else:
+            r = 2.0 * k[dom].get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024.0
+            res["fetch_size_calibration_note"] = "no calibration pass: the guide's factor 2 for wide coalesced reads applied"
         res["k_synth_hbm_write_bytes_per_launch"] = w
         res["k_synth_hbm_read_bytes_per_launch"] = r
         res["k_synth_hbm_bytes_per_launch"] = w + r

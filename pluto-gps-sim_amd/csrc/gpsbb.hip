@@ -3468,6 +3468,53 @@ extern "C" int gpsbb_test_model_err(gpsbb_batch_t *b, double *maxima, unsigned l
     return GPSBB_OK;
 }
 
+/* What the pre-pass of the batch's LAST run left for the model kernels — every tile state (bit patterns), every tile's data bits,
+ * every end-of-block state — as three 64-bit sums of mixed words: the lap-parallel pre-pass (its reference
+ * states on the model or pushed far off it: GPSBB_LAP_JITTER) and the row walks must leave the same bits, whatever the IQ makes of
+ * them (tools/table_check.py). */
+extern "C" int gpsbb_test_table_digest(gpsbb_batch_t *b, unsigned long long out[3])
+{
+    if (!b || !out || !b->ran || !b->ev)
+        return GPSBB_E_STATE;
+    gpsbb *h = b->h;
+    const int rc = gpsbb_sync(h);
+    if (rc != GPSBB_OK)
+        return rc;
+    const BatchDev p = batch_dev(b, b->last_set);
+    auto mix = [](unsigned long long z) { z ^= z >> 31; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 29; return z; };
+    const size_t nx = (size_t)b->nblocks * 2 * b->nch * b->ntiles, nn = (size_t)b->nblocks * b->nch * b->ntiles, ne = (size_t)b->nblocks * b->nch;
+    std::vector<unsigned long long> hx(nx);
+    std::vector<uint32_t> hn(nn);
+    std::vector<gpsbb_chan_state_t> he(ne);
+    HIPCHK(h, hipMemcpy(hx.data(), p.tile_x, nx * 8, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(hn.data(), p.tile_nav, nn * 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(he.data(), p.end, ne * sizeof(gpsbb_chan_state_t), hipMemcpyDeviceToHost));
+    out[0] = out[1] = out[2] = 0;
+    /* (idle channels' entries are whatever the allocation held: only active block-channels count) */
+    std::vector<gpsbb_chan_t> hc(ne);
+    HIPCHK(h, hipMemcpy(hc.data(), p.ch, ne * sizeof(gpsbb_chan_t), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < ne; k++) {
+        if (hc[k].prn <= 0)
+            continue;
+        const size_t blk = k / (size_t)b->nch, i = k % (size_t)b->nch;
+        for (int kind = 0; kind < 2; kind++)
+            for (int t = 0; t < b->ntiles; t++) {
+                const size_t at = (blk * 2 * b->nch + 2 * i + kind) * (size_t)b->ntiles + t;
+                out[0] += mix(hx[at] + 0x9E3779B97F4A7C15ull * (at + 1));
+            }
+        for (int t = 0; t < b->ntiles; t++) {
+            const size_t at = k * (size_t)b->ntiles + t;
+            out[1] += mix((unsigned long long)(hn[at] & 3u) + 0x9E3779B97F4A7C15ull * (at + 1));
+        }
+        unsigned long long w[5];
+        memcpy(w, &he[k], sizeof w);
+        for (int q = 0; q < 4; q++) /* carr_phase, code_phase, (iword, ibit), (icode, dataBit); codeCA with the padding */
+            out[2] += mix(w[q] + 0x9E3779B97F4A7C15ull * (k * 5 + q + 1));
+        out[2] += mix((unsigned long long)(uint32_t)he[k].codeCA + 0x9E3779B97F4A7C15ull * (k * 5 + 5));
+    }
+    return GPSBB_OK;
+}
+
 /* the derived budgets this build was compiled with, in units of 2^-32: EV_MODEL_ERR, EV_T_EPS, PD_BAND */
 extern "C" void gpsbb_test_budgets(double out[3])
 {

@@ -251,3 +251,15 @@ def test_the_null_stream_owns_nothing(pkg, where):
     assert r.returncode == 0, r.stderr[-2000:]
     bad = json.loads(r.stdout.strip().splitlines()[-1])
     assert bad["null_memset"] and all(x["blocks_that_differ"] > 0 for x in bad["runs"]), bad   # every run, not one in a hundred
+
+
+def test_the_prepasses_leave_the_same_tables(pkg):
+    """The IQ cannot tell a tile state that is off by one grid step (it changes no sample), so the tables themselves are compared:
+    every tile state, every tile's data bits and every end-of-block state of 11 batches (both geometries, chained and independent,
+    Dopplers over seven decades and through zero, sign changes, re-allocated and idle channels) as left by the lap-parallel
+    pre-pass, by the same with its reference states pushed 1000 and 4e9 grid steps off the model (links that break, the repair
+    kernel at work) and by the row walks of rounds 1-4 — bit-identical (gpsbb_test_table_digest, experiments build)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "table_check.py"), "--cases", "8", "--seed", "5"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "tables bit-identical in every mode (11 workloads x 4 modes)" in r.stdout

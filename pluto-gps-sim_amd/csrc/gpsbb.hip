@@ -329,7 +329,8 @@ bool ev_plan(const gpsbb_chan_t *ch, int nblocks, int nch, double delt, std::vec
 }
 
 /* Does the lap-parallel pre-pass take these blocks (gpsbb_laps.hip.h, Eligibility)?  It is exact for any step it walks; what is
- * excluded is what its turn of the walk does not cover: steps more than 50 binades below the state (|step| < 2^-50, zero). */
+ * excluded is what its turn of the walk does not cover: steps more than 50 binades below the state (0 < |step| < 2^-50: below
+ * 2e-8 Hz at 25 MS/s).  A step of exactly zero — a carrier without Doppler — is taken: the phase stands still (round 6). */
 bool lap_eligible(const gpsbb_chan_t *ch, size_t nbc, double delt, bool fixed)
 {
     for (size_t k = 0; k < nbc; k++) {
@@ -339,7 +340,7 @@ bool lap_eligible(const gpsbb_chan_t *ch, size_t nbc, double delt, bool fixed)
         const volatile double sc = c.f_code * delt, sk = c.f_carr * delt;
         if (!(sc >= 0x1p-20))
             return false;
-        if (!fixed && !(std::fabs(sk) >= 0x1p-50))
+        if (!fixed && !(std::fabs(sk) >= 0x1p-50) && sk != 0.0) /* (exactly zero stands still: lap_run takes it) */
             return false;
     }
     return true;
@@ -3143,7 +3144,7 @@ extern "C" int gpsbb_chain_carrier(gpsbb_t *h, const gpsbb_chan_t *ch, int nbloc
     for (size_t k = 0; k < nbc_all && use_laps; k++)
         if (c->h_cd[k].prn > 0) {
             const volatile double sk = c->h_cd[k].f_carr * delt;
-            use_laps = std::fabs(sk) >= 0x1p-50;
+            use_laps = std::fabs(sk) >= 0x1p-50 || sk == 0.0;
         }
     if (use_laps) {
         if (!c->d_hz_scratch)

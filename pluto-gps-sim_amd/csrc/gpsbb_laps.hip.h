@@ -441,7 +441,8 @@ __device__ __forceinline__ void lap_enter_block(const BatchDev &p, const LapDev 
     w.c0 = bc.c0;
     const uint64_t sb = f64_bits(bc.s);
     w.es = (int)((sb >> 52) & 0x7ff);
-    w.tiemask = walk_tiemask(sb);
+    /* (a step of exactly zero — a carrier without Doppler: a bench-top scenario — ties nowhere: the state stands still, lap_run) */
+    w.tiemask = (sb << 1) == 0ull ? 0ull : walk_tiemask(sb);
     w.neg = bc.s < 0.0;
     w.tt = ((w.tiemask >> (((KIND == NCO_CARR ? 1022 : 1023 + 9) - w.es) & 63)) & 1ull) != 0ull;
     w.nmax = (w.b == w.bt) ? w.nt : p.nsamp;
@@ -525,7 +526,28 @@ __device__ __forceinline__ void lap_run(const BatchDev &p, int i, LapLane<KIND> 
     double x = w.x;
     int n = w.n;
     bool go = was, last_wrapped = false;
+    /* A step of exactly zero (round 6; until then one such channel sent its whole batch to the row walks): c:2741 adds nothing, the
+     * phase stands still to the end of the block or of the territory and every tile of the stretch starts from it — but for a phase
+     * of exactly 1.0, which the first step takes to 0.0 like any other (c:2743: one ordinary turn below, then it stands). */
+    const bool any_still = KIND == NCO_CARR && !SNEG && __ballot(was && s == 0.0) != 0ull;
     while (__ballot(go)) {
+        if (any_still) {
+            const bool still = go && s == 0.0 && x < 1.0;
+            if (__ballot(still)) {
+                const int k = still && nmax > n ? nmax - n : 0;
+                if (EMIT && p.tile_x) {
+                    const int t0 = (int)(((uint32_t)n + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
+                    if (__ballot(still && t0 * TILE <= n + k && t0 < p.ntiles))
+                        lap_emit_row<KIND>(p, i, still, w.b, n, k, x, 0.0, w.bits);
+                }
+                if (still) {
+                    n += k;
+                    last_wrapped = k > 0 ? false : last_wrapped;
+                    go = false;
+                }
+                continue;
+            }
+        }
 #ifdef GPSBB_LAP_DEBUG /* (how many turns does a wavefront take?  hazards[3] is scratch) */
         if (__lane_id() == (unsigned)__builtin_ctzll(__ballot(go)))
             atomicAdd(p.hazards + 3, 1ull);

@@ -56,14 +56,16 @@ def test_it_is_what_runs_by_default(pkg, fresh, oracle):
     s.set_option(pkg.OPT_SEED_WHERE, 1)
     s.fill_block(ch[0], 1 / 2.6e6, 30000)
     assert s.info(pkg.INFO_PREPASS) == 1
-    # a carrier that does not move is outside what the laps' turn covers: the row walks take the batch
+    # a carrier step below 2^-50 that is not zero is outside what the laps' turn covers: the row walks take the batch; a carrier
+    # that does not move at all stands still on the laps (round 6: test_a_carrier_without_doppler_stays_on_the_laps)
     s.set_option(pkg.OPT_SEED_WHERE, 3)
-    ch["f_carr"][:, 2] = 0.0
-    want_iq, _, _ = oracle.fill_blocks(ch, 1 / 25e6, 20000)
-    b = s.batch(ch, 1 / 25e6, 20000)
-    b.run(); s.sync()
-    assert s.info(pkg.INFO_PREPASS) == 1 and (b.read()[0] == want_iq).all()
-    b.close()
+    for f, want_prepass in ((1e-9, 1), (0.0, 3)):
+        ch["f_carr"][:, 2] = f
+        want_iq, _, _ = oracle.fill_blocks(ch, 1 / 25e6, 20000)
+        b = s.batch(ch, 1 / 25e6, 20000)
+        b.run(); s.sync()
+        assert s.info(pkg.INFO_PREPASS) == want_prepass and (b.read()[0] == want_iq).all(), f
+        b.close()
 
 
 def test_steps_that_tie_on_the_coarsest_grid(pkg, fresh, oracle):
@@ -263,3 +265,48 @@ def test_the_prepasses_leave_the_same_tables(pkg):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "tables bit-identical in every mode (11 workloads x 4 modes)" in r.stdout
+
+
+def test_a_carrier_without_doppler_stays_on_the_laps(pkg, fresh, oracle):
+    """A carrier step of exactly zero (f_carr = 0.0 / -0.0: a bench-top scenario; c:2741 adds nothing) used to send the WHOLE batch
+    to the row walks (the lap walk's turn did not cover it).  Round 6: the phase stands still, the lap-parallel pre-pass takes the
+    batch — one such channel among 15 ordinary ones, one whose Doppler is zero in some blocks only (its lap passes through them),
+    one standing on a phase of exactly 0.0 and one on exactly 1.0 (the table index 512 at every sample: the hazard counter counts
+    them like the oracle) — as a chained batch, as independent blocks, as a chained stream across pushes, and as the drop-in call."""
+    s = fresh
+    fs, nsamp, nch, nb = 25e6, 150000, 16, 12
+    ch = pkg.synth_descriptors(nb, nch=nch, seed=606)
+    ch["f_carr"][:, 3] = 0.0
+    ch["f_carr"][:, 7] = -0.0
+    ch["f_carr"][4:9, 5] = 0.0            # no Doppler for a while, in the middle of a chain
+    ch["f_carr"][:, 9] = 0.0
+    ch["carr_phase"][:, 9] = 0.0
+    ch["f_carr"][:, 11] = 0.0
+    ch["carr_phase"][:, 11] = 1.0
+    ch["f_code"] = 1.023e6 + ch["f_carr"] / 1540.0
+    for flags in (pkg.CHAIN_CARRIER, 0):
+        want_iq, want_st, want_hz = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=bool(flags))
+        s.hazards(reset=True)
+        b = s.batch(ch, 1 / fs, nsamp, flags=flags)
+        b.run()
+        s.sync()
+        iq, st = b.read()
+        b.close()
+        assert s.info(pkg.INFO_PREPASS) == 3 and s.info(pkg.INFO_LAST_KERNEL) == 2
+        assert (iq == want_iq).all()
+        for f in ("carr_phase", "code_phase"):
+            assert st[f].tobytes() == want_st[f].tobytes(), f
+        assert s.hazards(reset=True)["itable_512"] == int(want_hz["itable_512"]) > 0
+    want_iq, want_st, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
+    st_ = s.stream(nch, 1 / fs, nsamp, 4, depth=2, flags=pkg.CHAIN_CARRIER)
+    got = []
+    for k in range(3):
+        st_.push(ch[4 * k:4 * k + 4])
+        iq, es = st_.pop(copy=True)
+        got.append(np.asarray(iq).reshape(4, nsamp, 2))
+        assert es["carr_phase"].tobytes() == want_st["carr_phase"][4 * k:4 * k + 4].tobytes()
+    st_.close()
+    assert s.info(pkg.INFO_PREPASS) == 3 and (np.concatenate(got) == want_iq).all()
+    one_iq, one_st, _ = oracle.fill_blocks(ch[:1], 1 / fs, nsamp)
+    iq, st1 = s.fill_block(ch[0], 1 / fs, nsamp)
+    assert s.info(pkg.INFO_PREPASS) == 3 and (iq == one_iq[0]).all() and st1["carr_phase"].tobytes() == one_st["carr_phase"][0].tobytes()

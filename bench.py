@@ -39,8 +39,8 @@ duration against the 8 TB/s HBM peak.  Beside it, measured in the same invocatio
                 kernel by device-side digests, leading blocks against the oracle; `m1.gpu*` (resident re-runs of one batch) at N = 1
   fill_block    the drop-in call itself, gpsbb_fill_block_ref on the reference's channel_t layout with a pageable iq_buff: median /
                 p99 of 200 calls for the reference's block and for the headline's, each checked against the oracle once (rank 0)
-  cpu_baseline  the CPU restatement (oracle, 1 core) on a bounded sample of the same blocks, AT EVERY N: rank 0 runs it on a
-                thread of its own while the GPU legs that follow the timed regions run (it is CPU-only)
+  cpu_baseline  the CPU restatement (oracle, 1 core) on a bounded sample of the same blocks, AT EVERY N: rank 0 starts it as a
+                process of its own (bench.py --cpu-legs) once the timed regions are over; the GPU legs that follow run meanwhile
 `resident`, `m1.gpu*`, `roofline.alone` and the write ceiling run at N = 1 only (with N > 1 they would keep N - 1 GPUs idle behind
 rank 0 for most of the command).
   parity        blocks of the timed mode's ring against the CPU oracle (a handful: the oracle renders 2e7 samples/s) AND every
@@ -196,6 +196,31 @@ def cpu_baseline(ob, ch, delt, nsamp, budget_s=10.0):
         out["reference_loop_O0"] = {"value": nsamp / (time.perf_counter() - t0), "unit": "IQ samples/s",
                                     "cores": 1, "sample": "1 block, verbatim plutogpssim.c:2690-2756, -std=c11 -O0"}
     return out
+
+
+def cpu_legs_main(args):
+    """`bench.py --cpu-legs`: the two CPU baselines in a process of their own (no GPU, no torch) — rank 0 starts it once the timed
+    regions are over and reads its one JSON line at the end, so that the oracle's gigabyte of output and its core are not inside the
+    process whose threads drive the GPU legs (as a thread of rank 0 it cost the node driver's legs 10 - 30 %: one address space,
+    one allocator, one interpreter lock)."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_binding as ob
+    delt, nsamp, nch = 1.0 / args.fs, args.nsamp, args.nch
+    total = args.steps * STEP_PUSHES * args.push_blocks
+    n_main = int(max(1, min(total, 4 + args.cpu_budget * 3.0e7 / max(nsamp, 1))))   # more than the budget can take at 2.3e7 samples/s
+    mine = stream_descriptors(pkg, total, nch, first=0, count=n_main)
+    m_total = max(1, min(args.steps, M1_DESC_STEPS)) * STEP_PUSHES * args.m1_push_blocks
+    n_m1 = int(max(1, min(m_total, 4 + args.cpu_budget / 2 * 4.0e7 / max(args.m1_nsamp, 1))))
+    m1_mine = stream_descriptors(pkg, m_total, M1_NCH, seed=M1_SEED, first=0, count=n_m1)
+    out = {}
+    try:
+        out["cpu_baseline"] = cpu_baseline(ob, mine, delt, nsamp, budget_s=args.cpu_budget)
+        out["m1_cpu"] = cpu_baseline(ob, m1_mine, 1.0 / M1_FS, args.m1_nsamp, budget_s=args.cpu_budget / 2)
+    except Exception as e:
+        out["error"] = repr(e)
+    print(json.dumps(out))
 
 
 def block_digest(a):
@@ -424,7 +449,11 @@ def main():
     ap.add_argument("--m1-push-blocks", type=int, default=M1_PUSH_BLOCKS, help="blocks per push of the 2.6 MS/s stream leg")
     ap.add_argument("--m1-nsamp", type=int, default=M1_NSAMP, help="samples per block of the 2.6 MS/s legs (the reference's NUM_SAMPLES)")
     ap.add_argument("--fill-calls", type=int, default=200, help="gpsbb_fill_block_ref calls timed per case of the fill_block leg")
+    ap.add_argument("--no-m1-stream", action="store_true", help="skip the 2.6 MS/s stream leg (measurement aid)")
+    ap.add_argument("--cpu-legs", action="store_true", help="(internal) only the CPU baselines, as a process of their own: what rank 0 starts beside its GPU legs")
     args = ap.parse_args()
+    if args.cpu_legs:
+        return cpu_legs_main(args)
 
     import torch  # first: it brings the HIP runtime the library then shares
     import torch.distributed as dist
@@ -600,24 +629,20 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_binding as ob_all
         ob_all.Oracle().fill_blocks(mine[:1], delt, 1000)   # the oracle's one-time tables, before any thread uses it
-    if not args.no_extras:
+    if not args.no_extras and not args.no_m1_stream:
         m1_stream, m1_mine, m1_bad = m1_stream_leg(pkg, synth, torch, dist, use_dist, backend, dev, rank, world, ob_all, K, W, R, args.depth,
                                                    args.m1_push_blocks, args.m1_nsamp, max(1, min(args.parity_blocks, 8)), min(args.parity_spots, 4))
 
-    # ---- the CPU baselines, at every N: rank 0, on a thread of its own (the oracle is C: the call drops the GIL) while the legs
-    # below — GPU work that is not the headline's timed regions — run; joined before the line is printed ----
-    cpu_thread, cpu_out = None, {}
+    # ---- the CPU baselines, at every N: rank 0 starts them as a PROCESS of their own (bench.py --cpu-legs: no GPU, its own address
+    # space and interpreter) once the timed regions are over; its one JSON line is read before this rank prints its own.  The
+    # ranks' GPU legs below go on meanwhile: nobody waits for the CPU ----
+    cpu_proc, cpu_out = None, {}
     if rank == 0 and ob_all is not None:
-        import threading
-
-        def cpu_legs():
-            try:
-                cpu_out["cpu_baseline"] = cpu_baseline(ob_all, mine, delt, nsamp, budget_s=args.cpu_budget)
-                cpu_out["m1_cpu"] = cpu_baseline(ob_all, m1_mine, 1.0 / M1_FS, args.m1_nsamp, budget_s=args.cpu_budget / 2)
-            except Exception as e:  # reported in the line, never fatal for the GPU figures
-                cpu_out["error"] = repr(e)
-        cpu_thread = threading.Thread(target=cpu_legs, name="cpu-baseline")
-        cpu_thread.start()
+        import subprocess
+        cpu_proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-legs", "--steps", str(K), "--push-blocks", str(PB), "--nch", str(nch),
+                                     "--fs", repr(args.fs), "--nsamp", str(nsamp), "--cpu-budget", repr(args.cpu_budget),
+                                     "--m1-push-blocks", str(args.m1_push_blocks), "--m1-nsamp", str(args.m1_nsamp)],
+                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 
     # ---- the same pushes through the PRODUCT's node driver (include/gpsbb_node.h): one process, one producer thread +
     # handle + ring per shard, one sink.  N = 1 on this rank's GPU must agree with the headline (same ring, same pushes,
@@ -868,11 +893,15 @@ def main():
         m1f["synthesis_kernel"] = {1: "k_synth", 2: "k_synth_pd"}.get(synth.info(pkg.INFO_LAST_KERNEL), "?")
         res["m1"]["gpu_fixed_point_carrier"] = m1f
     fill_bad = False
-    if cpu_thread is not None:
-        cpu_thread.join()
+    if cpu_proc is not None:
+        try:
+            so, se = cpu_proc.communicate(timeout=600)
+            cpu_out = json.loads([l for l in so.splitlines() if l.startswith("{")][-1])
+        except Exception as e:  # reported in the line, never fatal for the GPU figures
+            cpu_out = {"error": repr(e)}
         if "cpu_baseline" in cpu_out:
             res["cpu_baseline"] = cpu_out["cpu_baseline"]
-            res["cpu_baseline"]["concurrency"] = "on a thread of rank 0 while that rank's post-timing GPU legs ran (one core busy with it; the rank is bound to its GPU's NUMA node)"
+            res["cpu_baseline"]["concurrency"] = "a process of its own (bench.py --cpu-legs, 1 thread) started by rank 0 after the timed regions, beside that rank's remaining GPU legs"
         if "m1_cpu" in cpu_out and "m1" in res:
             res["m1"]["cpu"] = cpu_out["m1_cpu"]
         if "error" in cpu_out:

@@ -472,10 +472,13 @@ constexpr int CHAIN_SEG_MIN_TILES = 16; /* ... but no segment shorter than this 
 constexpr int CHAIN_SEG_MAX = 8;        /* segments per block at most */
 constexpr int CHAIN_INDEP_MIN_TILES = 1024; /* independent blocks of at least this many tiles are cut into segments as well */
 constexpr long CHAIN_MODEL_MAX_SEGS = 4096; /* segments per channel up to which pass B starts from the host's drift model */
-constexpr unsigned STREAM_SEED_STREAMS = 3; /* pre-passes of a stream's pushes in flight.  Round 6, the lap-parallel pre-pass beside a synthesis
-                                               kernel that keeps every CU to the end of its launch: 2, 3 and 4 give the same rate (5.43 - 5.60e11 on the
-                                               boxes measured, tools/sweep_seed_streams.sh) and 3.2 / 3.1 / 3.6 - 4.3 ms of pre-pass per push:
-                                               what is in flight shares the slots the synthesis leaves */
+constexpr unsigned STREAM_SEED_STREAMS = 4; /* pre-passes of a stream's pushes in flight.  Round 6, the lap-parallel pre-pass beside a synthesis
+                                               kernel that keeps every CU to the end of its launch: for ONE handle 2, 3 and 4 give the same rate
+                                               (5.43 - 5.60e11, tools/sweep_seed_streams.sh; 3.2 / 3.1 / 3.6 - 4.3 ms of pre-pass per push: what is
+                                               in flight shares the slots the synthesis leaves) — but a second handle in the process (the node
+                                               driver's shard beside the host's own handle: bench.py's node_driver.one_shard) ran at 0.73 of the
+                                               headline with 3 and at 0.86 - 0.96 with 4 (tools/node_leg_exp.sh): which streams end up sharing a
+                                               hardware queue depends on how many each handle creates */
 
 struct gpsbb {
     int device = 0;

@@ -57,10 +57,11 @@ def stream_soak(a):
                         f[:, i] = fs * 2.0 ** -15
             if rng.random() < 0.2:
                 f[:, -1] = 0.0
+            if rng.random() < 0.2:                     # no Doppler for a stretch of blocks in the middle of a chain (round 6: the laps take it)
+                zb = int(rng.integers(0, nb)); f[zb:int(rng.integers(zb, nb + 1)), int(rng.integers(0, nch))] = 0.0 if rng.random() < 0.7 else -0.0
             if os.environ.get("GPSBB_FUZZ_WHERE") == "3":
-                # a campaign aimed at the lap-parallel pre-pass: nothing that sends the case elsewhere (a carrier that does not move
-                # at all, a rate only the per-sample kernel renders)
-                f[f == 0.0] = 1e-3
+                # a campaign aimed at the lap-parallel pre-pass: nothing that sends the case elsewhere (a rate only the per-sample
+                # kernel renders; a carrier that does not move at all no longer does: the laps take it since round 6)
                 if fs < 2e6:
                     fs = 2.6e6
             ch["f_carr"] = f

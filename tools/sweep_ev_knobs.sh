@@ -4,7 +4,7 @@ run default
 GPSBB_EV_CHUNK=1 run chunk1
 GPSBB_EV_CHUNK=3 run chunk3
 GPSBB_EV_CHUNK=4 run chunk4
-GPSBB_EV_MIN_WG=2 run minwg2
-GPSBB_EV_MIN_WG=4 run minwg4
-GPSBB_EV_MIN_WG=5 run minwg5
+GPSBB_EV_HELPERS=1 run helpers1x256
+GPSBB_EV_HELPERS=3 run helpers3x256
+GPSBB_EV_HELPERS=4 run helpers4x256
 run default

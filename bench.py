@@ -793,9 +793,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_synth_ev" if last_kernel == 2 else "k_synth", "ms_per_launch": ms_synth,
                          "launches_timed": stats["runs"], "algorithmic_bytes_per_launch": 4 * samples_per_launch,
-                         "note": "not HBM-bound: 31 VALU instructions per channel-run on four wavefronts per SIMD whose per-pair loads "
-                                 "(scalar cache + LDS) are not hidden; what the time is made of was measured by taking one resource out "
-                                 "at a time (tools/bound_hunt.sh, DESIGN.md 3.1)"},
+                         "note": "not HBM-bound: 31 VALU instructions per channel-run, and the package at its power limit (1.33 - 1.35 kW of 1.4 kW, shader "
+                                 "clock 2.05 - 2.3 GHz measured inside the kernel): the chip delivers the same vector-instruction rate with and without "
+                                 "the pre-pass of the next pushes beside this kernel, so `ms_per_launch` here = (this kernel's + the pre-pass's "
+                                 "instructions) at that rate; `alone` = this kernel's only (tools/corun_diag.py, tools/power_probe.sh, DESIGN.md 3.1)"},
             "prepass_ms_per_launch": ms_seed,
             "device_chain": chain_info,
             "shard_seed_s": seed_max, "descriptor_generation_s": t_gen,
@@ -835,6 +836,8 @@ def main():
                 res["roofline_valu"] = {"bound": "valu_issue", "kernel": "k_synth_ev", "valu_wave_insts_per_launch": insts,
                                         "cycles_per_wave_inst": sj["cycles_per_valu_wave_inst"], "simds": sj["simds"], "clock_ghz": sj["clock_ghz"],
                                         "issue_ms_per_launch": issue_ms, "ms_per_launch": ms_synth, "frac": issue_ms / ms_synth,
+                                        "note": "priced at the 2.4 GHz peak clock; under this kernel the package sits at its power limit and the clock measured "
+                                                "inside the kernel is 2.05 - 2.3 GHz (DESIGN.md 3.1)",
                                         "lds_bank_conflict_share_of_lds_active": sj.get("lds_bank_conflict_share"),
                                         "source": sj.get("source")}
             except Exception:

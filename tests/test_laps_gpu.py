@@ -310,3 +310,4 @@ def test_a_carrier_without_doppler_stays_on_the_laps(pkg, fresh, oracle):
     one_iq, one_st, _ = oracle.fill_blocks(ch[:1], 1 / fs, nsamp)
     iq, st1 = s.fill_block(ch[0], 1 / fs, nsamp)
     assert s.info(pkg.INFO_PREPASS) == 3 and (iq == one_iq[0]).all() and st1["carr_phase"].tobytes() == one_st["carr_phase"][0].tobytes()
+    s.hazards(reset=True)   # (the channel on phase 1.0 counted: the session's handle goes on clean)

@@ -16,7 +16,7 @@ tail -c 2500 "$OUT/bench.json"
 # per-kernel time of the TIMED LEG ALONE (--no-extras: no parity / cross-check / node-driver legs, whose launches run beside other
 # kernels and used to be averaged in): avg(k_synth_ev) x 8 pushes <= ms_per_step of the same run must hold
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/prof" -o trace -- python "$ROOT/bench.py" --no-extras --no-cpu > "$ROOT/$OUT/prof_stdout.log" 2>&1 )
-tail -1 "$OUT/prof_stdout.log" | cut -c1-400 > "$OUT/prof_bench_line.json"
+grep -o "^{\"metric\".*" "$OUT/prof_stdout.log" | tail -1 | cut -c1-400 > "$OUT/prof_bench_line.json"
 # HBM bytes of the headline leg: separate --pmc passes
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$ROOT/$OUT/pmc_w" -o pmc -- python "$ROOT/bench.py" --no-extras --steps 4 --repeats 1 --warmup 1 > "$ROOT/$OUT/pmc_w_stdout.log" 2>&1 )
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$ROOT/$OUT/pmc_r" -o pmc -- python "$ROOT/bench.py" --no-extras --steps 4 --repeats 1 --warmup 1 > "$ROOT/$OUT/pmc_r_stdout.log" 2>&1 )

@@ -50,6 +50,7 @@ rank 0 for most of the command).
                 sink and interleaved slots into the ordered one, every slot digested and compared with what the ranks rendered
 """
 import argparse
+import hashlib
 import json
 import os
 import statistics
@@ -377,19 +378,33 @@ def fill_block_leg(pkg, synth, ob, cases, calls=200):
             act = d["prn"][3] > 0
             ok = bool((iq == want_iq[0]).all()) and all(chan[f][act].tobytes() == want_st[f][0][act].astype(chan[f].dtype).tobytes()
                                                          for f in ("carr_phase", "code_phase", "iword", "ibit", "icode", "dataBit", "codeCA"))
-        ts = []
-        for k in range(calls):
-            chan, gain = pkg.ref_channels(d[k % 8])
-            t0 = time.perf_counter()
+        def timed():
+            ts = []
+            for k in range(calls):
+                chan, gain = pkg.ref_channels(d[k % 8])
+                t0 = time.perf_counter()
+                synth.fill_block_ref(chan, gain, 1.0 / fs, nsamp, iq, lay)
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            return {"median_ms": ts[len(ts) // 2] * 1e3, "p99_ms": ts[min(len(ts) - 1, int(len(ts) * 0.99))] * 1e3, "min_ms": ts[0] * 1e3,
+                    "samples_per_s_at_median": nsamp / ts[len(ts) // 2], "real_time_factor": (nsamp / fs) / ts[len(ts) // 2]}
+        out[name] = dict(timed(), calls=calls, nch=nch, fs=fs, nsamp=nsamp, equals_oracle=ok,
+                         prepass={3: "lap-parallel, on the device", 2: "host threads", 1: "row walks, on the device"}.get(synth.info(pkg.INFO_PREPASS), "?"))
+        # ... and with iq_buff registered once (gpsbb_host_register: what INTEGRATION.md adds after the reference's calloc, c:2604):
+        # the kernel renders straight into it, no copy at the end of the call
+        before = hashlib.sha256(iq.tobytes()).hexdigest()
+        synth.host_register(iq)
+        try:
+            iq[:] = 0
+            chan, gain = pkg.ref_channels(d[(calls - 1) % 8])
             synth.fill_block_ref(chan, gain, 1.0 / fs, nsamp, iq, lay)
-            ts.append(time.perf_counter() - t0)
-        ts.sort()
-        out[name] = {"median_ms": ts[len(ts) // 2] * 1e3, "p99_ms": ts[min(len(ts) - 1, int(len(ts) * 0.99))] * 1e3, "min_ms": ts[0] * 1e3,
-                     "calls": calls, "samples_per_s_at_median": nsamp / ts[len(ts) // 2], "nch": nch, "fs": fs, "nsamp": nsamp,
-                     "equals_oracle": ok, "prepass": {3: "lap-parallel, on the device", 2: "host threads", 1: "row walks, on the device"}.get(synth.info(pkg.INFO_PREPASS), "?"),
-                     "real_time_factor": (nsamp / fs) / ts[len(ts) // 2]}
+            same = hashlib.sha256(iq.tobytes()).hexdigest() == before
+            out[name]["registered"] = dict(timed(), same_bytes_as_copied=same)
+        finally:
+            synth.host_unregister(iq)
     out["what"] = ("gpsbb_fill_block_ref (include/gpsbb.h): the reference's channel_t[] and gain[] in, int16 IQ into a pageable host buffer, "
-                   "channel state updated in place; wall clock around the call, Python's ctypes overhead (~10 us) included")
+                   "channel state updated in place; wall clock around the call, Python's ctypes overhead (~10 us) included; "
+                   "`registered`: the same calls after gpsbb_host_register(iq_buff) - rendered straight into the caller's buffer")
     return out
 
 

@@ -101,7 +101,7 @@ API_SYMBOLS = [
     "gpsbb_get_hazards", "gpsbb_device_read", "gpsbb_device_digest", "gpsbb_slot_digest", "gpsbb_batch_last_timing", "gpsbb_batch_timing_stats", "gpsbb_fill_ceiling", "gpsbb_stream_create",
     "gpsbb_stream_destroy", "gpsbb_stream_push", "gpsbb_stream_pop", "gpsbb_stream_pending", "gpsbb_stream_timing_stats",
     "gpsbb_codegen", "gpsbb_sincos_tables", "gpsbb_chain_carrier_host", "gpsbb_chain_carrier", "gpsbb_set_option",
-    "gpsbb_get_info", "gpsbb_stream_reset", "gpsbb_device_affinity", "gpsbb_stream_push_ex",
+    "gpsbb_get_info", "gpsbb_stream_reset", "gpsbb_device_affinity", "gpsbb_stream_push_ex", "gpsbb_host_register", "gpsbb_host_unregister",
 ]
 # ... and include/gpsbb_node.h
 NODE_API_SYMBOLS = ["gpsbb_node_create", "gpsbb_node_run", "gpsbb_node_run_digest", "gpsbb_node_destroy", "gpsbb_node_plan", "gpsbb_node_begin", "gpsbb_node_feed", "gpsbb_node_end"]
@@ -182,6 +182,8 @@ def lib():
         L.gpsbb_node_run.argtypes = [vp, vp, C.c_long, vp, vp, vp]
         L.gpsbb_node_run_digest.argtypes = [vp, vp, C.c_long, vp, vp]
         L.gpsbb_slot_digest.argtypes = [vp, vp, C.c_long, C.c_int, vp]
+        L.gpsbb_host_register.argtypes = [vp, vp, C.c_size_t]
+        L.gpsbb_host_unregister.argtypes = [vp, vp]
         L.gpsbb_node_begin.argtypes = [vp, vp, vp]
         L.gpsbb_node_feed.argtypes = [vp, vp, C.c_long]
         L.gpsbb_node_end.argtypes = [vp, vp]
@@ -296,6 +298,13 @@ class Synth:
         layout = layout or ref_layout(chan.dtype)
         _chk(lib().gpsbb_fill_block_ref(self._h, chan.ctypes.data, C.byref(layout), chan.shape[0], gain.ctypes.data, delt, nsamp,
                                         iq.ctypes.data), "gpsbb_fill_block_ref")
+
+    def host_register(self, arr):
+        """gpsbb_host_register: fills into `arr` (the caller's iq_buff, kept alive by the caller) are rendered straight into it"""
+        _chk(lib().gpsbb_host_register(self._h, arr.ctypes.data, arr.nbytes), "gpsbb_host_register")
+
+    def host_unregister(self, arr):
+        _chk(lib().gpsbb_host_unregister(self._h, arr.ctypes.data), "gpsbb_host_unregister")
 
     def batch(self, ch, delt, nsamp, flags=0):
         return Batch(self, ch, delt, nsamp, flags)

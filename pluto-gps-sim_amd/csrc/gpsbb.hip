@@ -503,8 +503,12 @@ struct gpsbb {
     unsigned long long *d_hz = nullptr;
     int last_hip = 0;
     gpsbb_batch *scratch = nullptr;
+    unsigned char *h_bounce = nullptr; /* pinned: a fill whose iq_out lies partly in a registered range is copied through here */
+    size_t bounce_cap = 0;
     unsigned char *h_fill = nullptr; /* pinned: what the drop-in call brings back besides the IQ — the end states and the status word
                                         (fill_block_finish) */
+    struct HostReg { char *host; char *dev; size_t bytes; };
+    std::vector<HostReg> host_regs;         /* gpsbb_host_register: host ranges the device writes straight into */
     struct ChainOnly *chain_only = nullptr; /* device scratch of gpsbb_chain_carrier, kept between calls */
     int sm_count = 0;
     /* per-handle options (gpsbb_set_option) */
@@ -584,6 +588,8 @@ struct gpsbb_batch {
      * copy streams that makes four, and streams beyond the hardware queues share them. */
     hipStream_t seed_stream = nullptr;
     hipStream_t last_cs = nullptr; /* the synthesis stream of the last launch */
+    bool one_stream = false;       /* the drop-in call's scratch batch: upload, pre-pass and synthesis on the synthesis stream (a
+                                      hop from stream to stream is 16 us of nothing for a call that takes 150: gpsbb_fill_block_ex) */
     int nblocks = 0, nch = 0, nsamp = 0, ntiles = 0;
     double delt = 0.0;
     unsigned flags = 0;
@@ -810,6 +816,11 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
         gpsbb_batch_destroy(h->scratch);
     if (h->h_fill)
         (void)hipHostFree(h->h_fill);
+    if (h->h_bounce)
+        (void)hipHostFree(h->h_bounce);
+    for (const gpsbb::HostReg &r : h->host_regs)
+        (void)hipHostUnregister(r.host);
+    h->host_regs.clear();
     chain_only_free(h);
     if (h->s_seed)
         (void)hipStreamSynchronize(h->s_seed);
@@ -1011,9 +1022,9 @@ struct PushTrace {
         const double tot = std::chrono::duration<double, std::milli>(t[n - 1] - t[0]).count();
         if (tot < limit_ms)
             return;
-        fprintf(stderr, "[gpsbb push %.2f ms]", tot);
+        fprintf(stderr, "[gpsbb push %.3f ms]", tot);
         for (int i = 1; i < n; i++)
-            fprintf(stderr, " %s %.2f", what[i], std::chrono::duration<double, std::milli>(t[i] - t[i - 1]).count());
+            fprintf(stderr, " %s %.3f", what[i], std::chrono::duration<double, std::milli>(t[i] - t[i - 1]).count());
         fprintf(stderr, "\n");
     }
 };
@@ -1944,7 +1955,16 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     b->fix_epoch++; /* a number no earlier launch of this batch handed to k_chain_fix_par */
     const BatchDev p = batch_dev(b, set);
     const int lanes = (int)b->h_seed_order.size();
-    if (b->ev_used == b->evs.size()) {
+    /* (the drop-in call's scratch batch, everything on one stream and waited for before the call returns: no events — each record
+     * is a packet between two kernels, 5 us of nothing on a call of 140) */
+    const bool timed = !b->one_stream;
+    if (!timed && b->evs.empty()) {
+        gpsbb_batch::Ev4 t = {{nullptr, nullptr, nullptr, nullptr}};
+        b->evs.push_back(t);
+    }
+    if (!timed) {
+        b->ev_used = 0;
+    } else if (b->ev_used == b->evs.size()) {
         if (b->evs.size() >= 4096) {
             b->ev_used = 0; /* wrap: only the most recent runs are kept */
         } else {
@@ -1954,14 +1974,15 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
             b->evs.push_back(t);
         }
     }
-    hipEvent_t *ev = b->evs[b->ev_used++].e;
+    hipEvent_t *ev = timed ? b->evs[b->ev_used++].e : b->evs[0].e;
     PUSH_MARK("l_ev");
 
     /* The pre-pass runs on a seeding stream of its own: it may start as soon as the synthesis kernel that last
      * read this table set has finished, i.e. it overlaps the synthesis of the runs before it.  With three sets
      * consecutive runs take the handle's two seeding streams in turn, so that two pre-passes are in flight. */
-    hipStream_t ss = b->seed_stream;
-    if (b->nsets > 2) {
+    hipStream_t ss = b->one_stream ? h->s_compute : b->seed_stream;
+    if (b->one_stream) {
+    } else if (b->nsets > 2) {
         const unsigned base = b->seed_stream == h->s_seed ? 0u : 1u;
         HIPCHK(h, seed_stream_at(h, (base + b->run_count) % (unsigned)(b->nsets - 1), &ss));
     } else if (b->d_carry && b->chain_dev) {
@@ -1975,7 +1996,8 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         HIPCHK(h, hipStreamWaitEvent(ss, b->upload_done, 0));
     if (b->synth_pending[set])
         HIPCHK(h, hipStreamWaitEvent(ss, b->synth_done_ref[set], 0));
-    HIPCHK(h, hipEventRecord(ev[0], ss));
+    if (timed)
+        HIPCHK(h, hipEventRecord(ev[0], ss));
     bool ctr_reset_by_prepass = false;
     if (h->opt_skip_seed && b->run_count >= (unsigned)b->nsets) {
         /* measurement hook: time the synthesis kernel alone on tables already built */
@@ -2116,7 +2138,8 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         hipLaunchKernelGGL(k_seed<false>, dim3((lanes + GPSBB_SEED_WG - 1) / GPSBB_SEED_WG), dim3(GPSBB_SEED_WG), 0, ss, p);
     }
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(ev[1], ss));
+    if (timed)
+        HIPCHK(h, hipEventRecord(ev[1], ss));
     h->last_prepass = b->host_seed ? 2 : (b->ev && b->laps ? 3 : 1);
     PUSH_MARK("l_pre");
 
@@ -2126,13 +2149,15 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     /* consecutive launches take the two synthesis streams in turn — they work on different table sets (or, slots of
      * a ring, different batches) — except re-runs of a batch that has a single table set */
     hipStream_t sc = h->s_compute;
-    if (!one_cs && (b->nsets >= 2 || b->max_sets == 1) && ((h->compute_turn++) & 1u))
+    if (!one_cs && !b->one_stream && (b->nsets >= 2 || b->max_sets == 1) && ((h->compute_turn++) & 1u))
         sc = h->s_compute2;
     b->last_cs = sc;
-    HIPCHK(h, hipStreamWaitEvent(sc, ev[1], 0));
+    if (sc != ss)
+        HIPCHK(h, hipStreamWaitEvent(sc, ev[1], 0));
     if (!ctr_reset_by_prepass)
         HIPCHK(h, hipMemsetAsync(p.tile_ctr, 0, ((size_t)b->nblocks + 1) * sizeof(int32_t), sc));
-    HIPCHK(h, hipEventRecord(ev[2], sc));
+    if (timed)
+        HIPCHK(h, hipEventRecord(ev[2], sc));
     if (b->ev) {
         /* One workgroup of EV_WG lanes fits a CU (its LDS image takes ~140 - 156 KB).  Grid = the blocks' primaries, then the
          * helpers (ev_pick_block: a helper joins one of the blocks that still have tiles to hand out, chosen when it starts):
@@ -2177,12 +2202,13 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         hipLaunchKernelGGL(k_synth, dim3(gx, b->nblocks), dim3(TILE_THREADS), sizeof(SynthLds), sc, p, d_iq);
     }
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(ev[3], sc));
+    if (timed)
+        HIPCHK(h, hipEventRecord(ev[3], sc));
     /* the run's end-of-synthesis event doubles as "this table set is free again" and as what a stream's copy stream
      * waits for: every further record on the synthesis stream is another packet between two kernels */
     b->synth_done_ref[set] = ev[3];
     b->last_done = ev[3];
-    b->synth_pending[set] = true;
+    b->synth_pending[set] = timed;
     b->last_set = set;
     b->run_count++;
     b->ran = true;
@@ -2388,6 +2414,19 @@ extern "C" int gpsbb_fill_ceiling(gpsbb_t *h, void *d_dst, size_t bytes, int ite
  * -> synthesis by events), so ONE stream is waited for, not the handle's ten; the end states and the status word come back
  * through pinned memory behind the IQ on that stream instead of as two blocking copies of their own (each a round trip of
  * 25 - 30 us: with the ten-kernel pre-pass they were half of the call's 0.26 ms for the reference's block). */
+/* end states and status word into the handle's pinned page, written by the device: one launch behind the synthesis kernel
+ * instead of two copies (each a packet of its own and 4 us of blit kernel) */
+__global__ void k_fill_tail(const gpsbb_chan_state_t *end, const uint32_t *status, unsigned char *host, int nch, uint32_t *host_status)
+{
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(end);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(host);
+    const uint32_t words = end ? (uint32_t)nch * (uint32_t)(sizeof(gpsbb_chan_state_t) / 4) : 0u;
+    for (uint32_t k = threadIdx.x; k < words; k += blockDim.x)
+        dst[k] = src[k];
+    if (threadIdx.x == 0)
+        *host_status = *status;
+}
+
 static int fill_block_finish(gpsbb_t *h, gpsbb_batch *b, int nch, int nsamp, int16_t *iq_out, gpsbb_chan_state_t *end_state)
 {
     const size_t end_bytes = (size_t)GPSBB_MAX_CHAN * sizeof(gpsbb_chan_state_t);
@@ -2396,11 +2435,43 @@ static int fill_block_finish(gpsbb_t *h, gpsbb_batch *b, int nch, int nsamp, int
     hipStream_t cs = b->last_cs;
     uint32_t *st = reinterpret_cast<uint32_t *>(h->h_fill + end_bytes);
     *st = 0xffffffffu;
-    if (end_state)
-        HIPCHK(h, hipMemcpyAsync(h->h_fill, b->d_end[b->last_set].p, (size_t)nch * sizeof(gpsbb_chan_state_t), hipMemcpyDeviceToHost, cs));
-    HIPCHK(h, hipMemcpyAsync(st, h->d_status, 4, hipMemcpyDeviceToHost, cs));
-    HIPCHK(h, hipMemcpyAsync(iq_out, b->last_iq, (size_t)nsamp * 4, hipMemcpyDeviceToHost, cs));
+    if (GPSBB_KNOB_LONG("GPSBB_FILL_TAIL_KERNEL", 1) != 0) {
+        static_assert(sizeof(gpsbb_chan_state_t) % 4 == 0, "copied as 32-bit words");
+        hipLaunchKernelGGL(k_fill_tail, dim3(1), dim3(256), 0, cs, end_state ? b->d_end[b->last_set].p : nullptr, h->d_status, h->h_fill, nch, st);
+        HIPCHK(h, hipGetLastError());
+    } else {
+        if (end_state)
+            HIPCHK(h, hipMemcpyAsync(h->h_fill, b->d_end[b->last_set].p, (size_t)nch * sizeof(gpsbb_chan_state_t), hipMemcpyDeviceToHost, cs));
+        HIPCHK(h, hipMemcpyAsync(st, h->d_status, 4, hipMemcpyDeviceToHost, cs));
+    }
+    PUSH_MARK("tail");
+    /* (iq_out null: the synthesis kernel wrote into the caller's registered buffer.)  A destination that lies partly in pages a
+     * registration pinned is one the runtime's copy refuses (hipErrorInvalidValue): through a pinned buffer of the handle's then */
+    bool bounce = false;
+    if (iq_out) {
+        const uintptr_t page = 4096, a = (uintptr_t)iq_out, e = a + (size_t)nsamp * 4;
+        for (const gpsbb::HostReg &r : h->host_regs) {
+            const uintptr_t ra = (uintptr_t)r.host & ~(page - 1), re = ((uintptr_t)r.host + r.bytes + page - 1) & ~(page - 1);
+            bounce = bounce || (a < re && ra < e);
+        }
+    }
+    if (bounce) {
+        if (h->bounce_cap < (size_t)nsamp * 4) {
+            if (h->h_bounce)
+                (void)hipHostFree(h->h_bounce);
+            h->h_bounce = nullptr;
+            h->bounce_cap = 0;
+            HIPCHK(h, hipHostMalloc((void **)&h->h_bounce, (size_t)nsamp * 4, hipHostMallocDefault));
+            h->bounce_cap = (size_t)nsamp * 4;
+        }
+        HIPCHK(h, hipMemcpyAsync(h->h_bounce, b->last_iq, (size_t)nsamp * 4, hipMemcpyDeviceToHost, cs));
+    } else if (iq_out) {
+        HIPCHK(h, hipMemcpyAsync(iq_out, b->last_iq, (size_t)nsamp * 4, hipMemcpyDeviceToHost, cs));
+    }
+    PUSH_MARK("iq copy");
     HIPCHK(h, hipStreamSynchronize(cs));
+    if (bounce)
+        memcpy(iq_out, h->h_bounce, (size_t)nsamp * 4);
     if (end_state)
         memcpy(end_state, h->h_fill, (size_t)nch * sizeof(gpsbb_chan_state_t));
     if (*st) {
@@ -2408,6 +2479,42 @@ static int fill_block_finish(gpsbb_t *h, gpsbb_batch *b, int nch, int nsamp, int
         return GPSBB_E_INTERNAL;
     }
     return GPSBB_OK;
+}
+
+extern "C" int gpsbb_host_register(gpsbb_t *h, void *ptr, size_t bytes)
+{
+    if (!h || !ptr || !bytes)
+        return GPSBB_E_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    char *q = static_cast<char *>(ptr);
+    for (const gpsbb::HostReg &r : h->host_regs)
+        if (q < r.host + r.bytes && r.host < q + bytes)
+            return GPSBB_E_STATE; /* overlaps a range that is registered already */
+    HIPCHK(h, hipHostRegister(ptr, bytes, hipHostRegisterMapped));
+    void *dev = nullptr;
+    const hipError_t e = hipHostGetDevicePointer(&dev, ptr, 0);
+    if (e != hipSuccess || !dev) {
+        (void)hipHostUnregister(ptr);
+        h->last_hip = (int)e;
+        return GPSBB_E_HIP;
+    }
+    h->host_regs.push_back({q, static_cast<char *>(dev), bytes});
+    return GPSBB_OK;
+}
+
+extern "C" int gpsbb_host_unregister(gpsbb_t *h, void *ptr)
+{
+    if (!h || !ptr)
+        return GPSBB_E_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    for (size_t k = 0; k < h->host_regs.size(); k++)
+        if (h->host_regs[k].host == static_cast<char *>(ptr)) {
+            HIPCHK(h, hipStreamSynchronize(h->s_compute)); /* nothing of a fill is in flight once the call has returned; make sure */
+            HIPCHK(h, hipHostUnregister(ptr));
+            h->host_regs.erase(h->host_regs.begin() + (long)k);
+            return GPSBB_OK;
+        }
+    return GPSBB_E_STATE;
 }
 
 extern "C" int gpsbb_fill_block(gpsbb_t *h, const gpsbb_chan_t *ch, int nch, double delt, int nsamp,
@@ -2430,13 +2537,29 @@ extern "C" int gpsbb_fill_block_ex(gpsbb_t *h, const gpsbb_chan_t *ch, int nch, 
     gpsbb_batch *b = h->scratch;
     if (flags & ~GPSBB_FIXED_CARRIER & ~GPSBB_CHAIN_CARRIER)
         return GPSBB_E_BADARG;
-    int rc = batch_setup(b, ch, 1, nch, delt, nsamp, flags & GPSBB_FIXED_CARRIER, h->s_seed);
+    g_push_trace.start();
+    b->one_stream = GPSBB_KNOB_LONG("GPSBB_FILL_ONE_STREAM", 1) != 0;
+    int rc = batch_setup(b, ch, 1, nch, delt, nsamp, flags & GPSBB_FIXED_CARRIER, b->one_stream ? h->s_compute : h->s_seed);
     if (rc != GPSBB_OK)
         return rc;
-    rc = gpsbb_batch_run(b, nullptr);
+    PUSH_MARK("set-up");
+    /* iq_out inside a range the caller registered (gpsbb_host_register): the synthesis kernel's stores go there over the bus
+     * while it computes, and there is no copy to wait for afterwards */
+    int16_t *direct = nullptr;
+    for (const gpsbb::HostReg &r : h->host_regs) {
+        const char *q = reinterpret_cast<const char *>(iq_out);
+        if (q >= r.host && (size_t)(q - r.host) <= r.bytes && (size_t)nsamp * 4 <= r.bytes - (size_t)(q - r.host)) {
+            direct = reinterpret_cast<int16_t *>(r.dev + (q - r.host));
+            break;
+        }
+    }
+    rc = gpsbb_batch_run(b, direct);
     if (rc != GPSBB_OK)
         return rc;
-    return fill_block_finish(h, b, nch, nsamp, iq_out, end_state);
+    PUSH_MARK("launches");
+    rc = fill_block_finish(h, b, nch, nsamp, direct ? nullptr : iq_out, end_state);
+    g_push_trace.end();
+    return rc;
 }
 
 /* the reference's own channel_t[] / gain[] in, rendered, updated in place as its loop leaves them; fixed: the build without

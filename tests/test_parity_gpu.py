@@ -519,6 +519,45 @@ def test_reference_struct_layout_entry_point(pkg, synth, oracle):
         assert chan[f][act].tobytes() == want_st[f][0][act].astype(chan[f].dtype).tobytes(), f
 
 
+def test_a_registered_iq_buff_is_rendered_into(pkg, synth, oracle):
+    """gpsbb_host_register: the reference's iq_buff is one calloc for the life of the process (c:2604, freed c:2815); registered
+    once, the fill calls render straight into it (the synthesis kernel's stores cross the bus; no copy ends the call).  The bytes
+    are the oracle's whichever way they arrive: a block at the start of the registered range, one at an odd offset inside it, one
+    that starts inside it and ends beyond (copied, like one that lies outside altogether), the reference geometry, the
+    headline's, the per-sample kernel; nothing outside the block is touched; the state comes back as always.  Overlapping
+    registrations and unknown pointers are refused, and an unregistered buffer is copied into again."""
+    L = pkg.lib()
+    buf = np.zeros((700001, 2), np.int16)                 # "iq_buff", of which the first 500 000 samples are registered
+    nreg = 500000
+    assert L.gpsbb_host_register(synth._h, buf.ctypes.data, nreg * 4) == 0
+    lay = pkg.ref_layout()
+
+    def check(nch, fs, nsamp, at, seed):
+        d = pkg.synth_descriptors(1, nch=nch, seed=seed)
+        chan, gain = pkg.ref_channels(d[0])
+        want_iq, want_st, _ = oracle.fill_blocks(d, 1.0 / fs, nsamp)
+        buf[:] = 0x5a5a
+        iq = buf[at:at + nsamp]
+        synth.fill_block_ref(chan, gain, 1.0 / fs, nsamp, iq, lay)
+        assert (iq == want_iq[0]).all(), (nch, fs, nsamp, at)
+        assert (buf[:at] == 0x5a5a).all() and (buf[at + nsamp:] == 0x5a5a).all()
+        act = d["prn"][0] > 0
+        for f in ("carr_phase", "code_phase", "iword", "ibit", "icode", "dataBit", "codeCA"):
+            assert chan[f][act].tobytes() == want_st[f][0][act].astype(chan[f].dtype).tobytes(), f
+
+    try:
+        assert L.gpsbb_host_register(synth._h, buf.ctypes.data + 4096, 8192) == -7      # GPSBB_E_STATE: overlaps
+        assert L.gpsbb_host_register(synth._h, buf.ctypes.data - 64, 128) == -7
+        assert L.gpsbb_host_unregister(synth._h, buf.ctypes.data + 4096) == -7          # not the start of a range
+        for case in ((12, 2.6e6, 300000, 0, 5), (12, 2.6e6, 300000, 333, 6), (12, 2.6e6, nreg - 333, 333, 10), (16, 25e6, 400000, 1001, 7),
+                     (12, 2.6e6, 300000, 400000, 8), (12, 2.6e6, 200000, nreg, 11), (3, 1.0e6, 50000, 17, 9)):
+            check(*case)
+    finally:
+        assert L.gpsbb_host_unregister(synth._h, buf.ctypes.data) == 0
+    assert L.gpsbb_host_unregister(synth._h, buf.ctypes.data) == -7                     # gone
+    check(12, 2.6e6, 300000, 0, 5)                                                      # ... and copied into, as before
+
+
 def test_reference_struct_layout_entry_point_without_float_carr_phase(pkg, synth, oracle):
     """gpsbb_fill_block_ref_fixed: the caller keeps the channel_t of a reference built without FLOAT_CARR_PHASE (h:12
     removed; h:160-161: `unsigned int carr_phase; int carr_phasestep;`).  Two consecutive blocks through the struct, the

@@ -1902,7 +1902,14 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.seed_order = b->d_seed_order.p;
     p.seed_lanes = (int)b->h_seed_order.size();
     p.ev = b->ev ? 1 : 0;
-    const int ev_chunk = b->ev_all_dense ? (int)GPSBB_KNOB_LONG("GPSBB_PD_CHUNK", PD_CHUNK) : (int)GPSBB_KNOB_LONG("GPSBB_EV_CHUNK", EV_CHUNK);
+    int ev_chunk = b->ev_all_dense ? (int)GPSBB_KNOB_LONG("GPSBB_PD_CHUNK", PD_CHUNK) : (int)GPSBB_KNOB_LONG("GPSBB_EV_CHUNK", EV_CHUNK);
+    /* a batch too small to give every CU a workgroup's worth of chunks (the drop-in call's one block: 293 tiles) hands its tiles out
+     * in smaller chunks, down to one at a time: twice the workgroups, half the tiles each (0.116 -> 0.110 ms for the reference's
+     * block rendered into a registered buffer) */
+    const long cus = b->h->sm_count > 0 ? b->h->sm_count : 256;
+    while (ev_chunk > 1 && GPSBB_KNOB_LONG("GPSBB_SMALL_CHUNKS", 1) != 0 &&
+           (long)b->nblocks * (((long)b->ntiles + ev_chunk - 1) / ev_chunk) < cus * EV_WAVES)
+        ev_chunk--;
     p.ev_chunk = ev_chunk < 1 ? 1 : ev_chunk;
     p.pd_danger = (uint32_t)GPSBB_KNOB_LONG("GPSBB_PD_DANGER", 2u * PD_BAND); /* (larger: more lanes take the exact path; a test aid) */
     p.tile_x = b->d_tile_x[set].p;

@@ -25,7 +25,8 @@
  * reference's iio_buffer_push blocks until the hardware has room, c:2152; 100000 = real time, less = compressed time), counts
  * the blocks that were not there when their turn came (under-runs) and, with -S file, writes the latency distribution of
  * the drop-in call gpsbb_fill_block (p50 / p99 / max over all blocks) as JSON.  -Q n: blocks the device queues (libiio's
- * kernel buffers: 4 by default; a push only blocks when all are taken).  -k a,b,c keeps only those blocks in the
+ * kernel buffers: 4 by default; a push only blocks when all are taken).  -R: do not register iq_buff with the library
+ * (gpsbb_host_register: by default the drop-in call renders straight into it; with -R it ends with a copy, as for any buffer).  -k a,b,c keeps only those blocks in the
  * output file (a soak of hours of signal need not write them all).
  */
 #include <stdio.h>
@@ -150,7 +151,8 @@ int main(int argc, char **argv)
     long fs_hz = 3000000; /* TX_SAMPLE_FREQ c:43 */
     long nsamp = 300000;  /* NUM_SAMPLES c:44 */
     double duration = 1.0;
-    int gpu = 0, opt, fast = 0, nshards = 0, ndev = 0, interleaved = 0, contiguous = 0;
+    int gpu = 0, opt, fast = 0, no_register = 0, nshards = 0, ndev = 0, interleaved = 0, contiguous = 0;
+    int16_t *iq_registered = NULL;
     int devs[GPSBB_NODE_MAX_SHARDS];
     struct paced_sink paced;
     memset(&paced, 0, sizeof paced);
@@ -158,7 +160,7 @@ int main(int argc, char **argv)
     const char *stats_path = NULL;
     const char *out_path = NULL;
 
-    while ((opt = getopt(argc, argv, "e:u:c:l:s:Tt:in:N:d:o:g:3FG:P:S:k:Q:IC")) != -1) {
+    while ((opt = getopt(argc, argv, "e:u:c:l:s:Tt:in:N:d:o:g:3FG:P:S:k:Q:ICR")) != -1) {
         switch (opt) {
         case 'e': cfg.navfile = optarg; break;
         case 'u': cfg.motion_file = optarg; break;
@@ -208,6 +210,7 @@ int main(int argc, char **argv)
                 paced.keep[paced.nkeep++] = atol(t);
             break;
         case 'F': fast = 1; break;
+        case 'R': no_register = 1; break; /* the drop-in call copies into iq_buff instead of rendering straight into it */
         default: usage(); return 1;
         }
     }
@@ -372,6 +375,8 @@ int main(int argc, char **argv)
             (void)gpsbb_get_hazards(bb, &warm, 1);
         }
         int16_t *iq = gpsbb_tx_begin(tx);                           /* c:2689 */
+        if (blk == 0 && !no_register && gpsbb_host_register(bb, iq, (size_t)nsamp * 4) == GPSBB_OK)
+            iq_registered = iq; /* iq_buff is one allocation for the run (c:2604): rendered into directly from here on */
         struct timespec ta, tb;
         clock_gettime(CLOCK_MONOTONIC, &ta);
         rc = gpsbb_fill_block(bb, ch, cfg.max_chan, delt, (int)nsamp, iq, st); /* replaces c:2690-2756 */
@@ -387,6 +392,8 @@ int main(int argc, char **argv)
         if (stopped)
             break;
     }
+    if (iq_registered)
+        (void)gpsbb_host_unregister(bb, iq_registered); /* before the buffer is freed (c:2815) */
     gpsbb_tx_destroy(tx);
     if (fout != stdout)
         fclose(fout);

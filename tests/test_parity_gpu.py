@@ -710,6 +710,11 @@ def test_gpsbb_sim_end_to_end_file(pkg, tmp_path):
     iq = np.fromfile(out, np.int16).reshape(3, nsamp, 2)
     for blk in range(3):
         assert sha(iq[blk]) == str(z["iq_sha256"][blk]), blk
+    # (iq_buff is registered with the library by default — gpsbb_host_register: rendered into directly; -R: copied into)
+    copied = str(tmp_path / "iq_copied.bin")
+    subprocess.run([exe, "-e", os.path.join(GOLDEN, "synth3540.14n"), "-l", "30.286502,120.032669,100",
+                    "-s", "2600000", "-d", "0.3", "-R", "-o", copied], check=True, stderr=subprocess.DEVNULL)
+    assert open(copied, "rb").read() == open(out, "rb").read()
     # -F: the same bytes through the streaming ring (front end running ahead, host-chained carrier)
     fast = str(tmp_path / "iq_fast.bin")
     subprocess.run([exe, "-e", os.path.join(GOLDEN, "synth3540.14n"), "-l", "30.286502,120.032669,100",

@@ -46,6 +46,15 @@ for extra, name in ((tag + "_corun/corun_diag.txt", tag + "_corun_diag.txt"), (t
 sq = os.path.join(ROOT, "gpurun_out", tag + "_m1_sq.txt")
 if os.path.exists(sq):
     shutil.copy(sq, os.path.join(dst, tag + "_m1_sq_counters.txt"))
+with_tl = [(n, lab) for n, lab in (("fill_timeline.txt", "copied into a pageable iq_buff"), ("fill_timeline_registered.txt", "rendered into a registered iq_buff (gpsbb_host_register)"))
+           if os.path.exists(os.path.join(src, n))]
+if with_tl:
+    with open(os.path.join(dst, tag + "_fill_timeline.txt"), "w") as f:
+        f.write("# tools/fill_timeline.sh: rocprofv3 --kernel-trace --memory-copy-trace -- python tools/fill_timeline.py\n"
+                "# 40 gpsbb_fill_block_ref calls of the reference's block (12 ch, 2.6 MS/s, 300 000 samples); one call from the middle of the run,\n"
+                "# its kernels and copies on one axis (us; the tracer adds ~15 us to a call)\n")
+        for n, lab in with_tl:
+            f.write("== " + lab + "\n" + open(os.path.join(src, n)).read())
 if os.path.exists(os.path.join(src, "seed_rate.txt")):
     shutil.copy(os.path.join(src, "seed_rate.txt"), os.path.join(dst, tag + "_shard_seed_rate.txt"))
 m1db = os.path.join(src, "prof_m1", "trace_results.db")
@@ -66,7 +75,7 @@ json.dump(d, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
 b = json.load(open(os.path.join(src, "bench.json")))
 print("value %.4g  ms/step %.2f  seconds %s" % (b["value"], b["ms_per_step"], b["repeats"]["seconds"]))
 print("roofline", json.dumps(b["roofline"])[:700])
-for k in ("gather", "resident", "m1", "cpu_baseline", "prepass_ms_per_launch", "device_chain"):
-    print(k, json.dumps(b.get(k))[:420])
+for k in ("gather", "resident", "m1", "cpu_baseline", "prepass_ms_per_launch", "device_chain", "fill_block"):
+    print(k, json.dumps(b.get(k))[:900 if k == "fill_block" else 420])
 for k, v in s["kernels"].items():
     print(k, v.get("calls"), v.get("avg_us"), v.get("WRITE_SIZE_KiB_per_launch"), v.get("FETCH_SIZE_KiB_per_launch"))

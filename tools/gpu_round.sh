@@ -34,3 +34,6 @@ timeout 200 python tools/seed_rate.py --host > "$OUT/seed_rate.txt" 2>&1
 # what the co-run costs, from inside the kernels (trace build), and the package power beside it
 timeout 900 bash tools/corun_session.sh ${TAG}_corun nopmc > "$OUT/corun.log" 2>&1
 timeout 300 bash tools/power_probe.sh ${TAG}_power > "$OUT/power.log" 2>&1
+# the drop-in call on one time axis: copied into a pageable iq_buff, and rendered into a registered one
+timeout 300 bash tools/fill_timeline.sh ${TAG}_fill_tl > "$OUT/fill_timeline.txt" 2>&1
+FILL_REG=1 timeout 300 bash tools/fill_timeline.sh ${TAG}_fill_tl_reg > "$OUT/fill_timeline_registered.txt" 2>&1

@@ -283,10 +283,11 @@ class Synth:
     def __exit__(self, *a):
         self.close()
 
-    def fill_block(self, ch, delt, nsamp, flags=0):
-        """gpsbb_fill_block(_ex): ch = CHAN_DTYPE[nch] -> (int16 [nsamp,2], STATE_DTYPE[nch])"""
+    def fill_block(self, ch, delt, nsamp, flags=0, out=None):
+        """gpsbb_fill_block(_ex): ch = CHAN_DTYPE[nch] -> (int16 [nsamp,2], STATE_DTYPE[nch]); out: the caller's iq_buff"""
         ch = np.ascontiguousarray(ch, dtype=CHAN_DTYPE)
-        iq = np.empty((nsamp, 2), np.int16)
+        iq = np.empty((nsamp, 2), np.int16) if out is None else out
+        assert iq.dtype == np.int16 and iq.flags.c_contiguous and iq.size >= 2 * nsamp
         st = np.zeros(ch.shape[0], STATE_DTYPE)
         _chk(lib().gpsbb_fill_block_ex(self._h, ch.ctypes.data, ch.shape[0], delt, nsamp, flags, iq.ctypes.data,
                                        st.ctypes.data), "gpsbb_fill_block_ex")

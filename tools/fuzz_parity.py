@@ -174,7 +174,11 @@ def main():
               (25e6, 2500000, 16, 6), (1e6, 5000000, 3, 2)]
     used = {}
     prepass = {}
+    REG_SAMPLES = 400000
+    reg_buf = np.zeros((REG_SAMPLES, 2), np.int16)
+    dropin = 0
     with pkg.Synth(0) as synth:
+        synth.host_register(reg_buf)
         for case in range(len(shapes) * 2 if a.shapes else a.cases):
             fs = float(rng.choice([1e6, 2.6e6, 3e6, 4.092e6, 10e6, 16e6, 25e6, 30e6, 2.0 ** 25, 50e6]))
             nsamp = int(rng.choice([rng.integers(1, 3000), rng.integers(3000, 120000), 1024 * int(rng.integers(1, 60))]))
@@ -240,12 +244,32 @@ def main():
             for f in ("carr_phase", "code_phase", "iword", "ibit", "icode", "dataBit", "codeCA"):
                 if st[f][act].tobytes() != want_st[f][act].tobytes():
                     raise SystemExit("END STATE MISMATCH %r field %s" % (what, f))
+            # ... and the case's first block through the drop-in call: copied into a fresh buffer, then rendered into a registered one
+            # (gpsbb_host_register) at an offset that changes from case to case
+            if nsamp <= REG_SAMPLES - 4096:
+                f0 = pkg.FIXED_CARRIER if fixed else 0
+                iq1, st1 = synth.fill_block(ch[0], 1.0 / fs, nsamp, flags=f0)
+                at = int(rng.integers(0, 4096))
+                reg_buf[:] = 0x5a5a
+                iq2, st2 = synth.fill_block(ch[0], 1.0 / fs, nsamp, flags=f0, out=reg_buf[at:at + nsamp])
+                a0 = ch["prn"][0] > 0
+                for nm, q, s_ in (("copied", iq1, st1), ("registered", iq2[:nsamp], st2)):
+                    if not (q == want_iq[0]).all():
+                        np.save("gpurun_out/fuzz_fail_ch.npy", ch)
+                        raise SystemExit("MISMATCH of the drop-in call (%s) %r" % (nm, what))
+                    for f in ("carr_phase", "code_phase", "iword", "ibit", "icode", "dataBit", "codeCA"):
+                        if s_[f][a0].tobytes() != want_st[f][0][a0].tobytes():
+                            raise SystemExit("END STATE MISMATCH of the drop-in call (%s) %r field %s" % (nm, what, f))
+                if not ((reg_buf[:at] == 0x5a5a).all() and (reg_buf[at + nsamp:] == 0x5a5a).all()):
+                    raise SystemExit("the drop-in call wrote outside its block %r" % (what,))
+                dropin += 1
         exact_runs = synth.info(pkg.INFO_EXACT_RUNS)
         repairs, rewalked = synth.info(pkg.INFO_CHAIN_REPAIRS), synth.info(pkg.INFO_CHAIN_FALLBACKS)
-    print("fuzz_parity: %d cases bit-exact (seed %d); synthesis kernel used {1: per-sample, 2: breakpoint}: %r; "
+        synth.host_unregister(reg_buf)
+    print("fuzz_parity: %d cases bit-exact (seed %d), %d of them also as the drop-in call (copied / into a registered buffer); synthesis kernel used {1: per-sample, 2: breakpoint}: %r; "
           "lane-runs recomputed exactly by the breakpoint kernel: %d; pre-pass {1: row walks, 2: host threads, 3: lap-parallel}: %r; "
           "links that did not hold: %d, laps / blocks walked again: %d" %
-          (len(shapes) * 2 if a.shapes else a.cases, a.seed, used, exact_runs, prepass, repairs, rewalked))
+          (len(shapes) * 2 if a.shapes else a.cases, a.seed, dropin, used, exact_runs, prepass, repairs, rewalked))
 
 
 if __name__ == "__main__":

@@ -88,6 +88,7 @@ INFO_LAST_KERNEL, INFO_EXACT_RUNS, INFO_CHAIN_ON_DEVICE, INFO_CHAIN_FALLBACKS, I
 INFO_STREAMS, INFO_HW_QUEUES, INFO_TILES_RENDERED, INFO_PREPASS = 7, 8, 9, 10
 NODE_INDEXED, NODE_CONCURRENT, NODE_DEVICE_ONLY, NODE_NO_AFFINITY, NODE_FIXED_CARRIER, NODE_INTERLEAVED = 1, 2, 4, 8, 16, 32
 PUSH_NEW_CHAIN = 1
+PUSH_DIGEST = 2
 NODE_MAX_SHARDS = 64
 
 ERRORS = {0: "GPSBB_OK", -1: "GPSBB_E_BADARG", -2: "GPSBB_E_BADCHAN", -3: "GPSBB_E_HIP", -4: "GPSBB_E_NOMEM",
@@ -101,7 +102,7 @@ API_SYMBOLS = [
     "gpsbb_get_hazards", "gpsbb_device_read", "gpsbb_device_digest", "gpsbb_slot_digest", "gpsbb_batch_last_timing", "gpsbb_batch_timing_stats", "gpsbb_fill_ceiling", "gpsbb_stream_create",
     "gpsbb_stream_destroy", "gpsbb_stream_push", "gpsbb_stream_pop", "gpsbb_stream_pending", "gpsbb_stream_timing_stats",
     "gpsbb_codegen", "gpsbb_sincos_tables", "gpsbb_chain_carrier_host", "gpsbb_chain_carrier", "gpsbb_set_option",
-    "gpsbb_get_info", "gpsbb_stream_reset", "gpsbb_device_affinity", "gpsbb_stream_push_ex", "gpsbb_host_register", "gpsbb_host_unregister",
+    "gpsbb_get_info", "gpsbb_stream_reset", "gpsbb_device_affinity", "gpsbb_stream_push_ex", "gpsbb_stream_pop_digest", "gpsbb_host_register", "gpsbb_host_unregister",
 ]
 # ... and include/gpsbb_node.h
 NODE_API_SYMBOLS = ["gpsbb_node_create", "gpsbb_node_run", "gpsbb_node_run_digest", "gpsbb_node_destroy", "gpsbb_node_plan", "gpsbb_node_begin", "gpsbb_node_feed", "gpsbb_node_end"]
@@ -175,6 +176,7 @@ def lib():
         L.gpsbb_chain_carrier.argtypes = [vp, vp, i, i, d, i, vp, vp]
         L.gpsbb_stream_reset.argtypes = [vp]
         L.gpsbb_stream_push_ex.argtypes = [vp, vp, u]
+        L.gpsbb_stream_pop_digest.argtypes = [vp, C.POINTER(vp), vp, vp]
         L.gpsbb_device_affinity.argtypes = [i, C.POINTER(i), C.c_char_p, C.c_size_t]
         L.gpsbb_node_create.argtypes = [C.POINTER(vp), vp]
         L.gpsbb_node_destroy.argtypes = [vp]
@@ -453,14 +455,28 @@ class Stream:
         except Exception:
             pass
 
-    def push(self, ch, new_chain=False):
+    def push(self, ch, new_chain=False, digest=False):
+        """gpsbb_stream_push(_ex); digest: GPSBB_PUSH_DIGEST — the push is rendered with its blocks' digests (pop_digest)"""
         ch = _as_chan(ch)
         if ch.shape != (self.bps, self.nch):
             raise ValueError("push expects [blocks_per_slot, nch] descriptors")
-        if new_chain:
-            _chk(lib().gpsbb_stream_push_ex(self._s, ch.ctypes.data, PUSH_NEW_CHAIN), "gpsbb_stream_push_ex")
+        flags = (PUSH_NEW_CHAIN if new_chain else 0) | (PUSH_DIGEST if digest else 0)
+        if flags:
+            _chk(lib().gpsbb_stream_push_ex(self._s, ch.ctypes.data, flags), "gpsbb_stream_push_ex")
         else:
             _chk(lib().gpsbb_stream_push(self._s, ch.ctypes.data), "gpsbb_stream_push")
+
+    def pop_digest(self, copy=True):
+        """gpsbb_stream_pop_digest: pop() plus the popped push's block digests (uint64 [blocks_per_slot])"""
+        p = C.c_void_p()
+        st = np.zeros((self.bps, self.nch), STATE_DTYPE)
+        dig = np.zeros(self.bps, np.uint64)
+        _chk(lib().gpsbb_stream_pop_digest(self._s, C.byref(p), st.ctypes.data, dig.ctypes.data), "gpsbb_stream_pop_digest")
+        if self.device_only:
+            return p.value, st, dig
+        n = self.bps * self.nsamp * 2
+        view = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int16)), (n,)).reshape(self.bps, self.nsamp, 2)
+        return (view.copy() if copy else view), st, dig
 
     def pop(self, copy=True):
         """(IQ [blocks_per_slot, nsamp, 2] int16 in the slot's pinned host buffer, end states); a stream created with
@@ -629,11 +645,8 @@ def block_digest_host(iq):
     a = np.ascontiguousarray(iq, np.int16)
     w = a.view(np.uint32).reshape(a.shape[:-2] + (a.shape[-2],)).astype(np.uint64)
     with np.errstate(over="ignore"):
-        z = (np.arange(a.shape[-2], dtype=np.uint64) << np.uint64(32)) | w
-        z ^= z >> np.uint64(31)
-        z *= np.uint64(0xBF58476D1CE4E5B9)
-        z ^= z >> np.uint64(29)
-        return z.sum(axis=-1, dtype=np.uint64)
+        m = (np.arange(a.shape[-2], dtype=np.uint64) * np.uint64(0x9E3779BA) + np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+        return (w * m).sum(axis=-1, dtype=np.uint64)
 
 
 class SplitMix64:

@@ -494,6 +494,8 @@ struct gpsbb {
                                          output ranges, so the head of one may fill the CUs the tail of the other leaves idle */
     unsigned compute_turn = 0;
     hipStream_t s_copy = nullptr;    /* device-to-host gather                                            */
+    hipStream_t s_digest = nullptr;  /* gpsbb_slot_digest, created on first use: a stream nothing else waits on (the copy stream holds a
+                                        wait for every push in flight: a digest queued there ran when the whole ring had drained) */
     std::vector<uint32_t> h_ca;      /* host copy of the C/A chips (seeding of small batches on the host)  */
     unsigned long long host_dwrd_oob = 0, host_itable_512 = 0; /* hazards counted by host-side seeding      */
     WorkPool *pool = nullptr;        /* host threads for seeding small batches (created on first use)      */
@@ -588,6 +590,9 @@ struct gpsbb_batch {
      * copy streams that makes four, and streams beyond the hardware queues share them. */
     hipStream_t seed_stream = nullptr;
     hipStream_t last_cs = nullptr; /* the synthesis stream of the last launch */
+    bool want_digest = false;      /* this launch also leaves every block's digest in d_dig (GPSBB_PUSH_DIGEST): by the synthesis kernel
+                                      itself where there is a variant that does (k_synth_ev_digest), by k_block_digest behind it otherwise */
+    DevBuf<unsigned long long> d_dig;
     bool one_stream = false;       /* the drop-in call's scratch batch: upload, pre-pass and synthesis on the synthesis stream (a
                                       hop from stream to stream is 16 us of nothing for a call that takes 150: gpsbb_fill_block_ex) */
     int nblocks = 0, nch = 0, nsamp = 0, ntiles = 0;
@@ -771,7 +776,7 @@ extern "C" int gpsbb_get_info(gpsbb_t *h, int what, uint64_t *out)
         return GPSBB_OK;
     case GPSBB_INFO_STREAMS: {
         uint64_t n = 0;
-        for (hipStream_t st : {h->s_seed, h->s_upload, h->s_compute, h->s_compute2, h->s_copy})
+        for (hipStream_t st : {h->s_seed, h->s_upload, h->s_compute, h->s_compute2, h->s_copy, h->s_digest})
             n += st != nullptr;
         for (hipStream_t st : h->s_more)
             n += st != nullptr;
@@ -835,6 +840,8 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
         (void)hipStreamSynchronize(h->s_compute2);
     if (h->s_copy)
         (void)hipStreamSynchronize(h->s_copy);
+    if (h->s_digest)
+        (void)hipStreamSynchronize(h->s_digest);
     if (h->d_tabs)
         (void)hipFree(h->d_tabs);
     if (h->d_ca)
@@ -860,6 +867,8 @@ extern "C" void gpsbb_destroy(gpsbb_t *h)
         (void)hipStreamDestroy(h->s_compute2);
     if (h->s_copy)
         (void)hipStreamDestroy(h->s_copy);
+    if (h->s_digest)
+        (void)hipStreamDestroy(h->s_digest);
     delete h;
 }
 
@@ -968,6 +977,8 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(SynthLds))) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(EvLdsLean) + EV_PICK_LDS)) != hipSuccess) return fail(e);
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev_digest), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(EvLdsLean) + EV_PICK_LDS)) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_ev_dense), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(EvLds) + EV_PICK_LDS)) != hipSuccess) return fail(e);
@@ -1587,6 +1598,7 @@ extern "C" void gpsbb_batch_destroy(gpsbb_batch_t *b)
     if (b->hs_tile_nav)
         (void)hipHostFree(b->hs_tile_nav);
     b->d_iq.release();
+    b->d_dig.release();
     for (auto &t : b->evs)
         for (auto &e : t.e)
             if (e)
@@ -1899,6 +1911,7 @@ static BatchDev batch_dev(const gpsbb_batch *b, int set)
     p.end = b->d_end[set].p;
     p.status = b->h->d_status;
     p.hazards = b->h->d_hz;
+    p.digest = b->want_digest ? b->d_dig.p : nullptr;
     p.seed_order = b->d_seed_order.p;
     p.seed_lanes = (int)b->h_seed_order.size();
     p.ev = b->ev ? 1 : 0;
@@ -1960,6 +1973,8 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
     gpsbb *h = b->h;
     const int set = (int)(b->run_count % (unsigned)b->nsets);
     b->fix_epoch++; /* a number no earlier launch of this batch handed to k_chain_fix_par */
+    if (b->want_digest)
+        HIPCHK(h, (hipError_t)b->d_dig.reserve((size_t)b->nblocks));
     const BatchDev p = batch_dev(b, set);
     const int lanes = (int)b->h_seed_order.size();
     /* (the drop-in call's scratch batch, everything on one stream and waited for before the call returns: no events — each record
@@ -2165,6 +2180,9 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         HIPCHK(h, hipMemsetAsync(p.tile_ctr, 0, ((size_t)b->nblocks + 1) * sizeof(int32_t), sc));
     if (timed)
         HIPCHK(h, hipEventRecord(ev[2], sc));
+    if (b->want_digest)
+        HIPCHK(h, hipMemsetAsync(b->d_dig.p, 0, (size_t)b->nblocks * sizeof(unsigned long long), sc));
+    bool digest_fused = false;
     if (b->ev) {
         /* One workgroup of EV_WG lanes fits a CU (its LDS image takes ~140 - 156 KB).  Grid = the blocks' primaries, then the
          * helpers (ev_pick_block: a helper joins one of the blocks that still have tiles to hand out, chosen when it starts):
@@ -2189,7 +2207,10 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
             hipLaunchKernelGGL(k_synth_ev_dense, grid, dim3(EV_WG), sizeof(EvLds) + EV_PICK_LDS, sc, p, d_iq);
         else if (p.kph0)
             hipLaunchKernelGGL(k_synth_ev_fixed, grid, dim3(EV_WG), sizeof(EvLdsLean) + EV_PICK_LDS, sc, p, d_iq);
-        else
+        else if (b->want_digest) {
+            hipLaunchKernelGGL(k_synth_ev_digest, grid, dim3(EV_WG), sizeof(EvLdsLean) + EV_PICK_LDS, sc, p, d_iq);
+            digest_fused = true;
+        } else
             hipLaunchKernelGGL(k_synth_ev, grid, dim3(EV_WG), sizeof(EvLdsLean) + EV_PICK_LDS, sc, p, d_iq);
         h->last_kernel = 2;
         h->last_chain_dev = b->chain_dev && !b->chain_indep ? 1 : 0;
@@ -2207,6 +2228,13 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         want = want < 1 ? 1 : (want > max_useful ? max_useful : want);
         const int gx = (int)want;
         hipLaunchKernelGGL(k_synth, dim3(gx, b->nblocks), dim3(TILE_THREADS), sizeof(SynthLds), sc, p, d_iq);
+    }
+    if (b->want_digest && !digest_fused) {
+        /* a synthesis kernel without a digesting variant: the blocks read back behind it, on its stream */
+        long chunks = (2048 + b->nblocks - 1) / b->nblocks;
+        const long max_chunks = ((long)b->nsamp + 1023) / 1024;
+        chunks = chunks > max_chunks ? max_chunks : (chunks < 1 ? 1 : chunks);
+        hipLaunchKernelGGL(k_block_digest, dim3((unsigned)chunks, (unsigned)b->nblocks), dim3(256), 0, sc, (const uint32_t *)d_iq, b->nsamp, b->d_dig.p);
     }
     HIPCHK(h, hipGetLastError());
     if (timed)
@@ -2318,10 +2346,12 @@ extern "C" int gpsbb_slot_digest(gpsbb_t *h, const int16_t *d_iq, long nblocks, 
     if (!h || !d_iq || !digest_out || nblocks < 1 || nblocks > 65535 || nsamp < 1)
         return GPSBB_E_BADARG;
     HIPCHK(h, hipSetDevice(h->device));
-    hipStream_t cs = h->s_copy;
+    if (!h->s_digest)
+        HIPCHK(h, hipStreamCreateWithFlags(&h->s_digest, hipStreamNonBlocking));
+    hipStream_t cs = h->s_digest;
     HIPCHK(h, (hipError_t)h->d_digest.reserve((size_t)nblocks));
     HIPCHK(h, hipMemsetAsync(h->d_digest.p, 0, (size_t)nblocks * sizeof(unsigned long long), cs));
-    long chunks = (2048 + nblocks - 1) / nblocks;
+    long chunks = (GPSBB_KNOB_LONG("GPSBB_SLOT_DIGEST_WGS", 2048) + nblocks - 1) / nblocks;
     const long max_chunks = ((long)nsamp + 1023) / 1024;
     chunks = chunks > max_chunks ? max_chunks : (chunks < 1 ? 1 : chunks);
     hipLaunchKernelGGL(k_block_digest, dim3((unsigned)chunks, (unsigned)nblocks), dim3(256), 0, cs, (const uint32_t *)d_iq, nsamp, h->d_digest.p);
@@ -2660,6 +2690,8 @@ struct gpsbb_stream {
         gpsbb_batch *batch = nullptr;
         int16_t *h_iq = nullptr;            /* pinned */
         gpsbb_chan_state_t *h_end = nullptr; /* pinned */
+        unsigned long long *h_dig = nullptr; /* pinned, on the first GPSBB_PUSH_DIGEST: the push's block digests */
+        bool has_dig = false;
         hipEvent_t computed = nullptr, copied = nullptr;
     };
     std::vector<Slot> slots;
@@ -2701,6 +2733,7 @@ extern "C" void gpsbb_stream_destroy(gpsbb_stream_t *s)
     for (auto &sl : s->slots) {
         if (sl.batch) gpsbb_batch_destroy(sl.batch);
         if (sl.h_iq) (void)hipHostFree(sl.h_iq);
+        if (sl.h_dig) (void)hipHostFree(sl.h_dig);
         if (sl.h_end) (void)hipHostFree(sl.h_end);
         if (sl.computed) (void)hipEventDestroy(sl.computed);
         if (sl.copied) (void)hipEventDestroy(sl.copied);
@@ -2803,18 +2836,18 @@ extern "C" int gpsbb_stream_timing_stats(gpsbb_stream_t *s, int *nruns, float *m
     return GPSBB_OK;
 }
 
-static int stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch, bool new_chain);
+static int stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch, bool new_chain, bool want_digest);
 
-extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch) { return stream_push(s, ch, false); }
+extern "C" int gpsbb_stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch) { return stream_push(s, ch, false, false); }
 
 extern "C" int gpsbb_stream_push_ex(gpsbb_stream_t *s, const gpsbb_chan_t *ch, unsigned flags)
 {
-    if (flags & ~GPSBB_PUSH_NEW_CHAIN)
+    if (flags & ~(GPSBB_PUSH_NEW_CHAIN | GPSBB_PUSH_DIGEST))
         return GPSBB_E_BADARG;
-    return stream_push(s, ch, (flags & GPSBB_PUSH_NEW_CHAIN) != 0);
+    return stream_push(s, ch, (flags & GPSBB_PUSH_NEW_CHAIN) != 0, (flags & GPSBB_PUSH_DIGEST) != 0);
 }
 
-static int stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch, bool new_chain)
+static int stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch, bool new_chain, bool want_digest)
 {
     if (!s || !ch)
         return GPSBB_E_BADARG;
@@ -2965,6 +2998,10 @@ static int stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch, bool new_chain
         bool armed = true;
         ~Poison() { if (armed) s->poisoned = true; }
     } poison{s};
+    b->want_digest = want_digest;
+    if (want_digest && !sl.h_dig)
+        HIPCHK(h, hipHostMalloc((void **)&sl.h_dig, (size_t)s->bps * sizeof(unsigned long long), hipHostMallocDefault));
+    sl.has_dig = false;
     rc = batch_launch(b, b->d_iq.p);
     PUSH_MARK("launch");
     b->d_carry = nullptr;
@@ -2995,6 +3032,10 @@ static int stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch, bool new_chain
                            (uint4 *)sl.h_end, (bytes + 15) / 16, h->d_status, (uint32_t *)((char *)sl.h_end + ((bytes + 15) & ~(size_t)15)));
         HIPCHK(h, hipGetLastError());
     }
+    if (want_digest) {
+        HIPCHK(h, hipMemcpyAsync(sl.h_dig, b->d_dig.p, (size_t)s->bps * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+        sl.has_dig = true;
+    }
     PUSH_MARK("endst");
     HIPCHK(h, hipEventRecord(sl.copied, cs));
     /* commit */
@@ -3016,10 +3057,17 @@ static int stream_push(gpsbb_stream_t *s, const gpsbb_chan_t *ch, bool new_chain
 
 extern "C" int gpsbb_stream_pop(gpsbb_stream_t *s, const int16_t **iq, gpsbb_chan_state_t *end_state)
 {
+    return gpsbb_stream_pop_digest(s, iq, end_state, nullptr);
+}
+
+extern "C" int gpsbb_stream_pop_digest(gpsbb_stream_t *s, const int16_t **iq, gpsbb_chan_state_t *end_state, uint64_t *digests)
+{
     if (!s || !iq)
         return GPSBB_E_BADARG;
     if (s->poisoned || s->head == s->tail)
         return GPSBB_E_STATE;
+    if (digests && !s->slots[s->tail % s->depth].has_dig)
+        return GPSBB_E_STATE; /* the slot was not pushed with GPSBB_PUSH_DIGEST */
     gpsbb *h = s->h;
     HIPCHK(h, hipSetDevice(h->device));
     auto &sl = s->slots[s->tail % s->depth];
@@ -3027,6 +3075,8 @@ extern "C" int gpsbb_stream_pop(gpsbb_stream_t *s, const int16_t **iq, gpsbb_cha
     *iq = sl.h_iq ? sl.h_iq : sl.batch->d_iq.p; /* GPSBB_STREAM_DEVICE_ONLY: the slot's buffer in HBM */
     if (end_state)
         memcpy(end_state, sl.h_end, (size_t)s->bps * s->nch * sizeof(gpsbb_chan_state_t));
+    if (digests)
+        memcpy(digests, sl.h_dig, (size_t)s->bps * sizeof(unsigned long long));
     s->tail++;
     uint32_t st = 0;
     memcpy(&st, (const char *)sl.h_end + (((size_t)s->bps * s->nch * sizeof(gpsbb_chan_state_t) + 15) & ~(size_t)15), 4);

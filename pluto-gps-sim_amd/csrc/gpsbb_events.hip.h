@@ -610,7 +610,7 @@ __device__ __forceinline__ int ev_pick_block(const BatchDev &p, uint32_t slot)
  * that the common one keeps its register count: at <= 104 VGPRs four of its wavefronts leave room on a SIMD for a
  * wavefront of the pre-pass of the next push; at 120 they do not, and a CU that hosts walk wavefronts cannot take a
  * synthesis workgroup at all (measured: 2.2 -> 2.8 ms per launch beside the pre-passes). */
-template <bool DENSE, bool FIXED = false>
+template <bool DENSE, bool FIXED = false, bool DIGEST = false>
 __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__restrict__ iq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -833,6 +833,24 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         if (b == (GPSBB_SABOTAGE == 2 ? 6 : 1) && wt == 3 && lane == 5)
             o[7] ^= 1u;
 #endif
+        if (DIGEST) {
+            /* the block's digest as it is rendered (gpsbb_device_digest's number: the sum of pair_j * m_j, k_block_digest): the
+             * lane's 16 samples are in registers here, and reading the 4 GB of a push back for it costs the synthesis beside it a
+             * third of its rate */
+            uint32_t m = digest_weight((uint32_t)n0);
+            unsigned long long dg = 0ull;
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                if (j < nvalid)
+                    dg += (unsigned long long)o[j] * m;
+                m += DIGEST_STEP;
+            }
+#pragma unroll
+            for (int off2 = 32; off2 > 0; off2 >>= 1)
+                dg += (unsigned long long)__shfl_down((long long)dg, off2);
+            if (lane == 0 && dg)
+                atomicAdd(p.digest + b, dg);
+        }
         /* ---- store.  A lane holds 16 consecutive samples = 64 bytes, and a store instruction moves 16 bytes per lane: written
          * straight from the registers, every instruction touches 64 different 64-byte pieces a quarter full, four times the
          * write requests the data needs — measured, that pattern alone cost 0.27 ms of the kernel's 1.86 (tools/bound_hunt.sh:
@@ -890,6 +908,11 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
 __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_synth_ev(BatchDev p, int16_t *__restrict__ iq)
 {
     synth_ev_body<false>(p, iq);
+}
+/* ... that also leaves every block's digest (BatchDev::digest, zeroed by the host before the launch) */
+__global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_synth_ev_digest(BatchDev p, int16_t *__restrict__ iq)
+{
+    synth_ev_body<false, false, true>(p, iq);
 }
 __global__ __launch_bounds__(EV_WG) void k_synth_ev_dense(BatchDev p, int16_t *__restrict__ iq)
 {

@@ -246,6 +246,8 @@ struct BatchDev {
                                        wavefronts with few lanes (a wavefront runs as long as its longest chain
                                        and every extra lane adds turns of the loops its lanes do not share)   */
     uint32_t *status;               /* self-check word                                               */
+    unsigned long long *digest;     /* [nblocks] or null: k_synth_ev_digest adds every block's digest as it renders (gpsbb_device_digest's
+                                       number: GPSBB_PUSH_DIGEST) */
     unsigned long long *hazards;    /* [0] itable_512, [1] dwrd_oob, [2] lane-runs k_synth_ev recomputed exactly,
                                        [3] scratch (hazards seen by walks whose rows are not the final ones),
                                        [4] blocks k_chain_fix walked on its own, [5] wraps of falling phases whose
@@ -1383,28 +1385,49 @@ __global__ __launch_bounds__(256) void k_gather_to_host(const gather_u32x4 *__re
 }
 
 /* One 64-bit digest per block of int16 I/Q pairs in device memory (gpsbb_device_digest): the sum over the block's samples j of
- * mix((j << 32) | pair_j), mix = one round of a multiply-xorshift mixer — position-dependent, order-independent as a sum, so
- * that any partition of the block over lanes gives the same number.  Grid (chunks, blocks): every workgroup digests a
- * contiguous piece of one block (16-byte loads, 4 KB per workgroup turn) and adds its part with one atomic.  Reads every byte
- * once: bound by the HBM read stream. */
-__device__ __forceinline__ unsigned long long digest_mix(uint32_t j, uint32_t w)
-{
-    unsigned long long z = ((unsigned long long)j << 32) | w;
-    z ^= z >> 31;
-    z *= 0xBF58476D1CE4E5B9ull;
-    z ^= z >> 29;
-    return z;
-}
+ * pair_j * m_j modulo 2^64, m_j = (j * DIGEST_STEP + DIGEST_ODD) mod 2^32 — an odd weight per position, so one changed sample
+ * changes the sum and two samples swapped do; order-independent as a sum, so that any partition of the block over lanes gives
+ * the same number.  Grid (chunks, blocks): every workgroup digests a contiguous piece of one block — 16-byte loads between the
+ * ragged ends (a block starts on a 4-byte boundary only: nsamp is any number), one 32 x 32 + 64 multiply-add and one add per
+ * sample — and adds its part with one atomic.  (Rounds 4-5 mixed every sample through a 64-bit multiply-xorshift round: 15 vector
+ * instructions per sample, and the node driver's digest sink was bound by them — 2.2e11 samples/s beside a synthesis that renders
+ * 5.6e11: DESIGN.md 4.  This one is 3.) */
+constexpr uint32_t DIGEST_STEP = 0x9E3779BAu, DIGEST_ODD = 0x85EBCA6Bu;
+__device__ __forceinline__ uint32_t digest_weight(uint32_t j) { return j * DIGEST_STEP + DIGEST_ODD; }
 __global__ __launch_bounds__(256) void k_block_digest(const uint32_t *__restrict__ iq, int nsamp, unsigned long long *__restrict__ out)
 {
     const int b = blockIdx.y;
     const uint32_t *__restrict__ p = iq + (size_t)b * (size_t)nsamp;
+    const int per = (((nsamp + (int)gridDim.x - 1) / (int)gridDim.x) + 3) & ~3;
+    const int j0 = (int)blockIdx.x * per;
+    if (j0 >= nsamp)
+        return;
+    const int j1 = j0 + per < nsamp ? j0 + per : nsamp;
     unsigned long long acc = 0ull;
-    /* a block starts on a 4-byte boundary only (nsamp is any number): scalar loads at the ragged ends, vectors in between */
-    const int per = (nsamp + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int j0 = blockIdx.x * per, j1 = j0 + per < nsamp ? j0 + per : nsamp;
-    for (int j = j0 + (int)threadIdx.x; j < j1; j += 256)
-        acc += digest_mix((uint32_t)j, p[j]);
+    /* up to three samples before the first 16-byte boundary, whole vectors, up to three samples after the last one */
+    const int mis = (int)((reinterpret_cast<uintptr_t>(p + j0) >> 2) & 3u);
+    const int ja = j0 + ((4 - mis) & 3) < j1 ? j0 + ((4 - mis) & 3) : j1;
+    if ((int)threadIdx.x < ja - j0) {
+        const int j = j0 + (int)threadIdx.x;
+        acc += (unsigned long long)p[j] * digest_weight((uint32_t)j);
+    }
+    const int nvec = (j1 - ja) >> 2;
+    const gather_u32x4 *__restrict__ pv = reinterpret_cast<const gather_u32x4 *>(p + ja);
+    uint32_t m = digest_weight((uint32_t)(ja + 4 * (int)threadIdx.x));
+#pragma unroll 2
+    for (int v = (int)threadIdx.x; v < nvec; v += 256) {
+        const gather_u32x4 q = pv[v];
+        acc += (unsigned long long)q.x * m;
+        acc += (unsigned long long)q.y * (m + DIGEST_STEP);
+        acc += (unsigned long long)q.z * (m + 2u * DIGEST_STEP);
+        acc += (unsigned long long)q.w * (m + 3u * DIGEST_STEP);
+        m += 1024u * DIGEST_STEP;
+    }
+    const int jt = ja + 4 * nvec;
+    if ((int)threadIdx.x < j1 - jt) {
+        const int j = jt + (int)threadIdx.x;
+        acc += (unsigned long long)p[j] * digest_weight((uint32_t)j);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
         acc += (unsigned long long)__shfl_down((long long)acc, off);

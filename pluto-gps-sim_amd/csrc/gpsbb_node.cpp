@@ -67,6 +67,8 @@ struct Shard {
     int numa_node = -1, cpus_bound = 0;
     int create_rc = GPSBB_OK;
     std::vector<gpsbb_chan_t> slot_desc; /* a push's descriptors where they have to be edited: the shard's first slot (seed) and a padded tail */
+    std::vector<uint64_t> slot_dig;      /* gpsbb_node_run_digest over rings in HBM: the digests the slot just popped was rendered with */
+    bool slot_dig_valid = false;
     /* the job of the current run */
     long first = 0, count = 0;
     int rc = GPSBB_OK;
@@ -201,6 +203,26 @@ bool deliver(gpsbb_node *n, Shard &s, const int16_t *iq, long first_block, int n
     return rc >= 0;
 }
 
+/* the driver's own digest sink over rings in HBM: the pushes are rendered WITH their digests (GPSBB_PUSH_DIGEST: the synthesis
+ * kernel adds them up as it renders) and pop hands them out — nothing reads the slot back */
+inline bool digest_at_render(const gpsbb_node *n) { return n->digest_out != nullptr && (n->cfg.flags & GPSBB_NODE_DEVICE_ONLY) != 0; }
+inline int shard_push(gpsbb_node *n, Shard &s, const gpsbb_chan_t *desc, unsigned flags)
+{
+    if (digest_at_render(n))
+        flags |= GPSBB_PUSH_DIGEST;
+    return flags ? gpsbb_stream_push_ex(s.st, desc, flags) : gpsbb_stream_push(s.st, desc);
+}
+inline int shard_pop(gpsbb_node *n, Shard &s, const int16_t **iq)
+{
+    s.slot_dig_valid = false;
+    if (!digest_at_render(n))
+        return gpsbb_stream_pop(s.st, iq, nullptr);
+    s.slot_dig.resize((size_t)n->cfg.blocks_per_slot);
+    const int rc = gpsbb_stream_pop_digest(s.st, iq, nullptr, s.slot_dig.data());
+    s.slot_dig_valid = rc == GPSBB_OK;
+    return rc;
+}
+
 /* GPSBB_NODE_INTERLEAVED: shard g renders slots g, g + N, g + 2N ... of the stream, each a chain of its own */
 int run_shard_interleaved(gpsbb_node *n, Shard &s)
 {
@@ -275,13 +297,13 @@ int run_shard_interleaved(gpsbb_node *n, Shard &s)
             for (int i = 0; i < nch; i++)
                 if (s.slot_desc[i].prn > 0)
                     s.slot_desc[i].carr_phase = seeds[(size_t)b0 * nch + i];
-            rc = gpsbb_stream_push_ex(s.st, s.slot_desc.data(), GPSBB_PUSH_NEW_CHAIN);
+            rc = shard_push(n, s, s.slot_desc.data(), GPSBB_PUSH_NEW_CHAIN);
             if (rc != GPSBB_OK)
                 return rc;
             pushed++;
         }
         const int16_t *iq = nullptr;
-        rc = gpsbb_stream_pop(s.st, &iq, nullptr);
+        rc = shard_pop(n, s, &iq);
         if (rc != GPSBB_OK)
             return rc;
         const long b0 = ((long)s.index + popped * N) * bps;
@@ -338,7 +360,7 @@ int run_shard_feed(gpsbb_node *n, Shard &s)
                 n->cv.notify_all(); /* room for the feeder */
             }
             /* (one shard: consecutive slots of one stream, the ring's own chain carries the phase across them) */
-            rc = c.nshards == 1 ? gpsbb_stream_push(s.st, slot.desc.data()) : gpsbb_stream_push_ex(s.st, slot.desc.data(), GPSBB_PUSH_NEW_CHAIN);
+            rc = shard_push(n, s, slot.desc.data(), c.nshards == 1 ? 0u : GPSBB_PUSH_NEW_CHAIN);
             if (rc != GPSBB_OK)
                 return rc;
             flying.emplace_back(slot.slot * bps, slot.nb);
@@ -346,7 +368,7 @@ int run_shard_feed(gpsbb_node *n, Shard &s)
         if (!going || flying.empty())
             continue;
         const int16_t *iq = nullptr;
-        rc = gpsbb_stream_pop(s.st, &iq, nullptr);
+        rc = shard_pop(n, s, &iq);
         if (rc != GPSBB_OK)
             return rc;
         const std::pair<long, int> f = flying.front();
@@ -439,13 +461,13 @@ int run_shard(gpsbb_node *n, Shard &s)
                         s.slot_desc[i].carr_phase = seed[i];
                 src = s.slot_desc.data();
             }
-            rc = gpsbb_stream_push(s.st, src);
+            rc = shard_push(n, s, src, 0u);
             if (rc != GPSBB_OK)
                 return rc;
             pushed++;
         }
         const int16_t *iq = nullptr;
-        rc = gpsbb_stream_pop(s.st, &iq, nullptr);
+        rc = shard_pop(n, s, &iq);
         if (rc != GPSBB_OK)
             return rc;
         const long b0 = s.first + popped * bps;
@@ -892,20 +914,20 @@ int digest_sink(void *user, const int16_t *iq, long first_block, int nblocks, in
     gpsbb_node *n = static_cast<gpsbb_node *>(user);
     Shard &s = n->shards[shard];
     uint64_t *out = n->digest_out + first_block;
-    if (n->cfg.flags & GPSBB_NODE_DEVICE_ONLY)
+    if (n->cfg.flags & GPSBB_NODE_DEVICE_ONLY) {
+        if (s.slot_dig_valid) { /* rendered with its digests (shard_push / shard_pop) */
+            memcpy(out, s.slot_dig.data(), (size_t)nblocks * sizeof(uint64_t));
+            return 0;
+        }
         return gpsbb_slot_digest(s.h, iq, nblocks, n->cfg.nsamp, out);
+    }
     /* a ring in pinned host memory: the same number on the host (include/gpsbb.h, gpsbb_device_digest) */
     const uint32_t *w = reinterpret_cast<const uint32_t *>(iq);
     const size_t ns = (size_t)n->cfg.nsamp;
     for (int b = 0; b < nblocks; b++) {
         uint64_t acc = 0;
-        for (size_t j = 0; j < ns; j++) {
-            uint64_t z = ((uint64_t)j << 32) | w[(size_t)b * ns + j];
-            z ^= z >> 31;
-            z *= 0xBF58476D1CE4E5B9ull;
-            z ^= z >> 29;
-            acc += z;
-        }
+        for (size_t j = 0; j < ns; j++)
+            acc += (uint64_t)w[(size_t)b * ns + j] * (uint64_t)(uint32_t)((uint32_t)j * 0x9E3779BAu + 0x85EBCA6Bu);
         out[b] = acc;
     }
     return 0;

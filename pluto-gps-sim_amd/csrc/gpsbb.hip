@@ -988,6 +988,10 @@ extern "C" int gpsbb_create(gpsbb_t **out, int device)
                                  (int)sizeof(PdLds<true>) + EV_PICK_LDS)) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_pd<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(PdLds<false>) + EV_PICK_LDS)) != hipSuccess) return fail(e);
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_pd<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(PdLds<true>) + EV_PICK_LDS)) != hipSuccess) return fail(e);
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_synth_pd<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(PdLds<false>) + EV_PICK_LDS)) != hipSuccess) return fail(e);
     *out = h;
     return GPSBB_OK;
 }
@@ -2199,7 +2203,13 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
         if (helpers < 0)
             helpers = 0;
         const dim3 grid((unsigned)(b->nblocks + helpers));
-        if (b->ev_all_dense && b->nch <= PD_WIDE_CHAN)
+        if (b->ev_all_dense && b->want_digest) {
+            if (b->nch <= PD_WIDE_CHAN)
+                hipLaunchKernelGGL((k_synth_pd<true, true>), grid, dim3(EV_WG), sizeof(PdLds<true>) + EV_PICK_LDS, sc, p, d_iq);
+            else
+                hipLaunchKernelGGL((k_synth_pd<false, true>), grid, dim3(EV_WG), sizeof(PdLds<false>) + EV_PICK_LDS, sc, p, d_iq);
+            digest_fused = true;
+        } else if (b->ev_all_dense && b->nch <= PD_WIDE_CHAN)
             hipLaunchKernelGGL(k_synth_pd<true>, grid, dim3(EV_WG), sizeof(PdLds<true>) + EV_PICK_LDS, sc, p, d_iq);
         else if (b->ev_all_dense)
             hipLaunchKernelGGL(k_synth_pd<false>, grid, dim3(EV_WG), sizeof(PdLds<false>) + EV_PICK_LDS, sc, p, d_iq);

@@ -364,7 +364,8 @@ __device__ __forceinline__ void pd_model_of(const PdLds<WIDE> &L, const EvConst 
     M.neg_next = (dnext >> i) & 1u;
 }
 
-template <bool WIDE>
+/* (DIGEST: the kernel also leaves every block's digest — BatchDev::digest, GPSBB_PUSH_DIGEST) */
+template <bool WIDE, bool DIGEST = false>
 __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_synth_pd(BatchDev p, int16_t *__restrict__ iq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -545,6 +546,22 @@ __global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) v
         /* ---- the low halves of the two sums side by side, store (c:2754-2755): sample wt*TILE + j*64 + lane ---- */
         uint32_t *out = reinterpret_cast<uint32_t *>(iq) + (size_t)b * p.nsamp + (size_t)wt * TILE + lane;
         const int left = p.nsamp - wt * TILE - lane; /* samples j*64 < left exist */
+        if (DIGEST) {
+            /* the block's digest as it is rendered (see synth_ev_body): this lane's samples are wt*TILE + j*64 + lane */
+            uint32_t m = digest_weight((uint32_t)(wt * TILE + lane));
+            unsigned long long dg = 0ull;
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                if (j * 64 < left)
+                    dg += (unsigned long long)__builtin_amdgcn_perm(__float_as_uint(acc[j].y), __float_as_uint(acc[j].x), 0x05040100u) * m;
+                m += 64u * DIGEST_STEP;
+            }
+#pragma unroll
+            for (int off2 = 32; off2 > 0; off2 >>= 1)
+                dg += (unsigned long long)__shfl_down((long long)dg, off2);
+            if (lane == 0 && dg)
+                atomicAdd(p.digest + b, dg);
+        }
         if (__builtin_expect(p.nsamp - wt * TILE >= TILE, 1)) {
 #pragma unroll
             for (int j = 0; j < SPT; j++)

@@ -761,8 +761,8 @@ def main():
                             order.append(first)
                             return 0
                         stn = nd.run(full, sink)
-                legs[name] = {"value": full.shape[0] * nsamp / stn["seconds"], "unit": "IQ samples/s (digesting every slot inside the sink included)",
-                              "sink": "the driver's own: gpsbb_node_run_digest (C)" if name == "contiguous_indexed" else "a Python callback per slot, digesting with gpsbb_slot_digest",
+                legs[name] = {"value": full.shape[0] * nsamp / stn["seconds"], "unit": "IQ samples/s (a digest of every block included)",
+                              "sink": "the driver's own: gpsbb_node_run_digest (C; pushes rendered with their digests)" if name == "contiguous_indexed" else "a Python callback per slot, digesting with gpsbb_slot_digest",
                               "seconds": stn["seconds"], "blocks": int(full.shape[0]), "devices": devs,
                               "every_block_once": bool((seen == 1).all()), "in_stream_order": order == sorted(order),
                               "digests_equal_the_ranks": bool((got == iq_digs).all()),
@@ -774,10 +774,12 @@ def main():
                     hsyn.close()
             all_equal = all(legs[k]["digests_equal_the_ranks"] and legs[k]["every_block_once"] for k in legs)
             node["all_gpus"] = legs
-            node["all_gpus"]["expectation"] = ("N GPUs: contiguous shards into the driver's own digest sink scale with N (every GPU renders and is digested on its own, "
-                                               "by its shard's producer thread in C: the 1-GPU figure is the headline's minus the digest kernel's share of the chip); the ordered "
-                                               "sink over interleaved slots delivers in stream order at the same rate as long as the consumer keeps up — here ONE Python "
-                                               "callback per slot (0.7 ms of digest kernel + the interpreter), which at N = 8 is what bounds that leg, not the driver")
+            node["all_gpus"]["expectation"] = ("N GPUs: contiguous shards into the driver's own digest sink scale with N (every GPU renders its pushes WITH their digests - "
+                                               "GPSBB_PUSH_DIGEST: the synthesis kernel adds them up as it renders, nothing is read back - and its shard's producer thread "
+                                               "copies them out in C: the 1-GPU figure is ~0.9 x one_shard); the ordered sink over interleaved slots delivers in stream order "
+                                               "at the same rate as long as the consumer keeps up - here ONE Python callback per slot that reads the slot back "
+                                               "(gpsbb_slot_digest: 0.7 ms of digest kernel beside the synthesis, which it slows, + the interpreter), which at N = 8 is what "
+                                               "bounds that leg, not the driver")
             if not all_equal:
                 parity["node_driver_mismatch"] = True
         except Exception as e:

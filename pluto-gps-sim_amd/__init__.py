@@ -176,7 +176,8 @@ def lib():
         L.gpsbb_chain_carrier.argtypes = [vp, vp, i, i, d, i, vp, vp]
         L.gpsbb_stream_reset.argtypes = [vp]
         L.gpsbb_stream_push_ex.argtypes = [vp, vp, u]
-        L.gpsbb_stream_pop_digest.argtypes = [vp, C.POINTER(vp), vp, vp]
+        if hasattr(L, "gpsbb_stream_pop_digest"):  # (an older build loaded for an A/B: tools/ab_lib.sh)
+            L.gpsbb_stream_pop_digest.argtypes = [vp, C.POINTER(vp), vp, vp]
         L.gpsbb_device_affinity.argtypes = [i, C.POINTER(i), C.c_char_p, C.c_size_t]
         L.gpsbb_node_create.argtypes = [C.POINTER(vp), vp]
         L.gpsbb_node_destroy.argtypes = [vp]

@@ -738,10 +738,9 @@ def main():
         try:
             full = mine if world == 1 else stream_descriptors(pkg, total, nch)
             devs = list(range(max(ndev, 1))) if backend == "nccl" or world == 1 else [local]
-            helpers = {d: (synth if d == local else pkg.Synth(d)) for d in devs}
             legs = {}
             for name, nflags in (("contiguous_indexed", pkg.NODE_DEVICE_ONLY | pkg.NODE_INDEXED | pkg.NODE_CONCURRENT),
-                                 ("interleaved_ordered", pkg.NODE_DEVICE_ONLY | pkg.NODE_INTERLEAVED)):
+                                 ("interleaved_ordered", pkg.NODE_DEVICE_ONLY | pkg.NODE_INTERLEAVED | pkg.NODE_DIGESTS)):
                 got = np.zeros(full.shape[0], np.uint64)
                 seen = np.zeros(full.shape[0], np.int32)
                 order = []
@@ -756,30 +755,28 @@ def main():
                     else:
                         # the ordered consumer, as a host would write it in Python: one callback per slot, in stream order
                         def sink(iq, first, nb, shard):
-                            got[first:first + nb] = helpers[devs[shard]].slot_digest(iq, nb, nsamp)
+                            # (GPSBB_NODE_DIGESTS: the pushes were rendered with their digests; reading the slot back instead -
+                            # helpers[devs[shard]].slot_digest(iq, nb, nsamp) - costs the synthesis behind it a third of its rate)
+                            got[first:first + nb] = nd.slot_digests(shard, nb)
                             seen[first:first + nb] += 1
                             order.append(first)
                             return 0
                         stn = nd.run(full, sink)
                 legs[name] = {"value": full.shape[0] * nsamp / stn["seconds"], "unit": "IQ samples/s (a digest of every block included)",
-                              "sink": "the driver's own: gpsbb_node_run_digest (C; pushes rendered with their digests)" if name == "contiguous_indexed" else "a Python callback per slot, digesting with gpsbb_slot_digest",
+                              "sink": "the driver's own: gpsbb_node_run_digest (C; pushes rendered with their digests)" if name == "contiguous_indexed" else "a Python callback per slot, in stream order, taking the digests the slot was rendered with (GPSBB_NODE_DIGESTS, gpsbb_node_slot_digests)",
                               "seconds": stn["seconds"], "blocks": int(full.shape[0]), "devices": devs,
                               "every_block_once": bool((seen == 1).all()), "in_stream_order": order == sorted(order),
                               "digests_equal_the_ranks": bool((got == iq_digs).all()),
                               "blocks_that_differ": int((got != iq_digs).sum()),
                               "shards": [{k: x[k] for k in ("first_block", "nblocks", "device", "numa_node", "cpus_bound", "seed_seconds", "busy_seconds", "wait_seconds")}
                                          for x in stn["shards"]]}
-            for d, hsyn in helpers.items():
-                if hsyn is not synth:
-                    hsyn.close()
             all_equal = all(legs[k]["digests_equal_the_ranks"] and legs[k]["every_block_once"] for k in legs)
             node["all_gpus"] = legs
             node["all_gpus"]["expectation"] = ("N GPUs: contiguous shards into the driver's own digest sink scale with N (every GPU renders its pushes WITH their digests - "
                                                "GPSBB_PUSH_DIGEST: the synthesis kernel adds them up as it renders, nothing is read back - and its shard's producer thread "
                                                "copies them out in C: the 1-GPU figure is ~0.9 x one_shard); the ordered sink over interleaved slots delivers in stream order "
-                                               "at the same rate as long as the consumer keeps up - here ONE Python callback per slot that reads the slot back "
-                                               "(gpsbb_slot_digest: 0.7 ms of digest kernel beside the synthesis, which it slows, + the interpreter), which at N = 8 is what "
-                                               "bounds that leg, not the driver")
+                                               "at the same rate as long as the consumer keeps up - here ONE Python callback per slot (it takes the digests the slot was rendered with: "
+                                               "GPSBB_NODE_DIGESTS), which at N = 8 is what bounds that leg, not the driver")
             if not all_equal:
                 parity["node_driver_mismatch"] = True
         except Exception as e:

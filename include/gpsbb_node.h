@@ -50,6 +50,9 @@ extern "C" {
                                        0.1 s per 100 000 blocks, and pushes with GPSBB_PUSH_NEW_CHAIN).  With this layout the
                                        ORDERED sink scales too: while the consumer takes slot k from one GPU the others are
                                        rendering k + 1 ... k + nshards * depth - 1 */
+#define GPSBB_NODE_DIGESTS 64u      /* every push is rendered WITH the digests of its blocks (GPSBB_PUSH_DIGEST: include/gpsbb.h): a sink
+                                       that wants them calls gpsbb_node_slot_digests from inside its callback instead of reading the
+                                       slot back (gpsbb_slot_digest).  Costs the synthesis ~7 %, where reading back costs it a third */
 
 /*
  * The one consumer.  `iq` = nblocks consecutive blocks (nblocks * nsamp int16 I/Q pairs, interleaved), the first of them
@@ -107,14 +110,19 @@ int gpsbb_node_run(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nblocks, gpsbb_
 
 /*
  * gpsbb_node_run with the DRIVER'S OWN sink: digests[b] = the 64-bit digest of block b (gpsbb_device_digest's number), taken on
- * the GPU that rendered the block by the shard's producer thread as soon as the slot is complete (gpsbb_slot_digest: the ring
- * behind the slot keeps rendering), every shard on its own — what a host that keeps the IQ in HBM compares instead of the bytes,
- * and a consumer that costs the driver next to nothing: the rate of this call is the driver's own.  Rings in host memory
+ * the GPU that rendered the block, every shard on its own — what a host that keeps the IQ in HBM compares instead of the bytes,
+ * and a consumer that costs the driver next to nothing.  Rings in HBM (GPSBB_NODE_DEVICE_ONLY) are rendered WITH their digests
+ * (GPSBB_PUSH_DIGEST: the synthesis kernel adds them up as it renders, gpsbb_stream_pop_digest hands them to the shard's
+ * producer thread; nothing is read back): 0.93 x the rate of a sink that does nothing.  Rings in host memory
  * (no GPSBB_NODE_DEVICE_ONLY) are digested by the producer threads on the host, the same number.  The node's flags decide the
  * layout (contiguous / GPSBB_NODE_INTERLEAVED) as for gpsbb_node_run; the order of delivery does not matter to this sink: it is
  * entered as GPSBB_NODE_INDEXED | GPSBB_NODE_CONCURRENT whatever the flags say.
  */
 int gpsbb_node_run_digest(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nblocks, uint64_t *digests, gpsbb_node_stats_t *stats);
+
+/* From INSIDE a sink of a GPSBB_NODE_DIGESTS node: the digests of the `nblocks` blocks the sink has just been handed by `shard`
+ * (gpsbb_device_digest's numbers, computed as the blocks were rendered).  GPSBB_E_STATE anywhere else. */
+int gpsbb_node_slot_digests(gpsbb_node_t *n, int shard, uint64_t *digests, int nblocks);
 
 /*
  * The same stream, INCREMENTALLY — what the reference's loop does: it makes the descriptors of one block, renders it, and goes

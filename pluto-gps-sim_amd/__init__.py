@@ -86,7 +86,7 @@ STREAM_DEVICE_ONLY = 4
 OPT_SEED_WHERE, OPT_SYNTH_KERNEL, OPT_SKIP_SEED, OPT_CHAIN_WHERE = 1, 2, 3, 4
 INFO_LAST_KERNEL, INFO_EXACT_RUNS, INFO_CHAIN_ON_DEVICE, INFO_CHAIN_FALLBACKS, INFO_CHAIN_TIES, INFO_CHAIN_REPAIRS = 1, 2, 3, 4, 5, 6
 INFO_STREAMS, INFO_HW_QUEUES, INFO_TILES_RENDERED, INFO_PREPASS = 7, 8, 9, 10
-NODE_INDEXED, NODE_CONCURRENT, NODE_DEVICE_ONLY, NODE_NO_AFFINITY, NODE_FIXED_CARRIER, NODE_INTERLEAVED = 1, 2, 4, 8, 16, 32
+NODE_INDEXED, NODE_CONCURRENT, NODE_DEVICE_ONLY, NODE_NO_AFFINITY, NODE_FIXED_CARRIER, NODE_INTERLEAVED, NODE_DIGESTS = 1, 2, 4, 8, 16, 32, 64
 PUSH_NEW_CHAIN = 1
 PUSH_DIGEST = 2
 NODE_MAX_SHARDS = 64
@@ -105,7 +105,7 @@ API_SYMBOLS = [
     "gpsbb_get_info", "gpsbb_stream_reset", "gpsbb_device_affinity", "gpsbb_stream_push_ex", "gpsbb_stream_pop_digest", "gpsbb_host_register", "gpsbb_host_unregister",
 ]
 # ... and include/gpsbb_node.h
-NODE_API_SYMBOLS = ["gpsbb_node_create", "gpsbb_node_run", "gpsbb_node_run_digest", "gpsbb_node_destroy", "gpsbb_node_plan", "gpsbb_node_begin", "gpsbb_node_feed", "gpsbb_node_end"]
+NODE_API_SYMBOLS = ["gpsbb_node_create", "gpsbb_node_run", "gpsbb_node_run_digest", "gpsbb_node_slot_digests", "gpsbb_node_destroy", "gpsbb_node_plan", "gpsbb_node_begin", "gpsbb_node_feed", "gpsbb_node_end"]
 
 
 class GpsbbError(RuntimeError):
@@ -184,6 +184,7 @@ def lib():
         L.gpsbb_node_destroy.restype = None
         L.gpsbb_node_run.argtypes = [vp, vp, C.c_long, vp, vp, vp]
         L.gpsbb_node_run_digest.argtypes = [vp, vp, C.c_long, vp, vp]
+        L.gpsbb_node_slot_digests.argtypes = [vp, i, vp, i]
         L.gpsbb_slot_digest.argtypes = [vp, vp, C.c_long, C.c_int, vp]
         L.gpsbb_host_register.argtypes = [vp, vp, C.c_size_t]
         L.gpsbb_host_unregister.argtypes = [vp, vp]
@@ -609,6 +610,12 @@ class Node:
         _chk(lib().gpsbb_node_run_digest(self._n, ch.ctypes.data, ch.shape[0], digs.ctypes.data, C.byref(st)), "gpsbb_node_run_digest")
         return {"rc": 0, "seconds": st.seconds, "blocks": st.blocks,
                 "shards": [{k: getattr(st.shard[g], k) for k, _ in _NodeShardStats._fields_} for g in range(st.nshards)]}, digs
+
+    def slot_digests(self, shard, nblocks):
+        """gpsbb_node_slot_digests, from inside a sink of a NODE_DIGESTS node: the digests the blocks just handed over were rendered with"""
+        out = np.zeros(nblocks, np.uint64)
+        _chk(lib().gpsbb_node_slot_digests(self._n, shard, out.ctypes.data, nblocks), "gpsbb_node_slot_digests")
+        return out
 
     def begin(self, sink):
         """gpsbb_node_begin: an incremental run; feed() the stream as it comes, end() when it is over"""

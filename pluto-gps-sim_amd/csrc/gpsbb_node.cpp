@@ -200,12 +200,16 @@ bool deliver(gpsbb_node *n, Shard &s, const int16_t *iq, long first_block, int n
         }
     }
     s.stats.wait_seconds += now_s() - t0;
+    s.slot_dig_valid = false; /* (gpsbb_node_slot_digests: from inside the sink only) */
     return rc >= 0;
 }
 
 /* the driver's own digest sink over rings in HBM: the pushes are rendered WITH their digests (GPSBB_PUSH_DIGEST: the synthesis
  * kernel adds them up as it renders) and pop hands them out — nothing reads the slot back */
-inline bool digest_at_render(const gpsbb_node *n) { return n->digest_out != nullptr && (n->cfg.flags & GPSBB_NODE_DEVICE_ONLY) != 0; }
+inline bool digest_at_render(const gpsbb_node *n)
+{
+    return (n->digest_out != nullptr && (n->cfg.flags & GPSBB_NODE_DEVICE_ONLY) != 0) || (n->cfg.flags & GPSBB_NODE_DIGESTS) != 0;
+}
 inline int shard_push(gpsbb_node *n, Shard &s, const gpsbb_chan_t *desc, unsigned flags)
 {
     if (digest_at_render(n))
@@ -587,7 +591,7 @@ extern "C" int gpsbb_node_create(gpsbb_node_t **out, const gpsbb_node_config_t *
 {
     if (!out || !cfg || cfg->nshards < 1 || cfg->nshards > GPSBB_NODE_MAX_SHARDS || cfg->nch < 1 || cfg->nch > GPSBB_MAX_CHAN ||
         !(cfg->delt > 0.0) || cfg->nsamp < 1 || cfg->blocks_per_slot < 1 || cfg->depth < 2 ||
-        (cfg->flags & ~(GPSBB_NODE_INDEXED | GPSBB_NODE_CONCURRENT | GPSBB_NODE_DEVICE_ONLY | GPSBB_NODE_NO_AFFINITY | GPSBB_NODE_FIXED_CARRIER | GPSBB_NODE_INTERLEAVED)))
+        (cfg->flags & ~(GPSBB_NODE_INDEXED | GPSBB_NODE_CONCURRENT | GPSBB_NODE_DEVICE_ONLY | GPSBB_NODE_NO_AFFINITY | GPSBB_NODE_FIXED_CARRIER | GPSBB_NODE_INTERLEAVED | GPSBB_NODE_DIGESTS)))
         return GPSBB_E_BADARG;
     *out = nullptr;
     gpsbb_node *n = new (std::nothrow) gpsbb_node;
@@ -933,6 +937,17 @@ int digest_sink(void *user, const int16_t *iq, long first_block, int nblocks, in
     return 0;
 }
 } /* namespace */
+
+extern "C" int gpsbb_node_slot_digests(gpsbb_node_t *n, int shard, uint64_t *digests, int nblocks)
+{
+    if (!n || !digests || shard < 0 || shard >= (int)n->shards.size() || nblocks < 1 || nblocks > n->cfg.blocks_per_slot)
+        return GPSBB_E_BADARG;
+    const Shard &s = n->shards[(size_t)shard];
+    if (!s.slot_dig_valid)
+        return GPSBB_E_STATE; /* not a GPSBB_NODE_DIGESTS node, or not called from inside the sink */
+    memcpy(digests, s.slot_dig.data(), (size_t)nblocks * sizeof(uint64_t));
+    return GPSBB_OK;
+}
 
 extern "C" int gpsbb_node_run_digest(gpsbb_node_t *n, const gpsbb_chan_t *ch, long nblocks, uint64_t *digests, gpsbb_node_stats_t *stats)
 {

@@ -433,3 +433,44 @@ def test_the_drivers_own_digest_sink(pkg, synth, oracle):
     a = synth.slot_digest(dptr, bps, nsamp)
     assert (a == synth.device_digest(dptr, bps, nsamp)).all() and (a == want[:bps]).all()
     st_.close()
+
+
+@pytest.mark.gpu
+def test_a_sink_of_the_hosts_own_takes_the_digests_the_slots_were_rendered_with(pkg, oracle):
+    """GPSBB_NODE_DIGESTS: every push carries the digests of its blocks (the synthesis kernel adds them up as it renders) and
+    gpsbb_node_slot_digests hands them to a sink from inside its callback — equal to the digests of the oracle's bytes for 1 and 2
+    shards, contiguous and interleaved, rings in HBM and in host memory (where the sink also sees the bytes); outside a sink, and on
+    a node without the flag, the call is refused."""
+    nch, fs, nsamp, bps, nb = 9, 25e6, 30011, 4, 24
+    ch = pkg.synth_descriptors(nb, nch=nch, seed=99)
+    want_iq, _, _ = oracle.fill_blocks(ch, 1 / fs, nsamp, chain=True)
+    want = pkg.block_digest_host(want_iq)
+    for nshards in (1, 2):
+        for layout in (0, pkg.NODE_INTERLEAVED):
+            for ring in (pkg.NODE_DEVICE_ONLY, 0):
+                with pkg.Node(nshards, nch, 1 / fs, nsamp, bps, depth=3, flags=layout | ring | pkg.NODE_DIGESTS | pkg.NODE_INDEXED, devices=[0] * nshards) as nd:
+                    got = np.zeros(nb, np.uint64)
+
+                    def sink(iq, first, n, shard):
+                        got[first:first + n] = nd.slot_digests(shard, n)
+                        if not ring:
+                            import ctypes as C
+                            seen_iq = np.frombuffer((C.c_int16 * (n * nsamp * 2)).from_address(iq), np.int16).reshape(n, nsamp, 2)
+                            assert (seen_iq == want_iq[first:first + n]).all()
+                        return 0
+                    nd.run(ch, sink)
+                    assert (got == want).all(), (nshards, layout, ring)
+                    with pytest.raises(pkg.GpsbbError):
+                        nd.slot_digests(0, bps + 1)
+    with pkg.Node(1, nch, 1 / fs, nsamp, bps, depth=3, flags=pkg.NODE_DEVICE_ONLY | pkg.NODE_INDEXED, devices=[0]) as nd:
+        seen = []
+
+        def sink2(iq, first, n, shard):
+            try:
+                nd.slot_digests(shard, n)
+                seen.append("handed out")
+            except pkg.GpsbbError:
+                seen.append("refused")
+            return 0
+        nd.run(ch[:bps * 2], sink2)
+        assert seen == ["refused", "refused"]

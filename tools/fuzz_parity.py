@@ -27,6 +27,8 @@ def stream_soak(a):
     fallbacks = ties = 0
     prepass = {}
     with pkg.Synth(0) as synth:
+        rng_dig = np.random.default_rng(a.seed ^ 0xD16E57)
+        digested = 0
         for case in range(a.cases):
             fs = float(rng.choice([16.368e6, 20e6, 25e6, 30e6, 2.0 ** 25, 50e6]))
             low_rate = rng.random() < (1.0 if getattr(a, "low_rate", False) else 0.25)  # a rate below the breakpoint kernel's: k_synth_pd
@@ -88,10 +90,23 @@ def stream_soak(a):
             got = []
             k = 0
             popped = 0
+            # every other push (drawn from a generator of its own: the cases stay what their seeds always made them) is rendered WITH
+            # its block digests (GPSBB_PUSH_DIGEST: the synthesis kernel adds them up as it renders, or a digest kernel behind it):
+            # compared with the digests of the oracle's bytes — which also puts the IQ of HBM-only rings under the check
+            flagged = [bool(rng_dig.random() < 0.5) for _ in range(pushes)]
+            want_dig = pkg.block_digest_host(want_iq)
             while popped < pushes:
                 while k < pushes and st.pending < depth:
-                    st.push(ch[k * bps:(k + 1) * bps]); k += 1
-                iq, es = st.pop(copy=True)
+                    st.push(ch[k * bps:(k + 1) * bps], digest=flagged[k]); k += 1
+                if flagged[popped]:
+                    iq, es, dig = st.pop_digest(copy=True)
+                    if not (dig == want_dig[popped * bps:(popped + 1) * bps]).all():
+                        np.save("gpurun_out/fuzz_stream_fail_ch.npy", ch)
+                        raise SystemExit("STREAM DIGEST MISMATCH %r push %d blocks %r" % (dict(case=case, fs=fs, nsamp=nsamp, nch=nch, bps=bps, pushes=pushes, dev_only=dev_only, where=where, kern=kern), popped,
+                                                                                        np.argwhere(dig != want_dig[popped * bps:(popped + 1) * bps])[:, 0].tolist()[:10]))
+                    digested += bps
+                else:
+                    iq, es = st.pop(copy=True)
                 got.append((None if dev_only else np.asarray(iq).reshape(bps, -1), es))  # HBM-only ring: end states only
                 popped += 1
             st.close()
@@ -134,9 +149,9 @@ def stream_soak(a):
         ties = synth.info(pkg.INFO_CHAIN_TIES)
         on_dev = synth.info(pkg.INFO_CHAIN_ON_DEVICE)
         repairs = synth.info(pkg.INFO_CHAIN_REPAIRS)
-    print("fuzz_parity --stream: %d chained streams bit-exact (seed %d); last push chained on the device: %d; blocks / laps walked "
+    print("fuzz_parity --stream: %d chained streams bit-exact (seed %d), %d blocks' digests as rendered equal the oracle's bytes'; last push chained on the device: %d; blocks / laps walked "
           "again by the fix-up / the lap repair: %d; links / guesses that did not hold: %d; wrap ties recorded: %d; pre-pass of each case's "
-          "last push {1: row walks, 2: host threads, 3: lap-parallel}: %r" % (a.cases, a.seed, on_dev, fallbacks, repairs, ties, prepass))
+          "last push {1: row walks, 2: host threads, 3: lap-parallel}: %r" % (a.cases, a.seed, digested, on_dev, fallbacks, repairs, ties, prepass))
 
 
 def main():

@@ -2048,6 +2048,10 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
          * block of the reference's geometry: 98 -> 50 us), and a big batch's two plan kernels (16 wavefronts each, 0.1 - 0.2 ms)
          * run side by side.  A stream's pushes keep the kinds apart: their code chains wait for nobody, their carriers for the
          * push before (GPSBB_LAP_MERGE=1, experiments build: merged there too). */
+        /* pass 2 writes the tile states in 32- / 16-byte pieces where the geometry has them (several tiles per lap: a code period is
+         * 1023 chips / (1.023e6 * delt) samples) — k_lap_pass2<., true>; at the reference's 2.6 MS/s a period is 2.5 tiles and the
+         * plain loop is the faster one */
+        const bool wide = GPSBB_KNOB_LONG("GPSBB_LAP_WIDE", b->delt <= 1.0 / 8.0e6 ? 1 : 0) != 0;
         const bool merged = !p.kph0 && (!(b->d_carry && b->ev_fix) || GPSBB_KNOB_LONG("GPSBB_LAP_MERGE", 0) == 1) &&
                             GPSBB_KNOB_LONG("GPSBB_LAP_MERGE", 0) != 2;
         /* a stream's carry (ChainCarryDev) is read by this push's carrier plan and written by its repair (exact_end AND approx_end):
@@ -2074,14 +2078,20 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
             hipLaunchKernelGGL(k_lap_plan2, dim3(2 * b->nch), dim3(64), 0, ss, p, L);
             hipLaunchKernelGGL(k_lap_pass1_2, dim3(cc + ck), dim3(LAP_WG), 0, ss, p, L);
             hipLaunchKernelGGL(k_lap_scan2, dim3(2 * b->nch), dim3(64), 0, ss, p, L);
-            hipLaunchKernelGGL(k_lap_pass2_2, dim3(cc + ck), dim3(LAP_WG), 0, ss, p, L);
+            if (wide)
+                hipLaunchKernelGGL(k_lap_pass2_2<true>, dim3(cc + ck), dim3(LAP_WG), 0, ss, p, L);
+            else
+                hipLaunchKernelGGL(k_lap_pass2_2<false>, dim3(cc + ck), dim3(LAP_WG), 0, ss, p, L);
             hipLaunchKernelGGL(k_lap_repair2, dim3(2 * b->nch), dim3(64), 0, ss, p, L);
             HIPCHK(h, carry_done());
         } else {
             hipLaunchKernelGGL(k_lap_plan<NCO_CODE>, dim3(b->nch), dim3(64), 0, ss, p, L);
             hipLaunchKernelGGL(k_lap_pass1<NCO_CODE>, dim3(cc), dim3(LAP_WG), 0, ss, p, L);
             hipLaunchKernelGGL(k_lap_scan<NCO_CODE>, dim3(b->nch), dim3(64), 0, ss, p, L);
-            hipLaunchKernelGGL(k_lap_pass2<NCO_CODE>, dim3(cc), dim3(LAP_WG), 0, ss, p, L);
+            if (wide)
+                hipLaunchKernelGGL((k_lap_pass2<NCO_CODE, true>), dim3(cc), dim3(LAP_WG), 0, ss, p, L);
+            else
+                hipLaunchKernelGGL((k_lap_pass2<NCO_CODE, false>), dim3(cc), dim3(LAP_WG), 0, ss, p, L);
             hipLaunchKernelGGL(k_lap_repair<NCO_CODE>, dim3(b->nch), dim3(64), 0, ss, p, L);
             if (p.kph0) {
                 /* fixed-point carrier: no chain to walk; the plan kernel leaves the end states, the tile states are a closed form */
@@ -2092,7 +2102,10 @@ static int batch_launch(gpsbb_batch *b, int16_t *d_iq)
                 hipLaunchKernelGGL(k_lap_plan<NCO_CARR>, dim3(b->nch), dim3(64), 0, ss, p, L);
                 hipLaunchKernelGGL(k_lap_pass1<NCO_CARR>, dim3(ck), dim3(LAP_WG), 0, ss, p, L);
                 hipLaunchKernelGGL(k_lap_scan<NCO_CARR>, dim3(b->nch), dim3(64), 0, ss, p, L);
-                hipLaunchKernelGGL(k_lap_pass2<NCO_CARR>, dim3(ck), dim3(LAP_WG), 0, ss, p, L);
+                if (wide)
+                    hipLaunchKernelGGL((k_lap_pass2<NCO_CARR, true>), dim3(ck), dim3(LAP_WG), 0, ss, p, L);
+                else
+                    hipLaunchKernelGGL((k_lap_pass2<NCO_CARR, false>), dim3(ck), dim3(LAP_WG), 0, ss, p, L);
                 hipLaunchKernelGGL(k_lap_repair<NCO_CARR>, dim3(b->nch), dim3(64), 0, ss, p, L);
                 HIPCHK(h, carry_done());
             }

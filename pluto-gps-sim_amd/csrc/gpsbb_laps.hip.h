@@ -415,6 +415,7 @@ struct LapLane {
     bool one_lap;      /* stop at the first wrap wherever it falls (the repair's walks; a lane otherwise goes on through the wraps
                           inside its territory: it holds several laps, LapDev::unit) */
     LapMap acc;        /* pass 1: what the wraps and top-binade entries so far do to an offset, besides carrying it along */
+    int32_t navt;      /* code, pass 2: the first tile of the block whose data bits this lane has not written yet (lap_nav_out) */
 };
 
 /* the data bits of code period c of a channel (c:2717-2733): bit 0: the bit in force is -1; bit 1: the one in force after the
@@ -449,7 +450,45 @@ __device__ __forceinline__ void lap_enter_block(const BatchDev &p, const LapDev 
 }
 
 /* tile states of a row: samples n .. n + k, state x at n, increment S */
+/* The data bits of the tiles of a code period (bit 0: the bit in force is -1, bit 1: the one after the next roll-over is): the same
+ * for every tile whose first sample lies in the period, so they go out when the period is over (or the lane's walk is) — two dozen
+ * consecutive words, in 32- and 16-byte pieces — instead of one word with every tile state: stored one by one, four bytes at a
+ * time, they were more than half of what the pre-pass writes to HBM (a sector of 32 bytes per word: WRITE_SIZE).  Tiles
+ * [w.navt, the first tile whose first sample is n_excl or later). */
 template <int KIND>
+__device__ __forceinline__ void lap_nav_out(const BatchDev &p, int i, LapLane<KIND> &w, bool on, int n_excl, uint32_t bits)
+{
+    typedef uint32_t lap_u4 __attribute__((ext_vector_type(4)));
+    const int t = w.navt;
+    int t_end = (int)(((uint32_t)n_excl + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
+    t_end = t_end < p.ntiles ? t_end : p.ntiles;
+    int cnt = on && t_end > t ? t_end - t : 0;
+    if (cnt > 0)
+        w.navt = t_end;
+    if (!__ballot(cnt > 0))
+        return;
+    uint32_t *pn = p.tile_nav + ((size_t)w.b * (size_t)p.nch + i) * (size_t)p.ntiles + t;
+    const lap_u4 b4 = lap_u4{bits, bits, bits, bits};
+    while (__ballot(cnt > 0)) {
+        const bool oct = cnt >= 8 && (reinterpret_cast<uintptr_t>(pn) & 31u) == 0;
+        const bool quad = !oct && cnt >= 4 && (reinterpret_cast<uintptr_t>(pn) & 15u) == 0;
+        if (__ballot(oct)) {
+            if (oct) {
+                reinterpret_cast<lap_u4 *>(pn)[0] = b4;
+                reinterpret_cast<lap_u4 *>(pn)[1] = b4;
+            }
+        }
+        if (quad)
+            *reinterpret_cast<lap_u4 *>(pn) = b4;
+        if (cnt > 0 && !oct && !quad)
+            *pn = bits;
+        const int adv = oct ? 8 : (quad ? 4 : (cnt > 0 ? 1 : 0));
+        pn += adv;
+        cnt -= adv;
+    }
+}
+
+template <int KIND, bool WIDE>
 __device__ __forceinline__ void lap_emit_row(const BatchDev &p, int i, bool on, int b, int n, int k, double x, double S, uint32_t bits)
 {
     int t = (int)(((uint32_t)n + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
@@ -460,7 +499,6 @@ __device__ __forceinline__ void lap_emit_row(const BatchDev &p, int i, bool on, 
     if (!__ballot(cnt > 0))
         return;
     double *__restrict__ tx = p.tile_x + ((size_t)b * (2 * (size_t)p.nch) + 2 * i + KIND) * (size_t)p.ntiles;
-    uint32_t *__restrict__ tn = p.tile_nav + ((size_t)b * (size_t)p.nch + i) * (size_t)p.ntiles;
     /* A turn of the loop below costs the wavefront the same whether one lane or all of them have a tile to write: fine where the
      * lanes' rows are alike (neighbouring laps of one chain: each has its dozen tiles).  A FEW lanes with very long rows — a slow
      * chain, hundreds of tiles in one row, beside lanes that have none — are written by the whole wavefront instead, a lane per
@@ -476,12 +514,12 @@ __device__ __forceinline__ void lap_emit_row(const BatchDev &p, int i, bool on, 
             const double xx = bits_f64(readlane_u64(f64_bits(x), src)), SS = bits_f64(readlane_u64(f64_bits(S), src));
             const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)bits, src);
             double *txs = (double *)readlane_u64((uint64_t)tx, src);
-            uint32_t *tns = (uint32_t *)readlane_u64((uint64_t)tn, src);
+            uint32_t *tns = (uint32_t *)readlane_u64((uint64_t)(p.tile_nav + ((size_t)b * (size_t)p.nch + i) * (size_t)p.ntiles), src);
             for (int q = lane; q < c; q += 64) {
                 const int tt = t0 + q;
                 const double v = __fma_rn((double)(tt * TILE - nn), SS, xx);
                 txs[tt] = KIND == NCO_CARR ? mul_rn(v, 512.0) : v;
-                if (KIND == NCO_CODE)
+                if (!WIDE && KIND == NCO_CODE)
                     tns[tt] = bb;
             }
             if (lane == src)
@@ -492,16 +530,60 @@ __device__ __forceinline__ void lap_emit_row(const BatchDev &p, int i, bool on, 
     double v = __fma_rn((double)(t * TILE - n), S, x);
     const double dv = mul_rn(S, (double)TILE); /* exact: a power of two */
     double *px = tx + t;
-    uint32_t *pn = tn + t;
-    for (; __ballot(cnt > 0); cnt--) {
-        if (cnt > 0) {
-            *px = KIND == NCO_CARR ? mul_rn(v, 512.0) : v;
-            if (KIND == NCO_CODE)
-                *pn = bits;
+    if (!WIDE) {
+        /* (geometries whose rows hold a tile at most — the reference's 2.6 MS/s: a code period is 2.5 tiles — keep the plain loop:
+         * there the pieces below find nothing to join and cost pass 2 its eighth wavefront per SIMD: - 1.8 % on that leg) */
+        uint32_t *pn = p.tile_nav + ((size_t)b * (size_t)p.nch + i) * (size_t)p.ntiles + t;
+        for (; __ballot(cnt > 0); cnt--) {
+            if (cnt > 0) {
+                *px = KIND == NCO_CARR ? mul_rn(v, 512.0) : v;
+                if (KIND == NCO_CODE)
+                    *pn = bits;
+            }
+            v = add_rn(v, dv);
+            px++;
+            pn++;
         }
-        v = add_rn(v, dv);
-        px++;
-        pn++;
+        return;
+    }
+    /* Where a row holds a whole 32-byte sector of the block's row of tile states (four tiles from a 32-byte boundary on: the long
+     * rows of the upper binades), the four go out in one piece.  Stored one by one as they come, every state leaves a sector dirty
+     * that is evicted long before its neighbours arrive (the open lines of the wavefronts in flight are ten times the L2):
+     * WRITE_SIZE 2 - 4 x the bytes — and what the pre-pass's write traffic costs shows when it is doubled
+     * (profiles/r06_sweeps.txt, GPSBB_X_TILE_DUP: the pre-pass of a push 3.8 -> 7.8 ms, the synthesis beside it 1.73 -> 1.93 ms). */
+    typedef double lap_d2 __attribute__((ext_vector_type(2)));
+    while (__ballot(cnt > 0)) {
+        const bool quad = cnt >= 4 && (reinterpret_cast<uintptr_t>(px) & 31u) == 0;
+        const bool pair = !quad && cnt >= 2 && (reinterpret_cast<uintptr_t>(px) & 15u) == 0;
+        const bool one = cnt > 0 && !quad && !pair;
+        double v3 = v;
+        if (__ballot(pair)) {
+            if (pair) {
+                v3 = add_rn(v, dv);
+                lap_d2 *q = reinterpret_cast<lap_d2 *>(px);
+                q[0] = KIND == NCO_CARR ? lap_d2{mul_rn(v, 512.0), mul_rn(v3, 512.0)} : lap_d2{v, v3};
+            }
+        }
+        if (__ballot(quad)) {
+            if (quad) {
+                const double v1 = add_rn(v, dv), v2 = add_rn(v1, dv);
+                v3 = add_rn(v2, dv);
+                lap_d2 *q = reinterpret_cast<lap_d2 *>(px);
+                if (KIND == NCO_CARR) {
+                    q[0] = lap_d2{mul_rn(v, 512.0), mul_rn(v1, 512.0)};
+                    q[1] = lap_d2{mul_rn(v2, 512.0), mul_rn(v3, 512.0)};
+                } else {
+                    q[0] = lap_d2{v, v1};
+                    q[1] = lap_d2{v2, v3};
+                }
+            }
+        }
+        if (one)
+            *px = KIND == NCO_CARR ? mul_rn(v, 512.0) : v;
+        const int adv = quad ? 4 : (pair ? 2 : (one ? 1 : 0));
+        v = add_rn(quad || pair ? v3 : v, dv);
+        px += adv;
+        cnt -= adv;
     }
 }
 
@@ -512,7 +594,7 @@ __device__ __forceinline__ void lap_emit_row(const BatchDev &p, int i, bool on, 
  * (LAP_OUT_LATE), or stands at its block's last sample + 1 (outcome 0, n == nsamp: the caller's).
  */
 constexpr int LAP_BURST = 16;
-template <int KIND, bool SNEG, bool EMIT, bool TIES>
+template <int KIND, bool SNEG, bool EMIT, bool TIES, bool WIDE>
 __device__ __forceinline__ void lap_run(const BatchDev &p, int i, LapLane<KIND> &w, const bool was, const int L_burst)
 {
     constexpr int TOPEX = LapK<KIND>::TOPEX;
@@ -538,7 +620,7 @@ __device__ __forceinline__ void lap_run(const BatchDev &p, int i, LapLane<KIND> 
                 if (EMIT && p.tile_x) {
                     const int t0 = (int)(((uint32_t)n + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
                     if (__ballot(still && t0 * TILE <= n + k && t0 < p.ntiles))
-                        lap_emit_row<KIND>(p, i, still, w.b, n, k, x, 0.0, w.bits);
+                        lap_emit_row<KIND, WIDE>(p, i, still, w.b, n, k, x, 0.0, w.bits);
                 }
                 if (still) {
                     n += k;
@@ -640,7 +722,7 @@ __device__ __forceinline__ void lap_run(const BatchDev &p, int i, LapLane<KIND> 
             /* does a tile start inside the row (samples n .. n1)? */
             const int t0 = (int)(((uint32_t)n + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
             if (__ballot(go && t0 * TILE <= n1 && t0 < p.ntiles))
-                lap_emit_row<KIND>(p, i, go, w.b, n, k, x, S, w.bits);
+                lap_emit_row<KIND, WIDE>(p, i, go, w.b, n, k, x, S, w.bits);
         }
         const bool step = go && n1 < nmax;
         double x2 = add_rn(x1, s);
@@ -690,6 +772,8 @@ __device__ __forceinline__ void lap_run(const BatchDev &p, int i, LapLane<KIND> 
                 w.acc = lap_compose(E, lap_compose(F, w.acc));
                 w.so = 0;
             }
+            if (KIND == NCO_CODE && EMIT && WIDE && p.tile_x)
+                lap_nav_out<KIND>(p, i, w, wrapped, n1 + 1, w.bits); /* the period's tiles: up to the one the next period's first sample starts */
             if (KIND == NCO_CODE && wrapped) {
                 /* a code period is over (c:2714-2733): the data bits of the next one, should the lane go on into it — and its
                  * roll-over's data-bit fetch (past dwrd[59]?  the fetch of the roll-over that ENDS the lane's walk is the next lane's
@@ -765,7 +849,7 @@ __device__ __forceinline__ void lap_block_end(const BatchDev &p, int i, LapLane<
  * Walk every active lane from (b, n, x) to the end of its lap or of its territory, whichever comes first.  The lanes of the
  * wavefront belong to one channel i.  EMIT: leave tile states, end-of-block states; count hazards either way (w.hz).
  */
-template <int KIND, bool EMIT, bool TIES>
+template <int KIND, bool EMIT, bool TIES, bool WIDE = false>
 __device__ __forceinline__ void lap_walk(const BatchDev &p, const LapDev &L, int i, LapLane<KIND> &w)
 {
     w.outcome = 0;
@@ -784,20 +868,22 @@ __device__ __forceinline__ void lap_walk(const BatchDev &p, const LapDev &L, int
             /* the roll-over that started this lap fetched a data bit (c:2732) if it started a bit: past dwrd[59]? */
             if (w.fresh && w.jc > 0 && c % 20u == 0u && c / 600u >= (uint32_t)GPSBB_N_DWRD)
                 w.hz++;
+            w.navt = (int32_t)(((uint32_t)w.n + (uint32_t)(TILE - 1)) / (uint32_t)TILE);
         }
         if (w.n >= w.nmax && w.b == w.bt) { /* an empty territory (the plan put two laps on one sample) */
             w.outcome = LAP_OUT_LATE;
             w.active = false;
         }
     }
+    const bool walked = w.active;
     while (__ballot(w.active)) {
         /* the lanes by the sign of their step, each group in its own straight-line loop (a wavefront's laps are neighbours in time:
          * it normally runs only one of the two) */
         const bool rise = w.active && !w.neg, fall = w.active && w.neg;
         if (__ballot(rise))
-            lap_run<KIND, false, EMIT, TIES>(p, i, w, rise, L.burst);
+            lap_run<KIND, false, EMIT, TIES, WIDE>(p, i, w, rise, L.burst);
         if (KIND == NCO_CARR && __ballot(fall))
-            lap_run<KIND, true, EMIT, TIES>(p, i, w, fall, L.burst);
+            lap_run<KIND, true, EMIT, TIES, WIDE>(p, i, w, fall, L.burst);
         /* lanes at the last sample + 1 of their block: the end state; the chain's next block, or the walk ends */
         const bool at_end = w.active && w.n >= p.nsamp;
         if (__ballot(at_end)) {
@@ -837,6 +923,8 @@ __device__ __forceinline__ void lap_walk(const BatchDev &p, const LapDev &L, int
         }
         w.active = w.active && w.outcome == 0;
     }
+    if (KIND == NCO_CODE && EMIT && WIDE && p.tile_x)
+        lap_nav_out<KIND>(p, i, w, walked, w.n, w.bits); /* what is left of the lane's last period */
 }
 
 /* ---- k_lap_plan ---------------------------------------------------------------------------------------------- */
@@ -1178,6 +1266,7 @@ __device__ __forceinline__ LapLane<KIND> lap_lane(bool on, double x, int32_t b, 
     w.tiemask = 0ull;
     w.jc = jc;
     w.c0 = 0;
+    w.navt = 0;
     w.bits = 0;
     w.hz = 0;
     w.bcflags = 0;
@@ -1344,7 +1433,7 @@ __device__ __forceinline__ void lap_scan_body(const BatchDev &p, const LapDev &L
     }
 }
 
-template <int KIND>
+template <int KIND, bool WIDE = false>
 __device__ __forceinline__ void lap_pass2_body(const BatchDev &p, const LapDev &L, const uint32_t bx)
 {
     __shared__ LapPassLds sh;
@@ -1408,7 +1497,7 @@ __device__ __forceinline__ void lap_pass2_body(const BatchDev &p, const LapDev &
     const double x0 = head ? rec.A : __fma_rn(m, lap_unit<KIND>(), rec.A);
     const double x_next = __fma_rn(m_after, lap_unit<KIND>(), lap_next(rec.A, sh.A[wave + 1], lane));
     LapLane<KIND> w = lap_lane<KIND>(mine, x0, rec.b, rec.n0, lap_jc_of<KIND>(p, L, i, r, rec.b), has_next, nb, nn0);
-    lap_walk<KIND, true, false>(p, L, i, w);
+    lap_walk<KIND, true, false, WIDE>(p, L, i, w);
     if (mine) {
         bool ok;
         if (has_next)
@@ -1672,8 +1761,10 @@ template <int KIND>
 __global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass1(BatchDev p, LapDev L) { lap_pass1_body<KIND>(p, L, blockIdx.x); }
 template <int KIND>
 __global__ __launch_bounds__(64) void k_lap_scan(BatchDev p, LapDev L) { lap_scan_body<KIND>(p, L, blockIdx.x); }
-template <int KIND>
-__global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass2(BatchDev p, LapDev L) { lap_pass2_body<KIND>(p, L, blockIdx.x); }
+/* (WIDE: the tile states go out in 32- / 16-byte pieces where a row holds them, a code period's data bits when it is over —
+ * lap_emit_row, lap_nav_out: geometries with several tiles per lap, >= 8 MS/s; the tables are the same bits either way) */
+template <int KIND, bool WIDE = false>
+__global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass2(BatchDev p, LapDev L) { lap_pass2_body<KIND, WIDE>(p, L, blockIdx.x); }
 template <int KIND>
 __global__ __launch_bounds__(64) void k_lap_repair(BatchDev p, LapDev L) { lap_repair_body<KIND>(p, L, blockIdx.x); }
 
@@ -1700,13 +1791,14 @@ __global__ __launch_bounds__(64) void k_lap_scan2(BatchDev p, LapDev L)
     else
         lap_scan_body<NCO_CARR>(p, L, blockIdx.x - (uint32_t)p.nch);
 }
+template <bool WIDE = false>
 __global__ __launch_bounds__(LAP_WG) GPSBB_LAP_OCC void k_lap_pass2_2(BatchDev p, LapDev L)
 {
     const uint32_t cc = L.chunk0[NCO_CODE][p.nch] - L.chunk0[NCO_CODE][0];
     if (blockIdx.x < cc)
-        lap_pass2_body<NCO_CODE>(p, L, blockIdx.x);
+        lap_pass2_body<NCO_CODE, WIDE>(p, L, blockIdx.x);
     else
-        lap_pass2_body<NCO_CARR>(p, L, blockIdx.x - cc);
+        lap_pass2_body<NCO_CARR, WIDE>(p, L, blockIdx.x - cc);
 }
 __global__ __launch_bounds__(64) void k_lap_repair2(BatchDev p, LapDev L)
 {

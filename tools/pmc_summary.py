@@ -32,7 +32,7 @@ def q(db, sql):
 KERNELS = ("k_synth_ev", "k_synth_ev_dense", "k_synth_ev_digest", "k_synth_pd<true>", "k_synth_pd<false>", "k_synth_pd<true, false>", "k_synth_pd<false, false>",
            "k_synth_pd<true, true>", "k_synth_pd<false, true>", "k_synth", "k_walk<0>", "k_walk<1>", "k_walk<2>", "k_walk<3>", "k_tiles",
            "k_chain_fix", "k_chain_fix_par<128>", "k_chain_fix_par<256>", "k_chain_prefix", "k_seed<true>", "k_seed<false>", "k_fill_ceiling",
-           "k_gather_to_host", "k_end_states_to_host", "k_read_pattern", "k_lap_pass1<0>", "k_lap_pass1<1>", "k_lap_pass2<0>", "k_lap_pass2<1>",
+           "k_gather_to_host", "k_end_states_to_host", "k_read_pattern", "k_lap_pass1<0>", "k_lap_pass1<1>", "k_lap_pass2<0>", "k_lap_pass2<1>", "k_lap_pass2<0, true>", "k_lap_pass2<1, true>", "k_lap_pass2<0, false>", "k_lap_pass2<1, false>", "k_lap_pass2_2<true>", "k_lap_pass2_2<false>",
            "k_lap_plan<0>", "k_lap_plan<1>", "k_lap_scan<0>", "k_lap_scan<1>", "k_lap_repair<0>", "k_lap_repair<1>", "k_block_digest")
 
 

@@ -905,7 +905,12 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
 
 /* The common kernel is held to the register budget of five wavefronts per SIMD (96 VGPRs; the allocator's count
  * wanders between 97 and 117 with the size of the chip table): four of them then leave room for a walk wavefront. */
-__global__ __launch_bounds__(EV_WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_synth_ev(BatchDev p, int16_t *__restrict__ iq)
+#ifdef GPSBB_EV_VGPRS /* (measurement: a register budget instead of five wavefronts per SIMD's 96) */
+#define GPSBB_EV_BUDGET __attribute__((amdgpu_num_vgpr(GPSBB_EV_VGPRS)))
+#else
+#define GPSBB_EV_BUDGET __attribute__((amdgpu_waves_per_eu(5, 5)))
+#endif
+__global__ __launch_bounds__(EV_WG) GPSBB_EV_BUDGET void k_synth_ev(BatchDev p, int16_t *__restrict__ iq)
 {
     synth_ev_body<false>(p, iq);
 }

@@ -723,8 +723,11 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
     const bool mirror = chain_lane && (lane & 1) && kb[lane >> 1].down != 0;
     /* this lane's chain (tile-contiguous) in the tile arrays */
     const double *__restrict__ txb = p.tile_x + (size_t)b * ntw * nch2;
-    const double *__restrict__ tx = txb + (size_t)(chain_lane ? lane : 0) * ntw;
-    const uint32_t *__restrict__ tn = p.tile_nav + ((size_t)b * p.nch + (lane < p.nch ? lane : 0)) * ntw;
+    /* (a scalar base and a 32-bit element offset per lane, not a 64-bit pointer per lane: the kernel is short of registers — what
+     * it spills goes to HBM, DESIGN.md 3 — and a running pointer per lane is what the compiler spilled first) */
+    const uint32_t tx_off = (uint32_t)(chain_lane ? lane : 0) * (uint32_t)ntw;
+    const uint32_t *__restrict__ tnb = p.tile_nav + (size_t)b * p.nch * ntw;
+    const uint32_t tn_off = (uint32_t)(lane < p.nch ? lane : 0) * (uint32_t)ntw;
     const double off = (double)(lane * SPT);
     /* this lane's chain in guard format, biased (the fixed-point carrier's index is exact: no bias, see ev_first) */
     const double guard_w = EV_GUARD + ((chain_lane && !(FIXED && (lane & 1))) ? kb[lane >> 1].W : 0.0);
@@ -752,8 +755,8 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
     double ts_v = 0.0;
     uint32_t nav_v = 0;
     if (base < ntw) {
-        ts_v = chain_lane ? tx[base] : 0.0;
-        nav_v = lane < p.nch ? tn[base] : 0u;
+        ts_v = chain_lane ? txb[tx_off + (uint32_t)base] : 0.0;
+        nav_v = lane < p.nch ? tnb[tn_off + (uint32_t)base] : 0u;
     }
     while (base < ntw) {
         const int wt = base + pos;
@@ -784,8 +787,8 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
         }
         const int wt_next = next_base + next_pos;
         if (wt_next < ntw) {
-            ts_v = chain_lane ? tx[wt_next] : 0.0;
-            nav_v = lane < p.nch ? tn[wt_next] : 0u;
+            ts_v = chain_lane ? txb[tx_off + (uint32_t)wt_next] : 0.0;
+            nav_v = lane < p.nch ? tnb[tn_off + (uint32_t)wt_next] : 0u;
         }
 
         const int n0 = wt * TILE + lane * SPT;
@@ -876,7 +879,11 @@ __device__ __forceinline__ void synth_ev_body(const BatchDev &p, int16_t *__rest
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 lds_write_at<ev_u32x4>(t_zero + (uint32_t)k * 1024u, ev_u32x4{0u, 0u, 0u, 0u});
-            ev_u32x4 *g = reinterpret_cast<ev_u32x4 *>(tile_out) + lane;
+            /* (the lane's offset made opaque here: hoisted out of the tile loop it is one more 64-bit value to keep — and the
+             * compiler kept it in scratch, a reload and a store with every tile that went to HBM: DESIGN.md 3) */
+            uint32_t lane_now = (uint32_t)lane;
+            asm volatile("" : "+v"(lane_now));
+            ev_u32x4 *g = reinterpret_cast<ev_u32x4 *>(tile_out) + lane_now;
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 g[k * 64] = v[k]; /* 1 KB of consecutive addresses per instruction */
